@@ -1,0 +1,561 @@
+"""CPU oracle for the ADI PSF-subtraction hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain-numpy restatement of the algorithm that ``vip_hci.psfsub.pca`` /
+``pca_annular`` execute (reference = vortex-exoplanet/VIP 2.0.1, mounted read-only at
+``/root/reference`` in the build container).  Every function cites the reference
+``file:line`` it restates.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module, and only as the checker /
+baseline -- the product (``vip_amd``) never falls back to it.
+
+Pinning: ``oracle/check_vs_reference.py`` compares every function below with the imported
+reference (via ``oracle/_shim.py``) and ``oracle/gen_golden.py`` freezes reference outputs
+into ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` re-checks this file against
+those fixtures everywhere (no reference needed).
+
+The restatement is written from the algorithm's definition, not
+transliterated: e.g. the rotation is expressed as per-line circular sinc shifts instead
+of the reference's fftshift/tile formulation (they agree to ~1e-14, see the check script).
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# geometry helpers
+# --------------------------------------------------------------------------------------
+
+
+def frame_center(shape_or_array):
+    """(cy, cx) = (ny//2, nx//2) for both parities.  Ref: var/coords.py:61-100."""
+    shp = shape_or_array.shape[-2:] if hasattr(shape_or_array, "shape") else tuple(shape_or_array)[-2:]
+    return int(shp[0] // 2), int(shp[1] // 2)
+
+
+def check_pa_vector(angle_list):
+    """Ref: preproc/parangles.py:405-458 (unit='deg')."""
+    a = np.array(angle_list, dtype=float, copy=True)
+    a[a < 0] += 360.0
+    if a.size > 1 and np.any(np.abs(np.diff(a)) > 180):
+        a[a < 180] += 360.0
+    return a
+
+
+def disk_indices(center, radius, shape):
+    """Pixels with ((r-cy)/R)^2 + ((c-cx)/R)^2 < 1 (scikit-image ``draw.disk`` rule),
+    row-major order.  Third-party dependency of the reference (scikit-image 0.25.2,
+    not vendored); used at var/shapes.py:88."""
+    cy, cx = center
+    rr, cc = np.mgrid[:shape[0], :shape[1]]
+    m = ((rr - cy) / radius) ** 2 + ((cc - cx) / radius) ** 2 < 1
+    return rr[m], cc[m]
+
+
+def mask_circle(array, radius, fillwith=0):
+    """mode='in' only.  Ref: var/shapes.py:38-113.  Note the reference indexes
+    ``[:, ind[1], ind[0]]`` for 3d/4d (transposed; symmetric for a centred disk)."""
+    if radius == 0:
+        return True * array
+    cy, cx = frame_center(array)
+    shape = array.shape[-2:]
+    ind = disk_indices((cy, cx), radius, shape)
+    out = array.copy()
+    if array.ndim == 2:
+        out[ind] = fillwith
+    elif array.ndim == 3:
+        out[:, ind[1], ind[0]] = fillwith
+    else:
+        out[:, :, ind[1], ind[0]] = fillwith
+    return out
+
+
+def matrix_scaling(matrix, scaling):
+    """sklearn.preprocessing.scale (1.7.2) arithmetic restated.
+    Ref: var/shapes.py:740-781; sklearn/preprocessing/_data.py::scale."""
+    if scaling is None:
+        return matrix
+    table = {"temp-mean": (0, False), "spat-mean": (1, False),
+             "temp-standard": (0, True), "spat-standard": (1, True)}
+    if scaling not in table:
+        raise ValueError("Scaling mode not recognized")
+    axis, with_std = table[scaling]
+    X = np.array(matrix, copy=True)
+    if X.dtype not in (np.float32, np.float64):
+        X = X.astype(np.float64)
+    mean_ = np.nanmean(X, axis)
+    if with_std:
+        scale_ = np.nanstd(X, axis)
+    Xr = np.rollaxis(X, axis)          # view: broadcasting axis first
+    Xr -= mean_
+    mean_1 = np.nanmean(Xr, axis=0)
+    if not np.allclose(mean_1, 0):
+        Xr -= mean_1
+    if with_std:
+        scale_ = np.array(scale_, copy=True)
+        scale_[scale_ < 10 * np.finfo(scale_.dtype).eps] = 1.0
+        Xr /= scale_
+        mean_2 = np.nanmean(Xr, axis=0)
+        if not np.allclose(mean_2, 0):
+            Xr -= mean_2
+    return X
+
+
+def prepare_matrix(cube, scaling=None, mask_center_px=None):
+    """mode='fullfr'.  Ref: var/shapes.py:857-873."""
+    arr = cube
+    if mask_center_px:
+        arr = mask_circle(arr, mask_center_px)
+    m = np.reshape(arr, (arr.shape[0], -1))
+    return matrix_scaling(m, scaling)
+
+
+# --------------------------------------------------------------------------------------
+# SVD / projection
+# --------------------------------------------------------------------------------------
+
+
+def randomized_svd(M, k, n_iter=2, n_oversamples=10, seed=0):
+    """Halko et al. randomized SVD as sklearn.utils.extmath.randomized_svd runs it for the
+    reference's call (svd.py:487-491): transpose='auto' (work on M.T when rows < cols),
+    power_iteration_normalizer='auto' -> 'none' for n_iter <= 2.  The reference is
+    unseeded; this restatement takes a seed (documented deviation)."""
+    rng = np.random.RandomState(seed)
+    A = M.T if M.shape[0] < M.shape[1] else M
+    transposed = A is not M
+    Q = rng.normal(size=(A.shape[1], k + n_oversamples)).astype(A.dtype)
+    for _ in range(n_iter):
+        Q = A @ Q
+        Q = A.T @ Q
+    Q, _ = np.linalg.qr(A @ Q, mode="reduced")
+    B = Q.T @ A
+    Uh, s, Vt = np.linalg.svd(B, full_matrices=False)
+    U = Q @ Uh
+    if transposed:
+        return Vt[:k].T, s[:k], U[:, :k].T
+    return U[:, :k], s[:k], Vt[:k]
+
+
+def svd_wrapper(matrix, mode, ncomp, full_output=False, seed=0):
+    """Returns V (k x P, rows = PCs) or (U, S, V).  Ref: psfsub/svd.py:342-620."""
+    if matrix.ndim != 2:
+        raise TypeError("Input matrix is not a 2d array")
+    if ncomp > min(matrix.shape):
+        raise RuntimeError("{} PCs cannot be obtained from a matrix with size [{},{}]."
+                           .format(ncomp, matrix.shape[0], matrix.shape[1]))
+    if mode == "lapack":
+        # svd of M.T (P x n): left vectors of M.T are the PCs (svd.py:466-475,598,615)
+        Ul, S, Vl = np.linalg.svd(matrix.T, full_matrices=False)
+        V = Ul[:, :ncomp].T
+        if full_output:
+            return Vl[:ncomp].T, S[:ncomp], V
+        return V
+    if mode == "eigen":
+        # svd.py:447-464
+        C = matrix @ matrix.T
+        e, EV = np.linalg.eigh(C)
+        pc = EV.T @ matrix
+        S = np.sqrt(np.abs(e))[::-1]
+        V = pc[::-1] / S[:, None]
+        V = V[:ncomp]
+        if full_output:
+            U = (EV / np.sqrt(np.abs(e)))[:ncomp]      # reference quirk kept (svd.py:460-462)
+            return U, S, V
+        return V
+    if mode == "randsvd":
+        U, S, V = randomized_svd(matrix, ncomp, seed=seed)
+        if full_output:
+            return U, S, V
+        return V
+    raise ValueError("The SVD `mode` is not recognized")
+
+
+def cevr_to_ncomp(cube, cevr, scaling=None, svd_mode="lapack"):
+    """float ncomp -> int k.  Ref: psfsub/svd.py:182-185,204-207,253-257,335 (note: the
+    reference's SVDecomposer ignores mask_center_px here)."""
+    m = prepare_matrix(cube, scaling, None)
+    _, S, _ = svd_wrapper(m, svd_mode, min(m.shape), full_output=True)
+    ev = S ** 2 / (S.shape[0] - 1)
+    c = np.cumsum(ev / np.sum(ev))
+    return int(np.searchsorted(c, cevr) + 1)
+
+
+def project_subtract(cube, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
+                     cube_ref=None, full_output=False, seed=0):
+    """Whole-matrix branch of ``_project_subtract``.  Ref: psfsub/pca_fullfr.py:1649-1737."""
+    n, y, x = cube.shape
+    if isinstance(ncomp, (float, np.floating)):
+        if not 1 > ncomp > 0:
+            raise ValueError("if `ncomp` is float, it must lie in the interval (0,1]")
+        ncomp = cevr_to_ncomp(cube, ncomp, scaling, svd_mode)
+    matrix = prepare_matrix(cube, scaling, mask_center_px)
+    ref_lib = matrix if cube_ref is None else prepare_matrix(cube_ref, scaling, mask_center_px)
+    V = svd_wrapper(ref_lib, svd_mode, ncomp, seed=seed)
+    transformed = V @ matrix.T
+    reconstructed = transformed.T @ V
+    residuals = (matrix - reconstructed).reshape(n, y, x)
+    if full_output:
+        return residuals, reconstructed, V
+    return residuals
+
+
+# --------------------------------------------------------------------------------------
+# FFT 3-shear rotation (imlib='vip-fft')
+# --------------------------------------------------------------------------------------
+
+
+def rot_geometry(N):
+    """Padded sizes for an N-pixel axis.  Ref: derotation.py:154-158 (1.5x canvas, parity
+    matched), cosmetics.py:210-215 (x 4/1.5, parity matched), derotation.py:583-599.
+    Returns (L, Le, off): padded period, even work length, offset of the frame in the
+    canvas (pixel N//2 lands on L//2)."""
+    n1 = int(N * 1.5)
+    if n1 % 2 != N % 2:
+        n1 += 1
+    L = int(round(n1 * (4 / 1.5)))
+    if L % 2 != n1 % 2:
+        L -= 1
+    Le = L if L % 2 == 0 else L - 1
+    off = L // 2 - N // 2
+    return L, Le, off
+
+
+def rot_angle_split(angle):
+    """Wrap to [0, 360], split into q quarter turns (np.rint: half-to-even) and residual d.
+    Ref: derotation.py:577-596."""
+    a = float(angle)
+    while a < 0:
+        a += 360
+    while a > 360:
+        a -= 360
+    if a > 45:
+        d = a % 90
+        if d > 45:
+            d = -(90 - d)
+        q = int(np.rint(a / 90))
+    else:
+        d = a
+        q = 0
+    return q, d
+
+
+def _line_shift(arr, shifts, axis):
+    """Circular sinc shift (period = len along ``axis``) of every line along ``axis`` by
+    ``shifts[line]`` pixels: ifft(fft(line) * exp(-2 pi i f s)).  Ref: derotation.py:625-640
+    (the four full-array fftshifts cancel for even lengths)."""
+    Le = arr.shape[axis]
+    f = np.fft.fftfreq(Le)
+    if axis == 1:
+        ph = np.exp(-2j * np.pi * shifts[:, None] * f[None, :])
+    else:
+        ph = np.exp(-2j * np.pi * f[:, None] * shifts[None, :])
+    return np.fft.ifft(np.fft.fft(arr, axis=axis) * ph, axis=axis)
+
+
+def frame_rotate_fft(frame, angle, mask_val=np.nan):
+    """frame_rotate(..., imlib='vip-fft', edge_blend=None) -> float64 (Ny, Nx).
+    Ref: derotation.py:129-222,236-237,324-326,542-640."""
+    if frame.ndim != 2:
+        raise TypeError("Input array is not a frame or 2d array")
+    Ny, Nx = frame.shape
+    if Ny != Nx:
+        raise ValueError("oracle restates the square-frame case only")
+    N = Ny
+    L, Le, off = rot_geometry(N)
+    if np.isnan(mask_val):
+        mask_ori = np.isnan(frame)
+    else:
+        mask_ori = frame == mask_val
+    canvas = np.zeros((L + 1, L + 1))                 # odd embedding so the pivot is a pixel
+    canvas[off:off + N, off:off + N] = np.where(np.isnan(frame), 0.0, frame)
+    if L % 2:                                         # odd L is already odd: no embedding
+        canvas = canvas[:L, :L]
+    q, d = rot_angle_split(angle)
+    if q:
+        canvas = np.rot90(canvas, q)
+    W = canvas[:Le, :Le].astype(complex)
+    a = np.tan(np.deg2rad(d) / 2)
+    b = -np.sin(np.deg2rad(d))
+    c = L // 2
+    coord = np.arange(Le) - c
+    W = _line_shift(W, a * coord, axis=1)             # rows shifted along x by a*(y-c)
+    W = _line_shift(W, b * coord, axis=0)             # cols shifted along y by b*(x-c)
+    W = _line_shift(W, a * coord, axis=1)
+    out = np.real(W)[off:off + N, off:off + N].copy()
+    out[mask_ori] = mask_val
+    return out
+
+
+def cube_derotate(cube, angle_list, mask_val=np.nan, out_dtype=None):
+    """nproc=1 semantics: output dtype = input dtype.  Ref: derotation.py:383-391."""
+    if cube.ndim != 3:
+        raise TypeError("Input array is not a cube or 3d array.")
+    out = np.zeros_like(cube) if out_dtype is None else np.zeros(cube.shape, out_dtype)
+    for i in range(cube.shape[0]):
+        out[i] = frame_rotate_fft(cube[i], -angle_list[i], mask_val=mask_val)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# collapse
+# --------------------------------------------------------------------------------------
+
+
+def cube_collapse(cube, mode="median", n=50, w=None):
+    """3-D: axis 0, 4-D: axis 1.  numpy nan-functions (bottleneck absent == numpy
+    semantics).  Ref: preproc/subsampling.py:30-116."""
+    if cube.ndim == 3:
+        ax = 0
+    elif cube.ndim == 4:
+        ax = 1
+    else:
+        raise TypeError("The input array is not a cube or 3d array.")
+    if mode == "mean":
+        return np.nanmean(cube, axis=ax)
+    if mode == "median":
+        return np.nanmedian(cube, axis=ax)
+    if mode == "sum":
+        return np.nansum(cube, axis=ax)
+    if mode == "max":
+        return np.nanmax(cube, axis=ax)
+    if mode == "absmean":
+        return np.nanmean(np.abs(cube), axis=ax)
+    if mode == "wmean":
+        if w is None:
+            raise ValueError("Weights have to be provided for weighted mean mode")
+        if len(w) != cube.shape[0]:
+            raise TypeError("Weights need same length as cube")
+        arr = np.where(np.isnan(cube), 0, cube)
+        if ax == 0:
+            return np.inner(np.asarray(w), np.moveaxis(arr, 0, -1))
+        return np.stack([np.inner(np.asarray(w), np.moveaxis(arr[j], 0, -1))
+                         for j in range(arr.shape[0])])
+    if mode == "trimmean":
+        if ax != 0:
+            raise NotImplementedError
+        N = cube.shape[0]
+        k = (N - n) // 2
+        if N % 2 != n % 2:
+            n += 1
+        srt = np.sort(cube, axis=0)
+        return np.nanmean(srt[k:k + n], axis=0).astype(cube.dtype)
+    raise TypeError("mode not recognized")
+
+
+# --------------------------------------------------------------------------------------
+# ADI index helpers (bit-exact contracts)
+# --------------------------------------------------------------------------------------
+
+
+def find_indices_adi(angle_list, frame, thr, truncate=False, max_frames=200):
+    """Library indices for ``frame``.  Ref: preproc/derotation.py:410-496 (nframes=None,
+    out_closest=False branch)."""
+    n = angle_list.shape[0]
+    index_prev = 0
+    for i in range(frame):
+        if abs(angle_list[frame] - angle_list[i]) < thr:
+            break
+        index_prev += 1
+    index_foll = frame
+    for k in range(frame, n):
+        if abs(angle_list[k] - angle_list[frame]) > thr:
+            break
+        index_foll += 1
+    idx = np.array(list(range(0, index_prev)) + list(range(index_foll, n)), dtype="int32")
+    if truncate:
+        lim = min(n - 1, max_frames)
+        if len(idx) > lim:
+            allidx = np.array(list(range(0, index_prev)) + list(range(index_foll, n)))
+            dpa = np.abs(angle_list[allidx] - angle_list[frame])
+            idx = np.sort(allidx[np.argsort(dpa)][:lim])
+    return idx
+
+
+def compute_pa_thresh(ann_center, fwhm, delta_rot=1):
+    """Ref: preproc/derotation.py:499-504."""
+    return np.rad2deg(2 * np.arctan(delta_rot * fwhm / (2 * ann_center)))
+
+
+def define_annuli(angle_list, ann, n_annuli, fwhm, radius_int, annulus_width, delta_rot,
+                  strict=True):
+    """Ref: preproc/derotation.py:507-539 (prints dropped)."""
+    if ann == n_annuli - 1:
+        inner_radius = radius_int + (ann * annulus_width - 1)
+    else:
+        inner_radius = radius_int + ann * annulus_width
+    ann_center = inner_radius + (annulus_width / 2)
+    pa_threshold = compute_pa_thresh(ann_center, fwhm, delta_rot)
+    mid_range = np.abs(np.amax(angle_list) - np.amin(angle_list)) / 2
+    if pa_threshold >= mid_range - mid_range * 0.1 and not strict:
+        pa_threshold = float(mid_range - mid_range * 0.1)
+    return pa_threshold, inner_radius, ann_center
+
+
+def get_annulus_segments(shape, inner_radius, width, nsegm=1, theta_init=0):
+    """mode='ind', optim_scale_fact=1.  Ref: var/shapes.py:474-581."""
+    if not isinstance(nsegm, int):
+        raise TypeError("`nsegm` must be an integer")
+    cy, cx = frame_center(shape)
+    az = np.deg2rad(int(np.ceil(360 / nsegm)))
+    twopi = 2 * np.pi
+    yy, xx = np.mgrid[:shape[0], :shape[1]]
+    rad = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+    phirot = np.arctan2(yy - cy, xx - cx) % twopi
+    outer = inner_radius + width
+    ring = (rad >= inner_radius) & (rad < outer)
+    res = []
+    for i in range(nsegm):
+        ps = np.deg2rad(theta_init) + i * az
+        pe = ps + az
+        if ps < twopi and pe > twopi:
+            m = ring & (phirot >= ps) & (phirot <= twopi) | ring & (phirot >= 0) & (phirot < pe - twopi)
+        elif ps >= twopi and pe > twopi:
+            m = ring & (phirot >= ps - twopi) & (phirot < pe - twopi)
+        else:
+            m = ring & (phirot >= ps) & (phirot < pe)
+        res.append(np.where(m))
+    return res
+
+
+# --------------------------------------------------------------------------------------
+# end-to-end entry points
+# --------------------------------------------------------------------------------------
+
+
+def pca_fullframe(cube, angle_list, ncomp=1, svd_mode="lapack", scaling=None,
+                  mask_center_px=None, collapse="median", cube_ref=None, weights=None,
+                  full_output=False, seed=0, rot_options=None):
+    """3-D ADI / RDI branch of ``pca``.  Ref: psfsub/pca_fullfr.py:412-415,661-701,
+    801-1007,759-793."""
+    if cube.ndim != 3:
+        raise TypeError("`cube` must be a 3d numpy ndarray")
+    n = cube.shape[0]
+    rot_options = dict(rot_options or {})
+    if mask_center_px and len(rot_options) == 0:
+        rot_options = {"mask_val": 0, "ker": 1, "interp_zeros": True}
+    mask_val = rot_options.get("mask_val", np.nan)
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    if n != angle_list.shape[0]:
+        raise ValueError("`angle_list` vector has wrong length. It must equal the number of "
+                         "frames in the cube")
+    nref = n if cube_ref is None else cube_ref.shape[0]
+    if isinstance(ncomp, (int, np.integer)) and ncomp > nref:
+        ncomp = min(ncomp, nref)
+    elif ncomp <= 0:
+        raise ValueError("Number of PCs too low. It should be > 0.")
+    res, recon, V = project_subtract(cube, ncomp, scaling, mask_center_px, svd_mode,
+                                     cube_ref=cube_ref, full_output=True, seed=seed)
+    y, x = cube.shape[1:]
+    pcs = V.reshape(V.shape[0], y, x)
+    recon = recon.reshape(n, y, x)
+    res_der = cube_derotate(res, angle_list, mask_val=mask_val)
+    frame = cube_collapse(res_der, mode=collapse, w=weights)
+    if mask_center_px:
+        res_der = mask_circle(res_der, mask_center_px)
+        frame = mask_circle(frame, mask_center_px)
+    if full_output:
+        return frame, pcs, recon, res, res_der
+    return frame
+
+
+def pca_4d(cube, angle_list, ncomp=1, collapse_ifs="mean", full_output=False, **kw):
+    """4-D cube, scale_list=None: per-channel full-frame PCA then spectral collapse.
+    Ref: psfsub/pca_fullfr.py:544-658,770-774."""
+    nch, nz, ny, nx = cube.shape
+    ncomps = ncomp if isinstance(ncomp, list) else [ncomp] * nch
+    ifs = np.zeros([nch, ny, nx])
+    pcs, recon, res, resd = [], [], [], []
+    for ch in range(nch):
+        out = pca_fullframe(cube[ch], angle_list, ncomp=ncomps[ch], full_output=True, **kw)
+        ifs[ch] = out[0]
+        pcs.append(out[1]); recon.append(out[2]); res.append(out[3]); resd.append(out[4])
+    frame = cube_collapse(ifs, mode=collapse_ifs)
+    if full_output:
+        return frame, np.array(pcs), np.array(recon), np.array(res), np.array(resd), ifs
+    return frame
+
+
+def pca_annular(cube, angle_list, radius_int=0, fwhm=4, asize=4, n_segments=1,
+                delta_rot=(0.1, 1), ncomp=1, svd_mode="lapack", min_frames_lib=2,
+                max_frames_lib=200, scaling=None, collapse="median", theta_init=0,
+                weights=None, full_output=False, rot_options=None):
+    """3-D ADI annular PCA (int / per-annulus tuple ncomp).  Ref: psfsub/pca_local.py:
+    228-278,594-827 and do_pca_patch :830-909; get_eigenvectors svd.py:694-700."""
+    if cube.ndim != 3:
+        raise TypeError("Input array is not a cube or 3d array")
+    if cube.shape[0] != np.asarray(angle_list).shape[0]:
+        raise TypeError("Input vector or parallactic angles has wrong length")
+    n, y, x = cube.shape
+    rot_options = dict(rot_options or {})
+    if radius_int and len(rot_options) == 0:
+        rot_options = {"mask_val": 0, "ker": 1, "interp_zeros": True}
+    mask_val = rot_options.get("mask_val", np.nan)
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    n_annuli = int((y / 2 - radius_int) / asize)
+    if isinstance(delta_rot, tuple):
+        delta_rot = np.linspace(delta_rot[0], delta_rot[1], num=n_annuli)
+    elif np.isscalar(delta_rot):
+        delta_rot = [delta_rot] * n_annuli
+    if isinstance(n_segments, int):
+        n_segments = [n_segments] * n_annuli
+    elif n_segments == "auto":
+        n_segments = [2, 3]
+        ld = 2 * np.tan(360 / 4 / 2) * asize          # radians quirk kept (pca_local.py:648)
+        for i in range(2, n_annuli):
+            ang = np.rad2deg(2 * np.arctan(ld / (2 * i * asize)))
+            n_segments.append(int(np.ceil(360 / ang)))
+    cube_out = np.zeros_like(cube)
+    for ann in range(n_annuli):
+        if isinstance(ncomp, (tuple, np.ndarray)):
+            if len(ncomp) != n_annuli:
+                raise TypeError("If `ncomp` is a tuple, its length must match the number of annuli")
+            k_ann = ncomp[ann]
+        else:
+            k_ann = ncomp
+        pa_thr, inner_radius, _ = define_annuli(angle_list, ann, n_annuli, fwhm, radius_int,
+                                                asize, delta_rot[ann], strict=True)
+        segs = get_annulus_segments((y, x), inner_radius, asize, n_segments[ann], theta_init)
+        for yy, xx in segs:
+            m = matrix_scaling(cube[:, yy, xx], scaling)
+            for fr in range(n):
+                if pa_thr != 0:
+                    idx = find_indices_adi(angle_list, fr, pa_thr, truncate=True,
+                                           max_frames=max_frames_lib)
+                    lib = m[idx]
+                    if lib.shape[0] < min_frames_lib:
+                        raise RuntimeError("Too few frames left in the PCA library.")
+                else:
+                    lib = m
+                k = min(k_ann, min(lib.shape))
+                V = svd_wrapper(lib, svd_mode, k)
+                cur = m[fr]
+                cube_out[fr][yy, xx] = cur - (cur @ V.T) @ V
+    cube_der = cube_derotate(cube_out, angle_list, mask_val=mask_val)
+    frame = cube_collapse(cube_der, mode=collapse, w=weights)
+    if full_output:
+        return cube_out, cube_der, frame
+    return frame
+
+
+# --------------------------------------------------------------------------------------
+# synthetic ADI cubes (SURVEY.md section 8(d) generator; shared with tests/bench)
+# --------------------------------------------------------------------------------------
+
+
+def synth_adi(n, N, seed=0, planet=True, dtype=np.float32):
+    """Halo + 30 geometric-spectrum speckle modes + unit noise, max|cube| ~ 10."""
+    rng = np.random.default_rng(seed)
+    c = N // 2
+    yy, xx = np.mgrid[:N, :N]
+    r = np.sqrt((yy - c) ** 2 + (xx - c) ** 2)
+    env = np.exp(-r / (N / 8))
+    nmodes = 30
+    modes = rng.standard_normal((nmodes, N, N)) * env
+    coef = rng.standard_normal((n, nmodes)) * 2.0 ** (-np.arange(nmodes) / 3)
+    cube = np.tensordot(coef, modes, axes=1) + env[None] * 3.0
+    angles = np.linspace(0, 90, n)
+    if planet:
+        sig = 4 / 2.3548200450309493
+        for i, th in enumerate(np.deg2rad(angles)):
+            py, px = c + (N / 4) * np.sin(th), c + (N / 4) * np.cos(th)
+            cube[i] += 0.5 * np.exp(-((yy - py) ** 2 + (xx - px) ** 2) / (2 * sig ** 2))
+    cube *= 9.0 / np.max(np.abs(cube))
+    cube += rng.standard_normal((n, N, N))
+    cube *= 10.0 / np.max(np.abs(cube))
+    return cube.astype(dtype), angles
