@@ -1,0 +1,134 @@
+/* vipmi.h -- C ABI of libvipmi.so: MI355X (gfx950) kernels for the ADI PSF-subtraction hot path
+ * of vortex-exoplanet/VIP (vip_hci.psfsub.pca / pca_annular -> svd_wrapper -> project/subtract ->
+ * cube_derotate -> cube_collapse).
+ *
+ * The reference has no FFI for this path (it is pure Python over numpy/scipy); each
+ * entry point below therefore names the reference *function* it replaces (file:line under
+ * /root/reference/src/vip_hci) -- that is the interface a maintainer binds with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative vipmi_status otherwise; never throws.
+ *     vipmi_last_error() returns a thread-local message for the last failure.
+ *   - array arguments are CALLER-OWNED DEVICE pointers (e.g. torch.Tensor.data_ptr()), C-order,
+ *     contiguous, unless the name ends in _host.  Sizes are explicit int64.
+ *   - a vipmi_ctx owns a device id, a stream and a growable scratch workspace; one ctx per
+ *     (device, stream); a ctx is not thread-safe, distinct ctxs are independent.
+ *   - all work is enqueued on the ctx stream; nothing synchronises unless stated.
+ */
+#ifndef VIPMI_H
+#define VIPMI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vipmi_ctx vipmi_ctx;
+
+typedef enum {
+  VIPMI_OK = 0,
+  VIPMI_ERR_ARG = -1,      /* bad argument (maps to TypeError/ValueError on the Python side) */
+  VIPMI_ERR_HIP = -2,      /* HIP runtime error */
+  VIPMI_ERR_NOMEM = -3,    /* workspace allocation failed */
+  VIPMI_ERR_NOCONV = -4,   /* eigensolver did not converge */
+  VIPMI_ERR_UNSUPPORTED = -5
+} vipmi_status;
+
+enum { VIPMI_SCALE_TEMP_MEAN = 1, VIPMI_SCALE_TEMP_STANDARD = 2,
+       VIPMI_SCALE_SPAT_MEAN = 3, VIPMI_SCALE_SPAT_STANDARD = 4 };
+enum { VIPMI_COLLAPSE_MEDIAN = 0, VIPMI_COLLAPSE_MEAN = 1, VIPMI_COLLAPSE_SUM = 2,
+       VIPMI_COLLAPSE_MAX = 3, VIPMI_COLLAPSE_ABSMEAN = 4, VIPMI_COLLAPSE_WMEAN = 5,
+       VIPMI_COLLAPSE_TRIMMEAN = 6 };
+enum { VIPMI_ROT_AUTO = 0, VIPMI_ROT_DIRECT = 1, VIPMI_ROT_FFT = 2 };
+
+int vipmi_version(void);
+const char* vipmi_last_error(void);
+
+/* ctx: device = HIP ordinal; stream = hipStream_t (NULL = default stream). */
+int vipmi_create(int device, void* stream, vipmi_ctx** out);
+int vipmi_destroy(vipmi_ctx* ctx);
+int vipmi_set_stream(vipmi_ctx* ctx, void* stream);
+int vipmi_synchronize(vipmi_ctx* ctx);
+/* tuning knobs (key/value); see DESIGN.md.  Unknown key -> VIPMI_ERR_ARG. */
+int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value);
+int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key);   /* -1 if unset */
+/* elapsed ms between the start and the end of the most recent call of the named stage
+ * ("gram","eigh","project","derotate","collapse","scale"), measured with hipEvents on the ctx
+ * stream; synchronises.  <0 if the stage has not run. */
+float vipmi_stage_ms(vipmi_ctx* ctx, const char* stage);
+
+/* ---- prepare_matrix pieces: var/shapes.py:740-781 (matrix_scaling), :38-113 (mask_circle) ---- */
+/* out[n,P] = sklearn-style scale of in[n,P]; mode = VIPMI_SCALE_*; in == out allowed. */
+int vipmi_scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P, int mode);
+/* out[n,P] = in[n,P] with pixels whose mask byte != 0 set to fill (mask computed by the host with the
+ * reference's float64 disk rule so membership is bit-exact). */
+int vipmi_apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
+                         const uint8_t* mask, float fill);
+
+/* ---- svd_wrapper mode 'eigen'/'lapack' arithmetic: psfsub/svd.py:447-475 ---- */
+/* G[n,n] (float64, symmetric) = M[n,P] * M^T, M row-major with leading dimension ld (floats). */
+int vipmi_gram_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double* G);
+/* Cross product C[na,nb] (float64) = A[na,P] * B[nb,P]^T (used by RDI / cube_sig projections). */
+int vipmi_cross_gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb,
+                         int64_t P, int64_t ld, double* C);
+/* Batched symmetric eigendecomposition (float64, one-sided block Jacobi).  G: batch x n x n,
+ * destroyed.  evals: batch x n descending.  evecs: batch x n x n, row i = eigenvector of evals[i]
+ * (unit norm, sign: largest-|component| positive). */
+int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs);
+
+/* ---- _project_subtract: psfsub/pca_fullfr.py:1727-1731 ---- */
+/* B[k,P] = W[k,n] (float32) * M[n,P];  row c optionally scaled by rowscale[c] (may be NULL). */
+int vipmi_rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n,
+                            int64_t P, const float* rowscale, float* B);
+/* R[n,P] = M[n,P] - C[n,k]*B[k,P];  recon (may be NULL) receives C*B. */
+int vipmi_subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B,
+                            int64_t n, int64_t k, int64_t P, float* R, float* recon);
+
+/* ---- cube_derotate / frame_rotate(imlib='vip-fft'): preproc/derotation.py:51-328,331-399,542-640 ----
+ * out[n,N,N] = frames of in[n,N,N] rotated by -angles_host[i] degrees with the reference's 3-shear
+ * FFT rotation (1.5x then 4x zero padding, rot90 pre-step, complex field carried between shears).
+ * NaN input pixels are treated as 0 and restored as NaN in the output when mask_nan != 0;
+ * when mask_zero != 0 pixels equal to 0 in the input are restored to 0 (mask_val=0 semantics).
+ * method = VIPMI_ROT_*. */
+int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n,
+                       int64_t N, float* out, int mask_nan, int mask_zero, int method);
+
+/* ---- cube_collapse: preproc/subsampling.py:30-116 ---- */
+/* out[P] = collapse over the n frames of cube[n,P]; NaN-aware (nanmedian/nanmean/...).
+ * w (device, n floats) only for WMEAN; trim_n only for TRIMMEAN. */
+int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode,
+                       const float* w, int64_t trim_n, float* out);
+
+/* ---- pca_annular core: psfsub/pca_local.py:710-787,830-909 ----
+ * For one annulus segment matrix A[n,npx] (already gathered + scaled) and per-frame library index
+ * lists (lib_idx[n*max_lib], lib_len[n], device int32), computes residuals[n,npx] =
+ * A[j] - proj_{top-k PCs of A[lib_j]}(A[j]) through the sub-Gram identity. */
+int vipmi_annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
+                                const int32_t* lib_idx, const int32_t* lib_len, int64_t max_lib,
+                                int64_t ncomp, float* residuals);
+/* gather / scatter of annulus pixels: A[n,npx] = cube[n, pix[j]] and back. */
+int vipmi_gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
+                     int64_t npx, float* A);
+int vipmi_scatter_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t P, const int32_t* pix,
+                      int64_t npx, float* cube);
+
+/* ---- svd_wrapper + _project_subtract in one call: psfsub/svd.py:342-620, pca_fullfr.py:1717-1731 ----
+ * residuals[n,P] = M - proj(M onto the top-k PCs of ref[nref,P]) ; ref == M (same pointer) is ADI,
+ * otherwise RDI.  Optional outputs (may be NULL): recon[n,P], pcs[k,P] (orthonormal rows, the
+ * reference's V), evals_out[nref] (float64 eigenvalues of ref ref^T = squared singular values). */
+int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float* ref, int64_t nref,
+                          int64_t P, int64_t k, float* residuals, float* recon, float* pcs,
+                          double* evals_out);
+
+/* ---- fused full-frame ADI path: psfsub/pca_fullfr.py:801-1007 (3-D, int ncomp, no cube_ref) ----
+ * cube[n,N,N] float32 -> frame[N,N].  Optional outputs may be NULL: pcs[k,N,N], recon[n,N,N],
+ * residuals[n,N,N], residuals_der[n,N,N].  scaling: 0 or VIPMI_SCALE_*.  mask: N*N bytes or NULL. */
+int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* angles_host, int64_t n,
+                            int64_t N, int64_t ncomp, int scaling, const uint8_t* mask,
+                            int collapse_mode, float* frame, float* pcs, float* recon,
+                            float* residuals, float* residuals_der);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIPMI_H */

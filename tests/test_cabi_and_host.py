@@ -1,0 +1,151 @@
+"""CPU: the C-ABI library loads and exports every symbol of include/vipmi.h; host logic of the
+product (kwargs plumbing, index helpers, error conventions) -- no compute calls without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, ROOT
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "vipmi.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vipmi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    from vip_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libvipmi.so does not export %s" % s
+    assert set(_lib.EXPORTED_SYMBOLS) == set(syms)
+    assert lib.vipmi_version() >= 100
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vip_amd import _lib
+    from vip_amd.psfsub import pca
+    from vip_amd.preproc import cube_derotate, cube_collapse
+    cube = np.zeros((4, 8, 8), np.float32)
+    for fn in (lambda: pca(cube, np.zeros(4), ncomp=1, verbose=False),
+               lambda: cube_derotate(cube, np.zeros(4)),
+               lambda: cube_collapse(cube)):
+        with pytest.raises(_lib.VipmiError):
+            fn()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "vip_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in txt.replace("oracle-free", ""), "%s references the oracle" % fn
+                assert "/root/reference" not in txt
+
+
+def test_params_dataclasses_match_reference_order():
+    from vip_amd.psfsub import PCA_Params, PCA_ANNULAR_Params
+    import dataclasses
+    f = [x.name for x in dataclasses.fields(PCA_Params)]
+    assert f[:8] == ["cube", "angle_list", "cube_ref", "scale_list", "ncomp", "svd_mode", "scaling", "mask_center_px"]
+    assert len(f) == 34
+    p = PCA_Params()
+    assert p.ncomp == 1 and p.svd_mode == "lapack" and p.imlib == "vip-fft" and p.collapse == "median"
+    assert p.collapse_ifs == "mean" and p.nproc == 1 and p.full_output is False and p.min_frames_pca == 10
+    a = PCA_ANNULAR_Params()
+    assert a.asize == 4 and a.delta_rot == (0.1, 1) and a.max_frames_lib == 200 and a.min_frames_lib == 2
+    g = [x.name for x in dataclasses.fields(PCA_ANNULAR_Params)]
+    assert g[:11] == ["cube", "angle_list", "cube_ref", "scale_list", "radius_int", "fwhm", "asize",
+                      "n_segments", "delta_rot", "delta_sep", "ncomp"]
+
+
+def test_kwargs_split():
+    from vip_amd.config import separate_kwargs_dict
+    from vip_amd.psfsub import PCA_Params
+    cp, ro = separate_kwargs_dict(dict(ncomp=3, mask_val=0, border_mode="constant", verbose=False), PCA_Params)
+    assert cp == dict(ncomp=3, verbose=False) and ro == dict(mask_val=0, border_mode="constant")
+
+
+def test_host_index_helpers_against_golden():
+    from vip_amd.preproc import _find_indices_adi, _define_annuli, check_pa_vector
+    from vip_amd.var import get_annulus_segments, frame_center, disk_mask
+    g = load_golden("g5_indices")
+    for f in range(7):
+        got = _find_indices_adi(g["fi_angles"], f, 42)
+        assert got.dtype == np.int32 and np.array_equal(got, g["fi_%d" % f])
+    assert list(_find_indices_adi(g["fi_angles"], 3, 42, truncate=True, max_frames=3)) == [1, 5, 6]
+    assert _find_indices_adi(g["fi_angles"], 3, 42, out_closest=True) == (2, 4)
+    assert list(_find_indices_adi(g["fi_angles"], 3, 42, nframes=2)) == [1, 5]
+    al = g["fi_long_angles"]
+    for f in (0, 7, 30, 59):
+        for mf in (10, 25):
+            assert np.array_equal(_find_indices_adi(al, f, 3.0, truncate=True, max_frames=mf), g["fit_%d_%d" % (f, mf)])
+    for (N, inner, w, ns, th0) in ((64, 8, 8, 1, 0), (65, 7, 8, 3, 30), (512, 223, 32, 1, 0)):
+        segs = get_annulus_segments((N, N), inner, w, ns, th0)
+        for i in range(ns):
+            flat = (segs[i][0].astype(np.int64) * N + segs[i][1]).astype(np.int32)
+            assert np.array_equal(flat, g["seg_%d_%d_%d_%d_%d_s%d" % (N, inner, w, ns, th0, i)])
+    da = np.array([_define_annuli(al, ann, 4, 4, 2, 6, 0.5, 1, False, True) for ann in range(4)])
+    np.testing.assert_allclose(da, g["define_annuli"], rtol=1e-14)
+    for i in range(4):
+        assert np.array_equal(check_pa_vector(g["pa_in_%d" % i]), g["pa_out_%d" % i])
+    assert frame_center(np.zeros((7, 8))) == (3, 4)
+    # disk rule: 69 pixels for r=5 on a 21x21 frame (lattice points with r^2 < 25)
+    assert int(disk_mask((21, 21), 5).sum()) == 69
+    m3 = g["mask_in"]
+    from vip_amd.var.shapes import center_mask_u8
+    mk = center_mask_u8((21, 21), 5).astype(bool)
+    exp = m3.copy()
+    exp[:, mk] = 0
+    assert np.array_equal(exp, g["mask_out_5"])
+
+
+def test_annulus_plan_matches_oracle_structure():
+    from vip_amd.psfsub.pca_local import annulus_plan
+    from oracle import ref_cpu as O
+    ang = np.linspace(0, 90, 30)
+    plan = annulus_plan((64, 64), ang, 0, 4, 8, 1, (0.1, 1), 3, 2, 200)
+    assert len(plan) == 4
+    total = sum(len(s["pix"]) for s in plan)
+    segs = [O.get_annulus_segments((64, 64), O.define_annuli(ang, a, 4, 4, 0, 8, d)[1], 8)[0]
+            for a, d in zip(range(4), np.linspace(0.1, 1, 4))]
+    assert total == sum(len(s[0]) for s in segs)
+    for s, (yy, xx) in zip(plan, segs):
+        assert np.array_equal(s["pix"], (yy * 64 + xx).astype(np.int32))
+        for fr in (0, 13, 29):
+            assert np.array_equal(s["libs"][fr], O.find_indices_adi(ang, fr, s["pa_thr"], truncate=True, max_frames=200))
+
+
+def test_argument_errors_raise_before_touching_the_gpu():
+    from vip_amd.psfsub import pca, pca_annular
+    from vip_amd.psfsub.svd import svd_wrapper
+    cube = np.zeros((4, 8, 8), np.float32)
+    with pytest.raises(TypeError):
+        pca(np.zeros((8, 8), np.float32), np.zeros(4), verbose=False)
+    with pytest.raises(TypeError):
+        pca([1, 2, 3], np.zeros(4), verbose=False)
+    with pytest.raises(NotImplementedError):
+        pca(cube, np.zeros(4), scale_list=np.ones(4), verbose=False)
+    with pytest.raises(ValueError):
+        pca(cube, np.zeros(4), svd_mode="nope", verbose=False)
+    with pytest.raises(NotImplementedError):
+        pca(cube, np.zeros(4), left_eigv=True, verbose=False)
+    with pytest.raises(TypeError):
+        svd_wrapper(np.zeros((2, 3, 4)), "lapack", 1, False)
+    with pytest.raises(RuntimeError):
+        svd_wrapper(np.zeros((4, 10)), "lapack", 5, False)
+    with pytest.raises(ValueError):
+        svd_wrapper(np.zeros((4, 10)), "nope", 2, False)
+    with pytest.raises(NotImplementedError):
+        pca_annular(np.zeros((2, 4, 8, 8), np.float32), np.zeros(4), verbose=False)

@@ -1,0 +1,256 @@
+"""GPU parity tests, kernel level: every entry point of the C ABI (through vip_amd.backend) against the
+CPU oracle / numpy float64 on the same seeded inputs, plus the committed golden fixtures."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sign_align
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import torch
+    assert torch.cuda.is_available()
+    from vip_amd import backend
+    return backend
+
+
+def dev(B, a):
+    return B.to_device_f32(a)
+
+
+# ---- Gram -------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,P", [(5, 77), (16, 256), (50, 16384), (33, 10201), (100, 4096), (400, 8192)])
+@pytest.mark.parametrize("f32acc", [0, 1])
+def test_gram(B, n, P, f32acc):
+    rng = np.random.default_rng(n * 7 + P)
+    M = (rng.standard_normal((n, P)) * 3 + 0.5).astype(np.float32)
+    # asymmetric content so that a transposed tile write would be caught
+    M[:, : min(P, 64)] += np.arange(n, dtype=np.float32)[:, None]
+    ctx = B.get_context()
+    ctx.set_option("gram_f32", f32acc)
+    try:
+        G = B.gram(dev(B, M)).cpu().numpy()
+    finally:
+        ctx.set_option("gram_f32", 0)
+    ref = M.astype(np.float64) @ M.astype(np.float64).T
+    scale = np.abs(ref).max()
+    tol = 3e-6 if f32acc else 1e-12
+    assert np.abs(G - ref).max() <= tol * scale
+    assert np.array_equal(G, G.T)
+
+
+def test_gram_tile_variants(B):
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((70, 2048)).astype(np.float32)
+    ref = M.astype(np.float64) @ M.astype(np.float64).T
+    ctx = B.get_context()
+    for tb in (1, 2, 3, 4):
+        ctx.set_option("gram_tb", tb)
+        G = B.gram(dev(B, M)).cpu().numpy()
+        assert np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max(), tb
+    ctx.set_option("gram_tb", 0)
+
+
+def test_cross_gram(B):
+    rng = np.random.default_rng(6)
+    A = rng.standard_normal((37, 3000)).astype(np.float32)
+    Bm = rng.standard_normal((9, 3000)).astype(np.float32)
+    C = B.cross_gram(dev(B, A), dev(B, Bm)).cpu().numpy()
+    ref = A.astype(np.float64) @ Bm.astype(np.float64).T
+    assert C.shape == (37, 9)
+    assert np.abs(C - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+# ---- eigensolver -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [3, 16, 17, 50, 64, 100, 200, 400, 650])
+def test_eigh(B, n):
+    import torch
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, 3 * n + 5))
+    M[:, 0] *= 30
+    M[:, 1] *= 10
+    G = M @ M.T
+    evals, evecs = B.eigh(torch.from_numpy(G).cuda())
+    evals, evecs = evals.cpu().numpy(), evecs.cpu().numpy()
+    w, v = np.linalg.eigh(G)
+    w, v = w[::-1], v[:, ::-1].T
+    assert np.all(np.diff(evals) <= 0)
+    np.testing.assert_allclose(evals, w, rtol=1e-10, atol=1e-10 * w[0])
+    # orthonormal rows, and G v = lambda v
+    assert np.abs(evecs @ evecs.T - np.eye(n)).max() < 1e-9
+    assert np.abs(G @ evecs.T - evecs.T * evals).max() < 1e-9 * w[0]
+    k = min(n, 10)
+    assert np.abs(sign_align(evecs[:k], v[:k]) - v[:k]).max() < 1e-7
+
+
+def test_eigh_batched_and_rank_deficient(B):
+    import torch
+    rng = np.random.default_rng(0)
+    Gs = []
+    for i in range(5):
+        M = rng.standard_normal((40, 30 + 3 * i))      # rank < n for the first ones
+        Gs.append(M @ M.T)
+    Gs = np.stack(Gs)
+    evals, evecs = B.eigh(torch.from_numpy(Gs).cuda())
+    evals, evecs = evals.cpu().numpy(), evecs.cpu().numpy()
+    for i in range(5):
+        w = np.linalg.eigvalsh(Gs[i])[::-1]
+        np.testing.assert_allclose(evals[i], w, atol=1e-10 * w[0])
+        r = 30 + 3 * i if 30 + 3 * i < 40 else 40
+        E = evecs[i, :r]
+        assert np.abs(E @ E.T - np.eye(r)).max() < 1e-8
+
+
+# ---- projection kernels ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,k,P", [(12, 3, 1024), (50, 5, 16384), (37, 20, 10201), (100, 33, 4096), (64, 64, 640)])
+def test_rowspace_and_subtract_gemm(B, n, k, P):
+    rng = np.random.default_rng(n + k)
+    M = rng.standard_normal((n, P)).astype(np.float32)
+    W = rng.standard_normal((k, n)).astype(np.float32)
+    rs = (rng.random(k) + 0.5).astype(np.float32)
+    ctx = B.get_context()
+    Md, Wd, rsd = dev(B, M), dev(B, W), dev(B, rs)
+    T = B.empty((k, P))
+    ctx.call("vipmi_rowspace_gemm_f32", B.ptr(Wd), B.ptr(Md), k, n, P, B.ptr(rsd), B.ptr(T))
+    refT = (W.astype(np.float64) @ M.astype(np.float64)) * rs[:, None]
+    assert np.abs(T.cpu().numpy() - refT).max() <= 2e-5 * np.abs(refT).max()
+    C = rng.standard_normal((n, k)).astype(np.float32)
+    Tm = rng.standard_normal((k, P)).astype(np.float32)
+    R = B.empty((n, P))
+    recon = B.empty((n, P))
+    ctx.call("vipmi_subtract_gemm_f32", B.ptr(Md), B.ptr(dev(B, C)), B.ptr(dev(B, Tm)), n, k, P, B.ptr(R), B.ptr(recon))
+    refrec = C.astype(np.float64) @ Tm.astype(np.float64)
+    assert np.abs(recon.cpu().numpy() - refrec).max() <= 2e-5 * np.abs(refrec).max()
+    assert np.abs(R.cpu().numpy() - (M - refrec)).max() <= 2e-5 * np.abs(refrec).max()
+    R2 = B.empty((n, P))
+    ctx.call("vipmi_subtract_gemm_f32", B.ptr(Md), B.ptr(dev(B, C)), B.ptr(dev(B, Tm)), n, k, P, B.ptr(R2), B.ptr(None))
+    assert np.array_equal(R.cpu().numpy(), R2.cpu().numpy())
+
+
+def test_pca_project_matches_golden(B):
+    g = load_golden("g2_project_subtract")
+    cube = g["cube"]
+    M = dev(B, cube.reshape(cube.shape[0], -1))
+    res, recon, pcs, evals = B.pca_project(M, 3, want_recon=True, want_pcs=True, want_evals=True)
+    assert np.abs(res.cpu().numpy().reshape(cube.shape) - g["res_None_None"]).max() < 1e-4
+    V = pcs.cpu().numpy()
+    assert np.abs(V @ V.T - np.eye(3)).max() < 1e-5
+    g1 = load_golden("g1_svd")
+    for tag in ("a", "b"):
+        Md = dev(B, g1["M_" + tag])
+        _, _, pcs, evals = B.pca_project(Md, 6, want_pcs=True, want_evals=True)
+        Vr = g1["V_lapack_" + tag]
+        assert np.abs(sign_align(pcs.cpu().numpy(), Vr) - Vr).max() < 3e-5
+        np.testing.assert_allclose(np.sqrt(evals.cpu().numpy()[:6]), g1["S_lapack_" + tag], rtol=1e-5)
+
+
+# ---- scaling / mask --------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["temp-mean", "temp-standard", "spat-mean", "spat-standard"])
+def test_scale(B, mode):
+    rng = np.random.default_rng(3)
+    m = (rng.standard_normal((12, 999)) * 3 + 5).astype(np.float32)
+    m[:, 7] = 2.5
+    out = B.scale(dev(B, m), mode).cpu().numpy()
+    ref = O.matrix_scaling(m, mode)
+    assert np.abs(out - ref).max() < 5e-6
+    out2 = B.scale(dev(B, m), mode, out=None)
+    assert np.array_equal(out, out2.cpu().numpy())
+
+
+def test_mask(B):
+    import torch
+    from vip_amd.var import mask_circle
+    g = load_golden("g5_indices")
+    out = mask_circle(g["mask_in"], 5)
+    assert np.array_equal(out, g["mask_out_5"])
+    rng = np.random.default_rng(1)
+    a2 = rng.standard_normal((33, 33)).astype(np.float32)
+    assert np.array_equal(mask_circle(a2, 6.5), O.mask_circle(a2, 6.5))
+    assert np.array_equal(mask_circle(a2, 0), a2)
+
+
+# ---- collapse -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [7, 8])
+def test_collapse_golden(B, n):
+    from vip_amd.preproc import cube_collapse
+    g = load_golden("g4_collapse")
+    for mode in ("median", "max"):
+        for tag in ("", "_nan"):
+            got = cube_collapse(g["cube%s_%d" % (tag, n)], mode)
+            exp = g["%s%s_%d" % (mode, tag, n)]
+            assert got.dtype == np.float32
+            assert np.array_equal(got, exp, equal_nan=True), (mode, tag)
+    for mode in ("mean", "sum", "absmean"):
+        for tag in ("", "_nan"):
+            got = cube_collapse(g["cube%s_%d" % (tag, n)], mode)
+            exp = g["%s%s_%d" % (mode, tag, n)]
+            assert np.array_equal(np.isnan(got), np.isnan(exp))
+            assert np.nanmax(np.abs(got - exp)) < 2e-6
+    got = cube_collapse(g["cube_%d" % n], "wmean", w=g["w_%d" % n])
+    assert np.abs(got - g["wmean_%d" % n]).max() < 2e-6
+
+
+@pytest.mark.parametrize("n,P", [(1, 100), (2, 100), (63, 1000), (64, 1000), (65, 333), (129, 257), (400, 4096), (1000, 70)])
+def test_median_sizes_bitexact(B, n, P):
+    rng = np.random.default_rng(n + P)
+    cube = rng.standard_normal((n, P)).astype(np.float32)
+    cube[rng.random((n, P)) < 0.02] = np.nan
+    cube[:, 3] = np.nan
+    cube[:, 5] = 1.25                                  # all duplicates
+    cube[: n // 2, 6] = -0.0
+    cube[n // 2:, 6] = 0.0
+    got = B.collapse(dev(B, cube).reshape(n, P, 1), "median").cpu().numpy().reshape(P)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = np.nanmedian(cube, axis=0)
+    assert np.array_equal(got, exp, equal_nan=True)
+
+
+# ---- rotation (generic direct path) ------------------------------------------------------------------
+
+@pytest.mark.parametrize("N", [32, 33, 64])
+def test_frame_rotate_golden_direct(B, N):
+    from vip_amd.preproc import frame_rotate
+    g = load_golden("g3_rotate")
+    fr = g["frame_%d" % N]
+    for i, th in enumerate(g["angles"]):
+        got = frame_rotate(fr, th, method="direct")
+        assert got.dtype == np.float64
+        assert np.abs(got - g["rot_%d" % N][i]).max() < 2e-5, th
+
+
+def test_rotate_masks_and_cube_direct(B):
+    from vip_amd.preproc import frame_rotate, cube_derotate
+    g = load_golden("g3_rotate")
+    got = frame_rotate(g["frame_nan"], 33.0, method="direct")
+    assert np.array_equal(np.isnan(got), np.isnan(g["rot_nan"]))
+    assert np.nanmax(np.abs(got - g["rot_nan"])) < 2e-5
+    got = frame_rotate(g["frame_zero"], 33.0, mask_val=0, interp_zeros=True, ker=1, method="direct")
+    assert np.abs(got - g["rot_zero"]).max() < 2e-5
+    got = cube_derotate(g["cube_33"], g["cube_33_angles"], method="direct")
+    assert got.dtype == np.float32
+    assert np.abs(got - g["derot_33"]).max() < 5e-5
+    got = cube_derotate(g["cube_128"], g["cube_128_angles"], method="direct")
+    assert np.abs(got - g["derot_128"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("N", [80, 81])
+def test_cube_derotate_reference_roundtrip(B, N):
+    # reference tests/pre_3_10/test_preproc_rotation.py:21-69: 24 successive derotations of ones
+    from vip_amd.preproc import cube_derotate
+    arr = np.ones((4, N, N), np.float32)
+    angs = np.array([120, 90, 60, 45.])
+    cur = arr.copy()
+    for _ in range(24):
+        cur = cube_derotate(cur, angs)
+    c0 = N // 2 - 25
+    assert np.allclose(cur[:, c0:c0 + 50, c0:c0 + 50], 1.0, rtol=1e-1, atol=1e-1)

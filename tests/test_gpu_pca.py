@@ -1,0 +1,138 @@
+"""GPU parity tests, end to end: vip_amd.psfsub.pca / cube_derotate / cube_collapse through the C ABI
+against fixtures frozen from the reference (tests/golden) and the CPU oracle; tolerances: residual
+cubes and frames max|d| < 1e-4 on max|cube| ~ 10 data (BASELINE.json), index sets bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sign_align
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("tag,kw", [("k3", dict(ncomp=3)), ("eigen", dict(ncomp=3, svd_mode="eigen")),
+                                    ("tmean", dict(ncomp=2, scaling="temp-mean")),
+                                    ("tstd", dict(ncomp=2, scaling="temp-standard")),
+                                    ("smean", dict(ncomp=2, scaling="spat-mean")),
+                                    ("sstd", dict(ncomp=2, scaling="spat-standard")),
+                                    ("mask", dict(ncomp=3, mask_center_px=5)),
+                                    ("mean", dict(ncomp=4, collapse="mean"))])
+def test_pca_small_golden(tag, kw):
+    from vip_amd.psfsub import pca
+    g = load_golden("g6_pca_small")
+    out = pca(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    assert len(out) == 5
+    for nm, a in zip(("frame", "pcs", "recon", "res", "resder"), out):
+        b = g["%s_%s" % (tag, nm)]
+        assert a.shape == b.shape and a.dtype == b.dtype, nm
+        if nm == "pcs":
+            a = sign_align(a, b)
+        assert np.abs(a - b).max() < (5e-4 if nm == "recon" else TOL), (tag, nm, np.abs(a - b).max())
+    fr = pca(g["cube"], g["angles"], verbose=False, **kw)
+    assert np.abs(fr - g[tag + "_frame"]).max() < TOL
+
+
+def test_pca_c1_golden():
+    """BASELINE.json configs[0]: 50x128x128, ncomp=5 (FFT derotation path, L=512)."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g6_pca_c1")
+    cube, ang = O.synth_adi(50, 128, seed=int(g["seed"]))
+    fr, pcs, recon, res, resd = pca(cube, ang, ncomp=5, full_output=True, verbose=False)
+    c0 = 64 - 8
+    assert np.abs(fr - g["frame"]).max() < TOL
+    assert np.abs(res[:, c0:c0 + 16, c0:c0 + 16] - g["res_crop"]).max() < TOL
+    assert np.abs(resd[:, c0:c0 + 16, c0:c0 + 16] - g["resder_crop"]).max() < TOL
+    assert np.abs(np.sum(res.astype(np.float64), axis=0) - g["res_sum"]).max() < 2e-3
+    assert np.abs(np.sum(resd.astype(np.float64), axis=0) - g["resder_sum"]).max() < 2e-3
+
+
+def test_pca_rdi_and_cevr_and_clamp(capsys):
+    from vip_amd.psfsub import pca
+    g = load_golden("g6_pca_small")
+    fr = pca(g["cube"], g["angles"], cube_ref=g["cube_ref"], ncomp=3, verbose=False)
+    assert np.abs(fr - g["rdi_frame"]).max() < TOL
+    fo = O.pca_fullframe(g["cube"], g["angles"], ncomp=3, cube_ref=g["cube_ref"], full_output=True)
+    out = pca(g["cube"], g["angles"], cube_ref=g["cube_ref"], ncomp=3, verbose=False, full_output=True)
+    for nm, a, b in zip(("frame", "pcs", "recon", "res", "resder"), out, fo):
+        if nm == "pcs":
+            a = sign_align(a, b)
+        assert np.abs(a - b).max() < (5e-4 if nm == "recon" else TOL), nm
+    # float ncomp (CEVR)
+    fr = pca(g["cube"], g["angles"], ncomp=0.9, verbose=False)
+    assert np.abs(fr - O.pca_fullframe(g["cube"], g["angles"], ncomp=0.9)).max() < TOL
+    # ncomp > n is clamped with a message, not an error
+    fr = pca(g["cube"], g["angles"], ncomp=40, verbose=False)
+    assert "Number of PCs too high" in capsys.readouterr().out
+    assert np.abs(fr).max() < 1e-3
+    with pytest.raises(ValueError):
+        pca(g["cube"], g["angles"], ncomp=0, verbose=False)
+    with pytest.raises(ValueError):
+        pca(g["cube"], g["angles"][:-1], ncomp=2, verbose=False)
+
+
+def test_pca_4d_golden():
+    from vip_amd.psfsub import pca
+    g = load_golden("g6_pca_4d")
+    out = pca(g["cube"], g["angles"], ncomp=2, full_output=True, verbose=False)
+    assert len(out) == 6
+    frame, pcs, recon, res, resd, ifs = out
+    assert frame.dtype == np.float64 and ifs.dtype == np.float64 and res.dtype == np.float32
+    assert pcs.shape == (3, 2, 32, 32) and recon.shape == g["cube"].shape
+    assert np.abs(frame - g["frame"]).max() < TOL
+    assert np.abs(res - g["res"]).max() < TOL
+    assert np.abs(resd - g["resder"]).max() < TOL
+    assert np.abs(ifs - g["ifs"]).max() < TOL
+    assert np.abs(pca(g["cube"], g["angles"], ncomp=2, verbose=False) - g["frame"]).max() < TOL
+
+
+def test_device_tensor_api_and_algo_params():
+    import torch
+    from vip_amd.psfsub import pca, PCA_Params
+    g = load_golden("g6_pca_small")
+    ct = torch.from_numpy(g["cube"]).cuda()
+    fr = pca(ct, g["angles"], ncomp=3, verbose=False)
+    assert isinstance(fr, torch.Tensor) and fr.is_cuda
+    assert np.abs(fr.cpu().numpy() - g["k3_frame"]).max() < TOL
+    params = PCA_Params(cube=g["cube"], angle_list=g["angles"], ncomp=3, verbose=False)
+    fr2 = pca(algo_params=params)
+    assert np.abs(fr2 - g["k3_frame"]).max() < TOL
+    fr3 = pca(g["cube"].astype(np.float64), g["angles"], ncomp=3, verbose=False)
+    assert fr3.dtype == np.float64
+
+
+def test_svd_wrapper_golden():
+    from vip_amd.psfsub.svd import svd_wrapper
+    g = load_golden("g1_svd")
+    for tag in ("a", "b"):
+        M = g["M_" + tag]
+        for mode in ("lapack", "eigen"):
+            V = svd_wrapper(M, mode, 6, False)
+            Vr = g["V_%s_%s" % (mode, tag)]
+            assert V.shape == Vr.shape and V.dtype == np.float32
+            assert np.abs(sign_align(V, Vr) - Vr).max() < 3e-5
+            U, S, V2 = svd_wrapper(M, mode, 6, False, full_output=True)
+            np.testing.assert_allclose(S, g["S_%s_%s" % (mode, tag)], rtol=2e-5)
+            assert U.shape == ((M.shape[0], 6) if mode == "lapack" else (6, M.shape[0]))
+    # reference tests/pre_3_10/test_pca_svd.py:10-20
+    mat = np.random.RandomState(42).randn(20, 100)
+    U, S, V = svd_wrapper(mat, "lapack", 20, False, full_output=True)
+    assert np.allclose(np.abs(U @ np.diag(S) @ V), np.abs(mat), atol=1e-2)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_pca_vs_oracle_noise_and_structured(seed):
+    """Pure-noise cube (flat spectrum) and the structured generator at a non power-of-two size."""
+    from vip_amd.psfsub import pca
+    rng = np.random.default_rng(seed)
+    cube = rng.standard_normal((24, 45, 45)).astype(np.float32)
+    ang = np.linspace(-20, 200, 24)
+    fr = pca(cube, ang, ncomp=4, verbose=False)
+    assert np.abs(fr - O.pca_fullframe(cube, ang, ncomp=4)).max() < TOL
+    cube, ang = O.synth_adi(20, 101, seed=seed)
+    out = pca(cube, ang, ncomp=5, verbose=False, full_output=True)
+    ref = O.pca_fullframe(cube, ang, ncomp=5, full_output=True)
+    assert np.abs(out[0] - ref[0]).max() < TOL
+    assert np.abs(out[3] - ref[3]).max() < TOL
+    assert np.abs(out[4] - ref[4]).max() < TOL

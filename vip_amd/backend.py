@@ -1,0 +1,228 @@
+"""Device backend: torch tensors as device-array containers + calls into libvipmi.so.
+
+PyTorch is plumbing only (allocation, H2D/D2H, streams); all arithmetic happens in the HIP kernels of
+``vip_amd/csrc``.  One ``Context`` (vipmi_ctx) per (device, stream) is cached.
+"""
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+
+_ctx_cache = {}
+_ctx_lock = threading.Lock()
+
+SCALE_MODES = {None: 0, "temp-mean": 1, "temp-standard": 2, "spat-mean": 3, "spat-standard": 4}
+COLLAPSE_MODES = {"median": 0, "mean": 1, "sum": 2, "max": 3, "absmean": 4, "wmean": 5, "trimmean": 6}
+ROT_METHODS = {"auto": 0, "direct": 1, "fft": 2}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise _lib.VipmiError("vip_amd needs an AMD MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                              "and there is no CPU fallback")
+    return torch
+
+
+class Context:
+    def __init__(self, device=None):
+        torch = require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.handle = ctypes.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        st = self.lib.vipmi_create(self.device, ctypes.c_void_p(stream), ctypes.byref(self.handle))
+        _lib.raise_for_status(st, "vipmi_create")
+
+    def bind_stream(self):
+        torch = _torch()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.vipmi_set_stream(self.handle, ctypes.c_void_p(stream))
+
+    def set_option(self, key, value):
+        _lib.raise_for_status(self.lib.vipmi_set_option(self.handle, key.encode(), int(value)))
+
+    def get_option(self, key):
+        return int(self.lib.vipmi_get_option(self.handle, key.encode()))
+
+    def stage_ms(self, stage):
+        return float(self.lib.vipmi_stage_ms(self.handle, stage.encode()))
+
+    def call(self, name, *args):
+        self.bind_stream()
+        st = getattr(self.lib, name)(self.handle, *args)
+        _lib.raise_for_status(st, name)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.vipmi_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def get_context(device=None):
+    torch = require_gpu()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    with _ctx_lock:
+        c = _ctx_cache.get(dev)
+        if c is None:
+            c = Context(dev)
+            _ctx_cache[dev] = c
+        return c
+
+
+# ---- array plumbing ------------------------------------------------------------------------------
+
+def is_device_tensor(x):
+    try:
+        import torch
+    except ImportError:
+        return False
+    return isinstance(x, torch.Tensor)
+
+
+def to_device_f32(x, device=None):
+    """numpy / torch -> contiguous float32 cuda tensor (no copy when already so)."""
+    torch = require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=dev, dtype=torch.float32)
+    else:
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        t = torch.from_numpy(a).to(dev)
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def empty(shape, dtype=None, device=None):
+    torch = require_gpu()
+    return torch.empty(shape, dtype=dtype or torch.float32,
+                       device=torch.device("cuda", torch.cuda.current_device() if device is None else int(device)))
+
+
+def host_f64(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---- thin wrappers (device tensors in, device tensors out) ----------------------------------------
+
+def scale(M, mode, out=None):
+    ctx = get_context(M.device.index)
+    out = empty(M.shape, device=M.device.index) if out is None else out
+    n, P = M.shape
+    ctx.call("vipmi_scale_f32", ptr(M), ptr(out), n, P, SCALE_MODES[mode])
+    return out
+
+
+def apply_mask(M, mask_u8, fill=0.0, out=None):
+    ctx = get_context(M.device.index)
+    out = empty(M.shape, device=M.device.index) if out is None else out
+    P = mask_u8.numel()
+    n = M.numel() // P
+    ctx.call("vipmi_apply_mask_f32", ptr(M), ptr(out), n, P, ptr(mask_u8), ctypes.c_float(fill))
+    return out
+
+
+def gram(M):
+    torch = _torch()
+    ctx = get_context(M.device.index)
+    n, P = M.shape
+    G = empty((n, n), torch.float64, M.device.index)
+    ctx.call("vipmi_gram_f32", ptr(M), n, P, M.stride(0), ptr(G))
+    return G
+
+
+def cross_gram(A, B):
+    torch = _torch()
+    ctx = get_context(A.device.index)
+    na, P = A.shape
+    nb = B.shape[0]
+    C = empty((na, nb), torch.float64, A.device.index)
+    ctx.call("vipmi_cross_gram_f32", ptr(A), na, ptr(B), nb, P, A.stride(0), ptr(C))
+    return C
+
+
+def eigh(G):
+    """G: (batch, n, n) or (n, n) float64 cuda tensor (destroyed).  Returns (evals desc, evecs rows)."""
+    torch = _torch()
+    ctx = get_context(G.device.index)
+    single = G.dim() == 2
+    Gb = G.unsqueeze(0) if single else G
+    batch, n, _ = Gb.shape
+    Gb = Gb.contiguous()
+    evals = empty((batch, n), torch.float64, G.device.index)
+    evecs = empty((batch, n, n), torch.float64, G.device.index)
+    ctx.call("vipmi_eigh_f64", ptr(Gb), batch, n, ptr(evals), ptr(evecs))
+    return (evals[0], evecs[0]) if single else (evals, evecs)
+
+
+def pca_project(M, k, ref=None, want_recon=False, want_pcs=False, want_evals=False):
+    """residuals (and optionally recon, pcs, evals) of M w.r.t. the top-k PCs of ref (default M)."""
+    torch = _torch()
+    ctx = get_context(M.device.index)
+    n, P = M.shape
+    refm = M if ref is None else ref
+    nref = refm.shape[0]
+    dev = M.device.index
+    res = empty((n, P), device=dev)
+    recon = empty((n, P), device=dev) if want_recon else None
+    pcs = empty((k, P), device=dev) if want_pcs else None
+    evals = empty((nref,), torch.float64, dev) if want_evals else None
+    ctx.call("vipmi_pca_project_f32", ptr(M), n, ptr(refm), nref, P, k, ptr(res), ptr(recon), ptr(pcs), ptr(evals))
+    return res, recon, pcs, evals
+
+
+def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=None):
+    ctx = get_context(cube.device.index)
+    n, Ny, Nx = cube.shape
+    if Ny != Nx:
+        raise ValueError("vip-fft derotation on the device requires square frames")
+    out = empty(cube.shape, device=cube.device.index) if out is None else out
+    ah, ap = host_f64(angles)
+    ctx.call("vipmi_derotate_f32", ptr(cube), ap, n, Ny, ptr(out), int(bool(mask_nan)), int(bool(mask_zero)),
+             ROT_METHODS[method])
+    return out
+
+
+def collapse(cube, mode="median", w=None, trim_n=0):
+    ctx = get_context(cube.device.index)
+    n = cube.shape[0]
+    P = cube[0].numel()
+    out = empty(cube.shape[1:], device=cube.device.index)
+    wt = to_device_f32(w, cube.device.index) if w is not None else None
+    ctx.call("vipmi_collapse_f32", ptr(cube), n, P, COLLAPSE_MODES[mode], ptr(wt), int(trim_n), ptr(out))
+    return out
+
+
+def pca_fullframe(cube, angles, ncomp, scaling=None, mask_u8=None, collapse_mode="median",
+                  full_output=False):
+    """Fused 3-D ADI path.  Returns frame or (frame, pcs, recon, residuals, residuals_der)."""
+    ctx = get_context(cube.device.index)
+    n, N, _ = cube.shape
+    dev = cube.device.index
+    k = min(int(ncomp), n)
+    frame = empty((N, N), device=dev)
+    pcs = recon = res = der = None
+    if full_output:
+        pcs = empty((k, N, N), device=dev)
+        recon = empty((n, N, N), device=dev)
+        res = empty((n, N, N), device=dev)
+        der = empty((n, N, N), device=dev)
+    ah, ap = host_f64(angles)
+    ctx.call("vipmi_pca_fullframe_f32", ptr(cube), ap, n, N, int(ncomp), SCALE_MODES[scaling], ptr(mask_u8),
+             COLLAPSE_MODES[collapse_mode], ptr(frame), ptr(pcs), ptr(recon), ptr(res), ptr(der))
+    if full_output:
+        return frame, pcs, recon, res, der
+    return frame

@@ -1,0 +1,337 @@
+// api.hip -- extern "C" surface of libvipmi.so (see include/vipmi.h), ctx / workspace management and
+// the fused full-frame ADI pipeline (psfsub/pca_fullfr.py:801-1007).
+#include <stdarg.h>
+#include "common.h"
+
+namespace vipmi {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+// internal layouts (project.hip)
+int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n,
+                    int64_t P, const float* rowscale, float* T);
+int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, const float* T, int64_t n,
+                    int64_t k, int64_t P, float* R, float* recon);
+
+}  // namespace vipmi
+
+using namespace vipmi;
+
+int vipmi_ctx::get(const char* name, size_t bytes, void** out) {
+  Buffer& b = buffers[name];
+  if (bytes == 0) bytes = 16;
+  if (b.bytes < bytes) {
+    if (b.ptr) {
+      // the old buffer may still be in use by kernels queued on the stream
+      hipError_t e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) {
+        set_error("workspace sync failed: %s", hipGetErrorString(e));
+        return VIPMI_ERR_HIP;
+      }
+      (void)hipFree(b.ptr);
+      b.ptr = nullptr;
+      b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 8;     // some slack: avoid re-allocation on small growth
+    hipError_t e = hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) {
+      e = hipMalloc(&b.ptr, bytes);
+      want = bytes;
+    }
+    if (e != hipSuccess) {
+      b.ptr = nullptr;
+      set_error("workspace '%s': hipMalloc(%zu) failed: %s", name, bytes, hipGetErrorString(e));
+      return VIPMI_ERR_NOMEM;
+    }
+    b.bytes = want;
+    upload_keys.erase(name);
+  }
+  *out = b.ptr;
+  return VIPMI_OK;
+}
+
+int vipmi_ctx::upload_cached(const char* name, const std::string& key, const void* host, size_t bytes,
+                             void** out) {
+  void* p = nullptr;
+  int s = get(name, bytes, &p);
+  if (s != VIPMI_OK) return s;
+  auto it = upload_keys.find(name);
+  if (it == upload_keys.end() || it->second != key) {
+    hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+      set_error("upload '%s' failed: %s", name, hipGetErrorString(e));
+      return VIPMI_ERR_HIP;
+    }
+    upload_keys[name] = key;
+  }
+  *out = p;
+  return VIPMI_OK;
+}
+
+void vipmi_ctx::tic(const char* stage) {
+  if (!timing) return;
+  StageTimer& t = timers[stage];
+  if (!t.start) {
+    (void)hipEventCreate(&t.start);
+    (void)hipEventCreate(&t.stop);
+  }
+  (void)hipEventRecord(t.start, stream);
+  t.valid = false;
+}
+
+void vipmi_ctx::toc(const char* stage) {
+  if (!timing) return;
+  StageTimer& t = timers[stage];
+  if (!t.start) return;
+  (void)hipEventRecord(t.stop, stream);
+  t.valid = true;
+}
+
+extern "C" {
+
+int vipmi_version(void) { return 100; }
+
+const char* vipmi_last_error(void) { return g_err; }
+
+int vipmi_create(int device, void* stream, vipmi_ctx** out) {
+  VIPMI_REQUIRE(out != nullptr, "vipmi_create: out is null");
+  int ndev = 0;
+  VIPMI_CHECK_HIP(hipGetDeviceCount(&ndev));
+  VIPMI_REQUIRE(device >= 0 && device < ndev, "vipmi_create: device %d out of range (%d devices)", device, ndev);
+  VIPMI_CHECK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  VIPMI_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("libvipmi is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    return VIPMI_ERR_UNSUPPORTED;
+  }
+  vipmi_ctx* c = new vipmi_ctx();
+  c->device = device;
+  c->stream = reinterpret_cast<hipStream_t>(stream);
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = c;
+  return VIPMI_OK;
+}
+
+int vipmi_destroy(vipmi_ctx* ctx) {
+  if (!ctx) return VIPMI_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->buffers)
+    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  for (auto& kv : ctx->timers) {
+    if (kv.second.start) (void)hipEventDestroy(kv.second.start);
+    if (kv.second.stop) (void)hipEventDestroy(kv.second.stop);
+  }
+  delete ctx;
+  return VIPMI_OK;
+}
+
+int vipmi_set_stream(vipmi_ctx* ctx, void* stream) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  ctx->stream = reinterpret_cast<hipStream_t>(stream);
+  return VIPMI_OK;
+}
+
+int vipmi_synchronize(vipmi_ctx* ctx) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  VIPMI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return VIPMI_OK;
+}
+
+int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
+  VIPMI_REQUIRE(ctx && key, "null argument");
+  static const char* known[] = {"timing", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_variant", nullptr};
+  bool ok = false;
+  for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
+  VIPMI_REQUIRE(ok, "unknown option '%s'", key);
+  if (strcmp(key, "timing") == 0) ctx->timing = value != 0;
+  ctx->options[key] = value;
+  return VIPMI_OK;
+}
+
+int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key) {
+  if (!ctx || !key) return -1;
+  return ctx->opt(key, -1);
+}
+
+float vipmi_stage_ms(vipmi_ctx* ctx, const char* stage) {
+  if (!ctx || !stage) return -1.f;
+  auto it = ctx->timers.find(stage);
+  if (it == ctx->timers.end() || !it->second.valid) return -1.f;
+  if (hipEventSynchronize(it->second.stop) != hipSuccess) return -1.f;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, it->second.start, it->second.stop) != hipSuccess) return -1.f;
+  return ms;
+}
+
+#define CTX_GUARD()                      \
+  VIPMI_REQUIRE(ctx, "null ctx");        \
+  VIPMI_CHECK_HIP(hipSetDevice(ctx->device))
+
+int vipmi_scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P, int mode) {
+  CTX_GUARD();
+  return scale_f32(ctx, in, out, n, P, mode);
+}
+
+int vipmi_apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
+                         const uint8_t* mask, float fill) {
+  CTX_GUARD();
+  return apply_mask_f32(ctx, in, out, n, P, mask, fill);
+}
+
+int vipmi_gram_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double* G) {
+  CTX_GUARD();
+  return gram_f32(ctx, M, n, M, n, P, ld, G);
+}
+
+int vipmi_cross_gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb,
+                         int64_t P, int64_t ld, double* C) {
+  CTX_GUARD();
+  return gram_f32(ctx, A, na, B, nb, P, ld, C);
+}
+
+int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs) {
+  CTX_GUARD();
+  return eigh_f64(ctx, G, batch, n, evals, evecs);
+}
+
+int vipmi_rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n,
+                            int64_t P, const float* rowscale, float* B) {
+  CTX_GUARD();
+  return rowspace_gemm_f32(ctx, W, M, k, n, P, rowscale, B);
+}
+
+int vipmi_subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,
+                            int64_t k, int64_t P, float* R, float* recon) {
+  CTX_GUARD();
+  return subtract_gemm_f32(ctx, M, C, B, n, k, P, R, recon);
+}
+
+int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
+                       float* out, int mask_nan, int mask_zero, int method) {
+  CTX_GUARD();
+  return derotate_f32(ctx, in, angles_host, n, N, out, mask_nan, mask_zero, method);
+}
+
+int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,
+                       int64_t trim_n, float* out) {
+  CTX_GUARD();
+  return collapse_f32(ctx, cube, n, P, mode, w, trim_n, out);
+}
+
+int vipmi_gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
+                     int64_t npx, float* A) {
+  CTX_GUARD();
+  return gather_f32(ctx, cube, n, P, pix, npx, A);
+}
+
+int vipmi_scatter_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t P, const int32_t* pix, int64_t npx,
+                      float* cube) {
+  CTX_GUARD();
+  return scatter_f32(ctx, A, n, P, pix, npx, cube);
+}
+
+int vipmi_annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
+                                const int32_t* lib_idx, const int32_t* lib_len, int64_t max_lib,
+                                int64_t ncomp, float* residuals) {
+  CTX_GUARD();
+  return annular_residuals_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, ncomp, residuals);
+}
+
+// PCs / residuals of M[n,P] with respect to the top-k principal components of ref[nref,P]
+// (ref == M for ADI).  Internal building block of vipmi_pca_fullframe_f32 and of the RDI path.
+int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float* ref, int64_t nref,
+                          int64_t P, int64_t k, float* residuals, float* recon, float* pcs,
+                          double* evals_out) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(M && ref && residuals, "pca_project: null pointer");
+  VIPMI_REQUIRE(k > 0 && k <= nref && k <= P, "%ld PCs cannot be obtained from a matrix with size [%ld,%ld].",
+                (long)k, (long)nref, (long)P);
+  double *G = nullptr, *evals = nullptr, *evecs = nullptr;
+  VIPMI_TRY(ws(ctx, "pca_G", (size_t)nref * nref, &G));
+  VIPMI_TRY(ws(ctx, "pca_evals", (size_t)nref, &evals));
+  VIPMI_TRY(ws(ctx, "pca_evecs", (size_t)nref * nref, &evecs));
+  VIPMI_TRY(gram_f32(ctx, ref, nref, ref, nref, P, P, G));
+  VIPMI_TRY(eigh_f64(ctx, G, 1, nref, evals, evecs));
+  const int nld = (int)cdiv(nref, 32) * 32, kld = (int)cdiv(k, 32) * 32;
+  float *Ekn = nullptr, *Enk = nullptr, *isig = nullptr;
+  VIPMI_TRY(ws(ctx, "pca_Ekn", (size_t)kld * nld, &Ekn));
+  VIPMI_TRY(ws(ctx, "pca_Enk", (size_t)nld * kld, &Enk));
+  VIPMI_TRY(ws(ctx, "pca_isig", (size_t)kld, &isig));
+  VIPMI_TRY(convert_evecs(ctx, evecs, evals, nref, k, Ekn, Enk, isig));
+  if (evals_out)
+    VIPMI_CHECK_HIP(hipMemcpyAsync(evals_out, evals, sizeof(double) * nref, hipMemcpyDeviceToDevice, ctx->stream));
+  float* T = nullptr;
+  VIPMI_TRY(ws(ctx, "pca_T", (size_t)k * P, &T));
+  {
+    StageScope sc(ctx, "project");
+    if (ref == M && nref == n) {
+      // ADI: reconstructed = E (E^T M)
+      VIPMI_TRY(rowspace_gemm_t(ctx, Enk, kld, M, k, n, P, nullptr, T));
+      VIPMI_TRY(subtract_gemm_t(ctx, M, Ekn, nld, T, n, k, P, residuals, recon));
+      if (pcs) VIPMI_TRY(scale_rows(ctx, T, isig, k, P, pcs));     // V = S^-1 E^T M
+    } else {
+      // RDI: V = S^-1 E^T ref ; coefficients C = M V^T (n x k) ; reconstructed = C V
+      float* V = pcs ? pcs : T;
+      VIPMI_TRY(rowspace_gemm_t(ctx, Enk, kld, ref, k, nref, P, isig, V));
+      double* C64 = nullptr;
+      VIPMI_TRY(ws(ctx, "pca_C64", (size_t)n * k, &C64));
+      VIPMI_TRY(gram_f32(ctx, M, n, V, k, P, P, C64));
+      // C (n x k, f64) -> Ct [k][nld2] f32
+      const int nld2 = (int)cdiv(n, 32) * 32;
+      float* Ct = nullptr;
+      VIPMI_TRY(ws(ctx, "pca_Ct", (size_t)kld * nld2, &Ct));
+      VIPMI_TRY(convert_coeffs(ctx, C64, n, k, Ct, nld2));
+      VIPMI_TRY(subtract_gemm_t(ctx, M, Ct, nld2, V, n, k, P, residuals, recon));
+    }
+  }
+  return VIPMI_OK;
+}
+
+int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* angles_host, int64_t n,
+                            int64_t N, int64_t ncomp, int scaling, const uint8_t* mask, int collapse_mode,
+                            float* frame, float* pcs, float* recon, float* residuals, float* residuals_der) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(cube && angles_host && frame, "pca_fullframe: null pointer");
+  VIPMI_REQUIRE(n > 0 && N > 1, "pca_fullframe: bad sizes");
+  VIPMI_REQUIRE(ncomp > 0, "Number of PCs too low. It should be > 0.");
+  const int64_t P = N * N;
+  int64_t k = ncomp > n ? n : ncomp;            // pca_fullfr.py:876-881 (clamp, not an error)
+  const float* M = cube;
+  float* scratch = nullptr;
+  if (mask || scaling) VIPMI_TRY(ws(ctx, "pca_M", (size_t)n * P, &scratch));
+  if (mask) {
+    VIPMI_TRY(apply_mask_f32(ctx, M, scratch, n, P, mask, 0.f));
+    M = scratch;
+  }
+  if (scaling) {
+    VIPMI_TRY(scale_f32(ctx, M, scratch, n, P, scaling));
+    M = scratch;
+  }
+  float* res = residuals;
+  if (!res) VIPMI_TRY(ws(ctx, "pca_res", (size_t)n * P, &res));
+  VIPMI_TRY(vipmi_pca_project_f32(ctx, M, n, M, n, P, k, res, recon, pcs, nullptr));
+  float* der = residuals_der;
+  if (!der) VIPMI_TRY(ws(ctx, "pca_der", (size_t)n * P, &der));
+  // pca(): mask_center_px without rot_options -> mask_val=0 (pca_fullfr.py:412-415)
+  VIPMI_TRY(derotate_f32(ctx, res, angles_host, n, N, der, mask ? 0 : 1, mask ? 1 : 0, VIPMI_ROT_AUTO));
+  VIPMI_TRY(collapse_f32(ctx, der, n, P, collapse_mode, nullptr, 0, frame));
+  if (mask) {
+    // pca_fullfr.py:985-987: residuals_cube_ and frame are masked again
+    if (residuals_der) VIPMI_TRY(apply_mask_f32(ctx, der, der, n, P, mask, 0.f));
+    VIPMI_TRY(apply_mask_f32(ctx, frame, frame, 1, P, mask, 0.f));
+  }
+  return VIPMI_OK;
+}
+
+}  // extern "C"

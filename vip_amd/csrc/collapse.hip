@@ -1,0 +1,187 @@
+// collapse.hip -- cube_collapse (preproc/subsampling.py:30-116): per-pixel NaN-aware reduction
+// over the n frames of a cube[n,P].
+//
+//  * mean / sum / max / absmean / wmean: one thread per pixel column, coalesced streaming read of
+//    the cube (HBM-bound: n*P*4 bytes in, P*4 out).
+//  * median (nanmedian): a workgroup stages a [n frames][TP pixels] tile in LDS with coalesced
+//    128-byte row segments (row stride TP+1 floats: the transposed read is bank-conflict free);
+//    then ONE WAVE PER PIXEL holds the pixel's n values in registers (n/64 per lane) as
+//    order-preserving uint32 keys and finds the rank-k key by a 32-step bitwise bisection; each
+//    step is RPL v_cmp + s_bcnt1 (wave ballots), no sort and no further LDS traffic.  For an even
+//    number of valid samples the upper median is the smallest key above the lower one (or the lower
+//    one again if it is duplicated) and the result is (a+b)*0.5 in float32, as numpy computes it.
+#include "common.h"
+
+namespace vipmi {
+
+namespace {
+
+__device__ __forceinline__ unsigned f2key(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+template <int RPL>
+__global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ cube, int n, int64_t P,
+                                                     int TP, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // n x (TP+1)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const int ldt = TP + 1;
+  const int64_t p0 = (int64_t)blockIdx.x * TP;
+  // stage: TP consecutive pixels of every frame
+  for (int e = threadIdx.x; e < n * TP; e += blockDim.x) {
+    const int f = e / TP, j = e % TP;
+    const int64_t p = p0 + j;
+    tile[f * ldt + j] = (p < P) ? cube[(int64_t)f * P + p] : 0.f;
+  }
+  __syncthreads();
+  for (int j = wave; j < TP; j += nw) {
+    const int64_t p = p0 + j;
+    if (p >= P) break;
+    unsigned key[RPL];
+    int nvalid_lane = 0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int f = lane + 64 * r;
+      unsigned kk = 0xffffffffu;                // padding and NaN sort last
+      if (f < n) {
+        const float v = tile[f * ldt + j];
+        if (v == v) {
+          kk = f2key(v);
+          ++nvalid_lane;
+        }
+      }
+      key[r] = kk;
+    }
+    int m = nvalid_lane;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m += __shfl_xor(m, s, 64);
+    float res;
+    if (m == 0) {
+      res = __uint_as_float(0x7fc00000u);
+    } else {
+      const int k = (m - 1) >> 1;              // lower median rank (0-based)
+      unsigned ans = 0;
+      for (int b = 31; b >= 0; --b) {
+        const unsigned cand = ans | (1u << b);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) cnt += __popcll(__ballot(key[r] < cand));
+        if (cnt <= k) ans = cand;
+      }
+      const float lo = key2f(ans);
+      if (m & 1) {
+        res = lo;
+      } else {
+        int cle = 0;
+        unsigned nxt = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          cle += __popcll(__ballot(key[r] <= ans));
+          if (key[r] > ans && key[r] < nxt) nxt = key[r];
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+          unsigned o = __shfl_xor(nxt, s, 64);
+          nxt = o < nxt ? o : nxt;
+        }
+        const float hi = (cle >= k + 2) ? lo : key2f(nxt);
+        res = (lo + hi) * 0.5f;
+      }
+    }
+    if (lane == 0) out[p] = res;
+  }
+}
+
+__global__ void colreduce_kernel(const float* __restrict__ cube, int n, int64_t P, int mode,
+                                 const float* __restrict__ w, float* __restrict__ out) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0;
+    float mx = -__builtin_inff();
+    int cnt = 0;
+    for (int f = 0; f < n; ++f) {
+      const float v = cube[(int64_t)f * P + p];
+      if (v == v) {
+        ++cnt;
+        if (mode == VIPMI_COLLAPSE_ABSMEAN) s += fabsf(v);
+        else if (mode == VIPMI_COLLAPSE_WMEAN) s += (double)w[f] * v;
+        else s += v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    float r;
+    const float nanv = __uint_as_float(0x7fc00000u);
+    switch (mode) {
+      case VIPMI_COLLAPSE_MEAN:
+      case VIPMI_COLLAPSE_ABSMEAN: r = cnt ? (float)(s / cnt) : nanv; break;
+      case VIPMI_COLLAPSE_SUM:
+      case VIPMI_COLLAPSE_WMEAN: r = (float)s; break;
+      default: r = cnt ? mx : nanv; break;
+    }
+    out[p] = r;
+  }
+}
+
+template <int RPL>
+int launch_median(vipmi_ctx* ctx, const float* cube, int n, int64_t P, float* out) {
+  int TP = 32;
+  while (TP > 1 && (size_t)n * (TP + 1) * 4 > 150 * 1024) TP >>= 1;
+  const size_t lds = (size_t)n * (TP + 1) * 4;
+  auto kern = median_kernel<RPL>;
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(256), lds, ctx->stream, cube, n, P, TP, out);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+}  // namespace
+
+int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,
+                 int64_t trim_n, float* out) {
+  VIPMI_REQUIRE(cube && out, "collapse: null pointer");
+  VIPMI_REQUIRE(n > 0 && P > 0, "collapse: bad sizes");
+  StageScope sc(ctx, "collapse");
+  (void)trim_n;
+  switch (mode) {
+    case VIPMI_COLLAPSE_MEDIAN: {
+      const int rpl = (int)cdiv(n, 64);
+      if (rpl <= 1) return launch_median<1>(ctx, cube, (int)n, P, out);
+      if (rpl <= 2) return launch_median<2>(ctx, cube, (int)n, P, out);
+      if (rpl <= 4) return launch_median<4>(ctx, cube, (int)n, P, out);
+      if (rpl <= 8) return launch_median<8>(ctx, cube, (int)n, P, out);
+      if (rpl <= 16) return launch_median<16>(ctx, cube, (int)n, P, out);
+      if (rpl <= 32) return launch_median<32>(ctx, cube, (int)n, P, out);
+      if (rpl <= 64) return launch_median<64>(ctx, cube, (int)n, P, out);
+      set_error("collapse(median): more than 4096 frames not supported");
+      return VIPMI_ERR_UNSUPPORTED;
+    }
+    case VIPMI_COLLAPSE_WMEAN:
+      VIPMI_REQUIRE(w != nullptr, "Weights have to be provided for weighted mean mode");
+      // fallthrough
+    case VIPMI_COLLAPSE_MEAN:
+    case VIPMI_COLLAPSE_SUM:
+    case VIPMI_COLLAPSE_MAX:
+    case VIPMI_COLLAPSE_ABSMEAN: {
+      int64_t b = cdiv(P, 256);
+      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, ctx->stream,
+                         cube, (int)n, P, mode, w, out);
+      VIPMI_CHECK_HIP(hipGetLastError());
+      return VIPMI_OK;
+    }
+    case VIPMI_COLLAPSE_TRIMMEAN:
+      set_error("collapse: trimmean not implemented yet");
+      return VIPMI_ERR_UNSUPPORTED;
+    default:
+      set_error("mode not recognized");
+      return VIPMI_ERR_ARG;
+  }
+}
+
+}  // namespace vipmi

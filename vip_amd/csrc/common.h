@@ -1,0 +1,123 @@
+// common.h -- internal helpers shared by the libvipmi translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/vipmi.h"
+
+namespace vipmi {
+
+void set_error(const char* fmt, ...);
+
+#define VIPMI_CHECK_HIP(expr)                                                          \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      vipmi::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return VIPMI_ERR_HIP;                                                            \
+    }                                                                                  \
+  } while (0)
+
+#define VIPMI_REQUIRE(cond, ...)                  \
+  do {                                            \
+    if (!(cond)) {                                \
+      vipmi::set_error(__VA_ARGS__);              \
+      return VIPMI_ERR_ARG;                       \
+    }                                             \
+  } while (0)
+
+#define VIPMI_TRY(expr)            \
+  do {                             \
+    int _s = (expr);               \
+    if (_s != VIPMI_OK) return _s; \
+  } while (0)
+
+// Named scratch buffers that live as long as the ctx (grow-only).
+struct Buffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+
+struct StageTimer {
+  hipEvent_t start = nullptr, stop = nullptr;
+  bool valid = false;
+};
+
+}  // namespace vipmi
+
+struct vipmi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::map<std::string, vipmi::Buffer> buffers;
+  std::map<std::string, vipmi::StageTimer> timers;
+  std::map<std::string, int64_t> options;
+  std::map<std::string, std::string> upload_keys;
+  int num_cu = 256;
+  bool timing = false;
+
+  // returns a device buffer of at least `bytes` (contents undefined)
+  int get(const char* name, size_t bytes, void** out);
+  // device copy of a small host table, re-uploaded only when `key` changes (synchronous upload)
+  int upload_cached(const char* name, const std::string& key, const void* host, size_t bytes,
+                    void** out);
+  int64_t opt(const char* key, int64_t dflt) const {
+    auto it = options.find(key);
+    return it == options.end() ? dflt : it->second;
+  }
+  void tic(const char* stage);
+  void toc(const char* stage);
+};
+
+namespace vipmi {
+
+template <typename T>
+inline int ws(vipmi_ctx* ctx, const char* name, size_t count, T** out) {
+  void* p = nullptr;
+  int s = ctx->get(name, count * sizeof(T), &p);
+  *out = reinterpret_cast<T*>(p);
+  return s;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+struct StageScope {
+  vipmi_ctx* c;
+  const char* s;
+  StageScope(vipmi_ctx* ctx, const char* stage) : c(ctx), s(stage) { c->tic(s); }
+  ~StageScope() { c->toc(s); }
+};
+
+// ---- internal entry points implemented per .hip file (all enqueue on ctx->stream) ----
+int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb, int64_t P,
+             int64_t ld, double* G);
+int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs);
+int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,
+                      const float* rowscale, float* B);
+int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,
+                      int64_t k, int64_t P, float* R, float* recon);
+int scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P, int mode);
+int apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
+                   const uint8_t* mask, float fill);
+int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
+                 float* out, int mask_nan, int mask_zero, int method);
+int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,
+                 int64_t trim_n, float* out);
+int gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
+               int64_t npx, float* A);
+int scatter_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t P, const int32_t* pix, int64_t npx,
+                float* cube);
+int annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                          const int32_t* lib_len, int64_t max_lib, int64_t ncomp, float* residuals);
+// small device helpers (util.hip)
+int convert_evecs(vipmi_ctx* ctx, const double* evecs, const double* evals, int64_t n, int64_t k,
+                  float* Ekn, float* Enk, float* inv_sigma);
+// Ct[k][nld] (f32, zero padded) = C[n][k]^T (f64)
+int convert_coeffs(vipmi_ctx* ctx, const double* C, int64_t n, int64_t k, float* Ct, int nld);
+// out[k][P] = rowscale[c] * in[k][P]
+int scale_rows(vipmi_ctx* ctx, const float* in, const float* rowscale, int64_t k, int64_t P, float* out);
+
+}  // namespace vipmi

@@ -1,0 +1,268 @@
+// gram.hip -- C[na,nb] (float64) = A[na,P] * B[nb,P]^T on the CDNA4 matrix cores.
+//
+// Replaces the covariance product of svd_wrapper(mode='eigen') (psfsub/svd.py:449,
+// `C = np.dot(matrix, matrix.T)`) and, through the Gram identity, the thin SVD of
+// mode='lapack' (svd.py:470).  A == B gives the symmetric Gram matrix (upper block triangle
+// computed once, mirrored by the reducer).
+//
+// Design (MFMA-bound: AI = n/2 flop/B at n frames):
+//  * the contraction index is the PIXEL axis (P ~ 2.6e5), the output is tiny (n x n), so the
+//    kernel is split-K: grid.x = K-slices, every workgroup owns one slice of pixels and computes
+//    (a group of) all output tiles for it; partial tiles go to a scratch buffer and a second
+//    kernel sums the slices in float64 in a fixed order (deterministic, no atomics).
+//  * one wave owns a TB x TB super-tile of 16x16 MFMA blocks and keeps it in accumulator
+//    registers for the whole slice.  Operands are loaded straight from global memory in MFMA
+//    fragment layout with 16-byte loads: lane (r = lane&15, kq = lane>>4) loads
+//    A[row0 + r][k0 + 4*kq .. +3]; component c of that float4 feeds MFMA number c.  Because both
+//    operands use the same k permutation the contraction is unchanged, and no LDS staging,
+//    barrier or transpose is needed (each load instruction covers 16 rows x 64 contiguous bytes).
+//    All waves of a workgroup walk the same pixel slice, so rows are shared through L1/L2.
+//  * accumulation: v_mfma_f64_16x16x4_f64 (inputs converted f32->f64, exact products, f64 sums)
+//    by default -- the Gram matrix squares the condition number, so it is kept at f64 accuracy;
+//    option "gram_f32" selects v_mfma_f32_16x16x4_f32 (2x MFMA rate, f32 chains per slice).
+#include "common.h"
+
+namespace vipmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_frag(const float* __restrict__ row, bool row_ok, int64_t off,
+                                           int64_t P) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!row_ok) return v;
+  if (VEC && off + 4 <= P) {
+    v = *reinterpret_cast<const f32x4*>(row + off);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (off + c < P) v[c] = row[off + c];
+  }
+  return v;
+}
+
+// tiles: int2 (ti, tj) list.  partial layout: [slice][tile][bi][bj][256] (Acc type),
+// element index inside a block = row*16 + col.
+template <int TB>
+constexpr int gram_max_waves() { return TB <= 2 ? 16 : 8; }
+
+template <int TB, bool ACC64, bool VEC>
+__global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, int na, int nb, int64_t P, int64_t ld,
+    const int2* __restrict__ tiles, int ntiles, int waves_per_wg, int64_t klen, int symmetric,
+    void* __restrict__ partial_) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y * waves_per_wg + wave;
+  if (tile >= ntiles) return;
+  const int slice = blockIdx.x;
+  const int2 t = tiles[tile];
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t kbeg = (int64_t)slice * klen;
+  int64_t kend = kbeg + klen;
+  if (kend > P) kend = P;
+
+  const float* pa[TB];
+  const float* pb[TB];
+  bool oka[TB], okb[TB];
+  bool blka[TB], blkb[TB];
+#pragma unroll
+  for (int i = 0; i < TB; ++i) {
+    int ra = (t.x * TB + i) * 16 + r;
+    int rb = (t.y * TB + i) * 16 + r;
+    oka[i] = ra < na;
+    okb[i] = rb < nb;
+    blka[i] = (t.x * TB + i) * 16 < na;   // wave-uniform
+    blkb[i] = (t.y * TB + i) * 16 < nb;
+    pa[i] = A + (int64_t)(oka[i] ? ra : 0) * ld;
+    pb[i] = B + (int64_t)(okb[i] ? rb : 0) * ld;
+  }
+  const bool diag = symmetric && (t.x == t.y);
+
+  using acc_t = typename std::conditional<ACC64, f64x4, f32x4>::type;
+  acc_t acc[TB][TB];
+#pragma unroll
+  for (int i = 0; i < TB; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  f32x4 fa[TB], fb[TB];
+  if (kbeg < kend) {
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      fa[i] = load_frag<VEC>(pa[i], oka[i], kbeg + 4 * kq, kend);
+      fb[i] = load_frag<VEC>(pb[i], okb[i], kbeg + 4 * kq, kend);
+    }
+  }
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
+    f32x4 na_[TB], nb_[TB];
+    const int64_t kn = k0 + 16;
+    if (kn < kend) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        na_[i] = load_frag<VEC>(pa[i], oka[i], kn + 4 * kq, kend);
+        nb_[i] = load_frag<VEC>(pb[i], okb[i], kn + 4 * kq, kend);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        na_[i] = f32x4{0, 0, 0, 0};
+        nb_[i] = f32x4{0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        if (!blka[i]) continue;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+          if (!blkb[j]) continue;
+          if (diag && j < i) continue;
+          if constexpr (ACC64) {
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[i][c], (double)fb[j][c],
+                                                             acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      fa[i] = na_[i];
+      fb[i] = nb_[i];
+    }
+  }
+
+  using sc_t = typename std::conditional<ACC64, double, float>::type;
+  sc_t* partial = reinterpret_cast<sc_t*>(partial_) +
+                  ((int64_t)slice * ntiles + tile) * (int64_t)(TB * TB * 256);
+  const int col = lane & 15;
+#pragma unroll
+  for (int i = 0; i < TB; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      if (!blka[i] || !blkb[j] || (diag && j < i)) continue;
+      sc_t* blk = partial + (i * TB + j) * 256;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // f64 16x16x4: row = (lane>>4) + 4*g ; f32 16x16x4: row = (lane>>4)*4 + g
+        int row = ACC64 ? ((lane >> 4) + 4 * g) : ((lane >> 4) * 4 + g);
+        blk[row * 16 + col] = acc[i][j][g];
+      }
+    }
+}
+
+template <int TB, bool ACC64>
+__global__ void gram_reduce_kernel(const void* __restrict__ partial_, const int2* __restrict__ tiles,
+                                   int ntiles, int nslices, int na, int nb, int symmetric,
+                                   double* __restrict__ G) {
+  using sc_t = typename std::conditional<ACC64, double, float>::type;
+  const sc_t* partial = reinterpret_cast<const sc_t*>(partial_);
+  const int64_t per_tile = TB * TB * 256;
+  const int64_t total = (int64_t)ntiles * per_tile;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int tile = (int)(e / per_tile);
+    int rem = (int)(e % per_tile);
+    int blk = rem >> 8, idx = rem & 255;
+    int bi = blk / TB, bj = blk % TB;
+    int2 t = tiles[tile];
+    int gi = (t.x * TB + bi) * 16 + (idx >> 4);
+    int gj = (t.y * TB + bj) * 16 + (idx & 15);
+    if (gi >= na || gj >= nb) continue;
+    if (symmetric && t.x == t.y && bj < bi) continue;
+    double s = 0.0;
+    for (int sl = 0; sl < nslices; ++sl) s += (double)partial[(int64_t)sl * total + e];
+    G[(int64_t)gi * nb + gj] = s;
+    if (symmetric) G[(int64_t)gj * nb + gi] = s;
+  }
+}
+
+template <int TB, bool ACC64>
+static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb, int64_t P,
+                  int64_t ld, double* G, bool symmetric) {
+  const int nba = (int)cdiv(na, 16), nbb = (int)cdiv(nb, 16);
+  const int nta = (int)cdiv(nba, TB), ntb = (int)cdiv(nbb, TB);
+  std::vector<int2> tiles;
+  for (int i = 0; i < nta; ++i)
+    for (int j = symmetric ? i : 0; j < ntb; ++j) tiles.push_back(int2{i, j});
+  const int ntiles = (int)tiles.size();
+  // waves per workgroup: the accumulator tile caps TB>=3 kernels at 2 waves/SIMD
+  const int max_waves = gram_max_waves<TB>();
+  int wpw = ntiles < max_waves ? ntiles : max_waves;
+  int ngroups = (int)cdiv(ntiles, wpw);
+  // slices: ~2 workgroups per CU in total, slice length a multiple of 16, >= 64 pixels
+  int64_t target = ctx->opt("gram_slices", 0);
+  if (target <= 0) target = cdiv((int64_t)2 * ctx->num_cu, ngroups);
+  int64_t klen = cdiv(cdiv(P, target), 16) * 16;
+  if (klen < 64) klen = 64;
+  int nslices = (int)cdiv(P, klen);
+  if (nslices > 8) {                       // keep same-slice workgroups on one XCD (b % 8)
+    nslices = (nslices / 8) * 8;
+    klen = cdiv(cdiv(P, nslices), 16) * 16;
+    nslices = (int)cdiv(P, klen);
+  }
+  int2* d_tiles = nullptr;
+  {
+    char key[96];
+    snprintf(key, sizeof key, "%d/%d/%d/%d", TB, nta, ntb, (int)symmetric);
+    void* p = nullptr;
+    VIPMI_TRY(ctx->upload_cached("gram_tiles", key, tiles.data(), sizeof(int2) * ntiles, &p));
+    d_tiles = reinterpret_cast<int2*>(p);
+  }
+  const size_t esz = ACC64 ? 8 : 4;
+  void* partial = nullptr;
+  VIPMI_TRY(ctx->get("gram_partial", (size_t)nslices * ntiles * TB * TB * 256 * esz, &partial));
+  // blocks that are skipped (out of range / lower triangle) are never read by the reducer
+  const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  dim3 grid(nslices, ngroups), block(64 * wpw);
+  if (vec)
+    hipLaunchKernelGGL((gram_partial_kernel<TB, ACC64, true>), grid, block, 0, ctx->stream, A, B,
+                       (int)na, (int)nb, P, ld, d_tiles, ntiles, wpw, klen, (int)symmetric, partial);
+  else
+    hipLaunchKernelGGL((gram_partial_kernel<TB, ACC64, false>), grid, block, 0, ctx->stream, A, B,
+                       (int)na, (int)nb, P, ld, d_tiles, ntiles, wpw, klen, (int)symmetric, partial);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  int64_t total = (int64_t)ntiles * TB * TB * 256;
+  int rb = (int)cdiv(total, 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL((gram_reduce_kernel<TB, ACC64>), dim3(rb), dim3(256), 0, ctx->stream, partial,
+                     d_tiles, ntiles, nslices, (int)na, (int)nb, (int)symmetric, G);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb, int64_t P,
+             int64_t ld, double* G) {
+  VIPMI_REQUIRE(A && B && G, "gram: null pointer");
+  VIPMI_REQUIRE(na > 0 && nb > 0 && P > 0 && ld >= P, "gram: bad sizes na=%ld nb=%ld P=%ld ld=%ld",
+                (long)na, (long)nb, (long)P, (long)ld);
+  VIPMI_REQUIRE(na < (1 << 20) && nb < (1 << 20), "gram: too many rows");
+  StageScope sc(ctx, "gram");
+  const bool symmetric = (A == B) && (na == nb);
+  const bool f32acc = ctx->opt("gram_f32", 0) != 0;
+  const int64_t nmax = na > nb ? na : nb;
+  int tb = (int)ctx->opt("gram_tb", 0);
+  if (tb <= 0) tb = nmax <= 16 ? 1 : (nmax <= 32 ? 2 : 4);
+  if (f32acc) {
+    switch (tb) {
+      case 1: return launch<1, false>(ctx, A, na, B, nb, P, ld, G, symmetric);
+      case 2: return launch<2, false>(ctx, A, na, B, nb, P, ld, G, symmetric);
+      case 3: return launch<3, false>(ctx, A, na, B, nb, P, ld, G, symmetric);
+      case 5: return launch<5, false>(ctx, A, na, B, nb, P, ld, G, symmetric);
+      default: return launch<4, false>(ctx, A, na, B, nb, P, ld, G, symmetric);
+    }
+  }
+  switch (tb) {
+    case 1: return launch<1, true>(ctx, A, na, B, nb, P, ld, G, symmetric);
+    case 2: return launch<2, true>(ctx, A, na, B, nb, P, ld, G, symmetric);
+    case 3: return launch<3, true>(ctx, A, na, B, nb, P, ld, G, symmetric);
+    default: return launch<4, true>(ctx, A, na, B, nb, P, ld, G, symmetric);
+  }
+}
+
+}  // namespace vipmi

@@ -1,0 +1,228 @@
+// project.hip -- the two skinny GEMMs of `_project_subtract` (psfsub/pca_fullfr.py:1727-1731):
+//     transformed   = V . M^T            (k x n)
+//     reconstructed = transformed^T . V  (n x P)
+//     residuals     = M - reconstructed
+// restated through the Gram identity V = S^-1 E^T M  =>  reconstructed = E (E^T M):
+//     rowspace_gemm :  T[k,P] = W[k,n] . M[n,P]        (W = E^T ; PCs = S^-1 T)
+//     subtract_gemm :  R[n,P] = M[n,P] - C[n,k] . T[k,P]  (C = E ; optional recon output)
+// Both stream M once from HBM (AI = k/2 flop/B -> HBM-bound) and keep the small operand in
+// registers / L1.  MFMA: v_mfma_f32_32x32x2_f32 (exact f32 FMA chains), one wave per 128-pixel
+// tile.  The streamed operand is loaded as float4 along the pixel axis: lane (j = lane&31,
+// kh = lane>>5) loads M[f0+kh][px0 + 4j .. 4j+3]; component c feeds MFMA number c whose output
+// column j is pixel px0 + 4j + c, so four 32x32 accumulators cover 128 contiguous pixels with
+// fully coalesced 512-byte row segments and no LDS transpose.
+#include "common.h"
+
+namespace vipmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 ldrow4(const float* __restrict__ base, int64_t row, int64_t nrows,
+                                        int64_t P, int64_t px) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (row >= nrows || px >= P) return v;
+  const float* p = base + row * P + px;
+  if (VEC && px + 4 <= P) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (px + c < P) v[c] = p[c];
+  }
+  return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ void strow4(float* __restrict__ base, int64_t row, int64_t nrows, int64_t P,
+                                       int64_t px, f32x4 v) {
+  if (row >= nrows || px >= P) return;
+  float* p = base + row * P + px;
+  if (VEC && px + 4 <= P) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (px + c < P) p[c] = v[c];
+  }
+}
+
+// T[k,P] = Wt[n,kld]^T . M[n,P];  Wt row f holds W[0..k)[f] (kld >= 32*groups, zero padded).
+template <bool VEC>
+__global__ __launch_bounds__(256) void rowspace_kernel(const float* __restrict__ Wt, int kld,
+                                                       const float* __restrict__ M, int k, int n,
+                                                       int64_t P, const float* __restrict__ rowscale,
+                                                       float* __restrict__ T) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t px0 = tile * 128;
+  if (px0 >= P) return;
+  const int grp = blockIdx.y;               // group of 32 output rows
+  const int jl = lane & 31, kh = lane >> 5;
+  const int64_t px = px0 + 4 * jl;
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  const float* wrow = Wt + grp * 32 + jl;   // A operand: W[grp*32 + i][f], i = lane&31
+  constexpr int U = 4;
+  for (int f0 = 0; f0 < n; f0 += 2 * U) {
+    f32x4 b[U];
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + 2 * u + kh;
+      b[u] = ldrow4<VEC>(M, f, n, P, px);
+      a[u] = (f < n) ? wrow[(int64_t)f * kld] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][c], acc[c], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (i < k) {
+      const float s = rowscale ? rowscale[i] : 1.f;
+      f32x4 v = {acc[0][r] * s, acc[1][r] * s, acc[2][r] * s, acc[3][r] * s};
+      strow4<VEC>(T, i, k, P, px, v);
+    }
+  }
+}
+
+// R[n,P] = M - Ct[k,nld]^T . T[k,P];  Ct row c holds C[0..n)[c] (nld >= n rounded to 32).
+template <bool VEC, bool RECON>
+__global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__ M,
+                                                       const float* __restrict__ Ct, int nld,
+                                                       const float* __restrict__ T, int n, int k,
+                                                       int64_t P, float* __restrict__ R,
+                                                       float* __restrict__ recon) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t px0 = tile * 128;
+  if (px0 >= P) return;
+  const int jl = lane & 31, kh = lane >> 5;
+  const int64_t px = px0 + 4 * jl;
+  constexpr int KS = 16;                       // component pairs held in registers per chunk
+  for (int fb = 0; fb < n; fb += 32) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    f32x4 m[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      m[r] = ldrow4<VEC>(M, f, n, P, px);
+    }
+    for (int c0 = 0; c0 < k; c0 += 2 * KS) {
+      f32x4 b[KS];
+      float a[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int comp = c0 + 2 * s + kh;
+        b[s] = ldrow4<VEC>(T, comp, k, P, px);
+        a[s] = (comp < k) ? Ct[(int64_t)comp * nld + fb + jl] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (c0 + 2 * s < k) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s][c], acc[c], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      f32x4 rec = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      f32x4 res = m[r] - rec;
+      strow4<VEC>(R, f, n, P, px, res);
+      if (RECON) strow4<VEC>(recon, f, n, P, px, rec);
+    }
+  }
+}
+
+// dst[cols, ldd] = src[rows, cols]^T, zero padded to ldd
+__global__ void transpose_pad_kernel(const float* __restrict__ src, int rows, int cols,
+                                     float* __restrict__ dst, int ldd) {
+  int64_t total = (int64_t)cols * ldd;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(e / ldd), r = (int)(e % ldd);
+    dst[e] = (r < rows) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+}
+
+}  // namespace
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// internal: operands already in the layouts the kernels want
+int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n,
+                    int64_t P, const float* rowscale, float* T) {
+  const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(T);
+  dim3 grid((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(k, 32)), block(256);
+  if (vec)
+    hipLaunchKernelGGL(rowspace_kernel<true>, grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P,
+                       rowscale, T);
+  else
+    hipLaunchKernelGGL(rowspace_kernel<false>, grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P,
+                       rowscale, T);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, const float* T, int64_t n,
+                    int64_t k, int64_t P, float* R, float* recon) {
+  const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(T) && aligned16(R) &&
+                   (!recon || aligned16(recon));
+  dim3 grid((unsigned)cdiv(cdiv(P, 128), 4)), block(256);
+#define LAUNCH(V, RC)                                                                             \
+  hipLaunchKernelGGL((subtract_kernel<V, RC>), grid, block, 0, ctx->stream, M, Ct, nld, T, (int)n, \
+                     (int)k, P, R, recon)
+  if (vec) {
+    if (recon) LAUNCH(true, true); else LAUNCH(true, false);
+  } else {
+    if (recon) LAUNCH(false, true); else LAUNCH(false, false);
+  }
+#undef LAUNCH
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,
+                      const float* rowscale, float* B) {
+  VIPMI_REQUIRE(W && M && B, "rowspace_gemm: null pointer");
+  VIPMI_REQUIRE(k > 0 && n > 0 && P > 0, "rowspace_gemm: bad sizes");
+  StageScope sc(ctx, "project");
+  const int kld = (int)cdiv(k, 32) * 32;
+  float* Wt = nullptr;
+  VIPMI_TRY(ws(ctx, "proj_wt", (size_t)n * kld, &Wt));
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3(64), dim3(256), 0, ctx->stream, W, (int)k, (int)n, Wt, kld);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return rowspace_gemm_t(ctx, Wt, kld, M, k, n, P, rowscale, B);
+}
+
+int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,
+                      int64_t k, int64_t P, float* R, float* recon) {
+  VIPMI_REQUIRE(M && C && B && R, "subtract_gemm: null pointer");
+  VIPMI_REQUIRE(k > 0 && n > 0 && P > 0, "subtract_gemm: bad sizes");
+  StageScope sc(ctx, "project");
+  const int nld = (int)cdiv(n, 32) * 32;
+  float* Ct = nullptr;
+  VIPMI_TRY(ws(ctx, "proj_ct", (size_t)k * nld, &Ct));
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3(64), dim3(256), 0, ctx->stream, C, (int)n, (int)k, Ct, nld);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return subtract_gemm_t(ctx, M, Ct, nld, B, n, k, P, R, recon);
+}
+
+}  // namespace vipmi

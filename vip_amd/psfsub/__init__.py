@@ -1,0 +1,4 @@
+"""Drop-in for the PCA entry points of ``vip_hci.psfsub`` (reference psfsub/__init__.py:14-24)."""
+from .pca_fullfr import pca, PCA_Params  # noqa: F401
+from .pca_local import pca_annular, PCA_ANNULAR_Params  # noqa: F401
+from .svd import svd_wrapper, SVDecomposer, get_eigenvectors  # noqa: F401

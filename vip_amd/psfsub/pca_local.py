@@ -1,0 +1,220 @@
+"""Annular PCA: drop-in for ``vip_hci.psfsub.pca_annular`` (reference psfsub/pca_local.py:39-70
+PCA_ANNULAR_Params, :73-462 pca_annular, :594-827 _pca_adi_rdi, :830-909 do_pca_patch) for 3-D ADI
+cubes.
+
+The reference runs one SVD per (annulus segment, frame) on the PA-thresholded library rows of the
+segment matrix.  Here each segment matrix is gathered once on the device, its Gram matrix is formed on
+the matrix cores, and every frame's library PCA is obtained from the corresponding Gram sub-block
+(SURVEY.md 8(a-ann)): residual_j = x_j - M_lib^T (E_k L_k^-1 E_k^T) G[lib, j], batched over frames.
+
+Not accelerated (NotImplementedError): 4-D input, ``cube_ref``, ``cube_sig``, ``left_eigv``,
+``ncomp='auto'``, list ``ncomp``.
+"""
+from dataclasses import dataclass
+from enum import Enum
+from typing import List, Tuple, Union
+
+import numpy as np
+
+from .. import backend as B
+from ..config.paramenum import ALGO_KEY, Collapse, Imlib, Interpolation, SvdMode
+from ..config.utils_param import separate_kwargs_dict, setup_parameters
+from ..preproc.derotation import _define_annuli, _find_indices_adi
+from ..preproc.parangles import check_pa_vector
+from ..var.shapes import get_annulus_segments
+
+AUTO = "auto"
+
+
+@dataclass
+class PCA_ANNULAR_Params:
+    """Parameters of ``pca_annular`` (field order == positional order of the reference)."""
+
+    cube: np.ndarray = None
+    angle_list: np.ndarray = None
+    cube_ref: np.ndarray = None
+    scale_list: np.ndarray = None
+    radius_int: int = 0
+    fwhm: float = 4
+    asize: float = 4
+    n_segments: Union[int, List[int], str] = 1
+    delta_rot: Union[float, Tuple[float], List[float]] = (0.1, 1)
+    delta_sep: Union[float, Tuple[float], List[float]] = (0.1, 1)
+    ncomp: Union[int, Tuple, np.ndarray, str] = 1
+    svd_mode: Enum = SvdMode.LAPACK
+    nproc: int = 1
+    min_frames_lib: int = 2
+    max_frames_lib: int = 200
+    tol: float = 1e-1
+    scaling: Enum = None
+    imlib: Enum = Imlib.VIPFFT
+    interpolation: Enum = Interpolation.LANCZOS4
+    collapse: Enum = Collapse.MEDIAN
+    collapse_ifs: Enum = Collapse.MEAN
+    ifs_collapse_range: Union[str, Tuple[int]] = "all"
+    theta_init: int = 0
+    weights: np.ndarray = None
+    cube_sig: np.ndarray = None
+    full_output: bool = False
+    verbose: bool = True
+    left_eigv: bool = False
+
+
+def _s(x):
+    return str(getattr(x, "value", x)) if x is not None else None
+
+
+def annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, delta_rot, ncomp, min_frames_lib,
+                 max_frames_lib, theta_init=0):
+    """Host-side plan of ``_pca_adi_rdi`` (pca_local.py:628-707): for every annulus segment, the flat
+    pixel indices, the number of PCs and the per-frame library index lists.  Pure index arithmetic
+    (bit-exact with the reference); returns a list of dicts."""
+    n = angle_list.shape[0]
+    y, x = shape
+    n_annuli = int((y / 2 - radius_int) / asize)
+    if isinstance(delta_rot, tuple):
+        delta_rot = np.linspace(delta_rot[0], delta_rot[1], num=n_annuli)
+    elif np.isscalar(delta_rot):
+        delta_rot = [delta_rot] * n_annuli
+    else:
+        if len(delta_rot) != n_annuli:
+            raise TypeError("If delta_rot is a list it should have n_annuli elements.")
+    if isinstance(n_segments, int):
+        n_segments = [n_segments for _ in range(n_annuli)]
+    elif n_segments == "auto":
+        n_segments = [2, 3]
+        ld = 2 * np.tan(360 / 4 / 2) * asize        # argument in radians, as in the reference (:648)
+        for i in range(2, n_annuli):
+            ang = np.rad2deg(2 * np.arctan(ld / (2 * i * asize)))
+            n_segments.append(int(np.ceil(360 / ang)))
+    plan = []
+    for ann in range(n_annuli):
+        if isinstance(ncomp, (tuple, np.ndarray)):
+            if len(ncomp) != n_annuli:
+                raise TypeError("If `ncomp` is a tuple, its length must match the number of annuli")
+            k_ann = int(ncomp[ann])
+        else:
+            k_ann = int(ncomp)
+        pa_thr, inner_radius, ann_center = _define_annuli(angle_list, ann, n_annuli, fwhm, radius_int, asize,
+                                                          delta_rot[ann], n_segments[ann], False, True)
+        segs = get_annulus_segments(np.zeros((y, x)), inner_radius, asize, n_segments[ann], theta_init)
+        if pa_thr != 0:
+            libs = [_find_indices_adi(angle_list, fr, pa_thr, truncate=True, max_frames=max_frames_lib)
+                    for fr in range(n)]
+            for fr, li in enumerate(libs):
+                if li.shape[0] < min_frames_lib:
+                    msg = "Too few frames left in the PCA library. Accepted indices length ({:.0f}) less than {:.0f}. "
+                    msg += "Try decreasing either delta_rot or min_frames_lib."
+                    raise RuntimeError(msg.format(len(li), min_frames_lib))
+        else:
+            libs = [np.arange(n, dtype=np.int32) for _ in range(n)]
+        for yy, xx in segs:
+            plan.append(dict(ann=ann, pix=(yy.astype(np.int64) * x + xx).astype(np.int32), ncomp=k_ann,
+                             libs=libs, pa_thr=pa_thr, inner_radius=inner_radius, ann_center=ann_center))
+    return plan
+
+
+def _pack_libs(libs):
+    n = len(libs)
+    max_lib = max(len(li) for li in libs)
+    idx = np.zeros((n, max_lib), dtype=np.int32)
+    ln = np.zeros(n, dtype=np.int32)
+    for j, li in enumerate(libs):
+        idx[j, :len(li)] = li
+        ln[j] = len(li)
+    return idx, ln, max_lib
+
+
+def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, delta_rot=1, ncomp=1,
+                 svd_mode="lapack", nproc=None, min_frames_lib=2, max_frames_lib=200, tol=1e-1,
+                 scaling=None, imlib="vip-fft", interpolation="lanczos4", collapse="median",
+                 full_output=False, verbose=1, cube_ref=None, theta_init=0, weights=None, cube_sig=None,
+                 left_eigv=False, **rot_options):
+    """Device version of the reference's ``_pca_adi_rdi``; ``cube`` is a float32 cuda tensor."""
+    torch = B._torch()
+    if cube.ndim != 3:
+        raise TypeError("Input array is not a cube or 3d array")
+    if cube.shape[0] != np.asarray(angle_list).shape[0]:
+        raise TypeError("Input vector or parallactic angles has wrong length")
+    if cube_ref is not None or cube_sig is not None or left_eigv:
+        raise NotImplementedError("cube_ref / cube_sig / left_eigv are outside the accelerated annular path")
+    if isinstance(ncomp, list) or isinstance(ncomp, str):
+        raise NotImplementedError("list / 'auto' ncomp is outside the accelerated annular path")
+    if _s(imlib) != "vip-fft":
+        raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
+    n, y, x = cube.shape
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
+    plan = annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot, ncomp,
+                        min_frames_lib, max_frames_lib, theta_init)
+    if verbose:
+        print("N annuli = {}, FWHM = {:.3f}".format(int((y / 2 - radius_int) / asize), fwhm))
+    ctx = B.get_context(cube.device.index)
+    dev = cube.device.index
+    P = y * x
+    cube_out = torch.zeros_like(cube)
+    scaling = _s(scaling)
+    lib_cache = {}
+    for seg in plan:
+        pix = torch.from_numpy(seg["pix"]).to(cube.device)
+        npx = int(pix.numel())
+        A = B.empty((n, npx), device=dev)
+        ctx.call("vipmi_gather_f32", B.ptr(cube), n, P, B.ptr(pix), npx, B.ptr(A))
+        if scaling is not None:
+            A = B.scale(A, scaling)
+        key = id(seg["libs"])
+        if key not in lib_cache:
+            idx, ln, max_lib = _pack_libs(seg["libs"])
+            lib_cache[key] = (torch.from_numpy(idx).to(cube.device), torch.from_numpy(ln).to(cube.device), max_lib)
+        idx_t, ln_t, max_lib = lib_cache[key]
+        R = B.empty((n, npx), device=dev)
+        ctx.call("vipmi_annular_residuals_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
+                 int(seg["ncomp"]), B.ptr(R))
+        ctx.call("vipmi_scatter_f32", B.ptr(R), n, P, B.ptr(pix), npx, B.ptr(cube_out))
+    mask_val = rot_options.get("mask_val", np.nan)
+    mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
+    if not mv_nan and mask_val != 0:
+        raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
+    cube_der = B.derotate(cube_out, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
+    frame = B.collapse(cube_der, _s(collapse), w=weights)
+    if verbose:
+        print("Done derotating and combining.")
+    if full_output:
+        return cube_out, cube_der, frame
+    return frame
+
+
+def pca_annular(*all_args: List, **all_kwargs: dict):
+    """Annular ADI PCA on the MI355X.  Returns ``frame`` or ``(cube_out, cube_der, frame)``."""
+    class_params, rot_options = separate_kwargs_dict(all_kwargs, PCA_ANNULAR_Params)
+    algo_params = None
+    if ALGO_KEY in rot_options.keys():
+        algo_params = rot_options[ALGO_KEY]
+        del rot_options[ALGO_KEY]
+    if algo_params is None:
+        algo_params = PCA_ANNULAR_Params(*all_args, **class_params)
+    # by default, interpolate masked area before derotation if a mask is used (pca_local.py:242-245)
+    if algo_params.radius_int and len(rot_options) == 0:
+        rot_options["mask_val"] = 0
+        rot_options["ker"] = 1
+        rot_options["interp_zeros"] = True
+    if algo_params.left_eigv:
+        raise NotImplementedError("left_eigv is outside the accelerated path")
+    cube = algo_params.cube
+    if not (isinstance(cube, np.ndarray) or B.is_device_tensor(cube)):
+        raise TypeError("`cube` must be a numpy ndarray")
+    if cube.ndim == 4 or algo_params.scale_list is not None:
+        raise NotImplementedError("4-D / mSDI annular PCA is not accelerated yet (SURVEY 8(f))")
+    if cube.ndim != 3:
+        raise TypeError("Input array is not a cube or 3d array")
+    dev_in = B.is_device_tensor(cube)
+    out_dtype = None if dev_in else (cube.dtype if cube.dtype.kind == "f" else np.float64)
+
+    def host(t):
+        return t if dev_in else t.cpu().numpy().astype(out_dtype, copy=False)
+
+    cube_t = B.to_device_f32(cube)
+    fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t, full_output=True)
+    cube_out, cube_der, frame = _pca_adi_rdi(**fp, **rot_options)
+    if algo_params.full_output:
+        return host(cube_out), host(cube_der), host(frame)
+    return host(frame)

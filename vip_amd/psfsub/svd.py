@@ -1,0 +1,126 @@
+"""svd_wrapper / SVDecomposer (reference psfsub/svd.py:28-702) on the device.
+
+Every ``svd_mode`` of the reference is an alternative back-end of the same mathematical object (the
+top-k right singular vectors of the n x P matrix).  Here all of them map onto ONE deterministic device
+algorithm: Gram matrix on the matrix cores (float64 accumulation) + one-sided block Jacobi
+eigensolver (float64) + back-projection, i.e. the arithmetic of the reference's ``'eigen'`` mode at
+LAPACK-class accuracy.  PCs are defined up to a per-row sign (sign convention: see DESIGN.md).
+"""
+import numpy as np
+
+from .. import backend as B
+from ..var import prepare_matrix
+
+SVD_MODES = ("lapack", "arpack", "eigen", "randsvd", "cupy", "eigencupy", "randcupy", "pytorch",
+             "eigenpytorch", "randpytorch")
+
+
+def _decompose(mat_t, ncomp, want_pcs=True):
+    """mat_t: (n, P) float32 cuda tensor.  Returns (sigma[k] f64, E[k, n] f64 rows = left vectors, V[k,P])."""
+    torch = B._torch()
+    n, P = mat_t.shape
+    G = B.gram(mat_t)
+    evals, evecs = B.eigh(G)
+    sig = torch.sqrt(torch.clamp(evals[:ncomp], min=0))
+    E = evecs[:ncomp]
+    V = None
+    if want_pcs:
+        inv = torch.where(evals[:ncomp] > evals[0] * 1e-12, 1.0 / torch.clamp(sig, min=1e-300),
+                          torch.zeros_like(sig)).to(torch.float32)
+        ctx = B.get_context(mat_t.device.index)
+        V = B.empty((ncomp, P), device=mat_t.device.index)
+        W = E.to(torch.float32).contiguous()
+        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(W), B.ptr(mat_t), ncomp, n, P, B.ptr(inv.contiguous()), B.ptr(V))
+    return sig, E, V
+
+
+def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=None, to_numpy=True,
+                left_eigv=False):
+    """Right singular vectors V (ncomp x P, orthonormal rows) of ``matrix`` (n x P).
+
+    ``full_output`` -> (U, S, V) with U of shape (n, ncomp) for ``mode='lapack'`` and (ncomp, n)
+    otherwise (the shapes the reference returns, svd.py:597-606).  ``to_numpy=False`` keeps the
+    results on the device (cuda tensors), mirroring the reference's GPU modes."""
+    if matrix.ndim != 2:
+        raise TypeError("Input matrix is not a 2d array")
+    if ncomp > min(matrix.shape[0], matrix.shape[1]):
+        msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
+        msg += " Increase the size of the patches or request less PCs"
+        raise RuntimeError(msg.format(ncomp, matrix.shape[0], matrix.shape[1]))
+    mode = str(getattr(mode, "value", mode))
+    if mode not in SVD_MODES:
+        raise ValueError("The SVD `mode` is not recognized")
+    if left_eigv:
+        raise NotImplementedError("left_eigv is outside the accelerated path")
+    dev_in = B.is_device_tensor(matrix)
+    t = B.to_device_f32(matrix)
+    sig, E, V = _decompose(t, int(ncomp))
+    if verbose:
+        print("Done SVD/PCA on MI355X (Gram + block-Jacobi eigensolver), requested mode '{}'".format(mode))
+    keep_dev = dev_in or not to_numpy
+    out_dtype = np.float64 if (not dev_in and matrix.dtype == np.float64) else np.float32
+
+    def fin(x, f32=True):
+        if keep_dev:
+            return x
+        return x.cpu().numpy().astype(out_dtype, copy=False)
+
+    if full_output:
+        U = E.T.contiguous() if mode == "lapack" else E
+        return fin(U.to(B._torch().float32)), fin(sig.to(B._torch().float32)), fin(V)
+    return fin(V)
+
+
+def get_eigenvectors(ncomp, data, svd_mode, mode="noise", noise_error=1e-3, cevr=0.9, max_evs=None,
+                     data_ref=None, debug=False, collapse=False, scaling=None, left_eigv=False):
+    """Integer ``ncomp`` branch of the reference (svd.py:694-700)."""
+    if ncomp is None:
+        raise ValueError("ncomp must be an integer or `auto`")
+    if isinstance(ncomp, str):
+        raise NotImplementedError("ncomp='auto' is outside the accelerated path")
+    if data_ref is None:
+        data_ref = data
+    ncomp = min(int(ncomp), min(data_ref.shape[0], data_ref.shape[1]))
+    return svd_wrapper(data_ref, svd_mode, ncomp, False, left_eigv=left_eigv)
+
+
+class SVDecomposer:
+    """Minimal mirror of the reference class (svd.py:28-339): full spectrum + CEVR -> ncomp.
+
+    Quirk kept: ``generate_matrix`` applies ``scaling`` but never ``mask_center_px`` (svd.py:182-185)."""
+
+    def __init__(self, data, mode="fullfr", inrad=10, outrad=15, svd_mode="lapack", scaling="temp-standard",
+                 scale_list=None, verbose=True):
+        if data.ndim not in (2, 3):
+            raise NotImplementedError("SVDecomposer on the device handles 2d matrices and 3d cubes")
+        if mode != "fullfr":
+            raise NotImplementedError("only mode='fullfr'")
+        self.data, self.mode, self.svd_mode, self.scaling, self.verbose = data, mode, svd_mode, scaling, verbose
+
+    def generate_matrix(self):
+        if self.data.ndim == 2:
+            self.matrix = self.data
+        else:
+            self.matrix = prepare_matrix(self.data, self.scaling, mode="fullfr", verbose=self.verbose)
+
+    def run(self):
+        if not hasattr(self, "matrix"):
+            self.generate_matrix()
+        t = B.to_device_f32(self.matrix)
+        evals, _ = B.eigh(B.gram(t))
+        self.s = B._torch().sqrt(B._torch().clamp(evals, min=0)).cpu().numpy()
+
+    def get_cevr(self, ncomp_list=None, plot=False, **_):
+        if not hasattr(self, "s"):
+            self.run()
+        exp_var = (self.s ** 2) / (self.s.shape[0] - 1)
+        self.explained_variance_ratio = exp_var / np.sum(exp_var)
+        self.cevr = np.cumsum(self.explained_variance_ratio)
+        return self.cevr
+
+    def cevr_to_ncomp(self, cevr=0.9):
+        if not hasattr(self, "cevr"):
+            self.get_cevr()
+        if isinstance(cevr, tuple):
+            return [int(np.searchsorted(self.cevr, c) + 1) for c in cevr]
+        return int(np.searchsorted(self.cevr, cevr) + 1)
