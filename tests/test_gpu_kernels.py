@@ -124,12 +124,13 @@ def test_rowspace_and_subtract_gemm(B, n, k, P):
     Tm = rng.standard_normal((k, P)).astype(np.float32)
     R = B.empty((n, P))
     recon = B.empty((n, P))
-    ctx.call("vipmi_subtract_gemm_f32", B.ptr(Md), B.ptr(dev(B, C)), B.ptr(dev(B, Tm)), n, k, P, B.ptr(R), B.ptr(recon))
+    Cd, Tmd = dev(B, C), dev(B, Tm)          # keep the device copies alive across the call
+    ctx.call("vipmi_subtract_gemm_f32", B.ptr(Md), B.ptr(Cd), B.ptr(Tmd), n, k, P, B.ptr(R), B.ptr(recon))
     refrec = C.astype(np.float64) @ Tm.astype(np.float64)
     assert np.abs(recon.cpu().numpy() - refrec).max() <= 2e-5 * np.abs(refrec).max()
     assert np.abs(R.cpu().numpy() - (M - refrec)).max() <= 2e-5 * np.abs(refrec).max()
     R2 = B.empty((n, P))
-    ctx.call("vipmi_subtract_gemm_f32", B.ptr(Md), B.ptr(dev(B, C)), B.ptr(dev(B, Tm)), n, k, P, B.ptr(R2), B.ptr(None))
+    ctx.call("vipmi_subtract_gemm_f32", B.ptr(Md), B.ptr(Cd), B.ptr(Tmd), n, k, P, B.ptr(R2), B.ptr(None))
     assert np.array_equal(R.cpu().numpy(), R2.cpu().numpy())
 
 

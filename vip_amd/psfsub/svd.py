@@ -16,12 +16,14 @@ SVD_MODES = ("lapack", "arpack", "eigen", "randsvd", "cupy", "eigencupy", "randc
 
 
 def _decompose(mat_t, ncomp, want_pcs=True):
-    """mat_t: (n, P) float32 cuda tensor.  Returns (sigma[k] f64, E[k, n] f64 rows = left vectors, V[k,P])."""
+    """mat_t: (n, P) float32 cuda tensor.  Returns (sigma[min(n,P)] f64, E[k, n] f64 rows = left
+    vectors, V[k,P])."""
     torch = B._torch()
     n, P = mat_t.shape
     G = B.gram(mat_t)
     evals, evecs = B.eigh(G)
-    sig = torch.sqrt(torch.clamp(evals[:ncomp], min=0))
+    sig_all = torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
+    sig = sig_all[:ncomp]
     E = evecs[:ncomp]
     V = None
     if want_pcs:
@@ -31,7 +33,7 @@ def _decompose(mat_t, ncomp, want_pcs=True):
         V = B.empty((ncomp, P), device=mat_t.device.index)
         W = E.to(torch.float32).contiguous()
         ctx.call("vipmi_rowspace_gemm_f32", B.ptr(W), B.ptr(mat_t), ncomp, n, P, B.ptr(inv.contiguous()), B.ptr(V))
-    return sig, E, V
+    return sig_all, E, V
 
 
 def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=None, to_numpy=True,
@@ -67,7 +69,9 @@ def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=No
 
     if full_output:
         U = E.T.contiguous() if mode == "lapack" else E
-        return fin(U.to(B._torch().float32)), fin(sig.to(B._torch().float32)), fin(V)
+        # the reference truncates S to ncomp except in the eigen-family modes (svd.py:454-459,473)
+        S = sig if mode in ("eigen", "eigencupy", "eigenpytorch") else sig[:int(ncomp)]
+        return fin(U.to(B._torch().float32)), fin(S.to(B._torch().float32)), fin(V)
     return fin(V)
 
 
