@@ -52,10 +52,14 @@ int vipmi_synchronize(vipmi_ctx* ctx);
 /* tuning knobs (key/value); see DESIGN.md.  Unknown key -> VIPMI_ERR_ARG. */
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value);
 int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key);   /* -1 if unset */
-/* elapsed ms between the start and the end of the most recent call of the named stage
- * ("gram","eigh","project","derotate","collapse","scale"), measured with hipEvents on the ctx
- * stream; synchronises.  <0 if the stage has not run. */
+/* With option "timing"=1 every stage / kernel records hipEvent pairs on the ctx stream.
+ * vipmi_stage_ms: total elapsed ms of all intervals of the named stage since the last
+ * vipmi_reset_timers (synchronises; <0 if none); vipmi_stage_count: number of intervals.
+ * Stages: "gram","eigh","project","derotate","collapse","scale"; single kernels:
+ * "k_gram","k_rowspace","k_subtract","k_rot_s1","k_rot_s2","k_rot_s3","k_median". */
 float vipmi_stage_ms(vipmi_ctx* ctx, const char* stage);
+int vipmi_stage_count(vipmi_ctx* ctx, const char* stage);
+int vipmi_reset_timers(vipmi_ctx* ctx);
 
 /* ---- prepare_matrix pieces: var/shapes.py:740-781 (matrix_scaling), :38-113 (mask_circle) ---- */
 /* out[n,P] = sklearn-style scale of in[n,P]; mode = VIPMI_SCALE_*; in == out allowed. */

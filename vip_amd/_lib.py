@@ -24,6 +24,8 @@ _SIGS = {
     "vipmi_set_option": ([ctypes.c_char_p, i64], True, ctypes.c_int),
     "vipmi_get_option": ([ctypes.c_char_p], True, i64),
     "vipmi_stage_ms": ([ctypes.c_char_p], True, ctypes.c_float),
+    "vipmi_stage_count": ([ctypes.c_char_p], True, ctypes.c_int),
+    "vipmi_reset_timers": ([], True, ctypes.c_int),
     "vipmi_scale_f32": ([c_f32p, c_f32p, i64, i64, ctypes.c_int], True, ctypes.c_int),
     "vipmi_apply_mask_f32": ([c_f32p, c_f32p, i64, i64, ctypes.c_void_p, ctypes.c_float], True, ctypes.c_int),
     "vipmi_gram_f32": ([c_f32p, i64, i64, i64, ctypes.c_void_p], True, ctypes.c_int),

@@ -55,6 +55,12 @@ class Context:
     def stage_ms(self, stage):
         return float(self.lib.vipmi_stage_ms(self.handle, stage.encode()))
 
+    def stage_count(self, stage):
+        return int(self.lib.vipmi_stage_count(self.handle, stage.encode()))
+
+    def reset_timers(self):
+        self.lib.vipmi_reset_timers(self.handle)
+
     def call(self, name, *args):
         self.bind_stream()
         st = getattr(self.lib, name)(self.handle, *args)

@@ -79,20 +79,24 @@ int vipmi_ctx::upload_cached(const char* name, const std::string& key, const voi
 void vipmi_ctx::tic(const char* stage) {
   if (!timing) return;
   StageTimer& t = timers[stage];
-  if (!t.start) {
-    (void)hipEventCreate(&t.start);
-    (void)hipEventCreate(&t.stop);
+  if (t.open) return;
+  if (t.used == (int)t.ev.size()) {
+    hipEvent_t a = nullptr, b = nullptr;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    t.ev.emplace_back(a, b);
   }
-  (void)hipEventRecord(t.start, stream);
-  t.valid = false;
+  (void)hipEventRecord(t.ev[t.used].first, stream);
+  t.open = true;
 }
 
 void vipmi_ctx::toc(const char* stage) {
   if (!timing) return;
   StageTimer& t = timers[stage];
-  if (!t.start) return;
-  (void)hipEventRecord(t.stop, stream);
-  t.valid = true;
+  if (!t.open) return;
+  (void)hipEventRecord(t.ev[t.used].second, stream);
+  t.used++;
+  t.open = false;
 }
 
 extern "C" {
@@ -127,10 +131,11 @@ int vipmi_destroy(vipmi_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->buffers)
     if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-  for (auto& kv : ctx->timers) {
-    if (kv.second.start) (void)hipEventDestroy(kv.second.start);
-    if (kv.second.stop) (void)hipEventDestroy(kv.second.stop);
-  }
+  for (auto& kv : ctx->timers)
+    for (auto& pr : kv.second.ev) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
   delete ctx;
   return VIPMI_OK;
 }
@@ -167,11 +172,31 @@ int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key) {
 float vipmi_stage_ms(vipmi_ctx* ctx, const char* stage) {
   if (!ctx || !stage) return -1.f;
   auto it = ctx->timers.find(stage);
-  if (it == ctx->timers.end() || !it->second.valid) return -1.f;
-  if (hipEventSynchronize(it->second.stop) != hipSuccess) return -1.f;
-  float ms = -1.f;
-  if (hipEventElapsedTime(&ms, it->second.start, it->second.stop) != hipSuccess) return -1.f;
-  return ms;
+  if (it == ctx->timers.end() || it->second.used == 0) return -1.f;
+  StageTimer& t = it->second;
+  if (hipEventSynchronize(t.ev[t.used - 1].second) != hipSuccess) return -1.f;
+  float total = 0.f;
+  for (int i = 0; i < t.used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.ev[i].first, t.ev[i].second) != hipSuccess) return -1.f;
+    total += ms;
+  }
+  return total;
+}
+
+int vipmi_stage_count(vipmi_ctx* ctx, const char* stage) {
+  if (!ctx || !stage) return -1;
+  auto it = ctx->timers.find(stage);
+  return it == ctx->timers.end() ? 0 : it->second.used;
+}
+
+int vipmi_reset_timers(vipmi_ctx* ctx) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  for (auto& kv : ctx->timers) {
+    kv.second.used = 0;
+    kv.second.open = false;
+  }
+  return VIPMI_OK;
 }
 
 #define CTX_GUARD()                      \

@@ -42,9 +42,11 @@ struct Buffer {
   size_t bytes = 0;
 };
 
+// accumulating stage timer: every tic/toc pair since the last reset is kept (hipEvents on the ctx stream)
 struct StageTimer {
-  hipEvent_t start = nullptr, stop = nullptr;
-  bool valid = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  int used = 0;
+  bool open = false;
 };
 
 }  // namespace vipmi
