@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Benchmark of the ADI PSF-subtraction hot path on MI355X (BASELINE.json metric:
+"ADI cube frames/sec (and ms/SVD) at ncomp=20, 400x512x512").
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full `vip_amd.psfsub.pca(cube, angles, ncomp=20)` call (Gram -> eigensolver ->
+project/subtract -> 3-shear FFT derotation -> median collapse -> D2H of the final frame) on a synthetic
+400x512x512 float32 cube that is already resident in HBM.  N > 1 (launched with torch.distributed.run,
+one rank per GPU): every rank processes its own cube -- the "survey mode" sharding of SURVEY.md 8(e):
+no data-path collective, only the barrier / max-over-ranks timing -- so scaling is weak.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     : dominant kernel (fft_shear2, the column shear of the derotation) -- algorithmic bytes of
+                 the derotation stage per launch / its average launch duration (hipEvents on the ctx stream)
+  cpu_baseline : the numpy oracle (oracle/ref_cpu.py, a port of the reference's svd_mode='lapack' +
+                 imlib='vip-fft' + nanmedian path) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TF = 157.3
+
+
+def cpu_baseline(n, N, k, budget_frames=4):
+    """Oracle (port of the reference path) on a bounded sample of the same workload; returns frames/s
+    extrapolated to the full cube: t = t_svd_project(full matrix) + n * t_derotate(1 frame) + t_median."""
+    from oracle import ref_cpu as O
+    from vip_amd.synth import synth_adi
+    cube, angles = synth_adi(n, N, seed=0)
+    t0 = time.perf_counter()
+    res = O.project_subtract(cube, k, None, None, "lapack")
+    t_svd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.cube_derotate(res[:budget_frames], angles[:budget_frames])
+    t_rot = (time.perf_counter() - t0) / budget_frames
+    step = 8
+    t0 = time.perf_counter()
+    O.cube_collapse(res[:, ::step, :], "median")
+    t_med = (time.perf_counter() - t0) * step
+    total = t_svd + n * t_rot + t_med
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": n / total, "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "sample": "full %dx%dx%d SVD+project (%.1fs, BLAS threads) + %d of %d frames derotated "
+                      "(%.2fs/frame, 1 thread) + median on 1/%d of the pixels (%.1fs scaled); "
+                      "extrapolated to the full cube = %.0fs" % (n, N, N, t_svd, budget_frames, n, t_rot, step, t_med, total),
+            "ms_per_svd": 1e3 * t_svd}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ncomp", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from vip_amd import backend as B
+    from vip_amd.psfsub import pca
+    from vip_amd.synth import synth_adi
+
+    n, N, k = args.frames, args.size, args.ncomp
+    cube, angles = synth_adi(n, N, seed=rank)
+    cube_t = torch.from_numpy(cube).cuda()
+    del cube
+    ctx = B.get_context()
+
+    def step():
+        frame = pca(cube_t, angles, ncomp=k, verbose=False, check_memory=False)
+        return frame.cpu()                      # D2H of the final frame is part of the metric
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out).all())
+
+    # per-stage / per-kernel timings over a second pass of the same K steps (hipEvents on the ctx stream;
+    # kept out of the throughput measurement so that event recording cannot perturb it)
+    roof = None
+    stages = {}
+    if rank == 0:
+        ctx.set_option("timing", 1)
+        ctx.reset_timers()
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        for s in ("scale", "gram", "eigh", "project", "derotate", "collapse", "k_rot_s1", "k_rot_s2", "k_rot_s3"):
+            ms, cnt = ctx.stage_ms(s), ctx.stage_count(s)
+            if cnt > 0 and ms >= 0:
+                stages[s] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+        ctx.set_option("timing", 0)
+        P = N * N
+        if "k_rot_s2" in stages:
+            launches = stages["k_rot_s2"]["launches_per_step"]
+            dur_ms = stages["k_rot_s2"]["ms_per_step"] / launches
+            frames_per_launch = n / launches
+            alg_bytes = 2.0 * P * 4 * frames_per_launch          # derotate = 2*P*4 bytes per frame
+            achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
+            L = 4 * N
+            real_bytes = 2.0 * frames_per_launch * N * L * 8      # what this kernel actually moves (A1 in, A2 out)
+            roof = {"bound": "hbm", "kernel": "fft_shear2", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": dur_ms, "frames_per_launch": frames_per_launch,
+                    "intermediate_GBps": real_bytes / (dur_ms * 1e-3) / 1e9,
+                    "note": "VALU/LDS-bound FFT kernel; see DESIGN.md for the flop-based fraction"}
+        ms_svd = sum(stages[s]["ms_per_step"] for s in ("scale", "gram", "eigh") if s in stages)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * n * args.steps / elapsed
+        rec = {
+            "metric": "ADI cube frames/sec at ncomp=%d, %dx%dx%d" % (k, n, N, N),
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %dx%dx%d ADI cube, full-frame PCA ncomp=%d, float32, "
+                                   "vip-fft derotation, median collapse" % (n, N, N, k),
+                       "cubes_per_step": world, "parallelism": "one cube per GPU (no data-path collective)"},
+            "ms_per_svd": ms_svd if rank == 0 and stages else None,
+            "stages": stages,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(n, N, k)
+        print(json.dumps(rec))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

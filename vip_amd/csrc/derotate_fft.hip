@@ -120,7 +120,7 @@ struct Dft<16, INV> {
   }
 };
 
-template <int R1_, int R2_, int R3_, int S1_, int T1_, int T2_, int WPB_>
+template <int R1_, int R2_, int R3_, int S1_, int T1_, int T2_, int WPB_, int WPL_>
 struct Plan {
   static constexpr int R1 = R1_, R2 = R2_, R3 = R3_;
   static constexpr int L = R1 * R2 * R3, M1 = L / R1, M2 = R3;
@@ -129,57 +129,60 @@ struct Plan {
   static constexpr int S1 = S1_, T1 = T1_, T2 = T2_;   // LDS strides (complex elements)
   static constexpr int LDS_ELEMS = (R1 * S1 > R1 * T1) ? R1 * S1 : R1 * T1;
   static constexpr int WPB = WPB_;                     // waves per workgroup
+  static constexpr int WPL = WPL_;                     // waves cooperating on one line
+  static constexpr int LPB = WPB_ / WPL_;              // lines in flight per workgroup
+  static constexpr int U1L = U1 / WPL_, U2L = U2 / WPL_, U3L = U3 / WPL_;
+  static constexpr int VL = VPT / WPL_;                // complex registers per lane
+  static_assert(U1L * WPL_ == U1 && U2L * WPL_ == U2 && U3L * WPL_ == U3, "radix plan not divisible by WPL");
   // a frame of N = L/4 pixels sits at canvas offset 3L/8: line elements M1*n1 + n2 with
   // n1 in [NLO, NLO + NCNT) are exactly the N output positions; inputs may be shifted by one
   // (rot90 pre-step), which adds n1 = NLO + NCNT.
   static constexpr int NLO = 3 * R1_ / 8, NCNT = R1_ / 4;
   static_assert(U1 * R1 == VPT && U2 * R2 == VPT && U3 * R3 == VPT, "bad radix plan");
 };
-using Plan512 = Plan<8, 8, 8, 72, 72, 9, 8>;
-using Plan1024 = Plan<16, 8, 8, 72, 72, 9, 8>;
-using Plan2048 = Plan<16, 16, 8, 136, 152, 9, 8>;
-using Plan4096 = Plan<16, 16, 16, 272, 272, 17, 4>;
+// WPL > 1: the line is split over WPL waves (VL = 16 complex registers per lane instead of 32/64), which
+// keeps the kernels under 128 VGPRs (4 waves/SIMD, no spills); the exchanges then need a workgroup barrier.
+using Plan512 = Plan<8, 8, 8, 72, 72, 9, 8, 1>;
+using Plan1024 = Plan<16, 8, 8, 72, 72, 9, 8, 1>;
+using Plan2048 = Plan<16, 16, 8, 136, 152, 9, 16, 2>;
+using Plan4096 = Plan<16, 16, 16, 272, 272, 17, 16, 4>;
 
-// exp(-2 pi i j/64), j = 0..63 (indices are compile-time constants after unrolling)
-__device__ __forceinline__ cf root64(int j) {
-  constexpr float C[64] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 6.123233996e-17f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, -1.836970199e-16f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f};
-  constexpr float S[64] = {-0.000000000e+00f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, -1.224646799e-16f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f, 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f};
-  return make_float2(C[j & 63], S[j & 63]);
-}
+// exp(-2 pi i j/64), j = 0..63
+__device__ const float ROOT64_C[64] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 6.123233996e-17f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, -1.836970199e-16f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f};
+__device__ const float ROOT64_S[64] = {-0.000000000e+00f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, -1.224646799e-16f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f, 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f};
+__device__ __forceinline__ cf root64(int j) { return make_float2(ROOT64_C[j & 63], ROOT64_S[j & 63]); }
 
 template <class P>
 struct Twiddles {
   // Stage-1 twiddle w_L^(n2*k1), n2 = lane + 64u, k1 = 4h + l, factorises into
-  //   w_L^(lane*l) * w_L^(4*lane*h)   (per lane: 3 + (R1/4 - 1) complex registers)
-  //   * w_(L/64)^(u*k1) = root64(...)  (compile-time constant, u > 0 only)
-  // and the stage-2 twiddle w_M1^(b*ka), b = lane % M2, ka = 4h + l, likewise.  Keeping the digit
-  // factors instead of all R-1 products costs one extra complex multiply per element and frees
-  // ~36 VGPRs (the Le = 2048 plan would otherwise spill inside the line loop).
-  cf t1l[3], t1h[P::R1 / 4 > 1 ? P::R1 / 4 - 1 : 1];
-  cf t2l[3], t2h[P::R2 / 4 > 1 ? P::R2 / 4 - 1 : 1];
-
+  //   w_L^(lane*l) * w_L^(4*lane*h)        (per lane: 3 + (R1/4 - 1) complex)
+  //   * w_(L/64)^(u*k1) = root64(...)       (lane independent, u > 0 only)
+  // and the stage-2 twiddle w_M1^(b*ka), b = lane % M2, ka = 4h + l, likewise.  The per-lane digit
+  // factors (PER_LANE complex, float64-accurate, computed on the host) live in a small LDS table
+  // [PER_LANE][64 lanes] shared by all waves of the workgroup and are re-read where they are used:
+  // keeping them (or, worse, all R-1 products, which LICM would otherwise rebuild) in registers pushes
+  // the Le = 2048 kernels over 128 VGPRs and makes them spill inside the line loop.
   static constexpr int N1H = P::R1 / 4 - 1, N2H = P::R2 / 4 - 1;
   static constexpr int PER_LANE = 6 + N1H + N2H;          // table entries per lane
-  // table[lane][PER_LANE] is computed on the host in float64 (fill_table) and cached on the device
-  __device__ __forceinline__ void init(const cf* __restrict__ table, int lane) {
-    const cf* t = table + lane * PER_LANE;
-#pragma unroll
-    for (int l = 0; l < 3; ++l) t1l[l] = t[l];
-#pragma unroll
-    for (int h = 0; h < N1H; ++h) t1h[h] = t[3 + h];
-#pragma unroll
-    for (int l = 0; l < 3; ++l) t2l[l] = t[3 + N1H + l];
-#pragma unroll
-    for (int h = 0; h < N2H; ++h) t2h[h] = t[6 + N1H + h];
+  static constexpr int LDS_ELEMS = PER_LANE * 64;
+  const cf* tab;                                          // LDS, already offset by lane
+
+  __device__ __forceinline__ void init(const cf* __restrict__ gtab, cf* __restrict__ ltab, int lane) {
+    for (int e = threadIdx.x; e < PER_LANE * 64; e += blockDim.x) {
+      const int ln = e / PER_LANE, j = e % PER_LANE;
+      ltab[j * 64 + ln] = gtab[e];
+    }
+    __syncthreads();
+    tab = ltab + lane;
   }
-  static void fill_table(std::vector<cf>& tab) {
-    tab.resize(64 * PER_LANE);
+  static void fill_table(std::vector<cf>& tabv) {
+    tabv.resize(64 * PER_LANE);
     auto unit = [](long e, long period) {
       const double ang = -2.0 * M_PI * (double)(e % period) / (double)period;
       return make_float2((float)cos(ang), (float)sin(ang));
     };
     for (int lane = 0; lane < 64; ++lane) {
-      cf* t = &tab[lane * PER_LANE];
+      cf* t = &tabv[lane * PER_LANE];
       const int b = lane % P::M2;
       for (int l = 1; l < 4; ++l) t[l - 1] = unit(lane * l, P::L);
       for (int h = 1; h <= N1H; ++h) t[3 + h - 1] = unit(4 * lane * h, P::L);
@@ -187,85 +190,84 @@ struct Twiddles {
       for (int h = 1; h <= N2H; ++h) t[6 + N1H + h - 1] = unit(4 * b * h, P::M1);
     }
   }
-  // The digit factors are loop invariant; without this the compiler hoists all R-1 products out of the
-  // line loop (LICM), rebuilding the full tables and spilling them.  An empty asm makes them opaque.
-  __device__ __forceinline__ void touch() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      asm volatile("" : "+v"(t1l[i].x), "+v"(t1l[i].y), "+v"(t2l[i].x), "+v"(t2l[i].y));
-    }
-#pragma unroll
-    for (int i = 0; i < N1H; ++i) asm volatile("" : "+v"(t1h[i].x), "+v"(t1h[i].y));
-#pragma unroll
-    for (int i = 0; i < N2H; ++i) asm volatile("" : "+v"(t2h[i].x), "+v"(t2h[i].y));
-  }
+  __device__ __forceinline__ cf t1l(int l) const { return tab[(l - 1) * 64]; }
+  __device__ __forceinline__ cf t1h(int h) const { return tab[(3 + h - 1) * 64]; }
+  __device__ __forceinline__ cf t2l(int l) const { return tab[(3 + N1H + l - 1) * 64]; }
+  __device__ __forceinline__ cf t2h(int h) const { return tab[(6 + N1H + h - 1) * 64]; }
   template <bool CONJ>
   __device__ __forceinline__ cf apply1(cf v, int u, int k1) const {
     const int h = k1 >> 2, l = k1 & 3;
     cf w;
-    if (h && l) w = cmul(t1h[h - 1], t1l[l - 1]);
-    else if (h) w = t1h[h - 1];
-    else w = t1l[l - 1];
-    if (u != 0) w = cmul(w, root64((u * k1 * (4096 / P::L)) & 63));
+    if (h && l) w = cmul(t1h(h), t1l(l));
+    else if (h) w = t1h(h);
+    else w = t1l(l);
+    if (u != 0) w = cmul(w, root64(u * k1 * (4096 / P::L)));   // u is wave-uniform
     return CONJ ? cmulc(v, w) : cmul(v, w);
   }
   template <bool CONJ>
   __device__ __forceinline__ cf apply2(cf v, int ka) const {
     const int h = ka >> 2, l = ka & 3;
     cf w;
-    if (h && l) w = cmul(t2h[h - 1], t2l[l - 1]);
-    else if (h) w = t2h[h - 1];
-    else w = t2l[l - 1];
+    if (h && l) w = cmul(t2h(h), t2l(l));
+    else if (h) w = t2h(h);
+    else w = t2l(l);
     return CONJ ? cmulc(v, w) : cmul(v, w);
   }
 };
 
-// y = ifft(fft(x) * exp(-2 pi i f s)) for the line held in v (distribution D1 in, D1 out):
-// v[u*R1 + n1] = x[M1*n1 + lane + 64*u].
 template <class P>
-__device__ __forceinline__ void line_shift(cf (&v)[P::VPT], const Twiddles<P>& tw, cf* __restrict__ lds,
-                                           double s, int lane) {
+__device__ __forceinline__ void xbar() {
+  if (P::WPL > 1) __syncthreads();          // all waves of the workgroup run the same line count
+  else __builtin_amdgcn_wave_barrier();
+}
+
+// y = ifft(fft(x) * exp(-2 pi i f s)) for a line distributed over WPL waves (sub = wave % WPL):
+// distribution D1 in and out: v[ul*R1 + n1] = x[M1*n1 + lane + 64*(sub*U1L + ul)].
+template <class P>
+__device__ __forceinline__ void line_shift(cf (&v)[P::VL], const Twiddles<P>& tw, cf* __restrict__ lds,
+                                           double s, int lane, int sub) {
   constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3, M2 = P::M2;
   // ---------------- forward (DIF) ----------------
 #pragma unroll
-  for (int u = 0; u < P::U1; ++u) {
-    Dft<R1, false>::run(&v[u * R1]);
+  for (int ul = 0; ul < P::U1L; ++ul) {
+    const int u = sub * P::U1L + ul;
+    Dft<R1, false>::run(&v[ul * R1]);
 #pragma unroll
-    for (int k1 = 1; k1 < R1; ++k1) v[u * R1 + k1] = tw.template apply1<false>(v[u * R1 + k1], u, k1);
+    for (int k1 = 1; k1 < R1; ++k1) v[ul * R1 + k1] = tw.template apply1<false>(v[ul * R1 + k1], u, k1);
 #pragma unroll
-    for (int k1 = 0; k1 < R1; ++k1) lds[k1 * P::S1 + lane + 64 * u] = v[u * R1 + k1];
+    for (int k1 = 0; k1 < R1; ++k1) lds[k1 * P::S1 + lane + 64 * u] = v[ul * R1 + k1];
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
 #pragma unroll
-  for (int u = 0; u < P::U2; ++u) {
-    const int t = lane + 64 * u, k1 = t / M2, b = t % M2;
+  for (int ul = 0; ul < P::U2L; ++ul) {
+    const int t = lane + 64 * (sub * P::U2L + ul), k1 = t / M2, b = t % M2;
 #pragma unroll
-    for (int a = 0; a < R2; ++a) v[u * R2 + a] = lds[k1 * P::S1 + M2 * a + b];
+    for (int a = 0; a < R2; ++a) v[ul * R2 + a] = lds[k1 * P::S1 + M2 * a + b];
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
 #pragma unroll
-  for (int u = 0; u < P::U2; ++u) {
-    const int t = lane + 64 * u, k1 = t / M2, b = t % M2;
-    Dft<R2, false>::run(&v[u * R2]);
+  for (int ul = 0; ul < P::U2L; ++ul) {
+    const int t = lane + 64 * (sub * P::U2L + ul), k1 = t / M2, b = t % M2;
+    Dft<R2, false>::run(&v[ul * R2]);
 #pragma unroll
-    for (int ka = 1; ka < R2; ++ka) v[u * R2 + ka] = tw.template apply2<false>(v[u * R2 + ka], ka);
+    for (int ka = 1; ka < R2; ++ka) v[ul * R2 + ka] = tw.template apply2<false>(v[ul * R2 + ka], ka);
 #pragma unroll
-    for (int ka = 0; ka < R2; ++ka) lds[k1 * P::T1 + ka * P::T2 + b] = v[u * R2 + ka];
+    for (int ka = 0; ka < R2; ++ka) lds[k1 * P::T1 + ka * P::T2 + b] = v[ul * R2 + ka];
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
 #pragma unroll
-  for (int u = 0; u < P::U3; ++u) {
-    const int w = lane + 64 * u, k1 = w / R2, ka = w % R2;
+  for (int ul = 0; ul < P::U3L; ++ul) {
+    const int w = lane + 64 * (sub * P::U3L + ul), k1 = w / R2, ka = w % R2;
 #pragma unroll
-    for (int b = 0; b < R3; ++b) v[u * R3 + b] = lds[k1 * P::T1 + ka * P::T2 + b];
+    for (int b = 0; b < R3; ++b) v[ul * R3 + b] = lds[k1 * P::T1 + ka * P::T2 + b];
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
   // ---------------- spectrum: phase ramp of the shear, 1/L normalisation ----------------
-  // frequency index of v[u*R3 + kb] is k = k1 + R1*ka + R1*R2*kb with (k1, ka) = divmod(lane + 64u, R2),
+  // frequency index of v[ul*R3 + kb] is k = k1 + R1*ka + R1*R2*kb with (k1, ka) = divmod(lane + 64u, R2),
   // signed (numpy fftfreq order) through kb.  exp(-2 pi i k s/L) = pa0 * z^u * w^kbs with
   //   pa0 = exp(-2 pi i (lane/R2 + R1*(lane%R2)) s/L)   (per lane)
   //   z   = exp(-2 pi i (64/R2) s/L),  w = exp(-2 pi i R1 R2 s/L)   (wave-uniform)
-  // three sincos per line (arguments reduced in float64), the rest are complex multiplies.
+  // a few sincos per line (arguments reduced in float64), the rest are complex multiplies.
   {
     const double sl = s / (double)P::L;
     auto expi = [](double turns) {
@@ -276,7 +278,8 @@ __device__ __forceinline__ void line_shift(cf (&v)[P::VPT], const Twiddles<P>& t
     };
     const cf w = expi((double)(R1 * R2) * sl);
     const cf z = expi((double)(64 / R2) * sl);
-    cf pa = expi((double)(lane / R2 + R1 * (lane % R2)) * sl);
+    const int u0 = sub * P::U3L;
+    cf pa = expi((double)(lane / R2 + (64 / R2) * u0 + R1 * (lane % R2)) * sl);
     pa = make_float2(pa.x * (1.0f / (float)P::L), pa.y * (1.0f / (float)P::L));
     cf pb[R3];                                   // w^kbs, kbs = 0..R3/2-1, -R3/2..-1
     pb[0] = make_float2(1.f, 0.f);
@@ -290,47 +293,49 @@ __device__ __forceinline__ void line_shift(cf (&v)[P::VPT], const Twiddles<P>& t
       pb[R3 / 2] = make_float2(wh.x, -wh.y);
     }
 #pragma unroll
-    for (int u = 0; u < P::U3; ++u) {
-      const int wq = lane + 64 * u, k1 = wq / R2, ka = wq % R2;
-      Dft<R3, false>::run(&v[u * R3]);
+    for (int ul = 0; ul < P::U3L; ++ul) {
+      const int wq = lane + 64 * (u0 + ul), k1 = wq / R2, ka = wq % R2;
+      Dft<R3, false>::run(&v[ul * R3]);
 #pragma unroll
-      for (int kb = 0; kb < R3; ++kb) v[u * R3 + kb] = cmul(v[u * R3 + kb], cmul(pa, pb[kb]));
+      for (int kb = 0; kb < R3; ++kb) v[ul * R3 + kb] = cmul(v[ul * R3 + kb], cmul(pa, pb[kb]));
       // ---------------- inverse (DIT) ----------------
-      Dft<R3, true>::run(&v[u * R3]);
+      Dft<R3, true>::run(&v[ul * R3]);
 #pragma unroll
-      for (int b = 0; b < R3; ++b) lds[k1 * P::T1 + ka * P::T2 + b] = v[u * R3 + b];
+      for (int b = 0; b < R3; ++b) lds[k1 * P::T1 + ka * P::T2 + b] = v[ul * R3 + b];
       pa = cmul(pa, z);
     }
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
 #pragma unroll
-  for (int u = 0; u < P::U2; ++u) {
-    const int t = lane + 64 * u, k1 = t / M2, b = t % M2;
+  for (int ul = 0; ul < P::U2L; ++ul) {
+    const int t = lane + 64 * (sub * P::U2L + ul), k1 = t / M2, b = t % M2;
 #pragma unroll
-    for (int ka = 0; ka < R2; ++ka) v[u * R2 + ka] = lds[k1 * P::T1 + ka * P::T2 + b];
+    for (int ka = 0; ka < R2; ++ka) v[ul * R2 + ka] = lds[k1 * P::T1 + ka * P::T2 + b];
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
 #pragma unroll
-  for (int u = 0; u < P::U2; ++u) {
-    const int t = lane + 64 * u, k1 = t / M2, b = t % M2;
+  for (int ul = 0; ul < P::U2L; ++ul) {
+    const int t = lane + 64 * (sub * P::U2L + ul), k1 = t / M2, b = t % M2;
 #pragma unroll
-    for (int ka = 1; ka < R2; ++ka) v[u * R2 + ka] = tw.template apply2<true>(v[u * R2 + ka], ka);
-    Dft<R2, true>::run(&v[u * R2]);
+    for (int ka = 1; ka < R2; ++ka) v[ul * R2 + ka] = tw.template apply2<true>(v[ul * R2 + ka], ka);
+    Dft<R2, true>::run(&v[ul * R2]);
 #pragma unroll
-    for (int a = 0; a < R2; ++a) lds[k1 * P::S1 + M2 * a + b] = v[u * R2 + a];
+    for (int a = 0; a < R2; ++a) lds[k1 * P::S1 + M2 * a + b] = v[ul * R2 + a];
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
 #pragma unroll
-  for (int u = 0; u < P::U1; ++u) {
+  for (int ul = 0; ul < P::U1L; ++ul) {
+    const int u = sub * P::U1L + ul;
 #pragma unroll
-    for (int k1 = 0; k1 < R1; ++k1) v[u * R1 + k1] = lds[k1 * P::S1 + lane + 64 * u];
+    for (int k1 = 0; k1 < R1; ++k1) v[ul * R1 + k1] = lds[k1 * P::S1 + lane + 64 * u];
   }
-  __builtin_amdgcn_wave_barrier();
+  xbar<P>();
 #pragma unroll
-  for (int u = 0; u < P::U1; ++u) {
+  for (int ul = 0; ul < P::U1L; ++ul) {
+    const int u = sub * P::U1L + ul;
 #pragma unroll
-    for (int k1 = 1; k1 < R1; ++k1) v[u * R1 + k1] = tw.template apply1<true>(v[u * R1 + k1], u, k1);
-    Dft<R1, true>::run(&v[u * R1]);
+    for (int k1 = 1; k1 < R1; ++k1) v[ul * R1 + k1] = tw.template apply1<true>(v[ul * R1 + k1], u, k1);
+    Dft<R1, true>::run(&v[ul * R1]);
   }
 }
 
@@ -343,11 +348,16 @@ __global__ __launch_bounds__(64 * P::WPB) void fft_shear1(const float* __restric
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
-  cf* lds = lds_all + wave * P::LDS_ELEMS;
+  const int sub = wave % P::WPL, slot = wave / P::WPL;
+  cf* lds = lds_all + slot * P::LDS_ELEMS;
   Twiddles<P> tw;
-  tw.init(twtab, lane);
+  tw.init(twtab, lds_all + P::LPB * P::LDS_ELEMS, lane);   // table sits after the line regions
   const int nlines = nf * g.N;
-  for (int line = blockIdx.x * P::WPB + wave; line < nlines; line += gridDim.x * P::WPB) {
+  const int niter = (nlines + gridDim.x * P::LPB - 1) / (gridDim.x * P::LPB);   // uniform trip count
+  for (int it = 0; it < niter; ++it) {
+    int line = (it * gridDim.x + blockIdx.x) * P::LPB + slot;
+    const bool live = line < nlines;
+    if (!live) line = nlines - 1;               // idle slots redo the last line (keeps barriers uniform)
     const int fl = line / g.N, yrel = line % g.N, f = f0 + fl;
     const RotFrame p = fr[f];
     const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
@@ -362,45 +372,48 @@ __global__ __launch_bounds__(64 * P::WPB) void fft_shear1(const float* __restric
       case 3: stride = -g.N; base = (g.Lc - g.off) * g.N + (Y - g.off); break;
       default: stride = 1; base = (Y - g.off) * g.N - g.off; break;
     }
-    cf v[P::VPT];
+    cf v[P::VL];
 #pragma unroll
-    for (int u = 0; u < P::U1; ++u)
+    for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
       for (int n1 = 0; n1 < P::R1; ++n1) {
         float val = 0.f;
         if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {       // compile-time window
-          const int X = P::M1 * n1 + lane + 64 * u;
+          const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
           if (X >= c0 && X < c0 + g.N) {
             const float t = frame[base + X * stride];
             val = (t == t) ? t : 0.f;
           }
         }
-        v[u * P::R1 + n1] = make_float2(val, 0.f);
+        v[ul * P::R1 + n1] = make_float2(val, 0.f);
       }
-    tw.touch();
-    line_shift<P>(v, tw, lds, p.a * (double)(Y - g.c), lane);
-    cf* orow = A1 + ((int64_t)fl * g.N + yrel) * P::L;
+    line_shift<P>(v, tw, lds, p.a * (double)(Y - g.c), lane, sub);
+    if (live) {
+      cf* orow = A1 + ((int64_t)fl * g.N + yrel) * P::L;
 #pragma unroll
-    for (int u = 0; u < P::U1; ++u)
+      for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
-      for (int n1 = 0; n1 < P::R1; ++n1) orow[P::M1 * n1 + lane + 64 * u] = v[u * P::R1 + n1];
+        for (int n1 = 0; n1 < P::R1; ++n1)
+          orow[P::M1 * n1 + lane + 64 * (sub * P::U1L + ul)] = v[ul * P::R1 + n1];
+    }
   }
 }
 
-// ---- shear 2: columns, WPB adjacent columns per workgroup, tiles staged through LDS ----
+// ---- shear 2: columns, LPB adjacent columns per workgroup, tiles staged through LDS ----
 template <class P>
 __global__ __launch_bounds__(64 * P::WPB) void fft_shear2(const cf* __restrict__ A1,
                                                           const RotFrame* __restrict__ fr, RotGeom g,
                                                           cf* __restrict__ A2, int f0, int nf,
                                                           const cf* __restrict__ twtab) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
-  constexpr int W = P::WPB, LDT = W + 1;      // tile row stride (complex): conflict-free column reads
+  constexpr int W = P::LPB, LDT = W + 1;      // tile row stride (complex): conflict-free column reads
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
-  cf* lds = lds_all + wave * P::LDS_ELEMS;
+  const int sub = wave % P::WPL, slot = wave / P::WPL;
+  cf* lds = lds_all + slot * P::LDS_ELEMS;
   cf* tile = lds_all;                          // [N][LDT], aliases the exchange regions between phases
   Twiddles<P> tw;
-  tw.init(twtab, lane);
+  tw.init(twtab, lds_all + P::LPB * P::LDS_ELEMS, lane);   // table sits after the line regions
   const int groups = P::L / W;
   const int units = nf * groups;
   for (int uu = blockIdx.x * 2; uu < units; uu += gridDim.x * 2) {
@@ -411,38 +424,37 @@ __global__ __launch_bounds__(64 * P::WPB) void fft_shear2(const cf* __restrict__
       const RotFrame p = fr[f];
       const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
       const cf* src = A1 + (int64_t)fl * g.N * P::L + X0;
-      for (int e = threadIdx.x; e < g.N * W; e += 64 * W) {
+      for (int e = threadIdx.x; e < g.N * W; e += 64 * P::WPB) {
         const int row = e / W, c = e % W;
         tile[row * LDT + c] = src[(int64_t)row * P::L + c];
       }
       __syncthreads();
-      cf v[P::VPT];
+      cf v[P::VL];
 #pragma unroll
-      for (int u = 0; u < P::U1; ++u)
+      for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
         for (int n1 = 0; n1 < P::R1; ++n1) {
           cf val = make_float2(0.f, 0.f);
           if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {     // compile-time window
-            const int yrel = P::M1 * n1 + lane + 64 * u - r0;
-            if (yrel >= 0 && yrel < g.N) val = tile[yrel * LDT + wave];
+            const int yrel = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul) - r0;
+            if (yrel >= 0 && yrel < g.N) val = tile[yrel * LDT + slot];
           }
-          v[u * P::R1 + n1] = val;
+          v[ul * P::R1 + n1] = val;
         }
       __syncthreads();
-      const int X = X0 + wave;
-      tw.touch();
-      line_shift<P>(v, tw, lds, p.b * (double)(X - g.c), lane);
+      const int X = X0 + slot;
+        line_shift<P>(v, tw, lds, p.b * (double)(X - g.c), lane, sub);
       __syncthreads();
 #pragma unroll
-      for (int u = 0; u < P::U1; ++u)
+      for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
         for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
-          const int m = P::M1 * (n1 - P::NLO) + lane + 64 * u;      // off == M1*NLO
-          tile[m * LDT + wave] = v[u * P::R1 + n1];
+          const int m = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);      // off == M1*NLO
+          tile[m * LDT + slot] = v[ul * P::R1 + n1];
         }
       __syncthreads();
       cf* dst = A2 + (int64_t)fl * g.N * P::L + X0;
-      for (int e = threadIdx.x; e < g.N * W; e += 64 * W) {
+      for (int e = threadIdx.x; e < g.N * W; e += 64 * P::WPB) {
         const int row = e / W, c = e % W;
         dst[(int64_t)row * P::L + c] = tile[row * LDT + c];
       }
@@ -462,34 +474,40 @@ __global__ __launch_bounds__(64 * P::WPB) void fft_shear3(const cf* __restrict__
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
-  cf* lds = lds_all + wave * P::LDS_ELEMS;
+  const int sub = wave % P::WPL, slot = wave / P::WPL;
+  cf* lds = lds_all + slot * P::LDS_ELEMS;
   Twiddles<P> tw;
-  tw.init(twtab, lane);
+  tw.init(twtab, lds_all + P::LPB * P::LDS_ELEMS, lane);   // table sits after the line regions
   const int nlines = nf * g.N;
-  for (int line = blockIdx.x * P::WPB + wave; line < nlines; line += gridDim.x * P::WPB) {
+  const int niter = (nlines + gridDim.x * P::LPB - 1) / (gridDim.x * P::LPB);   // uniform trip count
+  for (int it = 0; it < niter; ++it) {
+    int line = (it * gridDim.x + blockIdx.x) * P::LPB + slot;
+    const bool live = line < nlines;
+    if (!live) line = nlines - 1;
     const int fl = line / g.N, m = line % g.N, f = f0 + fl;
     const RotFrame p = fr[f];
     const int Y = g.off + m;
     const cf* irow = A2 + ((int64_t)fl * g.N + m) * P::L;
-    cf v[P::VPT];
+    cf v[P::VL];
 #pragma unroll
-    for (int u = 0; u < P::U1; ++u)
+    for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
-      for (int n1 = 0; n1 < P::R1; ++n1) v[u * P::R1 + n1] = irow[P::M1 * n1 + lane + 64 * u];
-    tw.touch();
-    line_shift<P>(v, tw, lds, p.a * (double)(Y - g.c), lane);
-    const int64_t obase = ((int64_t)f * g.N + m) * g.N;
+      for (int n1 = 0; n1 < P::R1; ++n1) v[ul * P::R1 + n1] = irow[P::M1 * n1 + lane + 64 * (sub * P::U1L + ul)];
+    line_shift<P>(v, tw, lds, p.a * (double)(Y - g.c), lane, sub);
+    if (live) {
+      const int64_t obase = ((int64_t)f * g.N + m) * g.N;
 #pragma unroll
-    for (int u = 0; u < P::U1; ++u)
+      for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
-      for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
-        const int j = P::M1 * (n1 - P::NLO) + lane + 64 * u;        // off == M1*NLO
-        float re = v[u * P::R1 + n1].x;
-        const float src = in[obase + j];
-        if (mask_nan && !(src == src)) re = __uint_as_float(0x7fc00000u);
-        if (mask_zero && src == 0.f) re = 0.f;
-        out[obase + j] = re;
-      }
+        for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
+          const int j = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);        // off == M1*NLO
+          float re = v[ul * P::R1 + n1].x;
+          const float src = in[obase + j];
+          if (mask_nan && !(src == src)) re = __uint_as_float(0x7fc00000u);
+          if (mask_zero && src == 0.f) re = 0.f;
+          out[obase + j] = re;
+        }
+    }
   }
 }
 
@@ -507,9 +525,10 @@ int run_plan(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const Ro
   cf *A1 = nullptr, *A2 = nullptr;
   VIPMI_TRY(ws(ctx, "rot_a1", (size_t)(chunk * per_frame), &A1));
   VIPMI_TRY(ws(ctx, "rot_a2", (size_t)(chunk * per_frame), &A2));
-  size_t lds = (size_t)P::WPB * P::LDS_ELEMS * sizeof(cf);
-  const size_t tile = (size_t)g.N * (P::WPB + 1) * sizeof(cf);
-  if (tile > lds) lds = tile;
+  size_t lds = (size_t)P::LPB * P::LDS_ELEMS * sizeof(cf);
+  const size_t tile = (size_t)g.N * (P::LPB + 1) * sizeof(cf);
+  VIPMI_REQUIRE(tile <= lds, "derotate(fft): staging tile larger than the exchange regions");
+  lds += (size_t)Twiddles<P>::LDS_ELEMS * sizeof(cf);
   VIPMI_REQUIRE(lds <= 160 * 1024, "derotate(fft): LDS budget exceeded (%zu)", lds);
   cf* twtab = nullptr;
   {
@@ -532,9 +551,9 @@ int run_plan(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const Ro
   for (int64_t f0 = 0; f0 < n; f0 += chunk) {
     const int nf = (int)((n - f0) < chunk ? (n - f0) : chunk);
     const int64_t nlines = (int64_t)nf * g.N;
-    int gr = (int)cdiv(nlines, P::WPB);
+    int gr = (int)cdiv(nlines, P::LPB);
     if (gr > maxwg) gr = maxwg;
-    const int64_t units = (int64_t)nf * (P::L / P::WPB);
+    const int64_t units = (int64_t)nf * (P::L / P::LPB);
     int gc = (int)cdiv(units, 2);
     if (gc > maxwg) gc = maxwg;
     ctx->tic("k_rot_s1");
