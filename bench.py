@@ -61,6 +61,24 @@ def cpu_baseline(n, N, k, budget_frames=4):
             "ms_per_svd": 1e3 * t_svd}
 
 
+def pmc_traffic(frames_per_launch, N):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of the same
+    workload and corrected as MI355X_MICROARCH.md prescribes); scaled per frame.  None if absent / other size."""
+    import glob
+    if N != 512:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        per100 = doc["fft_shear2_traffic_bytes_per_launch_100_frames"]
+        return per100 * frames_per_launch / 100.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +163,8 @@ def main():
             L = 4 * N
             real_bytes = 2.0 * frames_per_launch * N * L * 8      # what this kernel actually moves (A1 in, A2 out)
             roof = {"bound": "hbm", "kernel": "fft_shear2", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(frames_per_launch, N),
                     "avg_launch_ms": dur_ms, "frames_per_launch": frames_per_launch,
                     "intermediate_GBps": real_bytes / (dur_ms * 1e-3) / 1e9,
                     "note": "VALU/LDS-bound FFT kernel; see DESIGN.md for the flop-based fraction"}
