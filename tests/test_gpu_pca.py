@@ -136,3 +136,31 @@ def test_pca_vs_oracle_noise_and_structured(seed):
     assert np.abs(out[0] - ref[0]).max() < TOL
     assert np.abs(out[3] - ref[3]).max() < TOL
     assert np.abs(out[4] - ref[4]).max() < TOL
+
+
+@pytest.mark.parametrize("tag,kw", [("a", dict(asize=8, ncomp=3, fwhm=4, delta_rot=(0.1, 1))),
+                                    ("b", dict(asize=8, ncomp=2, fwhm=4, delta_rot=0.5, radius_int=4, max_frames_lib=12)),
+                                    ("c", dict(asize=10, ncomp=(1, 2, 3), fwhm=4, delta_rot=(0.1, 1), n_segments=2))])
+def test_pca_annular_golden(tag, kw):
+    from vip_amd.psfsub import pca_annular
+    g = load_golden("g6_pca_annular")
+    cube_out, cube_der, frame = pca_annular(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    assert cube_out.shape == g["cube"].shape and cube_out.dtype == np.float32
+    assert np.abs(cube_out - g[tag + "_cube_out"]).max() < TOL
+    assert np.abs(frame - g[tag + "_frame"]).max() < TOL
+    fr = pca_annular(g["cube"], g["angles"], verbose=False, **kw)
+    assert np.abs(fr - g[tag + "_frame"]).max() < TOL
+
+
+def test_pca_annular_scaling_and_errors():
+    from vip_amd.psfsub import pca_annular
+    cube, ang = O.synth_adi(20, 48, seed=4)
+    for sc in ("temp-mean", "spat-standard"):
+        got = pca_annular(cube, ang, asize=6, ncomp=2, fwhm=4, delta_rot=0.3, scaling=sc, verbose=False, full_output=True)
+        ref = O.pca_annular(cube, ang, asize=6, ncomp=2, fwhm=4, delta_rot=0.3, scaling=sc, full_output=True)
+        assert np.abs(got[0] - ref[0]).max() < TOL, sc
+        assert np.abs(got[2] - ref[2]).max() < TOL, sc
+    with pytest.raises(RuntimeError):
+        pca_annular(cube, np.linspace(0, 1, 20), asize=6, ncomp=2, fwhm=4, delta_rot=5.0, verbose=False)
+    with pytest.raises(TypeError):
+        pca_annular(cube, ang[:-1], asize=6, ncomp=2, verbose=False)

@@ -1,13 +1,99 @@
-// annular.hip -- per-frame library PCA of one annulus segment (psfsub/pca_local.py:830-909).
+// annular.hip -- per-frame library PCA of one annulus segment: the reference's
+// `do_pca_patch` (psfsub/pca_local.py:830-909) for all n frames of a segment matrix at once.
+//
+// Reference: for every frame j, library rows lib_j = `_find_indices_adi(...)` of the segment matrix
+// A (n x npx); V = top-k right singular vectors of A[lib_j]; residual_j = A[j] - (A[j] V^T) V.
+// That is n thin SVDs per segment.  Sub-Gram identity: with G = A A^T,
+//   H_j = G[lib_j, lib_j] = E L E^T      (m x m, m <= max_frames_lib)
+//   c_j = E_k L_k^-1 E_k^T G[lib_j, j]   (coefficients of the library frames)
+//   residual_j = A[j] - sum_i c_j[i] A[lib_j[i]]
+// so ONE Gram per segment (matrix cores), n small eigenproblems solved by the batched block-Jacobi
+// kernel, and one dense n x n x npx projection GEMM (matrix cores) reproduce the n SVDs exactly.
 #include "common.h"
 
 namespace vipmi {
 
+namespace {
+
+// H[j][a][b] = G[idx[j][a]][idx[j][b]] for a,b < len[j], 0 elsewhere (zero padding only adds null
+// eigenvalues, sorted last)
+__global__ void subgram_kernel(const double* __restrict__ G, int n, const int32_t* __restrict__ idx,
+                               const int32_t* __restrict__ len, int max_lib, int m, double* __restrict__ H) {
+  const int j = blockIdx.x;
+  const int lj = len[j];
+  const int32_t* ij = idx + (size_t)j * max_lib;
+  double* Hj = H + (size_t)j * m * m;
+  for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+    const int a = e / m, b = e % m;
+    double v = 0.0;
+    if (a < lj && b < lj) v = G[(size_t)ij[a] * n + ij[b]];
+    Hj[e] = v;
+  }
+}
+
+// one workgroup per frame j: C[j][lib_j[a]] = sum_{c<k'} E[c][a] * (E[c] . g_j) / lambda_c
+__global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G, int n,
+                                                    const int32_t* __restrict__ idx,
+                                                    const int32_t* __restrict__ len, int max_lib, int m,
+                                                    const double* __restrict__ evals,
+                                                    const double* __restrict__ evecs, int k, int npx,
+                                                    float* __restrict__ C) {
+  extern __shared__ double sh[];      // g[m] | proj[k]
+  double* g = sh;
+  double* proj = sh + m;
+  const int j = blockIdx.x;
+  const int lj = len[j];
+  const int32_t* ij = idx + (size_t)j * max_lib;
+  const double* ev = evals + (size_t)j * m;
+  const double* E = evecs + (size_t)j * m * m;
+  int kk = k < lj ? k : lj;                    // get_eigenvectors: min(ncomp, min(shape)), svd.py:696
+  if (kk > npx) kk = npx;
+  for (int a = threadIdx.x; a < m; a += blockDim.x) g[a] = (a < lj) ? G[(size_t)ij[a] * n + j] : 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const double thr = ev[0] * 1e-12;
+  for (int c = wave; c < kk; c += nw) {
+    double s = 0;
+    for (int a = lane; a < lj; a += 64) s += E[(size_t)c * m + a] * g[a];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) proj[c] = (ev[c] > thr && ev[c] > 0) ? s / ev[c] : 0.0;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < lj; a += blockDim.x) {
+    double s = 0;
+    for (int c = 0; c < kk; ++c) s += E[(size_t)c * m + a] * proj[c];
+    C[(size_t)j * n + ij[a]] = (float)s;
+  }
+}
+
+}  // namespace
+
 int annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                           const int32_t* lib_len, int64_t max_lib, int64_t ncomp, float* residuals) {
-  (void)ctx; (void)A; (void)n; (void)npx; (void)lib_idx; (void)lib_len; (void)max_lib; (void)ncomp; (void)residuals;
-  set_error("annular_residuals: not implemented yet");
-  return VIPMI_ERR_UNSUPPORTED;
+  VIPMI_REQUIRE(A && lib_idx && lib_len && residuals, "annular_residuals: null pointer");
+  VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && ncomp > 0, "annular_residuals: bad sizes");
+  VIPMI_REQUIRE(max_lib <= n, "annular_residuals: max_lib > n");
+  const int m = (int)max_lib;
+  double *G = nullptr, *H = nullptr, *evals = nullptr, *evecs = nullptr;
+  float* C = nullptr;
+  VIPMI_TRY(ws(ctx, "ann_G", (size_t)n * n, &G));
+  VIPMI_TRY(ws(ctx, "ann_H", (size_t)n * m * m, &H));
+  VIPMI_TRY(ws(ctx, "ann_evals", (size_t)n * m, &evals));
+  VIPMI_TRY(ws(ctx, "ann_evecs", (size_t)n * m * m, &evecs));
+  VIPMI_TRY(ws(ctx, "ann_C", (size_t)n * n, &C));
+  VIPMI_TRY(gram_f32(ctx, A, n, A, n, npx, npx, G));
+  hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, G, (int)n, lib_idx, lib_len,
+                     (int)max_lib, m, H);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  VIPMI_TRY(eigh_f64(ctx, H, n, m, evals, evecs));
+  VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
+  const size_t shm = (size_t)(m + ncomp + 8) * sizeof(double);
+  hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
+                     (int)max_lib, m, evals, evecs, (int)ncomp, (int)npx, C);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  // residuals = A - C * A   (projection GEMM on the matrix cores: "components" are the n frames)
+  return subtract_gemm_f32(ctx, A, C, A, n, n, npx, residuals, nullptr);
 }
 
 }  // namespace vipmi

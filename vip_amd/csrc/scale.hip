@@ -102,7 +102,8 @@ __global__ void gather_kernel(const float* __restrict__ cube, int64_t n, int64_t
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = e / npx, j = e % npx;
-    A[e] = cube[f * P + pix[j]];
+    const int32_t p = pix[j];                 // negative = padding column (npx rounded up to 4)
+    A[e] = (p >= 0) ? cube[f * P + p] : 0.f;
   }
 }
 
@@ -112,7 +113,8 @@ __global__ void scatter_kernel(const float* __restrict__ A, int64_t n, int64_t P
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = e / npx, j = e % npx;
-    cube[f * P + pix[j]] = A[e];
+    const int32_t p = pix[j];
+    if (p >= 0) cube[f * P + p] = A[e];
   }
 }
 

@@ -155,7 +155,12 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     scaling = _s(scaling)
     lib_cache = {}
     for seg in plan:
-        pix = torch.from_numpy(seg["pix"]).to(cube.device)
+        pix_h = seg["pix"]
+        # pad to a multiple of 4 columns (-1 = zero column) so rows are 16-byte aligned; zero columns change
+        # neither the Gram matrix nor temporal statistics (spatial scaling needs the exact row length)
+        if pix_h.size % 4 and scaling not in ("spat-mean", "spat-standard"):
+            pix_h = np.concatenate([pix_h, np.full(4 - pix_h.size % 4, -1, dtype=np.int32)])
+        pix = torch.from_numpy(pix_h).to(cube.device)
         npx = int(pix.numel())
         A = B.empty((n, npx), device=dev)
         ctx.call("vipmi_gather_f32", B.ptr(cube), n, P, B.ptr(pix), npx, B.ptr(A))
