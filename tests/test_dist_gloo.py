@@ -1,0 +1,103 @@
+"""CPU, world_size 2, gloo: the sharding / gather logic of vip_amd.dist with the oracle as the per-unit
+compute stand-in (the device kernels need a GPU; the distributed plumbing does not)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vip_amd import dist as D
+        from vip_amd.psfsub.pca_local import annulus_plan
+        res = {}
+        # --- sharding helpers
+        res["rr"] = D.shard_round_robin(39)
+        res["bal"] = D.shard_balanced([3205, 9644, 16064, 22516, 28940, 35408, 41804, 48028])
+        # --- survey mode: 5 cubes over 2 ranks
+        cubes, angs = zip(*[O.synth_adi(8, 24, seed=s) for s in range(5)])
+        calls = []
+
+        def comp(c, a, **kw):
+            calls.append(1)
+            return O.pca_fullframe(c, a, **kw)
+        frames = D.pca_cubes(list(cubes), list(angs), compute=comp, ncomp=2)
+        res["frames"] = frames.numpy()
+        res["ncalls"] = len(calls)
+        # --- 4-D: 3 channels over 2 ranks
+        c4 = np.stack([O.synth_adi(8, 24, seed=10 + i)[0] for i in range(3)])
+        a4 = np.linspace(0, 70, 8)
+        frame, ifs = D.pca_4d(c4, a4, ncomp=2, compute=lambda c, a, ncomp: O.pca_fullframe(c, a, ncomp=ncomp),
+                              collapse=O.cube_collapse)
+        res["frame4d"], res["ifs"] = frame, ifs
+        # --- annular: segments over 2 ranks
+        cube, ang = O.synth_adi(12, 32, seed=3)
+        angc = O.check_pa_vector(ang)
+        plan = annulus_plan((32, 32), angc, 0, 4, 5, 1, (0.1, 1), 2, 2, 200)
+
+        def resid(seg):
+            yy, xx = np.divmod(seg["pix"], 32)
+            m = cube[:, yy, xx]
+            out = np.zeros_like(m)
+            for fr in range(12):
+                lib = m[seg["libs"][fr]]
+                V = O.svd_wrapper(lib, "lapack", min(seg["ncomp"], min(lib.shape)))
+                out[fr] = m[fr] - (m[fr] @ V.T) @ V
+            return out
+        res["cube_out"] = D.pca_annular_residuals(cube, angc, plan, resid).numpy()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = out[0], out[1]
+    # disjoint cover
+    assert sorted(r0["rr"] + r1["rr"]) == list(range(39)) and r0["rr"][:3] == [0, 2, 4]
+    assert sorted(r0["bal"] + r1["bal"]) == list(range(8))
+    w = np.array([3205, 9644, 16064, 22516, 28940, 35408, 41804, 48028])
+    assert abs(w[r0["bal"]].sum() - w[r1["bal"]].sum()) <= w.max() * 0.2
+    # each rank computed only its share, both hold the full result, identical to the serial computation
+    assert r0["ncalls"] == 3 and r1["ncalls"] == 2
+    cubes, angs = zip(*[O.synth_adi(8, 24, seed=s) for s in range(5)])
+    serial = np.stack([O.pca_fullframe(c, a, ncomp=2) for c, a in zip(cubes, angs)])
+    for r in (r0, r1):
+        assert np.array_equal(r["frames"], serial)
+    c4 = np.stack([O.synth_adi(8, 24, seed=10 + i)[0] for i in range(3)])
+    a4 = np.linspace(0, 70, 8)
+    f4 = O.pca_4d(c4, a4, ncomp=2, full_output=True)
+    for r in (r0, r1):
+        assert np.allclose(r["frame4d"], f4[0], atol=1e-6)
+        assert np.allclose(r["ifs"], f4[5], atol=1e-6)
+    cube, ang = O.synth_adi(12, 32, seed=3)
+    co = O.pca_annular(cube, ang, asize=5, ncomp=2, fwhm=4, delta_rot=(0.1, 1), full_output=True)[0]
+    for r in (r0, r1):
+        assert np.abs(r["cube_out"] - co).max() < 1e-5
