@@ -49,6 +49,9 @@ int vipmi_create(int device, void* stream, vipmi_ctx** out);
 int vipmi_destroy(vipmi_ctx* ctx);
 int vipmi_set_stream(vipmi_ctx* ctx, void* stream);
 int vipmi_synchronize(vipmi_ctx* ctx);
+/* With option "eigh_check"=0 calls never synchronise; convergence failures are latched on the device.
+ * vipmi_check_deferred synchronises the stream and returns VIPMI_ERR_NOCONV if any occurred since the last check. */
+int vipmi_check_deferred(vipmi_ctx* ctx);
 /* tuning knobs (key/value); see DESIGN.md.  Unknown key -> VIPMI_ERR_ARG. */
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value);
 int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key);   /* -1 if unset */

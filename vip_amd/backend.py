@@ -74,14 +74,43 @@ class Context:
             pass
 
 
+_async = {"on": False, "reserve_cus": 0}
+
+
+def set_async(on=True, reserve_cus=16):
+    """Asynchronous (pipelined) mode: calls enqueue all work on the current torch stream and never
+    synchronise (the eigensolver's convergence check is latched on the device and read by
+    ``check_deferred()``).  Each (device, stream) pair gets its own vipmi_ctx / workspace, so independent
+    calls issued on two streams overlap: the latency-bound Jacobi eigensolver of one cube (13 workgroups)
+    runs beside the FFT derotation of the previous one, for which ``reserve_cus`` CUs are left free."""
+    _async["on"] = bool(on)
+    _async["reserve_cus"] = int(reserve_cus) if on else 0
+    with _ctx_lock:
+        for c in _ctx_cache.values():
+            c.set_option("eigh_check", 0 if on else 1)
+            c.set_option("reserve_cus", _async["reserve_cus"])
+
+
+def check_deferred():
+    """Synchronise every context and raise if a deferred error (eigensolver non-convergence) was latched."""
+    with _ctx_lock:
+        ctxs = list(_ctx_cache.values())
+    for c in ctxs:
+        _lib.raise_for_status(c.lib.vipmi_check_deferred(c.handle), "vipmi_check_deferred")
+
+
 def get_context(device=None):
     torch = require_gpu()
     dev = torch.cuda.current_device() if device is None else int(device)
+    key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
     with _ctx_lock:
-        c = _ctx_cache.get(dev)
+        c = _ctx_cache.get(key)
         if c is None:
             c = Context(dev)
-            _ctx_cache[dev] = c
+            if _async["on"]:
+                c.set_option("eigh_check", 0)
+                c.set_option("reserve_cus", _async["reserve_cus"])
+            _ctx_cache[key] = c
         return c
 
 

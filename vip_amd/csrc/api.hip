@@ -76,6 +76,39 @@ int vipmi_ctx::upload_cached(const char* name, const std::string& key, const voi
   return VIPMI_OK;
 }
 
+int vipmi_ctx::upload_async(const char* name, const void* host, size_t bytes, void* dst) {
+  auto& ring = pinned[name];
+  if (ring.empty()) ring.resize(4);
+  PinnedSlot& sl = ring[pinned_next[name]++ % ring.size()];
+  if (sl.ev) {
+    hipError_t e = hipEventSynchronize(sl.ev);
+    if (e != hipSuccess) {
+      set_error("upload_async: %s", hipGetErrorString(e));
+      return VIPMI_ERR_HIP;
+    }
+  } else if (hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) {
+    set_error("upload_async: event creation failed");
+    return VIPMI_ERR_HIP;
+  }
+  if (sl.bytes < bytes) {
+    if (sl.host) (void)hipHostFree(sl.host);
+    sl.host = nullptr;
+    if (hipHostMalloc(&sl.host, bytes + bytes / 4 + 64, hipHostMallocDefault) != hipSuccess) {
+      set_error("upload_async: hipHostMalloc(%zu) failed", bytes);
+      return VIPMI_ERR_NOMEM;
+    }
+    sl.bytes = bytes + bytes / 4 + 64;
+  }
+  memcpy(sl.host, host, bytes);
+  hipError_t e = hipMemcpyAsync(dst, sl.host, bytes, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipEventRecord(sl.ev, stream);
+  if (e != hipSuccess) {
+    set_error("upload_async '%s': %s", name, hipGetErrorString(e));
+    return VIPMI_ERR_HIP;
+  }
+  return VIPMI_OK;
+}
+
 void vipmi_ctx::tic(const char* stage) {
   if (!timing) return;
   StageTimer& t = timers[stage];
@@ -131,6 +164,11 @@ int vipmi_destroy(vipmi_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->buffers)
     if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  for (auto& kv : ctx->pinned)
+    for (auto& sl : kv.second) {
+      if (sl.ev) (void)hipEventDestroy(sl.ev);
+      if (sl.host) (void)hipHostFree(sl.host);
+    }
   for (auto& kv : ctx->timers)
     for (auto& pr : kv.second.ev) {
       (void)hipEventDestroy(pr.first);
@@ -155,7 +193,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_variant", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_variant", "reserve_cus", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
@@ -195,6 +233,24 @@ int vipmi_reset_timers(vipmi_ctx* ctx) {
   for (auto& kv : ctx->timers) {
     kv.second.used = 0;
     kv.second.open = false;
+  }
+  return VIPMI_OK;
+}
+
+// Deferred error check for asynchronous use (option "eigh_check"=0): synchronises the stream and reports
+// whether any eigensolve since the last check failed to converge.
+int vipmi_check_deferred(vipmi_ctx* ctx) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  VIPMI_CHECK_HIP(hipSetDevice(ctx->device));
+  auto it = ctx->buffers.find("deferred_fail");
+  VIPMI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (it == ctx->buffers.end() || !it->second.ptr) return VIPMI_OK;
+  int h = 0;
+  VIPMI_CHECK_HIP(hipMemcpy(&h, it->second.ptr, sizeof(int), hipMemcpyDeviceToHost));
+  if (h != 0) {
+    VIPMI_CHECK_HIP(hipMemset(it->second.ptr, 0, sizeof(int)));
+    set_error("eigh: %d eigenproblem(s) did not converge", h);
+    return VIPMI_ERR_NOCONV;
   }
   return VIPMI_OK;
 }

@@ -58,6 +58,13 @@ struct vipmi_ctx {
   std::map<std::string, vipmi::StageTimer> timers;
   std::map<std::string, int64_t> options;
   std::map<std::string, std::string> upload_keys;
+  struct PinnedSlot {
+    void* host = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+  };
+  std::map<std::string, std::vector<PinnedSlot>> pinned;   // small rings of pinned staging buffers
+  std::map<std::string, int> pinned_next;
   int num_cu = 256;
   bool timing = false;
 
@@ -66,6 +73,9 @@ struct vipmi_ctx {
   // device copy of a small host table, re-uploaded only when `key` changes (synchronous upload)
   int upload_cached(const char* name, const std::string& key, const void* host, size_t bytes,
                     void** out);
+  // asynchronous H2D of a small host table through a ring of pinned staging buffers (never blocks the
+  // host unless the ring wraps onto a copy that is still in flight)
+  int upload_async(const char* name, const void* host, size_t bytes, void* dst);
   int64_t opt(const char* key, int64_t dflt) const {
     auto it = options.find(key);
     return it == options.end() ? dflt : it->second;

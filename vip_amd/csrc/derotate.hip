@@ -235,8 +235,7 @@ int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int
   for (int64_t i = 0; i < n; ++i) h[i] = rot_frame(-angles_host[i]);   // cube_derotate: -angle_list[i]
   RotFrame* d_frames = nullptr;
   VIPMI_TRY(ws(ctx, "rot_frames", (size_t)n, &d_frames));
-  VIPMI_CHECK_HIP(hipMemcpyAsync(d_frames, h.data(), sizeof(RotFrame) * n, hipMemcpyHostToDevice, ctx->stream));
-  VIPMI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  VIPMI_TRY(ctx->upload_async("rot_frames", h.data(), sizeof(RotFrame) * n, d_frames));
   bool use_fft = derotate_fft_supported(g);
   if (method == VIPMI_ROT_DIRECT) use_fft = false;
   if (method == VIPMI_ROT_FFT && !use_fft) {

@@ -547,7 +547,11 @@ int run_plan(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const Ro
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int wgs_per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-  const int maxwg = ctx->num_cu * wgs_per_cu;
+  // "reserve_cus": leave some CUs to a concurrently running latency-bound kernel of another stream
+  // (the 13-workgroup Jacobi eigensolver of the next cube when calls are pipelined over two streams)
+  int usable_cu = ctx->num_cu - (int)ctx->opt("reserve_cus", 0);
+  if (usable_cu < 1) usable_cu = 1;
+  const int maxwg = usable_cu * wgs_per_cu;
   for (int64_t f0 = 0; f0 < n; f0 += chunk) {
     const int nf = (int)((n - f0) < chunk ? (n - f0) : chunk);
     const int64_t nlines = (int64_t)nf * g.N;

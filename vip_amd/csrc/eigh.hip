@@ -130,7 +130,8 @@ template <int B, int RPL>
 __global__ __launch_bounds__(64 * B) void jacobi_kernel(
     double* __restrict__ Gall, int n, int nblk, int max_sweeps, double tol, unsigned* __restrict__ bars,
     unsigned* __restrict__ conv, int* __restrict__ info, double* __restrict__ evals_all,
-    double* __restrict__ evecs_all, double* __restrict__ norms_all, int prob0) {
+    double* __restrict__ evecs_all, double* __restrict__ norms_all, int prob0,
+    int* __restrict__ fail) {
   extern __shared__ __attribute__((aligned(16))) double lds[];   // B columns x ldn
   const int prob = prob0 + blockIdx.y;
   const int g = blockIdx.x, nwg = gridDim.x;
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
       if (i < n) evecs[(size_t)cnt * n + i] = mine[r] * sc;
     }
   }
-  if (g == 0 && threadIdx.x == 0) info[prob] = sweeps_done;
+  if (g == 0 && threadIdx.x == 0) {
+    info[prob] = sweeps_done;
+    if (sweeps_done < 0) atomicAdd(fail, 1);   // sticky: read by vipmi_check_deferred
+  }
 }
 
 template <int B, int RPL>
@@ -353,13 +357,19 @@ int launch_jacobi(vipmi_ctx* ctx, double* G, int64_t batch, int n, double* evals
   VIPMI_TRY(ws(ctx, "eigh_conv", (size_t)batch * max_sweeps, &conv));
   VIPMI_TRY(ws(ctx, "eigh_info", (size_t)batch, &info));
   VIPMI_TRY(ws(ctx, "eigh_norms", (size_t)batch * nblk * B, &norms));
+  int* fail = nullptr;
+  {
+    const bool fresh = ctx->buffers.find("deferred_fail") == ctx->buffers.end();
+    VIPMI_TRY(ws(ctx, "deferred_fail", 4, &fail));
+    if (fresh) VIPMI_CHECK_HIP(hipMemsetAsync(fail, 0, 4 * sizeof(int), ctx->stream));
+  }
   VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch, ctx->stream));
   VIPMI_CHECK_HIP(hipMemsetAsync(conv, 0, sizeof(unsigned) * batch * max_sweeps, ctx->stream));
   VIPMI_CHECK_HIP(hipMemsetAsync(info, 0xff, sizeof(int) * batch, ctx->stream));
   for (int64_t p0 = 0; p0 < batch; p0 += chunk) {
     int64_t nb = batch - p0 < chunk ? batch - p0 : chunk;
     hipLaunchKernelGGL(kern, dim3(nwg, (unsigned)nb), dim3(64 * B), lds_bytes, ctx->stream, G, n, nblk,
-                       max_sweeps, tol, bars, conv, info, evals, evecs, norms, (int)p0);
+                       max_sweeps, tol, bars, conv, info, evals, evecs, norms, (int)p0, fail);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   if (ctx->opt("eigh_check", 1)) {

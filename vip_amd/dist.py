@@ -8,7 +8,7 @@ the data path; the only communication is the final gather of the small per-unit 
 
 Every function takes the per-unit compute callable as an argument (default: the device implementation
 of `vip_amd.psfsub`), which is what lets the world_size-2 gloo tests exercise the sharding / gather
-logic on CPU with the oracle as the compute stand-in.
+logic on CPU with a numpy stand-in for the device kernels.
 """
 import numpy as np
 
