@@ -302,3 +302,25 @@ def test_derotate_fft_1024_delta(B):
     ref = O.cube_derotate(sm, np.array([12.5]))
     got = cube_derotate(sm, np.array([12.5]), method="fft")
     assert np.abs(got - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("N", [128, 256, 512])
+def test_derotate_fft_variants_agree(B, N):
+    """real-split two-for-one transforms (default) vs the complex-field formulation vs the oracle."""
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(N + 1)
+    angles = np.array([7.0, -47.5, 95.0, 200.1, 333.3, 135.0])
+    n = len(angles) if N < 512 else 3
+    cube = (rng.standard_normal((n, N, N)) * 3).astype(np.float32)
+    ctx = B.get_context()
+    outs = {}
+    for variant in (0, 1):
+        ctx.set_option("rot_variant", variant)
+        try:
+            outs[variant] = cube_derotate(cube, angles[:n], method="fft")
+        finally:
+            ctx.set_option("rot_variant", 0)
+    ref = O.cube_derotate(cube, angles[:n])
+    assert np.abs(outs[0] - ref).max() < 5e-5
+    assert np.abs(outs[1] - ref).max() < 5e-5
+    assert np.abs(outs[0] - outs[1]).max() < 5e-5

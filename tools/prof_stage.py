@@ -14,6 +14,9 @@ cube, ang = synth_adi(n, N, seed=0, planet=False)
 ct = torch.from_numpy(cube).cuda()
 ctx = B.get_context()
 ctx.set_option("timing", 1)
+for kv in os.environ.get("VIPMI_OPTS", "").split(","):
+    if "=" in kv:
+        k_, v_ = kv.split("="); ctx.set_option(k_, int(v_))
 for r in range(reps):
     ctx.reset_timers()
     if what == "derotate":

@@ -182,6 +182,8 @@ int derotate_direct(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, c
 int derotate_fft(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
                  float* out, int mask_nan, int mask_zero);   // derotate_fft.hip
 bool derotate_fft_supported(const RotGeom& g);
+int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
+                  float* out, int mask_nan, int mask_zero);  // derotate_fft2.hip (real-split, default)
 
 // host-side geometry / angle split (derotation.py:154-158, cosmetics.py:210-215, derotation.py:577-602)
 static void rot_geometry(int N, RotGeom& g) {
@@ -242,7 +244,11 @@ int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int
     set_error("derotate: FFT path needs a power-of-two padded length (frame size 128/256/512/1024), got Le=%d", g.Le);
     return VIPMI_ERR_UNSUPPORTED;
   }
-  if (use_fft) return derotate_fft(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+  if (use_fft) {
+    // rot_variant: 0 = real-split two-for-one transforms (default), 1 = complex field as the reference carries it
+    if (ctx->opt("rot_variant", 0) == 1) return derotate_fft(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    return derotate_fft2(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+  }
   return derotate_direct(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
 }
 

@@ -1,0 +1,504 @@
+// derotate_fft2.hip -- "real-split" FFT derotation: the default fast path for power-of-two padded lengths.
+//
+// The reference carries a COMPLEX field through its three shears (preproc/derotation.py:611-620) although the
+// image is real: the only source of an imaginary part is the Nyquist bin, whose phase exp(i pi s) is not +-1.
+// For a real line x the shift S_s x = ifft(fft(x) exp(-2 pi i f s)) splits exactly into
+//     S_s x = R_s x  +  i * n_s(x),      n_s(x)[m] = sin(pi s) * alt(x)/Le * (-1)^m,   alt(x) = sum_j (-1)^j x[j]
+// with R_s the REAL shift (Nyquist phase replaced by cos(pi s)).  Pushing this through the three shears
+// (linearity) leaves three passes of real shifts plus rank-one corrections:
+//   shear 1:  A1r[Y,:] = R_{a(Y-c)} x_Y                    beta_Y  = sin(pi s) alt(x_Y)/Le
+//   shear 2:  A2r[:,X] = R_{b(X-c)} A1r[:,X] - sin(pi s_X) (-1)^X Bf/Le (-1)^Y ,   Bf = sum_Y (-1)^Y beta_Y
+//             gamma_X  = sin(pi s_X) alt(A1r[:,X])/Le ,     Gam = sum_X (-1)^X gamma_X
+//   shear 3:  out[Y,:] = R_{a(Y-c)} A2r[Y,:] - sin(pi s_Y)/Le (K[Y] + Gam (-1)^Y) (-1)^m
+//             K[Y] = sum_X (R_{b(X-c)} beta)[Y] = ifft( fft(beta) g )[Y],  g(k) = sum_X exp(-2 pi i f_k b (X-c))
+//                                                                               (closed form: a Dirichlet ratio)
+// (verified against the reference to 1e-15 in float64).  Real shifts come two at a time out of one complex
+// transform: z = x1 + i x2, Z = fft(z), W[k] = Z[k] A[k] + conj(Z[-k]) B[k] with A,B = (p1 +- p2)/2, w = ifft(W) =
+// y1 + i y2 -- one extra LDS exchange (mirror bin -k) instead of a second forward+inverse pair.  Net: half the
+// transforms and half the intermediate bytes (float32 A1r/A2r) of the complex formulation in derotate_fft.hip.
+#include "common.h"
+#include "rot_common.h"
+#include "fft_wave.h"
+
+namespace vipmi {
+
+namespace {
+
+using namespace fftw;
+
+// sin(pi s), cos(pi s) with the argument reduced in float64 (|s| reaches hundreds of pixels), float32 evaluation
+__device__ __forceinline__ void sincos_pi(double s, float& sn, float& cs) {
+  const double r = s - 2.0 * rint(0.5 * s);      // in [-1, 1]
+  sincospif((float)r, &sn, &cs);
+}
+
+// v = x1 + i x2 (D1) -> y1 + i y2 (D1), real shifts by s1 / s2; alt1/alt2 = alternating sums of x1 / x2
+template <class P>
+__device__ __forceinline__ void pair_shift(cf (&v)[P::VL], const Twiddles<P>& tw, cf* __restrict__ lds, double s1,
+                                           double s2, int lane, int sub, float& alt1, float& alt2,
+                                           float& sin1, float& sin2) {   // sinX = sin(pi sX)/L
+  constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3;
+  fft_forward<P>(v, tw, lds, lane, sub);
+  const int u0 = sub * P::U3L;
+#pragma unroll
+  for (int ul = 0; ul < P::U3L; ++ul) {
+    const int wq = lane + 64 * (u0 + ul), k1 = wq / R2, ka = wq % R2;
+#pragma unroll
+    for (int kb = 0; kb < R3; ++kb) lds[k1 * P::T1 + ka * P::T2 + kb] = v[ul * R3 + kb];
+  }
+  xbar<P>(tw);
+  {
+    const cf zn = lds[R3 / 2];          // Z[Nyquist]: (k1, ka, kb) = (0, 0, R3/2)
+    alt1 = zn.x;
+    alt2 = zn.y;
+  }
+  ShearPhase<P> p1, p2;
+  p1.init(s1, lane, sub);
+  p2.init(s2, lane, sub);
+  float sn1, cn1, sn2, cn2;
+  sincos_pi(s1, sn1, cn1);
+  sincos_pi(s2, sn2, cn2);
+  const float c1n = cn1 * (1.0f / (float)P::L), c2n = cn2 * (1.0f / (float)P::L);
+  sin1 = sn1 * (1.0f / (float)P::L);
+  sin2 = sn2 * (1.0f / (float)P::L);
+#pragma unroll
+  for (int ul = 0; ul < P::U3L; ++ul) {
+    const int wq = lane + 64 * (u0 + ul), k1 = wq / R2, ka = wq % R2;
+    // mirror bin -k: digit-wise complement, with the borrow chain ending at the first non-zero digit
+    int k1m, kam;
+    bool special = false;
+    if (k1 > 0) {
+      k1m = R1 - k1;
+      kam = R2 - 1 - ka;
+    } else if (ka > 0) {
+      k1m = 0;
+      kam = R2 - ka;
+    } else {
+      k1m = 0;
+      kam = 0;
+      special = true;
+    }
+    const int mbase = k1m * P::T1 + kam * P::T2;
+#pragma unroll
+    for (int kb = 0; kb < R3; ++kb) {
+      const int kbm = special ? ((R3 - kb) % R3) : (R3 - 1 - kb);
+      const cf zm = lds[mbase + kbm];
+      cf q1 = cmul(p1.pa, p1.pb(kb)), q2 = cmul(p2.pa, p2.pb(kb));
+      if (kb == R3 / 2 && special) {           // Nyquist bin: real multipliers cos(pi s)
+        q1 = mkcf(c1n, 0.f);
+        q2 = mkcf(c2n, 0.f);
+      }
+      const cf A = mkcf(0.5f * (q1.x + q2.x), 0.5f * (q1.y + q2.y));
+      const cf B = mkcf(0.5f * (q1.x - q2.x), 0.5f * (q1.y - q2.y));
+      const cf z = v[ul * R3 + kb];
+      v[ul * R3 + kb] = mkcf(z.x * A.x - z.y * A.y + zm.x * B.x + zm.y * B.y,
+                                    z.x * A.y + z.y * A.x + zm.x * B.y - zm.y * B.x);
+    }
+    p1.next_u();
+    p2.next_u();
+  }
+  xbar<P>(tw);                               // every mirror read done before the inverse reuses the region
+  fft_inverse<P>(v, tw, lds, lane, sub);
+}
+
+struct Aux {          // per-batch auxiliary arrays (device)
+  float* beta;        // [nf][N]   beta_Y of the data rows
+  float* bf;          // [nf]      Bf
+  float* kv;          // [nf][N]   K[off + m]
+  float* gam;         // [nf][L]   (-1)^X gamma_X
+  float* gsum;        // [nf]      Gam
+};
+
+#define VIPMI_SLOT_PROLOGUE()                                                     \
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];                    \
+  const int lane = threadIdx.x & 63;                                              \
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);              \
+  const int sub = wave % P::WPL, slot = wave / P::WPL;                            \
+  cf* lds = lds_all + slot * P::LDS_ELEMS;                                        \
+  Twiddles<P> tw;                                                                 \
+  tw.init(twtab, lds_all + P::LPB * P::LDS_ELEMS, lane)
+
+// affine source map of canvas'(Y, X) -> frame[base + X*stride] (rot90 folded in)
+__device__ __forceinline__ void src_map(int q, int Y, const RotGeom& g, int& base, int& stride) {
+  switch (q) {
+    case 1: stride = g.N; base = -g.off * g.N + (g.Lc - Y - g.off); break;
+    case 2: stride = -1; base = (g.Lc - Y - g.off) * g.N + (g.Lc - g.off); break;
+    case 3: stride = -g.N; base = (g.Lc - g.off) * g.N + (Y - g.off); break;
+    default: stride = 1; base = (Y - g.off) * g.N - g.off; break;
+  }
+}
+
+// ---- shear 1: row pairs (2p, 2p+1) ----
+template <class P>
+__global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict__ in,
+                                                         const RotFrame* __restrict__ fr, RotGeom g,
+                                                         float* __restrict__ A1r, Aux aux, int f0, int nf,
+                                                         const cf* __restrict__ twtab) {
+  VIPMI_SLOT_PROLOGUE();
+  const int half = g.N / 2;
+  const int npairs = nf * half;
+  const int niter = (npairs + gridDim.x * P::LPB - 1) / (gridDim.x * P::LPB);
+  for (int it = 0; it < niter; ++it) {
+    int pr = (it * gridDim.x + blockIdx.x) * P::LPB + slot;
+    const bool live = pr < npairs;
+    if (!live) pr = npairs - 1;
+    const int fl = pr / half, yrel = 2 * (pr % half), f = f0 + fl;
+    const RotFrame p = fr[f];
+    const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+    const int c0 = (p.q == 2 || p.q == 3) ? g.alt0 : g.off;
+    const int Y1 = r0 + yrel, Y2 = Y1 + 1;
+    const float* frame = in + (int64_t)f * g.N * g.N;
+    int b1, st1, b2, st2;
+    src_map(p.q, Y1, g, b1, st1);
+    src_map(p.q, Y2, g, b2, st2);
+    cf v[P::VL];
+#pragma unroll
+    for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+      for (int n1 = 0; n1 < P::R1; ++n1) {
+        float x1 = 0.f, x2 = 0.f;
+        if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {       // compile-time window
+          const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
+          if (X >= c0 && X < c0 + g.N) {
+            const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
+            x1 = (t1 == t1) ? t1 : 0.f;
+            x2 = (t2 == t2) ? t2 : 0.f;
+          }
+        }
+        v[ul * P::R1 + n1] = mkcf(x1, x2);
+      }
+    const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
+    float alt1, alt2, sn1, sn2;
+    pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+    if (live) {
+      float* o1 = A1r + ((int64_t)fl * g.N + yrel) * P::L;
+      float* o2 = o1 + P::L;
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = 0; n1 < P::R1; ++n1) {
+          const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
+          o1[X] = v[ul * P::R1 + n1].x;
+          o2[X] = v[ul * P::R1 + n1].y;
+        }
+      if (sub == 0 && lane == 0) {
+        aux.beta[fl * g.N + yrel] = sn1 * alt1;
+        aux.beta[fl * g.N + yrel + 1] = sn2 * alt2;
+      }
+    }
+  }
+}
+
+// Bf[f] = sum_Y (-1)^Y beta_Y   (Y = canvas row of data row yrel)
+__global__ __launch_bounds__(256) void rs_bf_kernel(const RotFrame* __restrict__ fr, RotGeom g, Aux aux, int f0) {
+  __shared__ float sh[4];
+  const int fl = blockIdx.x;
+  const RotFrame p = fr[f0 + fl];
+  const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+  float s = 0.f;
+  for (int y = threadIdx.x; y < g.N; y += blockDim.x) {
+    const float b = aux.beta[fl * g.N + y];
+    s += ((r0 + y) & 1) ? -b : b;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) aux.bf[fl] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// K[fl][m] = ifft( fft(beta~) g )[off + m]: one line per frame
+template <class P>
+__global__ __launch_bounds__(64 * P::WPB) void rs_aux_k(const RotFrame* __restrict__ fr, RotGeom g, Aux aux, int f0,
+                                                        int nf, const cf* __restrict__ twtab) {
+  VIPMI_SLOT_PROLOGUE();
+  constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3;
+  const int niter = (nf + gridDim.x * P::LPB - 1) / (gridDim.x * P::LPB);
+  for (int it = 0; it < niter; ++it) {
+    int fl = (it * gridDim.x + blockIdx.x) * P::LPB + slot;
+    const bool live = fl < nf;
+    if (!live) fl = nf - 1;
+    const RotFrame p = fr[f0 + fl];
+    const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+    cf v[P::VL];
+#pragma unroll
+    for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+      for (int n1 = 0; n1 < P::R1; ++n1) {
+        float x = 0.f;
+        if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {
+          const int yrel = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul) - r0;
+          if (yrel >= 0 && yrel < g.N) x = aux.beta[fl * g.N + yrel];
+        }
+        v[ul * P::R1 + n1] = mkcf(x, 0.f);
+      }
+    fft_forward<P>(v, tw, lds, lane, sub);
+    // g(k) = sum_{X=0}^{L-1} exp(-2 pi i ks b (X - c)/L) = exp(-2 pi i ks b ((L-1)/2 - c)/L) sin(pi ks b)/sin(pi ks b/L)
+    const int u0 = sub * P::U3L;
+#pragma unroll
+    for (int ul = 0; ul < P::U3L; ++ul) {
+      const int wq = lane + 64 * (u0 + ul), k1 = wq / R2, ka = wq % R2;
+#pragma unroll
+      for (int kb = 0; kb < R3; ++kb) {
+        const int kbs = (kb < R3 / 2) ? kb : kb - R3;
+        const double kbv = (double)(k1 + R1 * ka + R1 * R2 * kbs) * p.b;
+        const double den = sinpi(kbv / (double)P::L);
+        const double ratio = (fabs(den) < 1e-300) ? (double)P::L : sinpi(kbv) / den;
+        double sn, cs;
+        sincospi(-2.0 * kbv * (0.5 * (double)(P::L - 1) - (double)g.c) / (double)P::L, &sn, &cs);
+        float gre = (float)(ratio * cs / (double)P::L), gim = (float)(ratio * sn / (double)P::L);
+        if (kb == R3 / 2 && wq == 0) gim = 0.f;          // Nyquist: sum of cos(pi s_X) (real part)
+        const cf z = v[ul * R3 + kb];
+        v[ul * R3 + kb] = mkcf(z.x * gre - z.y * gim, z.x * gim + z.y * gre);
+      }
+    }
+    fft_inverse<P>(v, tw, lds, lane, sub);
+    if (live) {
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
+          const int m = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);
+          aux.kv[fl * g.N + m] = v[ul * P::R1 + n1].x;
+        }
+    }
+  }
+}
+
+// ---- shear 2: column pairs; a workgroup handles 2*LPB adjacent columns, tile staged through LDS ----
+template <class P>
+__global__ __launch_bounds__(64 * P::WPB) void rs_shear2(const float* __restrict__ A1r,
+                                                         const RotFrame* __restrict__ fr, RotGeom g,
+                                                         float* __restrict__ A2r, Aux aux, int f0, int nf,
+                                                         const cf* __restrict__ twtab) {
+  VIPMI_SLOT_PROLOGUE();
+  constexpr int W = 2 * P::LPB, LDT = W + 1;      // tile row stride in floats (odd: conflict-free column reads)
+  float* tile = reinterpret_cast<float*>(lds_all);   // [N][LDT], aliases the exchange regions between phases
+  const int groups = (P::L + W - 1) / W;          // last group may be ragged (W need not divide L)
+  const int units = nf * groups;
+  for (int uu = blockIdx.x * 2; uu < units; uu += gridDim.x * 2) {
+    for (int h = 0; h < 2; ++h) {
+      const int unit = uu + h;
+      if (unit >= units) break;                // uniform across the workgroup
+      const int fl = unit / groups, X0 = (unit % groups) * W, f = f0 + fl;
+      const RotFrame p = fr[f];
+      const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+      const float* src = A1r + (int64_t)fl * g.N * P::L + X0;
+      const int wcols = (P::L - X0 < W) ? (P::L - X0) : W;
+      for (int e = threadIdx.x; e < g.N * W; e += 64 * P::WPB) {
+        const int row = e / W, c = e % W;
+        tile[row * LDT + c] = (c < wcols) ? src[(int64_t)row * P::L + c] : 0.f;
+      }
+      __syncthreads();
+      cf v[P::VL];
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = 0; n1 < P::R1; ++n1) {
+          cf val = mkcf(0.f, 0.f);
+          if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {     // compile-time window
+            const int yrel = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul) - r0;
+            if (yrel >= 0 && yrel < g.N) val = mkcf(tile[yrel * LDT + 2 * slot], tile[yrel * LDT + 2 * slot + 1]);
+          }
+          v[ul * P::R1 + n1] = val;
+        }
+      __syncthreads();
+      const int X1 = X0 + 2 * slot, X2 = X1 + 1;
+      const double s1 = p.b * (double)(X1 - g.c), s2 = p.b * (double)(X2 - g.c);
+      float alt1, alt2, sn1, sn2;
+      pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+      __syncthreads();
+      // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m
+      const float bfl = aux.bf[fl];
+      const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
+      const float k2c = sn2 * ((X2 & 1) ? -bfl : bfl);
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
+          const int m = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);      // off == M1*NLO
+          const float sg = ((g.off + m) & 1) ? -1.f : 1.f;
+          tile[m * LDT + 2 * slot] = v[ul * P::R1 + n1].x - sg * k1c;
+          tile[m * LDT + 2 * slot + 1] = v[ul * P::R1 + n1].y - sg * k2c;
+        }
+      if (sub == 0 && lane == 0 && X1 < P::L) {
+        aux.gam[fl * P::L + X1] = ((X1 & 1) ? -sn1 : sn1) * alt1;
+        aux.gam[fl * P::L + X2] = ((X2 & 1) ? -sn2 : sn2) * alt2;
+      }
+      __syncthreads();
+      float* dst = A2r + (int64_t)fl * g.N * P::L + X0;
+      for (int e = threadIdx.x; e < g.N * W; e += 64 * P::WPB) {
+        const int row = e / W, c = e % W;
+        if (c < wcols) dst[(int64_t)row * P::L + c] = tile[row * LDT + c];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Gam[f] = sum_X (-1)^X gamma_X  (fixed-order tree: deterministic)
+__global__ __launch_bounds__(256) void rs_gamma_kernel(Aux aux, int L) {
+  __shared__ float sh[4];
+  const int fl = blockIdx.x;
+  float s = 0.f;
+  for (int x = threadIdx.x; x < L; x += blockDim.x) s += aux.gam[fl * L + x];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) aux.gsum[fl] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- shear 3: row pairs of A2r -> final real frame rows, crop, mask restore ----
+template <class P>
+__global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict__ A2r,
+                                                         const RotFrame* __restrict__ fr, RotGeom g,
+                                                         const float* __restrict__ in, float* __restrict__ out,
+                                                         Aux aux, int f0, int nf, int mask_nan, int mask_zero,
+                                                         const cf* __restrict__ twtab) {
+  VIPMI_SLOT_PROLOGUE();
+  const int half = g.N / 2;
+  const int npairs = nf * half;
+  const int niter = (npairs + gridDim.x * P::LPB - 1) / (gridDim.x * P::LPB);
+  for (int it = 0; it < niter; ++it) {
+    int pr = (it * gridDim.x + blockIdx.x) * P::LPB + slot;
+    const bool live = pr < npairs;
+    if (!live) pr = npairs - 1;
+    const int fl = pr / half, m = 2 * (pr % half), f = f0 + fl;
+    const RotFrame p = fr[f];
+    const int Y1 = g.off + m, Y2 = Y1 + 1;
+    const float* i1 = A2r + ((int64_t)fl * g.N + m) * P::L;
+    const float* i2 = i1 + P::L;
+    cf v[P::VL];
+#pragma unroll
+    for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+      for (int n1 = 0; n1 < P::R1; ++n1) {
+        const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
+        v[ul * P::R1 + n1] = mkcf(i1[X], i2[X]);
+      }
+    const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
+    float alt1, alt2, sn1, sn2;
+    pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+    if (live) {
+      const float gs = aux.gsum[fl];
+      const float c1 = sn1 * (aux.kv[fl * g.N + m] + ((Y1 & 1) ? -gs : gs));
+      const float c2 = sn2 * (aux.kv[fl * g.N + m + 1] + ((Y2 & 1) ? -gs : gs));
+      const int64_t ob1 = ((int64_t)f * g.N + m) * g.N, ob2 = ob1 + g.N;
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
+          const int j = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);        // off == M1*NLO
+          const float sg = ((g.off + j) & 1) ? -1.f : 1.f;
+          float re1 = v[ul * P::R1 + n1].x - sg * c1;
+          float re2 = v[ul * P::R1 + n1].y - sg * c2;
+          const float src1 = in[ob1 + j], src2 = in[ob2 + j];
+          if (mask_nan && !(src1 == src1)) re1 = __uint_as_float(0x7fc00000u);
+          if (mask_nan && !(src2 == src2)) re2 = __uint_as_float(0x7fc00000u);
+          if (mask_zero && src1 == 0.f) re1 = 0.f;
+          if (mask_zero && src2 == 0.f) re2 = 0.f;
+          out[ob1 + j] = re1;
+          out[ob2 + j] = re2;
+        }
+    }
+  }
+}
+
+template <class P>
+int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n, float* out,
+              int mask_nan, int mask_zero) {
+  const int64_t per_frame = (int64_t)g.N * P::L;            // floats per intermediate per frame
+  int64_t chunk = ctx->opt("rot_batch", 0);
+  if (chunk <= 0) {
+    int64_t budget = ctx->opt("rot_ws_mb", 2048) * (int64_t)(1 << 20);
+    chunk = budget / (2 * per_frame * (int64_t)sizeof(float));
+  }
+  if (chunk < 1) chunk = 1;
+  if (chunk > n) chunk = n;
+  float *A1r = nullptr, *A2r = nullptr;
+  VIPMI_TRY(ws(ctx, "rot_a1", (size_t)(chunk * per_frame), &A1r));
+  VIPMI_TRY(ws(ctx, "rot_a2", (size_t)(chunk * per_frame), &A2r));
+  Aux aux;
+  VIPMI_TRY(ws(ctx, "rot_beta", (size_t)(chunk * g.N), &aux.beta));
+  VIPMI_TRY(ws(ctx, "rot_bf", (size_t)chunk, &aux.bf));
+  VIPMI_TRY(ws(ctx, "rot_kv", (size_t)(chunk * g.N), &aux.kv));
+  VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * P::L), &aux.gam));
+  VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
+  size_t lds = (size_t)P::LPB * P::LDS_ELEMS * sizeof(cf);
+  const size_t tile = (size_t)g.N * (2 * P::LPB + 1) * sizeof(float);
+  VIPMI_REQUIRE(tile <= lds, "derotate(fft2): staging tile larger than the exchange regions");
+  lds += (size_t)Twiddles<P>::LDS_ELEMS * sizeof(cf);
+  VIPMI_REQUIRE(lds <= 160 * 1024, "derotate(fft2): LDS budget exceeded (%zu)", lds);
+  cf* twtab = nullptr;
+  {
+    std::vector<cf> tab;
+    Twiddles<P>::fill_table(tab);
+    char key[32];
+    snprintf(key, sizeof key, "L%d", P::L);
+    void* pt = nullptr;
+    VIPMI_TRY(ctx->upload_cached("rot_twiddles", key, tab.data(), tab.size() * sizeof(cf), &pt));
+    twtab = reinterpret_cast<cf*>(pt);
+  }
+  auto k1 = rs_shear1<P>;
+  auto ka = rs_aux_k<P>;
+  auto k2 = rs_shear2<P>;
+  auto k3 = rs_shear3<P>;
+  for (const void* f : {reinterpret_cast<const void*>(k1), reinterpret_cast<const void*>(ka),
+                        reinterpret_cast<const void*>(k2), reinterpret_cast<const void*>(k3)})
+    VIPMI_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int wgs_per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  int usable_cu = ctx->num_cu - (int)ctx->opt("reserve_cus", 0);
+  if (usable_cu < 1) usable_cu = 1;
+  const int maxwg = usable_cu * wgs_per_cu;
+  const dim3 blk(64 * P::WPB);
+  for (int64_t f0 = 0; f0 < n; f0 += chunk) {
+    const int nf = (int)((n - f0) < chunk ? (n - f0) : chunk);
+    const int64_t npairs = (int64_t)nf * (g.N / 2);
+    int gr = (int)cdiv(npairs, P::LPB);
+    if (gr > maxwg) gr = maxwg;
+    const int64_t units = (int64_t)nf * ((P::L + 2 * P::LPB - 1) / (2 * P::LPB));
+    int gc = (int)cdiv(units, 2);
+    if (gc > maxwg) gc = maxwg;
+    int ga = (int)cdiv(nf, P::LPB);
+    if (ga > maxwg) ga = maxwg;
+    ctx->tic("k_rot_s1");
+    hipLaunchKernelGGL(k1, dim3(gr), blk, lds, ctx->stream, in, d_frames, g, A1r, aux, (int)f0, nf, twtab);
+    ctx->toc("k_rot_s1");
+    ctx->tic("k_rot_aux");
+    hipLaunchKernelGGL(rs_bf_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_frames, g, aux, (int)f0);
+    hipLaunchKernelGGL(ka, dim3(ga), blk, lds, ctx->stream, d_frames, g, aux, (int)f0, nf, twtab);
+    ctx->toc("k_rot_aux");
+    ctx->tic("k_rot_s2");
+    hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab);
+    ctx->toc("k_rot_s2");
+    ctx->tic("k_rot_aux");
+    hipLaunchKernelGGL(rs_gamma_kernel, dim3(nf), dim3(256), 0, ctx->stream, aux, P::L);
+    ctx->toc("k_rot_aux");
+    ctx->tic("k_rot_s3");
+    hipLaunchKernelGGL(k3, dim3(gr), blk, lds, ctx->stream, A2r, d_frames, g, in, out, aux, (int)f0, nf, mask_nan,
+                       mask_zero, twtab);
+    ctx->toc("k_rot_s3");
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  return VIPMI_OK;
+}
+
+}  // namespace
+
+int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
+                  float* out, int mask_nan, int mask_zero) {
+  switch (g.Le) {
+    case 512: return run_plan2<Plan512>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 2048:
+      if (ctx->opt("rot_wpb", 12) == 12) return run_plan2<Plan2048w12>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      return run_plan2<Plan2048>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 4096: return run_plan2<Plan4096>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    default:
+      set_error("derotate(fft2): unsupported padded length %d", g.Le);
+      return VIPMI_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace vipmi
