@@ -11,8 +11,9 @@ one rank per GPU): every rank processes its own cube -- the "survey mode" shardi
 no data-path collective, only the barrier / max-over-ranks timing -- so scaling is weak.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     : dominant kernel (fft_shear2, the column shear of the derotation) -- algorithmic bytes of
-                 the derotation stage per launch / its average launch duration (hipEvents on the ctx stream)
+  roofline     : dominant kernel (rs_shear2, the column shear of the real-split FFT derotation) -- algorithmic bytes of
+                 the derotation stage per launch / its average launch duration (hipEvent pairs recorded around
+                 the kernel on the stream it is launched on, inside the timed region)
   cpu_baseline : the numpy oracle (oracle/ref_cpu.py, a port of the reference's svd_mode='lapack' +
                  imlib='vip-fft' + nanmedian path) timed on this box's host cores on a bounded sample.
 """
@@ -61,10 +62,12 @@ def cpu_baseline(n, N, k, budget_frames=4):
             "ms_per_svd": 1e3 * t_svd}
 
 
-def pmc_traffic(frames_per_launch, N):
+def pmc_traffic(frames_per_launch, N, kernel="rs_shear2"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of the same
-    workload and corrected as MI355X_MICROARCH.md prescribes); scaled per frame.  None if absent / other size."""
+    (profiles/rNN_pmc_hbm.json, written by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE collected in separate
+    --pmc runs of one 400x512x512 pca() call).  The kernel reads 64-byte row segments (8 B/lane), for which the
+    gfx950 FETCH_SIZE counter needs no x2 correction (MI355X_MICROARCH.md, HBM section); scaled per frame.
+    None if absent / other frame size."""
     import glob
     if N != 512:
         return None
@@ -73,10 +76,13 @@ def pmc_traffic(frames_per_launch, N):
         return None
     try:
         doc = json.load(open(files[-1]))
-        per100 = doc["fft_shear2_traffic_bytes_per_launch_100_frames"]
-        return per100 * frames_per_launch / 100.0
+        for name, e in doc["kernels"].items():
+            if name.startswith(kernel):
+                per_launch = 1024.0 * (e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"])
+                return per_launch * frames_per_launch / (400.0 / e["launches"])
     except Exception:
         return None
+    return None
 
 
 def main():
@@ -88,7 +94,10 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ncomp", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
+    ap.add_argument("--no-stage-timing", action="store_true",
+                    help="do not record per-stage hipEvents inside the timed region (no roofline object)")
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="independent pca() calls in flight (one torch stream each); 1 = strictly serial")
     args = ap.parse_args()
 
@@ -145,8 +154,23 @@ def main():
                 frame = pca(cube_t, angles, ncomp=k, verbose=False, check_memory=False)
                 pinned[i].copy_(frame, non_blocking=True)
 
+    STAGES = ("scale", "gram", "eigh", "project", "derotate", "collapse", "k_rot_s1", "k_rot_s2", "k_rot_s3",
+              "k_rot_aux")
+    timing = not args.no_stage_timing
+
+    def set_timing(on):
+        for c in B.all_contexts():
+            c.set_option("timing", 1 if on else 0)
+
     torch.cuda.synchronize()
-    run(args.warmup)
+    run(depth)                                  # creates the per-stream contexts
+    torch.cuda.synchronize()
+    if timing:
+        set_timing(True)                        # hipEvent pairs around every stage / shear kernel, on the
+    run(args.warmup)                            # stream the kernels are launched on (events are created here)
+    torch.cuda.synchronize()
+    for c in B.all_contexts():
+        c.reset_timers()
     # timed region
     barrier()
     t0 = time.perf_counter()
@@ -155,37 +179,24 @@ def main():
     elapsed = time.perf_counter() - t0
     if depth > 1:
         B.check_deferred()
-        B.set_async(False)
     out = pinned[args.steps - 1]
-    # un-pipelined latency of one call, for reference
-    torch.cuda.synchronize()
-    step()
-    t1 = time.perf_counter()
-    for _ in range(3):
-        step()
-    latency_ms = (time.perf_counter() - t1) / 3 * 1e3
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(out).all())
 
-    # per-stage / per-kernel timings over a second pass of the same K steps (hipEvents on the ctx stream;
-    # kept out of the throughput measurement so that event recording cannot perturb it)
+    # per-stage / per-kernel durations of exactly the K timed steps, summed over the per-stream contexts
     roof = None
     stages = {}
-    if rank == 0:
-        ctx.set_option("timing", 1)
-        ctx.reset_timers()
-        torch.cuda.synchronize()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        for s in ("scale", "gram", "eigh", "project", "derotate", "collapse", "k_rot_s1", "k_rot_s2", "k_rot_s3"):
-            ms, cnt = ctx.stage_ms(s), ctx.stage_count(s)
-            if cnt > 0 and ms >= 0:
-                stages[s] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
-        ctx.set_option("timing", 0)
+    ms_svd = None
+    if timing:
+        for s_ in STAGES:
+            ms = sum(max(c.stage_ms(s_), 0.0) for c in B.all_contexts())
+            cnt = sum(c.stage_count(s_) for c in B.all_contexts())
+            if cnt > 0:
+                stages[s_] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+        set_timing(False)
         P = N * N
         if "k_rot_s2" in stages:
             launches = stages["k_rot_s2"]["launches_per_step"]
@@ -193,15 +204,37 @@ def main():
             frames_per_launch = n / launches
             alg_bytes = 2.0 * P * 4 * frames_per_launch          # derotate = 2*P*4 bytes per frame
             achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
-            L = 4 * N
-            real_bytes = 2.0 * frames_per_launch * N * L * 8      # what this kernel actually moves (A1 in, A2 out)
-            roof = {"bound": "hbm", "kernel": "fft_shear2", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            roof_launches, roof_alg_bytes = launches, alg_bytes
+            roof = {"bound": "hbm", "kernel": "rs_shear2", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(frames_per_launch, N),
                     "avg_launch_ms": dur_ms, "frames_per_launch": frames_per_launch,
-                    "intermediate_GBps": real_bytes / (dur_ms * 1e-3) / 1e9,
-                    "note": "VALU/LDS-bound FFT kernel; see DESIGN.md for the flop-based fraction"}
-        ms_svd = sum(stages[s]["ms_per_step"] for s in ("scale", "gram", "eigh") if s in stages)
+                    "note": "duration = hipEvents around the kernel inside the timed region, where it shares the GPU "
+                            "with the kernels of the other calls in flight (isolated_*: same kernel in a serial "
+                            "call); the kernel is VALU/LDS-bound (FFT), see DESIGN.md for the flop-based fraction"}
+        ms_svd = sum(stages[s_]["ms_per_step"] for s_ in ("scale", "gram", "eigh") if s_ in stages)
+    if depth > 1:
+        B.set_async(False)
+    # un-pipelined latency of one call and the stage / kernel durations when a call has the GPU to itself
+    latency_ms = None
+    stages_serial = {}
+    if not args.no_latency:
+        torch.cuda.synchronize()
+        step()
+        ctx.set_option("timing", 1)
+        ctx.reset_timers()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        latency_ms = (time.perf_counter() - t1) / 3 * 1e3
+        for s_ in STAGES:
+            if ctx.stage_count(s_) > 0:
+                stages_serial[s_] = ctx.stage_ms(s_) / 3
+        ctx.set_option("timing", 0)
+        if roof is not None and "k_rot_s2" in stages_serial:
+            iso_ms = stages_serial["k_rot_s2"] / roof_launches
+            roof["isolated_avg_launch_ms"] = iso_ms
+            roof["isolated_frac"] = roof_alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -215,8 +248,9 @@ def main():
                                    "vip-fft derotation, median collapse" % (n, N, N, k),
                        "cubes_per_step": world, "parallelism": "one cube per GPU (no data-path collective)",
                        "pipeline_depth": depth},
-            "ms_per_svd": ms_svd if rank == 0 and stages else None,
+            "ms_per_svd": ms_svd,
             "stages": stages,
+            "stages_serial_ms": stages_serial,
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -216,6 +216,34 @@ def test_median_sizes_bitexact(B, n, P):
     assert np.array_equal(got, exp, equal_nan=True)
 
 
+@pytest.mark.parametrize("n,P,tn", [(7, 50, 3), (8, 50, 3), (8, 64, 4), (7, 33, 9), (7, 33, 50), (65, 333, 20),
+                                    (400, 1024, 100), (129, 100, 129), (10, 40, 1)])
+def test_trimmean_sizes(B, n, P, tn):
+    rng = np.random.default_rng(n * 7 + P + tn)
+    cube = rng.standard_normal((n, P)).astype(np.float32)
+    cube[rng.random((n, P)) < 0.05] = np.nan
+    cube[:, 3] = np.nan
+    cube[:, 5] = 1.25
+    cube[: n // 2, 6] = -2.0
+    cube[n // 2:, 6] = 3.0
+    cube[:, 7] = np.round(cube[:, 7])                  # many duplicates at the slice edges
+    got = B.collapse(dev(B, cube).reshape(n, P, 1), "trimmean", trim_n=tn).cpu().numpy().reshape(P)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = O.cube_collapse(cube.reshape(n, P, 1), "trimmean", n=tn).reshape(P)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert np.nanmax(np.abs(got - exp)) < 2e-6
+
+
+def test_trimmean_golden(B):
+    from vip_amd.preproc import cube_collapse
+    g = load_golden("g4_collapse")
+    for n in (7, 8):
+        got = cube_collapse(g["cube_%d" % n], "trimmean", n=3)
+        assert np.abs(got - g["trimmean_%d" % n]).max() < 2e-6
+
+
 # ---- rotation (generic direct path) ------------------------------------------------------------------
 
 @pytest.mark.parametrize("N", [32, 33, 64])

@@ -99,6 +99,12 @@ def check_deferred():
         _lib.raise_for_status(c.lib.vipmi_check_deferred(c.handle), "vipmi_check_deferred")
 
 
+def all_contexts():
+    """Every live context (one per (device, stream) that has run a call)."""
+    with _ctx_lock:
+        return list(_ctx_cache.values())
+
+
 def get_context(device=None):
     torch = require_gpu()
     dev = torch.cuda.current_device() if device is None else int(device)

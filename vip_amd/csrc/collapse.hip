@@ -25,9 +25,25 @@ __device__ __forceinline__ float key2f(unsigned k) {
   return __uint_as_float(u);
 }
 
+// rank-k (0-based) order statistic of the wave's keys: 32-step bitwise bisection with wave ballots
 template <int RPL>
+__device__ __forceinline__ unsigned select_rank(const unsigned (&key)[RPL], int k) {
+  unsigned ans = 0;
+  for (int b = 31; b >= 0; --b) {
+    const unsigned cand = ans | (1u << b);
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) cnt += __popcll(__ballot(key[r] < cand));
+    if (cnt <= k) ans = cand;
+  }
+  return ans;
+}
+
+// TRIM = false: nanmedian.  TRIM = true: mean of sorted[t0 : t0+tn] (np.sort order, NaN last, then nanmean):
+// the reference's 'trimmean' (subsampling.py:87-96).
+template <int RPL, bool TRIM>
 __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ cube, int n, int64_t P,
-                                                     int TP, float* __restrict__ out) {
+                                                     int TP, float* __restrict__ out, int t0, int tn) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // n x (TP+1)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
@@ -62,18 +78,41 @@ __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ c
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) m += __shfl_xor(m, s, 64);
     float res;
-    if (m == 0) {
+    if (TRIM) {
+      int hi_end = t0 + tn;                    // slice [t0, hi_end) of the sorted samples, NaNs (rank >= m) dropped
+      if (hi_end > n) hi_end = n;
+      if (hi_end > m) hi_end = m;
+      if (t0 >= hi_end) {
+        res = __uint_as_float(0x7fc00000u);
+      } else {
+        const unsigned klo = select_rank<RPL>(key, t0), khi = select_rank<RPL>(key, hi_end - 1);
+        int clt_lo = 0, cle_lo = 0, clt_hi = 0;
+        double mid = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          clt_lo += __popcll(__ballot(key[r] < klo));
+          cle_lo += __popcll(__ballot(key[r] <= klo));
+          clt_hi += __popcll(__ballot(key[r] < khi));
+          if (key[r] > klo && key[r] < khi) mid += (double)key2f(key[r]);
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) mid += __shfl_xor(mid, s, 64);
+        double tot;
+        if (klo == khi) {
+          tot = (double)key2f(klo) * (double)(hi_end - t0);
+        } else {
+          const int nlo = (cle_lo < hi_end ? cle_lo : hi_end) - t0;      // copies of the low value inside the slice
+          const int nhi = hi_end - clt_hi;                                 // copies of the high value inside the slice
+          tot = mid + (double)key2f(klo) * nlo + (double)key2f(khi) * nhi;
+        }
+        (void)clt_lo;
+        res = (float)(tot / (double)(hi_end - t0));
+      }
+    } else if (m == 0) {
       res = __uint_as_float(0x7fc00000u);
     } else {
       const int k = (m - 1) >> 1;              // lower median rank (0-based)
-      unsigned ans = 0;
-      for (int b = 31; b >= 0; --b) {
-        const unsigned cand = ans | (1u << b);
-        int cnt = 0;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) cnt += __popcll(__ballot(key[r] < cand));
-        if (cnt <= k) ans = cand;
-      }
+      const unsigned ans = select_rank<RPL>(key, k);
       const float lo = key2f(ans);
       if (m & 1) {
         res = lo;
@@ -128,15 +167,15 @@ __global__ void colreduce_kernel(const float* __restrict__ cube, int n, int64_t 
   }
 }
 
-template <int RPL>
-int launch_median(vipmi_ctx* ctx, const float* cube, int n, int64_t P, float* out) {
+template <int RPL, bool TRIM>
+int launch_median(vipmi_ctx* ctx, const float* cube, int n, int64_t P, float* out, int t0, int tn) {
   int TP = 32;
   while (TP > 1 && (size_t)n * (TP + 1) * 4 > 150 * 1024) TP >>= 1;
   const size_t lds = (size_t)n * (TP + 1) * 4;
-  auto kern = median_kernel<RPL>;
+  auto kern = median_kernel<RPL, TRIM>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(256), lds, ctx->stream, cube, n, P, TP, out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(256), lds, ctx->stream, cube, n, P, TP, out, t0, tn);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -148,18 +187,39 @@ int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mo
   VIPMI_REQUIRE(cube && out, "collapse: null pointer");
   VIPMI_REQUIRE(n > 0 && P > 0, "collapse: bad sizes");
   StageScope sc(ctx, "collapse");
-  (void)trim_n;
   switch (mode) {
-    case VIPMI_COLLAPSE_MEDIAN: {
+    case VIPMI_COLLAPSE_MEDIAN:
+    case VIPMI_COLLAPSE_TRIMMEAN: {
+      const bool trim = mode == VIPMI_COLLAPSE_TRIMMEAN;
+      int t0 = 0, tn = 0;
+      if (trim) {
+        // reference: k = (N - n)//2 ; if N%2 != n%2: n += 1 ; mean(sorted[k:k+n])   (subsampling.py:88-96)
+        // with python slice semantics for k < 0 or k+n > N (e.g. the default n=50 on a short cube)
+        int64_t nn = trim_n;
+        VIPMI_REQUIRE(nn > 0, "collapse(trimmean): n must be positive");
+        int64_t k = (n - nn) >= 0 ? (n - nn) / 2 : -((nn - n + 1) / 2);   // floor division
+        if ((n % 2) != (nn % 2)) nn += 1;
+        int64_t e = k + nn;
+        if (k < 0) k = (k + n < 0) ? 0 : k + n;
+        if (k > n) k = n;
+        if (e < 0) e = (e + n < 0) ? 0 : e + n;
+        if (e > n) e = n;
+        t0 = (int)k;
+        tn = (int)(e > k ? e - k : 0);
+      }
       const int rpl = (int)cdiv(n, 64);
-      if (rpl <= 1) return launch_median<1>(ctx, cube, (int)n, P, out);
-      if (rpl <= 2) return launch_median<2>(ctx, cube, (int)n, P, out);
-      if (rpl <= 4) return launch_median<4>(ctx, cube, (int)n, P, out);
-      if (rpl <= 8) return launch_median<8>(ctx, cube, (int)n, P, out);
-      if (rpl <= 16) return launch_median<16>(ctx, cube, (int)n, P, out);
-      if (rpl <= 32) return launch_median<32>(ctx, cube, (int)n, P, out);
-      if (rpl <= 64) return launch_median<64>(ctx, cube, (int)n, P, out);
-      set_error("collapse(median): more than 4096 frames not supported");
+#define VIPMI_MED(R)                                                                              \
+  return trim ? launch_median<R, true>(ctx, cube, (int)n, P, out, t0, tn)                        \
+              : launch_median<R, false>(ctx, cube, (int)n, P, out, 0, 0)
+      if (rpl <= 1) { VIPMI_MED(1); }
+      if (rpl <= 2) { VIPMI_MED(2); }
+      if (rpl <= 4) { VIPMI_MED(4); }
+      if (rpl <= 8) { VIPMI_MED(8); }
+      if (rpl <= 16) { VIPMI_MED(16); }
+      if (rpl <= 32) { VIPMI_MED(32); }
+      if (rpl <= 64) { VIPMI_MED(64); }
+#undef VIPMI_MED
+      set_error("collapse(median/trimmean): more than 4096 frames not supported");
       return VIPMI_ERR_UNSUPPORTED;
     }
     case VIPMI_COLLAPSE_WMEAN:
@@ -175,9 +235,6 @@ int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mo
       VIPMI_CHECK_HIP(hipGetLastError());
       return VIPMI_OK;
     }
-    case VIPMI_COLLAPSE_TRIMMEAN:
-      set_error("collapse: trimmean not implemented yet");
-      return VIPMI_ERR_UNSUPPORTED;
     default:
       set_error("mode not recognized");
       return VIPMI_ERR_ARG;

@@ -18,8 +18,6 @@ def cube_collapse(cube, mode="median", n=50, w=None):
             raise TypeError("Weights need same length as cube")
     if mode not in B.COLLAPSE_MODES:
         raise TypeError("mode not recognized")
-    if mode == "trimmean":
-        raise NotImplementedError("collapse mode 'trimmean' is not accelerated yet (SURVEY 8(f))")
     dev_in = B.is_device_tensor(cube)
     t = B.to_device_f32(cube)
     if cube.ndim == 3:
