@@ -492,9 +492,14 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
     case 512: return run_plan2<Plan512>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     case 2048:
-      if (ctx->opt("rot_wpb", 12) == 12) return run_plan2<Plan2048w12>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      // rot_wpb = waves per workgroup: 8 (default) = one wave per line, 2 waves/SIMD with a 256-VGPR budget;
+      // 12 / 16 = two waves per line (more waves, but workgroup barriers and 1.5x the instructions per line)
+      if (ctx->opt("rot_wpb", 8) == 8) return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      if (ctx->opt("rot_wpb", 8) == 12) return run_plan2<Plan2048w12>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
       return run_plan2<Plan2048>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-    case 4096: return run_plan2<Plan4096>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 4096:
+      if (ctx->opt("rot_wpb", 8) == 8) return run_plan2<Plan4096w2>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      return run_plan2<Plan4096>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     default:
       set_error("derotate(fft2): unsupported padded length %d", g.Le);
       return VIPMI_ERR_UNSUPPORTED;
