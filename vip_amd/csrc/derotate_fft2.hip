@@ -276,9 +276,15 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2(const float* __restrict
   float* tile = reinterpret_cast<float*>(lds_all);   // [N][LDT], aliases the exchange regions between phases
   const int groups = (P::L + W - 1) / W;          // last group may be ragged (W need not divide L)
   const int units = nf * groups;
-  for (int uu = blockIdx.x * 2; uu < units; uu += gridDim.x * 2) {
-    for (int h = 0; h < 2; ++h) {
-      const int unit = uu + h;
+  // XCD-aware unit mapping: two adjacent column groups share every 128-byte line of A1r / A2r (a group is 64 or 48
+  // bytes wide).  They are given to workgroups b and b + 8 -- same XCD (XCD = b mod 8), hence same L2, and running
+  // in lock step -- so the second half of each line is an L2 hit instead of a second HBM fetch a unit later.
+  // (gridDim.x is a multiple of 16.)
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int pair0 = (jx >> 1) * 8 + xcd, npair = gridDim.x >> 1;
+  for (int q = pair0; 2 * q < units; q += npair) {
+    {
+      const int unit = 2 * q + (jx & 1);
       if (unit >= units) break;                // uniform across the workgroup
       const int fl = unit / groups, X0 = (unit % groups) * W, f = f0 + fl;
       const RotFrame p = fr[f];
@@ -458,8 +464,9 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     int gr = (int)cdiv(npairs, P::LPB);
     if (gr > maxwg) gr = maxwg;
     const int64_t units = (int64_t)nf * ((P::L + 2 * P::LPB - 1) / (2 * P::LPB));
-    int gc = (int)cdiv(units, 2);
-    if (gc > maxwg) gc = maxwg;
+    int gc = (int)cdiv(units, 16) * 16;         // rs_shear2 pairs workgroups b and b + 8: multiple of 16
+    if (gc > maxwg) gc = maxwg / 16 * 16;
+    if (gc < 16) gc = 16;
     int ga = (int)cdiv(nf, P::LPB);
     if (ga > maxwg) ga = maxwg;
     ctx->tic("k_rot_s1");
