@@ -52,6 +52,16 @@ int vipmi_synchronize(vipmi_ctx* ctx);
 /* With option "eigh_check"=0 calls never synchronise; convergence failures are latched on the device.
  * vipmi_check_deferred synchronises the stream and returns VIPMI_ERR_NOCONV if any occurred since the last check. */
 int vipmi_check_deferred(vipmi_ctx* ctx);
+
+/* Pipelining independent pca calls issued on several streams (one ctx per stream, asynchronous mode).  Contexts
+ * that share a gate run the chip-filling second half of vipmi_pca_fullframe_f32 (project/subtract, derotation,
+ * collapse) one call at a time, in issue order, while the latency-bound eigensolvers of the other calls run
+ * beside it on a few CUs -- without the gate identical calls drift into lock step (all in the eigensolver, then
+ * all in the derotation) and the chip idles.  Purely a scheduling hint: results do not depend on it. */
+typedef struct vipmi_gate vipmi_gate;
+int vipmi_gate_create(vipmi_gate** out);
+int vipmi_gate_destroy(vipmi_gate* gate);
+int vipmi_set_gate(vipmi_ctx* ctx, vipmi_gate* gate_or_null);
 /* tuning knobs (key/value); see DESIGN.md.  Unknown key -> VIPMI_ERR_ARG. */
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value);
 int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key);   /* -1 if unset */

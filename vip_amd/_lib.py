@@ -22,6 +22,9 @@ _SIGS = {
     "vipmi_set_stream": ([ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_synchronize": ([], True, ctypes.c_int),
     "vipmi_check_deferred": ([], True, ctypes.c_int),
+    "vipmi_gate_create": ([ctypes.POINTER(ctypes.c_void_p)], False, ctypes.c_int),
+    "vipmi_gate_destroy": ([ctypes.c_void_p], False, ctypes.c_int),
+    "vipmi_set_gate": ([ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_set_option": ([ctypes.c_char_p, i64], True, ctypes.c_int),
     "vipmi_get_option": ([ctypes.c_char_p], True, i64),
     "vipmi_stage_ms": ([ctypes.c_char_p], True, ctypes.c_float),

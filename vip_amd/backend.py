@@ -74,7 +74,17 @@ class Context:
             pass
 
 
-_async = {"on": False, "reserve_cus": 0}
+_async = {"on": False, "reserve_cus": 0, "gate": None}
+
+
+def _gate():
+    """Process-wide gate shared by every context while asynchronous mode is on (include/vipmi.h: vipmi_gate)."""
+    if _async["gate"] is None:
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.raise_for_status(lib.vipmi_gate_create(ctypes.byref(h)), "vipmi_gate_create")
+        _async["gate"] = h
+    return _async["gate"]
 
 
 def set_async(on=True, reserve_cus=16):
@@ -82,13 +92,17 @@ def set_async(on=True, reserve_cus=16):
     synchronise (the eigensolver's convergence check is latched on the device and read by
     ``check_deferred()``).  Each (device, stream) pair gets its own vipmi_ctx / workspace, so independent
     calls issued on two streams overlap: the latency-bound Jacobi eigensolver of one cube (13 workgroups)
-    runs beside the FFT derotation of the previous one, for which ``reserve_cus`` CUs are left free."""
+    runs beside the FFT derotation of the previous one, for which ``reserve_cus`` CUs are left free.  All
+    contexts share a gate that runs the chip-filling half of the calls one at a time in issue order (otherwise
+    identical calls drift into lock step and the chip idles while every stream sits in its eigensolver)."""
     _async["on"] = bool(on)
     _async["reserve_cus"] = int(reserve_cus) if on else 0
+    gate = _gate() if on else None
     with _ctx_lock:
         for c in _ctx_cache.values():
             c.set_option("eigh_check", 0 if on else 1)
             c.set_option("reserve_cus", _async["reserve_cus"])
+            c.lib.vipmi_set_gate(c.handle, gate)
 
 
 def check_deferred():
@@ -116,6 +130,7 @@ def get_context(device=None):
             if _async["on"]:
                 c.set_option("eigh_check", 0)
                 c.set_option("reserve_cus", _async["reserve_cus"])
+                c.lib.vipmi_set_gate(c.handle, _gate())
             _ctx_cache[key] = c
         return c
 

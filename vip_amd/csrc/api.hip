@@ -2,6 +2,7 @@
 // the fused full-frame ADI pipeline (psfsub/pca_fullfr.py:801-1007).
 #include <stdarg.h>
 #include "common.h"
+#include <new>
 
 namespace vipmi {
 
@@ -106,6 +107,31 @@ int vipmi_ctx::upload_async(const char* name, const void* host, size_t bytes, vo
     set_error("upload_async '%s': %s", name, hipGetErrorString(e));
     return VIPMI_ERR_HIP;
   }
+  return VIPMI_OK;
+}
+
+int vipmi_ctx::gate_enter() {
+  if (!gate || !gate_armed) return VIPMI_OK;
+  gate_armed = false;
+  std::lock_guard<std::mutex> lk(gate->mu);
+  if (gate->last) VIPMI_CHECK_HIP(hipStreamWaitEvent(stream, gate->last, 0));
+  return VIPMI_OK;
+}
+
+int vipmi_ctx::gate_leave() {
+  if (!gate) return VIPMI_OK;
+  std::lock_guard<std::mutex> lk(gate->mu);
+  if (gate->ring.size() < 64) {
+    hipEvent_t e = nullptr;
+    VIPMI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    gate->ring.push_back(e);
+    gate->next = (int)gate->ring.size() - 1;
+  } else {
+    gate->next = (gate->next + 1) % (int)gate->ring.size();
+  }
+  hipEvent_t e = gate->ring[gate->next];
+  VIPMI_CHECK_HIP(hipEventRecord(e, stream));
+  gate->last = e;
   return VIPMI_OK;
 }
 
@@ -255,6 +281,27 @@ int vipmi_check_deferred(vipmi_ctx* ctx) {
   return VIPMI_OK;
 }
 
+int vipmi_gate_create(vipmi_gate** out) {
+  VIPMI_REQUIRE(out, "vipmi_gate_create: out is null");
+  *out = new (std::nothrow) vipmi_gate();
+  VIPMI_REQUIRE(*out, "vipmi_gate_create: out of memory");
+  return VIPMI_OK;
+}
+
+int vipmi_gate_destroy(vipmi_gate* gate) {
+  if (!gate) return VIPMI_OK;
+  for (hipEvent_t e : gate->ring) (void)hipEventDestroy(e);
+  delete gate;
+  return VIPMI_OK;
+}
+
+int vipmi_set_gate(vipmi_ctx* ctx, vipmi_gate* gate) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  ctx->gate = gate;
+  ctx->gate_armed = false;
+  return VIPMI_OK;
+}
+
 #define CTX_GUARD()                      \
   VIPMI_REQUIRE(ctx, "null ctx");        \
   VIPMI_CHECK_HIP(hipSetDevice(ctx->device))
@@ -344,6 +391,7 @@ int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float
   VIPMI_TRY(ws(ctx, "pca_evecs", (size_t)nref * nref, &evecs));
   VIPMI_TRY(gram_f32(ctx, ref, nref, ref, nref, P, P, G));
   VIPMI_TRY(eigh_f64(ctx, G, 1, nref, evals, evecs));
+  VIPMI_TRY(ctx->gate_enter());
   const int nld = (int)cdiv(nref, 32) * 32, kld = (int)cdiv(k, 32) * 32;
   float *Ekn = nullptr, *Enk = nullptr, *isig = nullptr;
   VIPMI_TRY(ws(ctx, "pca_Ekn", (size_t)kld * nld, &Ekn));
@@ -401,12 +449,14 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
   }
   float* res = residuals;
   if (!res) VIPMI_TRY(ws(ctx, "pca_res", (size_t)n * P, &res));
+  ctx->gate_armed = ctx->gate != nullptr;
   VIPMI_TRY(vipmi_pca_project_f32(ctx, M, n, M, n, P, k, res, recon, pcs, nullptr));
   float* der = residuals_der;
   if (!der) VIPMI_TRY(ws(ctx, "pca_der", (size_t)n * P, &der));
   // pca(): mask_center_px without rot_options -> mask_val=0 (pca_fullfr.py:412-415)
   VIPMI_TRY(derotate_f32(ctx, res, angles_host, n, N, der, mask ? 0 : 1, mask ? 1 : 0, VIPMI_ROT_AUTO));
   VIPMI_TRY(collapse_f32(ctx, der, n, P, collapse_mode, nullptr, 0, frame));
+  VIPMI_TRY(ctx->gate_leave());
   if (mask) {
     // pca_fullfr.py:985-987: residuals_cube_ and frame are masked again
     if (residuals_der) VIPMI_TRY(apply_mask_f32(ctx, der, der, n, P, mask, 0.f));

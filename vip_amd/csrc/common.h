@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/vipmi.h"
@@ -51,7 +52,16 @@ struct StageTimer {
 
 }  // namespace vipmi
 
+struct vipmi_gate {
+  std::mutex mu;
+  std::vector<hipEvent_t> ring;     // completion events of the gated sections, reused round-robin
+  int next = 0;
+  hipEvent_t last = nullptr;
+};
+
 struct vipmi_ctx {
+  vipmi_gate* gate = nullptr;
+  bool gate_armed = false;          // set by the fused pca call: its project stage waits for the previous section
   int device = 0;
   hipStream_t stream = nullptr;
   std::map<std::string, vipmi::Buffer> buffers;
@@ -80,6 +90,9 @@ struct vipmi_ctx {
     auto it = options.find(key);
     return it == options.end() ? dflt : it->second;
   }
+  // gated section (see vipmi_set_gate): enter = wait for the previous section, leave = publish this one's end
+  int gate_enter();
+  int gate_leave();
   void tic(const char* stage);
   void toc(const char* stage);
 };

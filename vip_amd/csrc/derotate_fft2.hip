@@ -118,6 +118,45 @@ struct Aux {          // per-batch auxiliary arrays (device)
   Twiddles<P> tw;                                                                 \
   tw.init(twtab, lds_all + P::LPB * P::LDS_ELEMS, lane)
 
+// Dynamic work distribution.  The shear kernels are launched with one persistent workgroup per CU, but when they
+// share the GPU with another stream's eigensolver some of those workgroups only become resident once an earlier one
+// retires; with a static grid-stride split such a launch takes twice as long.  Tasks are therefore handed out
+// through per-XCD counters (8 words, zeroed before the launch): token t of XCD x is task (t/TPG*8 + x)*TPG + t%TPG, so
+// TPG consecutive tasks stay on one XCD (= one L2).  The token of the NEXT task is requested before the transforms
+// of the current one and consumed after them, which hides the atomic's round trip.
+//   WPL == 1 (row kernels): every wave owns its line pair and fetches for itself -- no workgroup barrier;
+//   otherwise / rs_shear2 : one token per workgroup, broadcast through two alternating LDS words.
+template <class P, bool PER_WAVE>
+struct Tasks {
+  int* ctr;
+  int xcd, pending, parity;
+  int* sh;
+  __device__ __forceinline__ void init(int* counters, cf* lds_all) {
+    xcd = blockIdx.x & 7;
+    ctr = counters + xcd * 32;        // one 128-byte line per queue
+    sh = reinterpret_cast<int*>(lds_all + P::LPB * P::LDS_ELEMS + Twiddles<P>::PER_LANE * 64) + 8;
+    parity = 0;
+    pending = 0;
+  }
+  __device__ __forceinline__ void request() {
+    pending = 0;
+    if (PER_WAVE ? ((threadIdx.x & 63) == 0) : (threadIdx.x == 0)) pending = atomicAdd(ctr, 1);
+  }
+  template <int TPG>
+  __device__ __forceinline__ int take() {       // contains a workgroup barrier unless PER_WAVE
+    int t;
+    if (PER_WAVE) {
+      t = __builtin_amdgcn_readfirstlane(pending);
+    } else {
+      if (threadIdx.x == 0) sh[parity] = pending;
+      __syncthreads();
+      t = sh[parity];
+      parity ^= 1;
+    }
+    return ((t / TPG) * 8 + xcd) * TPG + (t % TPG);
+  }
+};
+
 // affine source map of canvas'(Y, X) -> frame[base + X*stride] (rot90 folded in)
 __device__ __forceinline__ void src_map(int q, int Y, const RotGeom& g, int& base, int& stride) {
   switch (q) {
@@ -133,14 +172,23 @@ template <class P>
 __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict__ in,
                                                          const RotFrame* __restrict__ fr, RotGeom g,
                                                          float* __restrict__ A1r, Aux aux, int f0, int nf,
-                                                         const cf* __restrict__ twtab) {
+                                                         const cf* __restrict__ twtab, int* __restrict__ counters) {
   VIPMI_SLOT_PROLOGUE();
+  constexpr bool PW = false;   // one token per workgroup: its LPB line pairs are adjacent rows, which share the
+                               // source frame's 64-byte sectors when the rot90 pre-step makes the gather column-wise
+  Tasks<P, PW> tasks;
+  tasks.init(counters, lds_all);
   const int half = g.N / 2;
   const int npairs = nf * half;
-  const int niter = (npairs + gridDim.x * P::LPB - 1) / (gridDim.x * P::LPB);
-  for (int it = 0; it < niter; ++it) {
-    int pr = (it * gridDim.x + blockIdx.x) * P::LPB + slot;
+  constexpr int PPT = 4;                        // line pairs per token of a wave (keeps the atomics under ~25 per us)
+  const int ntask = PW ? (npairs + PPT - 1) / PPT : (npairs + P::LPB - 1) / P::LPB;
+  tasks.request();
+  for (int task = tasks.template take<1>(); task < ntask; task = tasks.template take<1>()) {
+    tasks.request();
+   for (int sub_task = 0; sub_task < (PW ? PPT : 1); ++sub_task) {
+    int pr = PW ? task * PPT + sub_task : task * P::LPB + slot;
     const bool live = pr < npairs;
+    if (PW && !live) break;
     if (!live) pr = npairs - 1;
     const int fl = pr / half, yrel = 2 * (pr % half), f = f0 + fl;
     const RotFrame p = fr[f];
@@ -186,6 +234,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
         aux.beta[fl * g.N + yrel + 1] = sn2 * alt2;
       }
     }
+   }
   }
 }
 
@@ -270,22 +319,21 @@ template <class P>
 __global__ __launch_bounds__(64 * P::WPB) void rs_shear2(const float* __restrict__ A1r,
                                                          const RotFrame* __restrict__ fr, RotGeom g,
                                                          float* __restrict__ A2r, Aux aux, int f0, int nf,
-                                                         const cf* __restrict__ twtab) {
+                                                         const cf* __restrict__ twtab, int* __restrict__ counters) {
   VIPMI_SLOT_PROLOGUE();
   constexpr int W = 2 * P::LPB, LDT = W + 1;      // tile row stride in floats (odd: conflict-free column reads)
   float* tile = reinterpret_cast<float*>(lds_all);   // [N][LDT], aliases the exchange regions between phases
   const int groups = (P::L + W - 1) / W;          // last group may be ragged (W need not divide L)
   const int units = nf * groups;
-  // XCD-aware unit mapping: two adjacent column groups share every 128-byte line of A1r / A2r (a group is 64 or 48
-  // bytes wide).  They are given to workgroups b and b + 8 -- same XCD (XCD = b mod 8), hence same L2, and running
-  // in lock step -- so the second half of each line is an L2 hit instead of a second HBM fetch a unit later.
-  // (gridDim.x is a multiple of 16.)
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int pair0 = (jx >> 1) * 8 + xcd, npair = gridDim.x >> 1;
-  for (int q = pair0; 2 * q < units; q += npair) {
+  // Two adjacent column groups share every 128-byte line of A1r / A2r (a group is 64 or 48 bytes wide): consecutive
+  // tokens of an XCD are the two halves of one such pair, so they are taken by two workgroups of the same XCD at
+  // about the same time and the second half of each line is an L2 hit instead of a second HBM fetch.
+  Tasks<P, false> tasks;
+  tasks.init(counters, lds_all);
+  tasks.request();
+  for (int unit = tasks.template take<2>(); unit < units; unit = tasks.template take<2>()) {
     {
-      const int unit = 2 * q + (jx & 1);
-      if (unit >= units) break;                // uniform across the workgroup
+      tasks.request();
       const int fl = unit / groups, X0 = (unit % groups) * W, f = f0 + fl;
       const RotFrame p = fr[f];
       const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
@@ -361,14 +409,22 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
                                                          const RotFrame* __restrict__ fr, RotGeom g,
                                                          const float* __restrict__ in, float* __restrict__ out,
                                                          Aux aux, int f0, int nf, int mask_nan, int mask_zero,
-                                                         const cf* __restrict__ twtab) {
+                                                         const cf* __restrict__ twtab, int* __restrict__ counters) {
   VIPMI_SLOT_PROLOGUE();
+  constexpr bool PW = P::WPL == 1;
+  Tasks<P, PW> tasks;
+  tasks.init(counters, lds_all);
   const int half = g.N / 2;
   const int npairs = nf * half;
-  const int niter = (npairs + gridDim.x * P::LPB - 1) / (gridDim.x * P::LPB);
-  for (int it = 0; it < niter; ++it) {
-    int pr = (it * gridDim.x + blockIdx.x) * P::LPB + slot;
+  constexpr int PPT = 4;                        // line pairs per token of a wave (keeps the atomics under ~25 per us)
+  const int ntask = PW ? (npairs + PPT - 1) / PPT : (npairs + P::LPB - 1) / P::LPB;
+  tasks.request();
+  for (int task = tasks.template take<1>(); task < ntask; task = tasks.template take<1>()) {
+    tasks.request();
+   for (int sub_task = 0; sub_task < (PW ? PPT : 1); ++sub_task) {
+    int pr = PW ? task * PPT + sub_task : task * P::LPB + slot;
     const bool live = pr < npairs;
+    if (PW && !live) break;
     if (!live) pr = npairs - 1;
     const int fl = pr / half, m = 2 * (pr % half), f = f0 + fl;
     const RotFrame p = fr[f];
@@ -408,6 +464,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
           out[ob2 + j] = re2;
         }
     }
+   }
   }
 }
 
@@ -431,6 +488,8 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   VIPMI_TRY(ws(ctx, "rot_kv", (size_t)(chunk * g.N), &aux.kv));
   VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * P::L), &aux.gam));
   VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
+  int* counters = nullptr;                       // 3 kernels x 8 task queues, one 128-byte line each
+  VIPMI_TRY(ws(ctx, "rot_counters", (size_t)3 * 256, &counters));
   size_t lds = (size_t)P::LPB * P::LDS_ELEMS * sizeof(cf);
   const size_t tile = (size_t)g.N * (2 * P::LPB + 1) * sizeof(float);
   VIPMI_REQUIRE(tile <= lds, "derotate(fft2): staging tile larger than the exchange regions");
@@ -463,28 +522,34 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     const int64_t npairs = (int64_t)nf * (g.N / 2);
     int gr = (int)cdiv(npairs, P::LPB);
     if (gr > maxwg) gr = maxwg;
+    if (gr < 8) gr = 8;
+    gr = gr / 8 * 8;
     const int64_t units = (int64_t)nf * ((P::L + 2 * P::LPB - 1) / (2 * P::LPB));
-    int gc = (int)cdiv(units, 16) * 16;         // rs_shear2 pairs workgroups b and b + 8: multiple of 16
-    if (gc > maxwg) gc = maxwg / 16 * 16;
-    if (gc < 16) gc = 16;
+    int gc = (int)(units < maxwg ? units : maxwg);
+    // tasks are dealt through 8 queues (queue = workgroup index mod 8): every queue needs a workgroup, and equal
+    // numbers of them
+    if (gc < 8) gc = 8;
+    gc = gc / 8 * 8;
     int ga = (int)cdiv(nf, P::LPB);
     if (ga > maxwg) ga = maxwg;
+    VIPMI_CHECK_HIP(hipMemsetAsync(counters, 0, 3 * 256 * sizeof(int), ctx->stream));
     ctx->tic("k_rot_s1");
-    hipLaunchKernelGGL(k1, dim3(gr), blk, lds, ctx->stream, in, d_frames, g, A1r, aux, (int)f0, nf, twtab);
+    hipLaunchKernelGGL(k1, dim3(gr), blk, lds, ctx->stream, in, d_frames, g, A1r, aux, (int)f0, nf, twtab, counters);
     ctx->toc("k_rot_s1");
     ctx->tic("k_rot_aux");
     hipLaunchKernelGGL(rs_bf_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_frames, g, aux, (int)f0);
     hipLaunchKernelGGL(ka, dim3(ga), blk, lds, ctx->stream, d_frames, g, aux, (int)f0, nf, twtab);
     ctx->toc("k_rot_aux");
     ctx->tic("k_rot_s2");
-    hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab);
+    hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
+                       counters + 256);
     ctx->toc("k_rot_s2");
     ctx->tic("k_rot_aux");
     hipLaunchKernelGGL(rs_gamma_kernel, dim3(nf), dim3(256), 0, ctx->stream, aux, P::L);
     ctx->toc("k_rot_aux");
     ctx->tic("k_rot_s3");
     hipLaunchKernelGGL(k3, dim3(gr), blk, lds, ctx->stream, A2r, d_frames, g, in, out, aux, (int)f0, nf, mask_nan,
-                       mask_zero, twtab);
+                       mask_zero, twtab, counters + 512);
     ctx->toc("k_rot_s3");
     VIPMI_CHECK_HIP(hipGetLastError());
   }
