@@ -142,7 +142,7 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(depth)]
     pinned = [torch.empty((N, N), dtype=torch.float32).pin_memory() for _ in range(max(args.steps, args.warmup, 1))]
     if depth > 1:
-        B.set_async(True, reserve_cus=16)
+        B.set_async(True, reserve_cus=int(os.environ.get("VIPMI_RESERVE_CUS", "16")))
 
     def run(nsteps):
         if depth == 1:

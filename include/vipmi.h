@@ -93,6 +93,14 @@ int vipmi_cross_gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float
  * (unit norm, sign: largest-|component| positive). */
 int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs);
 
+/* Leading k eigenpairs only (k <= 64, n <= 512: Householder tridiagonalisation + multisection + inverse iteration,
+ * one workgroup per problem; other sizes fall back to vipmi_eigh_f64).  Same layout as vipmi_eigh_f64 for the first
+ * k rows of evals / evecs; the other entries are unspecified.  nact (device int32[batch], may be NULL): active
+ * leading size of each zero-padded problem.  Replaces get_eigenvectors(ncomp, ...) (psfsub/svd.py:623-702) and the
+ * truncated decompositions of svd_wrapper (svd.py:342-620). */
+int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
+                        double* evals, double* evecs);
+
 /* ---- _project_subtract: psfsub/pca_fullfr.py:1727-1731 ---- */
 /* B[k,P] = W[k,n] (float32) * M[n,P];  row c optionally scaled by rowscale[c] (may be NULL). */
 int vipmi_rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n,

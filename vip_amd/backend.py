@@ -224,6 +224,21 @@ def eigh(G):
     return (evals[0], evecs[0]) if single else (evals, evecs)
 
 
+def eigh_topk(G, k, nact=None):
+    """Leading k eigenpairs of G: (batch, n, n) or (n, n) float64 cuda tensor (destroyed).  Returns
+    (evals (.., k) descending, evecs (.., k, n) rows).  nact: optional int32 cuda tensor of active sizes."""
+    torch = _torch()
+    ctx = get_context(G.device.index)
+    single = G.dim() == 2
+    Gb = (G.unsqueeze(0) if single else G).contiguous()
+    batch, n, _ = Gb.shape
+    evals = torch.zeros((batch, n), dtype=torch.float64, device=G.device)
+    evecs = torch.zeros((batch, n, n), dtype=torch.float64, device=G.device)
+    ctx.call("vipmi_eigh_topk_f64", ptr(Gb), batch, n, int(k), ptr(nact), ptr(evals), ptr(evecs))
+    ev, ec = evals[:, :k], evecs[:, :k, :]
+    return (ev[0], ec[0]) if single else (ev, ec)
+
+
 def pca_project(M, k, ref=None, want_recon=False, want_pcs=False, want_evals=False):
     """residuals (and optionally recon, pcs, evals) of M w.r.t. the top-k PCs of ref (default M)."""
     torch = _torch()

@@ -86,7 +86,7 @@ int annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx
   hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, G, (int)n, lib_idx, lib_len,
                      (int)max_lib, m, H);
   VIPMI_CHECK_HIP(hipGetLastError());
-  VIPMI_TRY(eigh_f64(ctx, H, n, m, evals, evecs));
+  VIPMI_TRY(eigh_leading(ctx, H, n, m, ncomp < m ? ncomp : m, lib_len, evals, evecs));
   VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
   const size_t shm = (size_t)(m + ncomp + 8) * sizeof(double);
   hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,

@@ -219,7 +219,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_variant", "reserve_cus", "rot_wpb", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_variant", "reserve_cus", "rot_wpb", "eigh_method", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
@@ -328,6 +328,15 @@ int vipmi_cross_gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float
   return gram_f32(ctx, A, na, B, nb, P, ld, C);
 }
 
+int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
+                        double* evals, double* evecs) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(G && evals && evecs, "eigh_topk: null pointer");
+  VIPMI_REQUIRE(batch > 0 && n > 0 && k > 0 && k <= n, "eigh_topk: bad sizes batch=%ld n=%ld k=%ld", (long)batch,
+                (long)n, (long)k);
+  return eigh_leading(ctx, G, batch, n, k, nact, evals, evecs);
+}
+
 int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs) {
   CTX_GUARD();
   return eigh_f64(ctx, G, batch, n, evals, evecs);
@@ -390,7 +399,10 @@ int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float
   VIPMI_TRY(ws(ctx, "pca_evals", (size_t)nref, &evals));
   VIPMI_TRY(ws(ctx, "pca_evecs", (size_t)nref * nref, &evecs));
   VIPMI_TRY(gram_f32(ctx, ref, nref, ref, nref, P, P, G));
-  VIPMI_TRY(eigh_f64(ctx, G, 1, nref, evals, evecs));
+  if (evals_out)      // the caller wants the whole spectrum
+    VIPMI_TRY(eigh_f64(ctx, G, 1, nref, evals, evecs));
+  else
+    VIPMI_TRY(eigh_leading(ctx, G, 1, nref, k, nullptr, evals, evecs));
   VIPMI_TRY(ctx->gate_enter());
   const int nld = (int)cdiv(nref, 32) * 32, kld = (int)cdiv(k, 32) * 32;
   float *Ekn = nullptr, *Enk = nullptr, *isig = nullptr;

@@ -120,6 +120,13 @@ struct StageScope {
 int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb, int64_t P,
              int64_t ld, double* G);
 int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs);
+// leading k eigenpairs only (eigh_tri.hip); falls back to eigh_f64 when the sizes are outside its range or
+// option "eigh_method" == 1.  nact: optional device array with the active size of each (zero padded) problem.
+bool eigh_topk_supported(int64_t n, int64_t k);
+int eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
+                  double* evals, double* evecs);
+int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
+                 double* evals, double* evecs);
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,
                       const float* rowscale, float* B);
 int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,

@@ -1,0 +1,532 @@
+// eigh_tri.hip -- top-k eigenpairs of small symmetric float64 matrices (n <= 512, k <= 64), batched: one
+// workgroup per problem, the classic dense path  A = Q T Q^T  ->  eig(T)  ->  back-transformation:
+//
+//   1. Householder tridiagonalisation (unblocked, right-looking).  The rank-2 update of step s-1 and the
+//      matrix-vector product of step s are fused into ONE pass over the trailing matrix (row s is updated first
+//      and yields the next Householder vector), so the matrix is read and written once per step.  The matrix
+//      lives in global memory (L2-resident: 400^2 float64 = 1.3 MB); vectors v, w, p, d, e in LDS.
+//   2. top-k eigenvalues of T by multisection: one wave per eigenvalue, 64 Sturm counts (one per lane) shrink
+//      the bracket 65x per sweep -- 10 sweeps instead of 53 bisection steps.
+//   3. eigenvectors of T by inverse iteration (one lane per vector, pivoted tridiagonal LU as LAPACK dlagtf,
+//      3 iterations), then modified Gram-Schmidt over the k vectors (one wave per vector, registers).
+//   4. back-transformation Z <- H_0 H_1 ... H_{n-3} Z, one wave per vector, no workgroup barrier.
+//
+// The PCA only needs the k leading eigenpairs of the Gram matrix (svd_wrapper(..., ncomp), psfsub/svd.py:342-620;
+// get_eigenvectors, svd.py:623-702); the one-sided Jacobi solver of eigh.hip computes all n of them through
+// ~5000 dependent rotation steps (10.6 ms at n = 400), this path needs ~n dependent steps.  Same output contract
+// as eigh.hip for the leading k rows: evals descending, evecs[c*n + i] unit norm with the largest-magnitude
+// component positive.  Zero-padded problems (annular PCA: library sizes differ per frame) pass their active size.
+#include "common.h"
+#include "wave_util.h"
+
+namespace vipmi {
+
+namespace {
+
+constexpr int TNT = 1024;           // threads per workgroup
+constexpr int TNW = TNT / 64;       // waves
+constexpr double TEPS = 2.220446049250313e-16;
+
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+
+// number of eigenvalues of the (scaled, max-norm 1) tridiagonal (d, e2 = e^2) strictly below sigma: sign changes of
+// the Sturm sequence p_i = (d_i - sigma) p_{i-1} - e_{i-1}^2 p_{i-2} (one dependent FMA per step instead of a
+// float64 division); the pair (p_i, p_{i-1}) is renormalised every 16 steps (|growth| <= 4 per step).  A zero term
+// counts as a sign change and is given the opposite sign, as LAPACK dstebz does with its pivmin clamp.
+__device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n,
+                                           double sigma) {
+  double pm = 1.0, p = d[0] - sigma;
+  bool neg = p < 0.0 || p == 0.0;          // effective sign of p_i (true = negative); p_0 = 1 is positive
+  if (p == 0.0) p = -1e-300;
+  int cnt = neg ? 1 : 0;
+  for (int i = 1; i < n; ++i) {
+    const double t = e2[i - 1] * pm;
+    double pn = fma(d[i] - sigma, p, -t);
+    if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
+    const bool nneg = pn < 0.0;
+    cnt += (nneg != neg) ? 1 : 0;
+    neg = nneg;
+    pm = p;
+    p = pn;
+    if ((i & 15) == 15) {
+      const int ex = ilogb(fabs(p) > fabs(pm) ? p : pm);
+      p = scalbn(p, -ex);
+      pm = scalbn(pm, -ex);
+    }
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ double hash_unit(unsigned a, unsigned b) {   // deterministic pseudo-random in (-1, 1)
+  unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  x *= 0x297A2D39u;
+  x ^= x >> 15;
+  return ((double)(x >> 8) + 0.5) * (2.0 / 16777216.0) - 1.0;
+}
+
+template <int RPL>
+__global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
+                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
+                                                      double* __restrict__ evecs_all, double* __restrict__ scratch_all,
+                                                      int kp) {
+  extern __shared__ double sm[];
+  double* vcur = sm;             // [n] Householder vector of the current step (indexed by absolute row)
+  double* vprev = vcur + n;      // [n] pending rank-2 update  A -= v w^T + w v^T
+  double* wprev = vprev + n;     // [n]
+  double* pcur = wprev + n;      // [n]
+  double* dd = pcur + n;         // [n] diagonal of T
+  double* ee = dd + n;           // [n] ee[i] couples i and i+1
+  double* tau = ee + n;          // [n] Householder scalars
+  double* e2 = tau + n;          // [n] (scaled) squared off-diagonals
+  double* lam = e2 + n;          // [64] scaled eigenvalues, descending
+  const int prob = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* A = Aall + (size_t)prob * n * n;
+  double* evals = evals_all + (size_t)prob * n;
+  double* evecs = evecs_all + (size_t)prob * n * n;
+  double* scr = scratch_all + (size_t)prob * 6 * n * kp;
+  int na = nact ? nact[prob] : n;
+  if (na > n) na = n;
+  const int kk = k < na ? k : na;
+  for (int i = tid; i < n; i += TNT) {
+    vprev[i] = 0.0;
+    wprev[i] = 0.0;
+    vcur[i] = 0.0;
+  }
+  __syncthreads();
+  const long long t_0 = wall_clock64();
+
+  // ---------------- 1. tridiagonalisation ----------------
+  // Per step: ONE global round trip (the trailing pass).  Its first batch of loads is issued before the
+  // Householder vector of the step is formed, and row s itself arrives through LDS (`nrow`, written by the wave
+  // that updated it in the previous pass) instead of being re-read from L2.
+  constexpr int RQ = 4;                                // rows per wave and batch
+  double* nrow = e2;                                   // [n] row s of the updated matrix (e2 is not yet in use)
+  for (int c = tid; c < na; c += TNT) nrow[c] = A[c];  // row 0
+  __syncthreads();
+  for (int s = 0; s + 2 < na; ++s) {
+    // first batch of the trailing pass: rows r0 .. r0+RQ-1 of this wave (independent of the new Householder vector)
+    double a[RQ][RPL];
+    const int rfirst = s + 1 + RQ * wave;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q)
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int c = s + 1 + lane + 64 * ch, r = rfirst + q;
+        a[q][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
+      }
+    if (wave == 0) {
+      // row s (already updated): its tail is the next Householder column
+      double nrm2 = 0.0;
+      for (int c = s + 1 + lane; c < na; c += 64) {
+        const double x = nrow[c];
+        vcur[c] = x;
+        nrm2 += x * x;
+      }
+      nrm2 = wave_sum(nrm2);
+      const double x0 = nrow[s + 1];
+      const double nrm = sqrt(nrm2);
+      const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+      const double v0 = x0 - alpha;
+      double rest = nrm2 - x0 * x0;
+      if (rest < 0.0) rest = 0.0;
+      const double vv = rest + v0 * v0;
+      const double beta = (nrm2 > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+        dd[s] = nrow[s];
+        vcur[s + 1] = v0;
+        ee[s] = (nrm2 > 0.0) ? alpha : 0.0;
+        tau[s] = beta;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int c = s + 1 + lane; c < na; c += 64) A[(size_t)s * n + c] = vcur[c];   // kept for the back-transform
+    }
+    __syncthreads();
+    const double beta = tau[s];
+    for (int r0 = rfirst; r0 < na; r0 += RQ * TNW) {
+      if (r0 != rfirst) {
+#pragma unroll
+        for (int q = 0; q < RQ; ++q)
+#pragma unroll
+          for (int ch = 0; ch < RPL; ++ch) {
+            const int c = s + 1 + lane + 64 * ch, r = r0 + q;
+            a[q][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        const int r = r0 + q;
+        if (r < na) {
+          const double vr = vprev[r], wr = wprev[r];
+          double acc = 0.0;
+#pragma unroll
+          for (int ch = 0; ch < RPL; ++ch) {
+            const int c = s + 1 + lane + 64 * ch;
+            if (c < na) {
+              const double t = a[q][ch] - vr * wprev[c] - wr * vprev[c];
+              A[(size_t)r * n + c] = t;
+              a[q][ch] = t;
+              acc += t * vcur[c];
+            }
+          }
+          acc = wave_sum(acc);
+          if (lane == 0) pcur[r] = beta * acc;
+        }
+      }
+      if (r0 == s + 1) {            // this wave holds row s+1: stash it (without the still pending update) for the next step
+#pragma unroll
+        for (int ch = 0; ch < RPL; ++ch) {
+          const int c = s + 1 + lane + 64 * ch;
+          if (c < na) nrow[c] = a[0][ch];
+        }
+      }
+    }
+    __syncthreads();
+    // K = beta/2 v.p (every wave computes it: no second barrier) ; w = p - K v becomes the pending update
+    double kd = 0.0;
+    for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pcur[r];
+    const double K = 0.5 * beta * wave_sum(kd);
+    const double vs1 = vcur[s + 1], ws1 = pcur[s + 1] - K * vs1;
+    for (int r = s + 1 + tid; r < na; r += TNT) {
+      const double v = vcur[r];
+      const double w = pcur[r] - K * v;
+      wprev[r] = w;
+      vprev[r] = v;
+      nrow[r] = nrow[r] - vs1 * w - ws1 * v;      // row s+1 with its own step's update: ready for the next step
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (na >= 2) {
+      const int a = na - 2, b = na - 1;
+      dd[a] = A[(size_t)a * n + a] - 2.0 * vprev[a] * wprev[a];
+      ee[a] = A[(size_t)a * n + b] - vprev[a] * wprev[b] - wprev[a] * vprev[b];
+      dd[b] = A[(size_t)b * n + b] - 2.0 * vprev[b] * wprev[b];
+      ee[b] = 0.0;
+    } else if (na == 1) {
+      dd[0] = A[0];
+      ee[0] = 0.0;
+    }
+  }
+  __syncthreads();
+
+  const long long t_1 = wall_clock64();
+  // ---------------- 2. leading eigenvalues of T (scaled to max-norm 1) ----------------
+  double scale = 0.0, glo = 0.0, ghi = 0.0;
+  {
+    double mx = 0.0;
+    for (int i = lane; i < na; i += 64) mx = fmax(mx, fmax(fabs(dd[i]), fabs(ee[i])));
+    scale = wave_max(mx);
+  }
+  const double iscale = scale > 0.0 ? 1.0 / scale : 0.0;
+  __syncthreads();
+  for (int i = tid; i < na; i += TNT) {
+    const double e = ee[i] * iscale;
+    dd[i] *= iscale;
+    ee[i] = e;
+    e2[i] = e * e;
+  }
+  __syncthreads();
+  {
+    double lo = 1e300, hi = -1e300;
+    for (int i = lane; i < na; i += 64) {
+      const double rad = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i + 1 < na ? fabs(ee[i]) : 0.0);
+      lo = fmin(lo, dd[i] - rad);
+      hi = fmax(hi, dd[i] + rad);
+    }
+    glo = -wave_max(-lo);
+    ghi = wave_max(hi);
+    const double margin = 4.0 * TEPS * (double)na + 1e-290;
+    glo -= margin;
+    ghi += margin;
+  }
+  for (int i = wave; i < kk; i += TNW) {
+    const int target = na - 1 - i;         // ascending index of the i-th largest eigenvalue
+    double a = glo, b = ghi;
+    for (int sweep = 0; sweep < 14; ++sweep) {
+      const double h = (b - a) * (1.0 / 65.0);
+      const double sigma = a + h * (double)(lane + 1);
+      const int cnt = sturm_count(dd, e2, na, sigma);
+      const unsigned long long below = __ballot(cnt <= target);    // sigma_l <= lambda_target
+      const int L = __popcll(below);
+      const double na_ = (L == 0) ? a : a + h * (double)L;
+      const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
+      a = na_;
+      b = nb_;
+      if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
+    }
+    if (lane == 0) lam[i] = 0.5 * (a + b);
+  }
+  __syncthreads();
+
+  const long long t_2 = wall_clock64();
+  // ---------------- 3. eigenvectors of T: inverse iteration, one lane per vector ----------------
+  double* __restrict__ U0 = scr;                       // [n][kp] reciprocal pivots
+  double* __restrict__ U1 = scr + (size_t)n * kp;      // first superdiagonal of U
+  double* __restrict__ U2 = scr + (size_t)2 * n * kp;  // second superdiagonal (row swaps)
+  double* __restrict__ Zg = scr + (size_t)3 * n * kp;  // rhs / solution, [n][kp]
+  double* __restrict__ Lm = scr + (size_t)4 * n * kp;  // multipliers of L
+  double* __restrict__ Ls = scr + (size_t)5 * n * kp;  // 1 where rows i, i+1 were swapped
+  if (tid < kk) {
+    const int c = tid;
+    // distinct shifts for (nearly) equal eigenvalues; the offsets are far below the eigenvalue accuracy that matters
+    const double lc = lam[c] - (double)(c + 1) * 4.0 * TEPS;
+    const double ptiny = 1e-3 * TEPS;      // pivot floor (scaled matrix has max-norm 1)
+    // factorisation P L U = T - lc I with partial pivoting (done once), first right-hand side on the fly
+    double p = dd[0] - lc, q = (na > 1) ? ee[0] : 0.0, r = 0.0;
+    double yc = hash_unit(0u, (unsigned)c);
+    for (int i = 0; i + 1 < na; ++i) {
+      const double sub = ee[i], nd = dd[i + 1] - lc, nu = (i + 2 < na) ? ee[i + 1] : 0.0;
+      const double yn = hash_unit((unsigned)(i + 1), (unsigned)c);
+      double inv, u1, u2, yi, m, sw;
+      if (fabs(sub) > fabs(p) && fabs(sub) >= ptiny) {         // swap rows i and i+1
+        inv = fast_rcp(sub);
+        u1 = nd; u2 = nu;
+        m = p * inv;
+        sw = 1.0;
+        yi = yn;
+        yc = yc - m * yn;
+        p = q - m * nd;
+        q = r - m * nu;
+        r = 0.0;
+      } else {
+        if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+        inv = fast_rcp(p);
+        u1 = q; u2 = r;
+        m = sub * inv;
+        sw = 0.0;
+        yi = yc;
+        yc = yn - m * yc;
+        p = nd - m * q;
+        q = nu - m * r;
+        r = 0.0;
+      }
+      U0[(size_t)i * kp + c] = inv;
+      U1[(size_t)i * kp + c] = u1;
+      U2[(size_t)i * kp + c] = u2;
+      Lm[(size_t)i * kp + c] = m;
+      Ls[(size_t)i * kp + c] = sw;
+      Zg[(size_t)i * kp + c] = yi;
+    }
+    if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+    const double invlast = fast_rcp(p);
+    double rs = 1.0;
+    for (int it = 0; it < 2; ++it) {
+      if (it > 0) {
+        // forward substitution of the previous solution (scaled to unit norm) through P L
+        yc = Zg[c] * rs;
+        for (int i = 0; i + 1 < na; ++i) {
+          const double yn = Zg[(size_t)(i + 1) * kp + c] * rs;
+          const double m = Lm[(size_t)i * kp + c];
+          const bool sw = Ls[(size_t)i * kp + c] != 0.0;
+          const double yi = sw ? yn : yc;
+          yc = sw ? (yc - m * yn) : (yn - m * yc);
+          Zg[(size_t)i * kp + c] = yi;
+        }
+      }
+      // back substitution
+      double x1 = yc * invlast, x2 = 0.0;
+      Zg[(size_t)(na - 1) * kp + c] = x1;
+      double acc = x1 * x1;
+      for (int i = na - 2; i >= 0; --i) {
+        const double x = (Zg[(size_t)i * kp + c] - U1[(size_t)i * kp + c] * x1 - U2[(size_t)i * kp + c] * x2) *
+                         U0[(size_t)i * kp + c];
+        Zg[(size_t)i * kp + c] = x;
+        acc += x * x;
+        x2 = x1;
+        x1 = x;
+      }
+      rs = acc > 0.0 ? 1.0 / sqrt(acc) : 1.0;
+    }
+    // the last solution is left un-normalised: Gram-Schmidt normalises
+  }
+  __syncthreads();
+
+  const long long t_3 = wall_clock64();
+  // ---------------- 3b. modified Gram-Schmidt, one wave per vector (registers), pivot vector through LDS -------------
+  constexpr int VPW = 4;                    // vectors per wave: c = wave + 16 v
+  double z[VPW][RPL];
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = wave + TNW * v;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      const int i = lane + 64 * rr;
+      z[v][rr] = (c < kk && i < na) ? Zg[(size_t)i * kp + c] : 0.0;
+    }
+  }
+  double* qv = pcur;                        // pivot vector [n]
+  for (int c = 0; c < kk; ++c) {
+    const int ow = c % TNW, ov = c / TNW;
+    if (wave == ow) {
+#pragma unroll
+      for (int v = 0; v < VPW; ++v)
+        if (v == ov) {
+          double s = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < RPL; ++rr) s += z[v][rr] * z[v][rr];
+          s = wave_sum(s);
+          const double inv = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+#pragma unroll
+          for (int rr = 0; rr < RPL; ++rr) {
+            z[v][rr] *= inv;
+            const int i = lane + 64 * rr;
+            if (i < n) qv[i] = z[v][rr];
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c2 = wave + TNW * v;
+      if (c2 > c && c2 < kk) {
+        double s = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+          const int i = lane + 64 * rr;
+          s += (i < n) ? z[v][rr] * qv[i] : 0.0;
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+          const int i = lane + 64 * rr;
+          if (i < n) z[v][rr] -= s * qv[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const long long t_4 = wall_clock64();
+  // ---------------- 4. back-transformation: reflectors staged through LDS in blocks, one wave per vector ------------
+  {
+    constexpr int RB = 6;                             // reflectors per block: RB * n doubles of LDS (vcur..ee reused;
+                                                      // tau, which is still needed, starts at 6n)
+    double* stage = sm;                               // [RB][n]; the tridiagonalisation vectors are dead by now
+    const int nv = (kk - wave + TNW - 1) / TNW;      // vectors of this wave (may be <= 0)
+    for (int jb = na - 3; jb >= 0; jb -= RB) {
+      __syncthreads();
+      for (int e = tid; e < RB * n; e += TNT) {
+        const int q = e / n, i = e - q * n, j = jb - q;
+        stage[e] = (j >= 0 && i > j && i < na) ? A[(size_t)j * n + i] : 0.0;
+      }
+      __syncthreads();
+      for (int q = 0; q < RB; ++q) {
+        const int j = jb - q;
+        if (j < 0) break;
+        const double beta = tau[j];
+        double vj[RPL];
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+          const int i = lane + 64 * rr;
+          vj[rr] = (i < n) ? stage[q * n + i] : 0.0;
+        }
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) {
+          if (v < nv) {
+            double sdot = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) sdot += vj[rr] * z[v][rr];
+            sdot = beta * wave_sum(sdot);
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) z[v][rr] -= sdot * vj[rr];
+          }
+        }
+      }
+    }
+  }
+
+  const long long t_5 = wall_clock64();
+  if (tid == 0 && n >= k + 8) {       // phase durations (100 MHz ticks) in the unused tail of evals: profiling aid
+    evals[n - 1] = (double)(t_1 - t_0);
+    evals[n - 2] = (double)(t_2 - t_1);
+    evals[n - 3] = (double)(t_3 - t_2);
+    evals[n - 4] = (double)(t_4 - t_3);
+    evals[n - 5] = (double)(t_5 - t_4);
+  }
+  // ---------------- output: sign convention of eigh.hip, zero padding ----------------
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = wave + TNW * v;
+    if (c < k) {
+      double best = -1.0, bval = 0.0;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        const double a = fabs(z[v][rr]);
+        if (i < na && a > best) {
+          best = a;
+          bval = z[v][rr];
+          bidx = i;
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(best, m, 64), ovv = __shfl_xor(bval, m, 64);
+        const int oi = __shfl_xor(bidx, m, 64);
+        if (ob > best || (ob == best && oi < bidx)) {
+          best = ob;
+          bval = ovv;
+          bidx = oi;
+        }
+      }
+      const double sg = (c < kk) ? (bval < 0.0 ? -1.0 : 1.0) : 0.0;
+#pragma unroll
+      for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        if (i < n) evecs[(size_t)c * n + i] = (i < na) ? z[v][rr] * sg : 0.0;
+      }
+      if (lane == 0) evals[c] = (c < kk) ? lam[c] * scale : 0.0;
+    }
+  }
+}
+
+template <int RPL>
+int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int32_t* nact, double* evals,
+               double* evecs) {
+  const int kp = (int)cdiv(k, 16) * 16;
+  double* scratch = nullptr;
+  VIPMI_TRY(ws(ctx, "eigh_tri_scratch", (size_t)batch * 6 * n * kp, &scratch));
+  const size_t lds = ((size_t)8 * n + 64 + 8) * sizeof(double);
+  auto kern = tri_eig_kernel<RPL>;
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(TNT), lds, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+}  // namespace
+
+bool eigh_topk_supported(int64_t n, int64_t k) { return n >= 1 && n <= 512 && k >= 1 && k <= 64; }
+
+// Leading k eigenpairs of `batch` symmetric n x n matrices (destroyed).  evals[p*n + c], evecs[p*n*n + c*n + i] for
+// c < k (other entries are not written).  nact (device, optional): active leading size of every problem.
+int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k, const int32_t* nact, double* evals,
+                  double* evecs) {
+  VIPMI_REQUIRE(A && evals && evecs, "eigh_topk: null pointer");
+  VIPMI_REQUIRE(batch > 0 && eigh_topk_supported(n, k), "eigh_topk: unsupported sizes n=%ld k=%ld", (long)n, (long)k);
+  StageScope sc(ctx, "eigh");
+  if (n <= 128) return launch_tri<2>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
+  if (n <= 256) return launch_tri<4>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
+  return launch_tri<8>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
+}
+
+int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact, double* evals,
+                 double* evecs) {
+  if (ctx->opt("eigh_method", 0) != 1 && eigh_topk_supported(n, k))
+    return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs);
+  return eigh_f64(ctx, G, batch, n, evals, evecs);
+}
+
+}  // namespace vipmi
