@@ -106,6 +106,88 @@ def test_eigh_batched_and_rank_deficient(B):
         assert np.abs(E @ E.T - np.eye(r)).max() < 1e-8
 
 
+def _topk_check(G, ev, ec, k, tol_proj=1e-10):
+    n = G.shape[0]
+    w, v = np.linalg.eigh(G)
+    w, v = w[::-1], v[:, ::-1]
+    scale = max(abs(w[0]), 1e-300)
+    np.testing.assert_allclose(ev, w[:k], atol=1e-12 * scale)
+    assert np.all(np.diff(ev) <= 1e-12 * scale)
+    X = ec.T                                               # n x k
+    assert np.abs(X.T @ X - np.eye(k)).max() < 1e-11
+    assert np.abs(G @ X - X * ev).max() < 1e-11 * scale
+    # sign convention: the largest-magnitude component of every vector is positive
+    assert np.all(X[np.abs(X).argmax(axis=0), np.arange(k)] > 0)
+    # projector onto the leading invariant subspace (well defined when lambda_k > lambda_k+1)
+    if k < n and (w[k - 1] - w[k]) > 1e-6 * scale:
+        assert np.abs(X @ X.T - v[:, :k] @ v[:, :k].T).max() < tol_proj
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 1), (2, 2), (3, 2), (17, 5), (64, 64), (65, 10), (128, 20), (200, 10),
+                                 (400, 20), (512, 64)])
+def test_eigh_topk(B, n, k):
+    import torch
+    rng = np.random.default_rng(n * 100 + k)
+    M = rng.standard_normal((n, 3 * n + 5))
+    M[:, 0] *= 30
+    M[:, 1] *= 10
+    G = M @ M.T
+    ev, ec = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), k)
+    _topk_check(G, ev.cpu().numpy(), ec.cpu().numpy(), k)
+
+
+def test_eigh_topk_degenerate_and_padded(B):
+    import torch
+    rng = np.random.default_rng(5)
+    n, k = 48, 6
+    mats = []
+    M = rng.standard_normal((n, 200)); M[1] = M[0]; M[7] = M[0]                  # duplicated frames: exact null space
+    mats.append(M @ M.T)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.r_[5.0, 5.0, 5.0, 3.0, 3.0, 1.0, np.zeros(n - 6)]                    # exactly repeated leading eigenvalues
+    mats.append((Q * lam) @ Q.T)
+    mats.append(np.zeros((n, n)))                                                 # zero matrix
+    mats.append(np.diag(np.arange(n, 0, -1.0)))                                   # already diagonal (all reflectors trivial)
+    T = np.diag(rng.random(n) + 1) + np.diag(rng.random(n - 1), 1); T = T + np.triu(T, 1).T
+    mats.append(T)                                                                # already tridiagonal
+    G = np.stack(mats)
+    ev, ec = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), k)
+    ev, ec = ev.cpu().numpy(), ec.cpu().numpy()
+    for i in (0, 3, 4):
+        _topk_check(G[i], ev[i], ec[i], k)
+    # repeated eigenvalues: the eigenvalues, orthonormality and the invariant subspace of the 6 non-zero ones
+    np.testing.assert_allclose(ev[1], lam[:k], atol=1e-12)
+    X = ec[1].T
+    assert np.abs(X.T @ X - np.eye(k)).max() < 1e-11
+    assert np.abs(X @ X.T - Q[:, :k] @ Q[:, :k].T).max() < 1e-9
+    assert np.abs(ev[2]).max() == 0.0 and np.all(np.isfinite(ec[2]))
+    # zero padding with per-problem active sizes (annular PCA: libraries of different length)
+    sizes = np.array([48, 30, 7, 1, 2], dtype=np.int32)
+    Gp = np.zeros_like(G)
+    for i, m in enumerate(sizes):
+        A = rng.standard_normal((m, 60))
+        Gp[i, :m, :m] = A @ A.T
+    ev, ec = B.eigh_topk(torch.from_numpy(Gp.copy()).cuda(), k, nact=torch.from_numpy(sizes).cuda())
+    ev, ec = ev.cpu().numpy(), ec.cpu().numpy()
+    for i, m in enumerate(sizes):
+        kk = min(k, m)
+        _topk_check(Gp[i, :m, :m], ev[i, :kk], ec[i, :kk, :m], kk)
+        assert np.all(ec[i, :, m:] == 0) and np.all(ev[i, kk:] == 0) and np.all(ec[i, kk:] == 0)
+
+
+def test_eigh_topk_matches_jacobi_in_pca(B):
+    """The fused PCA gives the same residuals with either eigensolver (option eigh_method)."""
+    from vip_amd.synth import synth_adi
+    cube, _ = synth_adi(60, 64, seed=3)
+    M = dev(B, cube.reshape(60, -1))
+    ctx = B.get_context()
+    ctx.set_option("eigh_method", 1)
+    r1 = B.pca_project(M, 7)[0].cpu().numpy()
+    ctx.set_option("eigh_method", 0)
+    r2 = B.pca_project(M, 7)[0].cpu().numpy()
+    assert np.abs(r1 - r2).max() < 2e-6
+
+
 # ---- projection kernels ---------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n,k,P", [(12, 3, 1024), (50, 5, 16384), (37, 20, 10201), (100, 33, 4096), (64, 64, 640)])
