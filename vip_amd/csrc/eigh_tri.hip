@@ -44,20 +44,30 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const d
   bool neg = p < 0.0 || p == 0.0;          // effective sign of p_i (true = negative); p_0 = 1 is positive
   if (p == 0.0) p = -1e-300;
   int cnt = neg ? 1 : 0;
-  for (int i = 1; i < n; ++i) {
-    const double t = e2[i - 1] * pm;
-    double pn = fma(d[i] - sigma, p, -t);
-    if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
-    const bool nneg = pn < 0.0;
-    cnt += (nneg != neg) ? 1 : 0;
-    neg = nneg;
-    pm = p;
-    p = pn;
-    if ((i & 15) == 15) {
-      const int ex = ilogb(fabs(p) > fabs(pm) ? p : pm);
-      p = scalbn(p, -ex);
-      pm = scalbn(pm, -ex);
+  for (int i0 = 1; i0 < n; i0 += 16) {
+    double db[16], eb[16];                 // operands of 16 steps fetched from LDS up front (uniform addresses)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u;
+      db[u] = (i < n) ? d[i] : 0.0;
+      eb[u] = (i < n) ? e2[i - 1] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (i0 + u < n) {
+        const double t = eb[u] * pm;
+        double pn = fma(db[u] - sigma, p, -t);
+        if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
+        const bool nneg = pn < 0.0;
+        cnt += (nneg != neg) ? 1 : 0;
+        neg = nneg;
+        pm = p;
+        p = pn;
+      }
+    }
+    const int ex = ilogb(fabs(p) > fabs(pm) ? p : pm);
+    p = scalbn(p, -ex);
+    pm = scalbn(pm, -ex);
   }
   return cnt;
 }
@@ -491,6 +501,460 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-workgroup variant for a single (or a few) larger problems: a lone CU streams the trailing matrix from L2 at
+// ~50 GB/s, which makes the tridiagonalisation of one 400 x 400 matrix take 7 ms.  Here W workgroups hold the matrix
+// in LDS (row r lives in workgroup r mod W) and exchange, per Householder step, only two vectors through global memory
+// behind ONE counter barrier:
+//     pass s   : own rows r > s:  row <- row - v'_r w' - w'_r v'  (pending update of step s-1),
+//                p[r] = beta_s row . v_s,   col[r] = row[s+1]            -> global, write-through
+//     barrier ; every workgroup gathers p and col (= row s+1 by symmetry), forms w_s = p - K v_s, applies the step's
+//     own update to row s+1 and derives v_{s+1}, beta_{s+1} redundantly -- no broadcast step.
+// Afterwards every workgroup computes the eigenvalues / inverse iterations / back-transformations of ITS vectors
+// (vector c belongs to workgroup c mod W, all scratch in LDS), one more barrier, and workgroup 0 orthonormalises.
+template <int RPL>
+__global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aall, int n, int k, int RW, int VW, int rows_d,
+                                                        double* __restrict__ evals_all, double* __restrict__ evecs_all,
+                                                        double* __restrict__ gbuf_all, unsigned* __restrict__ bars) {
+  extern __shared__ double sm[];
+  const int W = gridDim.x, wg = blockIdx.x, prob = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* rows = sm;                         // [RW][n]  row lr <-> global row lr*W + wg ; reused after phase 1
+  double* vbuf0 = rows + rows_d;             // Householder vector, double buffered (rows_d >= RW*n, 6*n*VW)
+  double* vbuf1 = vbuf0 + n;
+  double* vprev = vbuf1 + n;
+  double* wprev = vprev + n;
+  double* pfull = wprev + n;
+  double* cfull = pfull + n;
+  double* dd = cfull + n;
+  double* ee = dd + n;
+  double* tau = ee + n;
+  double* e2 = tau + n;
+  double* lam = e2 + n;                      // [64]
+  double* A = Aall + (size_t)prob * n * n;
+  double* evals = evals_all + (size_t)prob * n;
+  double* evecs = evecs_all + (size_t)prob * n * n;
+  double* gb = gbuf_all + (size_t)prob * 5 * n;
+  double* Pb = gb;                           // [2][n]
+  double* Cb = gb + 2 * n;                   // [2][n]
+  double* Db = gb + 4 * n;                   // [n] diagonal, last step only
+  unsigned* bar = bars + prob;
+  unsigned bar_target = 0;
+  const int na = n;
+  const int kk = k < na ? k : na;
+
+  // own rows into LDS; row 0 (input data, no synchronisation needed) gives v_0 in every workgroup
+  for (int e = tid; e < RW * n; e += TNT) {
+    const int lr = e / n, c = e - lr * n, r = lr * W + wg;
+    rows[e] = (r < n) ? A[(size_t)r * n + c] : 0.0;
+  }
+  for (int c = tid; c < n; c += TNT) {
+    cfull[c] = A[c];
+    vprev[c] = 0.0;
+    wprev[c] = 0.0;
+    pfull[c] = 0.0;
+  }
+  __syncthreads();
+  double* vcur = vbuf0;
+  double* vnext = vbuf1;
+  // derive (v_{s+1}, beta, alpha, diagonal) from x = updated row s+1 held in cfull[c], c >= s+1 ; every wave
+  // computes the norm redundantly, threads write disjoint elements
+  auto form_reflector = [&](int s1, double* vout) {      // s1 = index of the row that becomes the Householder column
+    double nrm2 = 0.0;
+    for (int c = s1 + 1 + lane; c < na; c += 64) {
+      const double x = cfull[c];
+      nrm2 += x * x;
+    }
+    nrm2 = wave_sum(nrm2);
+    const double x0 = cfull[s1 + 1];
+    const double nrm = sqrt(nrm2);
+    const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+    const double v0 = x0 - alpha;
+    double rest = nrm2 - x0 * x0;
+    if (rest < 0.0) rest = 0.0;
+    const double vv = rest + v0 * v0;
+    const double beta = (nrm2 > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
+    for (int c = s1 + 1 + tid; c < na; c += TNT) vout[c] = (c == s1 + 1) ? v0 : cfull[c];
+    if (tid == 0) {
+      dd[s1] = cfull[s1];
+      ee[s1] = (nrm2 > 0.0) ? alpha : 0.0;
+      tau[s1] = beta;
+    }
+  };
+  form_reflector(0, vcur);
+  __syncthreads();
+
+  // ---------------- 1. tridiagonalisation ----------------
+  for (int s = 0; s + 2 < na; ++s) {
+    const int par = s & 1;
+    const double beta = tau[s];
+    // the owner of row s keeps the reflector for the back-transformation
+    if (s % W == wg)
+      for (int c = s + 1 + tid; c < na; c += TNT) st_shared(&A[(size_t)s * n + c], vcur[c]);
+    const int lr0 = (s + 1 - wg + W - 1) / W;            // first local row with r >= s+1
+    for (int lr = (lr0 > 0 ? lr0 : 0) + wave; lr < RW; lr += TNW) {
+      const int r = lr * W + wg;
+      if (r >= na) break;
+      double* row = rows + (size_t)lr * n;
+      const double vr = vprev[r], wr = wprev[r];
+      double acc = 0.0, cval = 0.0, dval = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int c = s + 1 + lane + 64 * ch;
+        if (c < na) {
+          const double t = row[c] - vr * wprev[c] - wr * vprev[c];
+          row[c] = t;
+          acc += t * vcur[c];
+          if (ch == 0 && lane == 0) cval = t;
+          if (c == r) dval = t;
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        st_shared(&Pb[par * n + r], beta * acc);
+        st_shared(&Cb[par * n + r], cval);
+      }
+      if (s + 3 == na) {
+        const int dl = r - s - 1;
+        if (lane == (dl & 63)) st_shared(&Db[r], dval);
+      }
+    }
+    bar_target += W;
+    grid_barrier(bar, bar_target, W);
+    for (int c = s + 1 + tid; c < na; c += TNT) {
+      pfull[c] = ld_shared(&Pb[par * n + c]);
+      cfull[c] = ld_shared(&Cb[par * n + c]);
+    }
+    __syncthreads();
+    double kd = 0.0;
+    for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pfull[r];
+    const double K = 0.5 * beta * wave_sum(kd);
+    const double vs1 = vcur[s + 1], ws1 = pfull[s + 1] - K * vs1;
+    for (int r = s + 1 + tid; r < na; r += TNT) {
+      const double v = vcur[r];
+      const double w = pfull[r] - K * v;
+      wprev[r] = w;
+      vprev[r] = v;
+      cfull[r] = cfull[r] - vs1 * w - ws1 * v;          // row s+1 with this step's update
+    }
+    __syncthreads();
+    if (s + 3 < na) {
+      form_reflector(s + 1, vnext);
+      double* t = vcur;
+      vcur = vnext;
+      vnext = t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    // trailing 2 x 2 block: cfull holds row na-2 (fully updated) ; the last diagonal entry came through Db
+    const int a = na - 2, b = na - 1;
+    dd[a] = cfull[a];
+    ee[a] = cfull[b];
+    dd[b] = ld_shared(&Db[b]) - 2.0 * vprev[b] * wprev[b];
+    ee[b] = 0.0;
+  }
+  __syncthreads();
+
+  // ---------------- 2. eigenvalues of the vectors of this workgroup ----------------
+  double scale = 0.0, glo = 0.0, ghi = 0.0;
+  {
+    double mx = 0.0;
+    for (int i = lane; i < na; i += 64) mx = fmax(mx, fmax(fabs(dd[i]), fabs(ee[i])));
+    scale = wave_max(mx);
+  }
+  const double iscale = scale > 0.0 ? 1.0 / scale : 0.0;
+  __syncthreads();
+  for (int i = tid; i < na; i += TNT) {
+    const double e = ee[i] * iscale;
+    dd[i] *= iscale;
+    ee[i] = e;
+    e2[i] = e * e;
+  }
+  __syncthreads();
+  {
+    double lo = 1e300, hi = -1e300;
+    for (int i = lane; i < na; i += 64) {
+      const double rad = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i + 1 < na ? fabs(ee[i]) : 0.0);
+      lo = fmin(lo, dd[i] - rad);
+      hi = fmax(hi, dd[i] + rad);
+    }
+    glo = -wave_max(-lo);
+    ghi = wave_max(hi);
+    const double margin = 4.0 * TEPS * (double)na + 1e-290;
+    glo -= margin;
+    ghi += margin;
+  }
+  const int nmine = (kk - wg + W - 1) / W;               // vectors c = wg + W j, j < nmine (may be <= 0)
+  for (int j = wave; j < nmine; j += TNW) {
+    const int c = wg + W * j;
+    const int target = na - 1 - c;
+    double a = glo, b = ghi;
+    for (int sweep = 0; sweep < 14; ++sweep) {
+      const double h = (b - a) * (1.0 / 65.0);
+      const double sigma = a + h * (double)(lane + 1);
+      const int cnt = sturm_count(dd, e2, na, sigma);
+      const int L = __popcll(__ballot(cnt <= target));
+      const double na_ = (L == 0) ? a : a + h * (double)L;
+      const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
+      a = na_;
+      b = nb_;
+      if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
+    }
+    if (lane == 0) lam[j] = 0.5 * (a + b);
+  }
+  __syncthreads();
+
+  // ---------------- 3. inverse iteration, vectors of this workgroup, everything in LDS (rows region) ----------------
+  // VW = vectors per workgroup (ceil(k / W)) = row stride of the per-vector arrays
+  double* U0 = rows;                                      // [n][VW]
+  double* U1 = U0 + (size_t)n * VW;
+  double* U2 = U1 + (size_t)n * VW;
+  double* Lm = U2 + (size_t)n * VW;
+  double* Ls = Lm + (size_t)n * VW;
+  double* Zl = Ls + (size_t)n * VW;
+  if (tid < nmine) {
+    const int j = tid, c = wg + W * j;
+    const double lc = lam[j] - (double)(c + 1) * 4.0 * TEPS;
+    const double ptiny = 1e-3 * TEPS;
+    double p = dd[0] - lc, q = (na > 1) ? ee[0] : 0.0, r = 0.0;
+    double yc = hash_unit(0u, (unsigned)c);
+    for (int i = 0; i + 1 < na; ++i) {
+      const double sub = ee[i], nd = dd[i + 1] - lc, nu = (i + 2 < na) ? ee[i + 1] : 0.0;
+      const double yn = hash_unit((unsigned)(i + 1), (unsigned)c);
+      double inv, u1, u2, yi, m, sw;
+      if (fabs(sub) > fabs(p) && fabs(sub) >= ptiny) {
+        inv = fast_rcp(sub);
+        u1 = nd; u2 = nu;
+        m = p * inv;
+        sw = 1.0;
+        yi = yn;
+        yc = yc - m * yn;
+        p = q - m * nd;
+        q = r - m * nu;
+        r = 0.0;
+      } else {
+        if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+        inv = fast_rcp(p);
+        u1 = q; u2 = r;
+        m = sub * inv;
+        sw = 0.0;
+        yi = yc;
+        yc = yn - m * yc;
+        p = nd - m * q;
+        q = nu - m * r;
+        r = 0.0;
+      }
+      U0[i * VW + j] = inv;
+      U1[i * VW + j] = u1;
+      U2[i * VW + j] = u2;
+      Lm[i * VW + j] = m;
+      Ls[i * VW + j] = sw;
+      Zl[i * VW + j] = yi;
+    }
+    if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+    const double invlast = fast_rcp(p);
+    double rs = 1.0;
+    for (int it = 0; it < 2; ++it) {
+      if (it > 0) {
+        yc = Zl[j] * rs;
+        for (int i = 0; i + 1 < na; ++i) {
+          const double yn = Zl[(i + 1) * VW + j] * rs;
+          const double m = Lm[i * VW + j];
+          const bool sw = Ls[i * VW + j] != 0.0;
+          const double yi = sw ? yn : yc;
+          yc = sw ? (yc - m * yn) : (yn - m * yc);
+          Zl[i * VW + j] = yi;
+        }
+      }
+      double x1 = yc * invlast, x2 = 0.0;
+      Zl[(na - 1) * VW + j] = x1;
+      double acc = x1 * x1;
+      for (int i = na - 2; i >= 0; --i) {
+        const double x = (Zl[i * VW + j] - U1[i * VW + j] * x1 - U2[i * VW + j] * x2) * U0[i * VW + j];
+        Zl[i * VW + j] = x;
+        acc += x * x;
+        x2 = x1;
+        x1 = x;
+      }
+      rs = acc > 0.0 ? 1.0 / sqrt(acc) : 1.0;
+    }
+    lam[32 + j] = rs;                                     // normalisation of the final solution
+  }
+  __syncthreads();
+
+  // ---------------- 4. back-transformation of this workgroup's vectors: wave j <-> vector j ----------------
+  double z[RPL];
+  const bool have = wave < nmine;
+  {
+    const double rs = have ? lam[32 + wave] : 0.0;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      const int i = lane + 64 * rr;
+      z[rr] = (have && i < na) ? Zl[i * VW + wave] * rs : 0.0;
+    }
+  }
+  {
+    constexpr int RB = 4;                                 // reflectors per staged block
+    double* stage = vbuf0;                                // [RB][n] over vbuf0, vbuf1, vprev, wprev (dead)
+    for (int jb = na - 3; jb >= 0; jb -= RB) {
+      __syncthreads();
+      for (int e = tid; e < RB * n; e += TNT) {
+        const int q = e / n, i = e - q * n, j = jb - q;
+        stage[e] = (j >= 0 && i > j && i < na) ? ld_shared(&A[(size_t)j * n + i]) : 0.0;
+      }
+      __syncthreads();
+      if (have) {
+        for (int q = 0; q < RB; ++q) {
+          const int j = jb - q;
+          if (j < 0) break;
+          const double beta = tau[j];
+          double vj[RPL], sdot = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < RPL; ++rr) {
+            const int i = lane + 64 * rr;
+            vj[rr] = (i < n) ? stage[q * n + i] : 0.0;
+            sdot += vj[rr] * z[rr];
+          }
+          sdot = beta * wave_sum(sdot);
+#pragma unroll
+          for (int rr = 0; rr < RPL; ++rr) z[rr] -= sdot * vj[rr];
+        }
+      }
+    }
+  }
+  if (have) {
+    const int c = wg + W * wave;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      const int i = lane + 64 * rr;
+      if (i < n) st_shared(&evecs[(size_t)c * n + i], z[rr]);
+    }
+    if (lane == 0) st_shared(&evals[c], lam[wave] * scale);
+  }
+  bar_target += W;
+  grid_barrier(bar, bar_target, W);
+  if (wg != 0) return;
+
+  // ---------------- 5. workgroup 0: modified Gram-Schmidt over the k vectors, sign convention, output ----------------
+  constexpr int VPW = 4;
+  double zz[VPW][RPL];
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = wave + TNW * v;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      const int i = lane + 64 * rr;
+      zz[v][rr] = (c < kk && i < na) ? ld_shared(&evecs[(size_t)c * n + i]) : 0.0;
+    }
+  }
+  double* qv = pfull;
+  for (int c = 0; c < kk; ++c) {
+    const int ow = c % TNW, ov = c / TNW;
+    if (wave == ow) {
+#pragma unroll
+      for (int v = 0; v < VPW; ++v)
+        if (v == ov) {
+          double sq = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < RPL; ++rr) sq += zz[v][rr] * zz[v][rr];
+          sq = wave_sum(sq);
+          const double inv = sq > 0.0 ? 1.0 / sqrt(sq) : 0.0;
+#pragma unroll
+          for (int rr = 0; rr < RPL; ++rr) {
+            zz[v][rr] *= inv;
+            const int i = lane + 64 * rr;
+            if (i < n) qv[i] = zz[v][rr];
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c2 = wave + TNW * v;
+      if (c2 > c && c2 < kk) {
+        double sq = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+          const int i = lane + 64 * rr;
+          sq += (i < n) ? zz[v][rr] * qv[i] : 0.0;
+        }
+        sq = wave_sum(sq);
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+          const int i = lane + 64 * rr;
+          if (i < n) zz[v][rr] -= sq * qv[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = wave + TNW * v;
+    if (c < k) {
+      double best = -1.0, bval = 0.0;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        const double a = fabs(zz[v][rr]);
+        if (i < na && a > best) {
+          best = a;
+          bval = zz[v][rr];
+          bidx = i;
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(best, m, 64), ovv = __shfl_xor(bval, m, 64);
+        const int oi = __shfl_xor(bidx, m, 64);
+        if (ob > best || (ob == best && oi < bidx)) {
+          best = ob;
+          bval = ovv;
+          bidx = oi;
+        }
+      }
+      const double sg = (c < kk) ? (bval < 0.0 ? -1.0 : 1.0) : 0.0;
+#pragma unroll
+      for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        if (i < n) evecs[(size_t)c * n + i] = (i < na) ? zz[v][rr] * sg : 0.0;
+      }
+      if (lane == 0 && c >= kk) evals[c] = 0.0;
+    }
+  }
+}
+
+template <int RPL>
+int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, double* evals, double* evecs) {
+  const int W = n <= 256 ? 8 : (n <= 448 ? 16 : 32);
+  const int RW = (int)cdiv(n, W);
+  double* gbuf = nullptr;
+  unsigned* bars = nullptr;
+  VIPMI_TRY(ws(ctx, "eigh_tri_gbuf", (size_t)batch * 5 * n, &gbuf));
+  VIPMI_TRY(ws(ctx, "eigh_tri_bars", (size_t)batch, &bars));
+  VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch, ctx->stream));
+  size_t rows_d = (size_t)RW * n;
+  const int VW = (int)cdiv(k, W);
+  const size_t inv_d = (size_t)6 * n * VW;             // phase-3 scratch aliases the rows region
+  if (rows_d < inv_d) rows_d = inv_d;
+  const size_t lds = (rows_d + (size_t)10 * n + 64) * sizeof(double);
+  VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(multi): LDS budget exceeded (%zu)", lds);
+  auto kern = tri_multi_kernel<RPL>;
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+  // all W workgroups of a problem must be co-resident (counter barrier): one per CU, launch at most num_cu/W problems
+  const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
+  for (int64_t p0 = 0; p0 < batch; p0 += per_launch) {
+    const int64_t nb = batch - p0 < per_launch ? batch - p0 : per_launch;
+    hipLaunchKernelGGL(kern, dim3(W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW, (int)rows_d,
+                       evals + (size_t)p0 * n, evecs + (size_t)p0 * n * n, gbuf + (size_t)p0 * 5 * n, bars + p0);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  return VIPMI_OK;
+}
+
 template <int RPL>
 int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int32_t* nact, double* evals,
                double* evecs) {
@@ -517,6 +981,13 @@ int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k
   VIPMI_REQUIRE(A && evals && evecs, "eigh_topk: null pointer");
   VIPMI_REQUIRE(batch > 0 && eigh_topk_supported(n, k), "eigh_topk: unsupported sizes n=%ld k=%ld", (long)n, (long)k);
   StageScope sc(ctx, "eigh");
+  // a few larger problems: spread each over several CUs (LDS-resident matrix); many problems: one CU each
+  const bool multi = !nact && n >= 96 && batch <= 8 && ctx->opt("eigh_multi", 1) != 0;
+  if (multi) {
+    if (n <= 128) return launch_tri_multi<2>(ctx, A, batch, (int)n, (int)k, evals, evecs);
+    if (n <= 256) return launch_tri_multi<4>(ctx, A, batch, (int)n, (int)k, evals, evecs);
+    return launch_tri_multi<8>(ctx, A, batch, (int)n, (int)k, evals, evecs);
+  }
   if (n <= 128) return launch_tri<2>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
   if (n <= 256) return launch_tri<4>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
   return launch_tri<8>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);

@@ -37,4 +37,36 @@ __device__ __forceinline__ double wave_max(double v) {
   return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// Columns cross workgroups only through global memory.  They are written with agent-scope write-through
+// stores (global_store_dwordx2 sc1) and read back with sc1 loads (L1 bypassed), so the barrier needs no
+// release/acquire fences (no buffer_wbl2 / buffer_inv): every storing wave drains its stores, one lane
+// bumps the counter and polls it (MI355X guide, G16 recipe R1).
+__device__ __forceinline__ double ld_shared(const double* p) {
+  unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ void st_shared(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, int nwg) {
+  if (nwg == 1) {
+    __syncthreads();
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have landed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 28)) break;   // bounded spin: a lost workgroup must not hang the GPU
+    }
+  }
+  __syncthreads();
+}
+
 }  // namespace vipmi
