@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
     ap.add_argument("--no-stage-timing", action="store_true",
                     help="do not record per-stage hipEvents inside the timed region (no roofline object)")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=2,
                     help="independent pca() calls in flight (one torch stream each); 1 = strictly serial")
     args = ap.parse_args()
 

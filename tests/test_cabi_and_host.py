@@ -149,3 +149,18 @@ def test_argument_errors_raise_before_touching_the_gpu():
         svd_wrapper(np.zeros((4, 10)), "nope", 2, False)
     with pytest.raises(NotImplementedError):
         pca_annular(np.zeros((2, 4, 8, 8), np.float32), np.zeros(4), verbose=False)
+
+
+def test_find_indices_adi_all_matches_per_frame_scan():
+    """The vectorised library selection used by the annular plan is index-for-index (and dtype-for-dtype) the
+    reference's per-frame scan, including the argsort tie order of uniformly spaced angles."""
+    from vip_amd.preproc.derotation import _find_indices_adi, _find_indices_adi_all
+    rng = np.random.default_rng(0)
+    cases = [(np.linspace(0, 90, 200), 3.3, 50), (np.linspace(-40, 60, 400), 1.25, 200),
+             (np.sort(rng.random(150) * 120), 5.0, 40), (np.linspace(0, 30, 31), 1.0, 10),
+             (np.r_[np.linspace(300, 359, 60), np.linspace(360, 400, 41)], 2.0, 30), (np.linspace(0, 10, 50), 20.0, 200)]
+    for a, thr, mf in cases:
+        for tr in (True, False):
+            ref = [_find_indices_adi(a, j, thr, truncate=tr, max_frames=mf) for j in range(len(a))]
+            got = _find_indices_adi_all(a, thr, truncate=tr, max_frames=mf)
+            assert all(np.array_equal(r, g) and r.dtype == g.dtype for r, g in zip(ref, got))

@@ -100,6 +100,30 @@ def _find_indices_adi(angle_list, frame, thr, nframes=None, out_closest=False, t
     return indices
 
 
+def _find_indices_adi_all(angle_list, thr, truncate=False, max_frames=200):
+    """``[_find_indices_adi(angle_list, j, thr, truncate=truncate, max_frames=max_frames) for j in range(n)]``
+    with the two scans done for all frames at once on the |PA_j - PA_i| matrix (same float64 comparisons); the
+    truncation keeps the reference's per-frame ``np.argsort`` call so that ties break identically."""
+    a = np.asarray(angle_list)
+    n = a.shape[0]
+    D = np.abs(a[:, None] - a[None, :])
+    idx = np.arange(n)
+    below = (D < thr) & (idx[None, :] < idx[:, None])            # candidates i < j of the first scan
+    prev = np.where(below.any(axis=1), below.argmax(axis=1), idx)
+    above = (D > thr) & (idx[None, :] >= idx[:, None])           # candidates k >= j of the second scan
+    foll = np.where(above.any(axis=1), above.argmax(axis=1), n)
+    lim = min(n - 1, max_frames)
+    out = []
+    for j in range(n):
+        all_indices = np.concatenate([idx[:prev[j]], idx[foll[j]:]])
+        if truncate and all_indices.shape[0] > lim:
+            dPA = np.abs(a[all_indices] - a[j])
+            out.append(np.sort(all_indices[np.argsort(dPA)][:lim]))
+        else:
+            out.append(all_indices.astype("int32"))
+    return out
+
+
 def _compute_pa_thresh(ann_center, fwhm, delta_rot=1):
     return np.rad2deg(2 * np.arctan(delta_rot * fwhm / (2 * ann_center)))
 

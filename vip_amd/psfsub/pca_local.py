@@ -19,7 +19,7 @@ import numpy as np
 from .. import backend as B
 from ..config.paramenum import ALGO_KEY, Collapse, Imlib, Interpolation, SvdMode
 from ..config.utils_param import separate_kwargs_dict, setup_parameters
-from ..preproc.derotation import _define_annuli, _find_indices_adi
+from ..preproc.derotation import _define_annuli, _find_indices_adi_all
 from ..preproc.parangles import check_pa_vector
 from ..var.shapes import get_annulus_segments
 
@@ -99,8 +99,7 @@ def annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, delta_r
                                                           delta_rot[ann], n_segments[ann], False, True)
         segs = get_annulus_segments(np.zeros((y, x)), inner_radius, asize, n_segments[ann], theta_init)
         if pa_thr != 0:
-            libs = [_find_indices_adi(angle_list, fr, pa_thr, truncate=True, max_frames=max_frames_lib)
-                    for fr in range(n)]
+            libs = _find_indices_adi_all(angle_list, pa_thr, truncate=True, max_frames=max_frames_lib)
             for fr, li in enumerate(libs):
                 if li.shape[0] < min_frames_lib:
                     msg = "Too few frames left in the PCA library. Accepted indices length ({:.0f}) less than {:.0f}. "

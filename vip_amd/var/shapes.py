@@ -4,6 +4,8 @@ Index sets (disk / annulus membership) are computed on the host in float64 with 
 reference's expressions so that membership is bit-exact; the heavy array work (masking, scaling)
 runs on the device.
 """
+import functools
+
 import numpy as np
 
 from .. import backend as B
@@ -56,6 +58,19 @@ def mask_circle(array, radius, fillwith=0, mode="in", cy=None, cx=None, output="
     return out.cpu().numpy().astype(array.dtype, copy=False)
 
 
+@functools.lru_cache(maxsize=8)
+def _polar_grids(ny, nx):
+    """Radius and azimuth (mod 2 pi) of every pixel about frame_center: the same float64 expressions as
+    var/shapes.py:548-552, cached per frame shape (an annular PCA asks for them once per annulus)."""
+    cy, cx = frame_center(np.zeros((ny, nx)))
+    yy, xx = np.mgrid[:ny, :nx]
+    rad = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+    phirot = np.arctan2(yy - cy, xx - cx) % (2 * np.pi)
+    rad.setflags(write=False)
+    phirot.setflags(write=False)
+    return rad, phirot
+
+
 def get_annulus_segments(data, inner_radius, width, nsegm=1, theta_init=0, optim_scale_fact=1,
                          mode="ind", out=False):
     """var/shapes.py:474-581 (host; index membership is bit-exact)."""
@@ -67,12 +82,9 @@ def get_annulus_segments(data, inner_radius, width, nsegm=1, theta_init=0, optim
         raise TypeError("`data` must be a 2d array or a shape tuple")
     if not isinstance(nsegm, int):
         raise TypeError("`nsegm` must be an integer")
-    cy, cx = frame_center(array)
     azimuth_coverage = np.deg2rad(int(np.ceil(360 / nsegm)))
     twopi = 2 * np.pi
-    yy, xx = np.mgrid[:array.shape[0], :array.shape[1]]
-    rad = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
-    phirot = np.arctan2(yy - cy, xx - cx) % twopi
+    rad, phirot = _polar_grids(array.shape[0], array.shape[1])
     outer_radius = inner_radius + (width * optim_scale_fact)
     ring = (rad >= inner_radius) & (rad < outer_radius)
     masks = []
