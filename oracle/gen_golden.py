@@ -157,3 +157,24 @@ for tag, kw in (("a", dict(asize=8, ncomp=3, fwhm=4, delta_rot=(0.1, 1))),
     g[tag + "_cube_out"] = cr
     g[tag + "_frame"] = fr_
 save("g6_pca_annular", **g)
+
+# ---- G7: pca_grid (tuple / list ncomp) and PA-threshold frame rejection (source_xy) ----------------------------
+cube, ang = O.synth_adi(24, 48, seed=11)
+g = {"cube": cube, "angles": ang}
+out = ref.pca(cube, ang, ncomp=(1, 5), full_output=True, verbose=False)
+g["grid_a_frames"], g["grid_a_pcs"] = out[0], np.asarray(out[1])
+out = ref.pca(cube, ang, ncomp=(2, 9, 3), scaling="temp-mean", mask_center_px=4, verbose=False)
+g["grid_b_frames"] = out
+out = ref.pca(cube, ang, ncomp=[1, 4, 6], collapse="mean", verbose=False)
+g["grid_c_frames"] = out
+cref, _ = O.synth_adi(10, 48, seed=12)
+g["cube_ref"] = cref
+g["grid_d_frames"] = ref.pca(cube, ang, cube_ref=cref, ncomp=(1, 4), verbose=False)
+for tag, kw in (("rej_a", dict(ncomp=3, source_xy=(34, 24), fwhm=4, delta_rot=1, min_frames_pca=4)),
+                ("rej_b", dict(ncomp=2, source_xy=(30, 30), fwhm=4, delta_rot=0.5, min_frames_pca=3, max_frames_pca=8,
+                               scaling="temp-standard")),
+                ("rej_c", dict(ncomp=2, source_xy=(10, 24), fwhm=5, delta_rot=1, min_frames_pca=2, mask_center_px=3))):
+    fo = ref.pca(cube, ang, full_output=True, verbose=False, **kw)
+    for nm, a in zip(("frame", "recon", "res", "resder"), fo):
+        g["%s_%s" % (tag, nm)] = a
+save("g7_grid_rejection", **g)

@@ -454,6 +454,86 @@ def pca_fullframe(cube, angle_list, ncomp=1, svd_mode="lapack", scaling=None,
     return frame
 
 
+def pca_grid_frames(cube, angle_list, range_pcs, scaling=None, mask_center_px=None, collapse="median",
+                    cube_ref=None, weights=None, svd_mode="lapack", full_output=False, seed=0):
+    """``pca(cube, angles, ncomp=<tuple or list>)`` without ``source_xy``: the grid of final frames.
+    Ref: psfsub/pca_fullfr.py:412-415,1010-1035 -> psfsub/utils_pca.py:131-161 (truncate_svd_get_finframe),
+    :241-300 (pclist, one decomposition with pcmax), :418-428 (returns)."""
+    n, y, x = cube.shape
+    mask_val = 0 if mask_center_px else np.nan          # pca(): mask_center_px without rot_options -> mask_val=0
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    if isinstance(range_pcs, list):
+        pclist = list(range_pcs)
+        pcmax = max(pclist)
+    else:
+        if len(range_pcs) == 2:
+            pcmin, pcmax = range_pcs
+            pcmax = min(pcmax, n)
+            step = 1
+        elif len(range_pcs) == 3:
+            pcmin, pcmax, step = range_pcs
+            pcmax = min(pcmax, n)
+        else:
+            raise TypeError("`range_pcs` must be None or a tuple")
+        pclist = list(range(pcmin, pcmax + 1, step))
+    matrix = prepare_matrix(cube, scaling, mask_center_px)
+    ref_lib = prepare_matrix(cube_ref, scaling, mask_center_px) if cube_ref is not None else matrix
+    V = svd_wrapper(ref_lib, svd_mode, pcmax, seed=seed)
+    frames = []
+    for pc in pclist:
+        transformed = np.dot(V[:pc], matrix.T)
+        reconstructed = np.dot(transformed.T, V[:pc])
+        residuals = (matrix - reconstructed).reshape(n, y, x)
+        der = cube_derotate(residuals, angle_list, mask_val=mask_val)
+        frames.append(cube_collapse(der, mode=collapse, w=weights))
+    cubeout = np.array(frames)
+    if full_output:
+        return cubeout, pclist
+    return cubeout
+
+
+def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scaling=None, mask_center_px=None,
+                     min_frames_pca=10, max_frames_pca=None, collapse="median", svd_mode="lapack", weights=None,
+                     full_output=False, seed=0):
+    """``pca(cube, angles, ncomp=<int>, source_xy=(x, y), fwhm=..., delta_rot=...)``: every frame is modelled with
+    the PCs of the frames that rotated by more than the PA threshold at ``source_xy``.
+    Ref: psfsub/pca_fullfr.py:911-965 (threshold, per-frame loop), :1677-1713 (_project_subtract with indices/frame),
+    :966-991 (derotate, collapse, mask), :779-785 (returns)."""
+    n, y, x = cube.shape
+    mask_val = 0 if mask_center_px else np.nan
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    yc, xc = frame_center(cube[0])
+    x1, y1 = source_xy
+    ann_center = np.sqrt((yc - y1) ** 2 + (xc - x1) ** 2)
+    pa_thr = compute_pa_thresh(ann_center, fwhm, delta_rot)
+    truncate = max_frames_pca is not None
+    matrix = prepare_matrix(cube, scaling, mask_center_px)
+    residuals = np.zeros_like(matrix)
+    recon = np.zeros_like(matrix)
+    for fr in range(n):
+        ind = find_indices_adi(angle_list, fr, pa_thr, truncate=truncate, max_frames=max_frames_pca)
+        ref_lib = matrix[ind]
+        if ref_lib.shape[0] < min_frames_pca:
+            raise RuntimeError("{} frames comply to delta_rot condition < less than min_frames_pca ({})".format(
+                ref_lib.shape[0], min_frames_pca))
+        if ref_lib.shape[0] < ncomp:
+            raise RuntimeError("{} frames comply to delta_rot condition < less than ncomp ({})".format(
+                ref_lib.shape[0], ncomp))
+        V = svd_wrapper(ref_lib, svd_mode, ncomp, seed=seed)
+        transformed = np.dot(matrix[fr], V.T)
+        recon[fr] = np.dot(transformed.T, V)
+        residuals[fr] = matrix[fr] - recon[fr]
+    res_cube = residuals.reshape(n, y, x)
+    der = cube_derotate(res_cube, angle_list, mask_val=mask_val)
+    frame = cube_collapse(der, mode=collapse, w=weights)
+    if mask_center_px:
+        der = mask_circle(der, mask_center_px)
+        frame = mask_circle(frame, mask_center_px)
+    if full_output:
+        return frame, recon.reshape(n, y, x), res_cube, der
+    return frame
+
+
 def pca_4d(cube, angle_list, ncomp=1, collapse_ifs="mean", full_output=False, **kw):
     """4-D cube, scale_list=None: per-channel full-frame PCA then spectral collapse.
     Ref: psfsub/pca_fullfr.py:544-658,770-774."""

@@ -164,3 +164,56 @@ def test_pca_annular_scaling_and_errors():
         pca_annular(cube, np.linspace(0, 1, 20), asize=6, ncomp=2, fwhm=4, delta_rot=5.0, verbose=False)
     with pytest.raises(TypeError):
         pca_annular(cube, ang[:-1], asize=6, ncomp=2, verbose=False)
+
+
+# ---- grid of PCs and PA-threshold frame rejection ------------------------------------------------
+
+@pytest.mark.parametrize("tag,kw", [("grid_a", dict(ncomp=(1, 5))),
+                                    ("grid_b", dict(ncomp=(2, 9, 3), scaling="temp-mean", mask_center_px=4)),
+                                    ("grid_c", dict(ncomp=[1, 4, 6], collapse="mean")),
+                                    ("grid_d", dict(ncomp=(1, 4), rdi=True))])
+def test_pca_grid_golden(tag, kw):
+    from vip_amd.psfsub import pca
+    g = load_golden("g7_grid_rejection")
+    kw = dict(kw)
+    if kw.pop("rdi", False):
+        kw["cube_ref"] = g["cube_ref"]
+    out = pca(g["cube"], g["angles"], verbose=False, **kw)
+    exp = g[tag + "_frames"]
+    assert out.shape == exp.shape and out.dtype == exp.dtype
+    assert np.abs(out - exp).max() < TOL
+    fo = pca(g["cube"], g["angles"], verbose=False, full_output=True, **kw)
+    assert len(fo) == 2 and np.abs(fo[0] - exp).max() < TOL
+    if tag == "grid_a":
+        assert list(fo[1]) == list(g["grid_a_pcs"])
+        med = pca(g["cube"], g["angles"], verbose=False, med_of_npcs=True, **kw)
+        assert np.abs(med - np.median(exp, axis=0)).max() < TOL
+
+
+@pytest.mark.parametrize("tag,kw", [("rej_a", dict(ncomp=3, source_xy=(34, 24), fwhm=4, delta_rot=1, min_frames_pca=4)),
+                                    ("rej_b", dict(ncomp=2, source_xy=(30, 30), fwhm=4, delta_rot=0.5, min_frames_pca=3,
+                                                   max_frames_pca=8, scaling="temp-standard")),
+                                    ("rej_c", dict(ncomp=2, source_xy=(10, 24), fwhm=5, delta_rot=1, min_frames_pca=2,
+                                                   mask_center_px=3))])
+def test_pca_pa_rejection_golden(tag, kw):
+    from vip_amd.psfsub import pca
+    g = load_golden("g7_grid_rejection")
+    out = pca(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    assert len(out) == 4
+    for nm, a in zip(("frame", "recon", "res", "resder"), out):
+        b = g["%s_%s" % (tag, nm)]
+        assert a.shape == b.shape and a.dtype == b.dtype, nm
+        assert np.abs(a - b).max() < (5e-4 if nm == "recon" else TOL), (tag, nm, np.abs(a - b).max())
+    fr = pca(g["cube"], g["angles"], verbose=False, **kw)
+    assert np.abs(fr - g[tag + "_frame"]).max() < TOL
+
+
+def test_pca_pa_rejection_errors():
+    from vip_amd.psfsub import pca
+    g = load_golden("g7_grid_rejection")
+    with pytest.raises(TypeError):
+        pca(g["cube"], g["angles"], ncomp=2, source_xy=(34, 24), verbose=False)            # fwhm / delta_rot missing
+    with pytest.raises(RuntimeError):
+        pca(g["cube"], g["angles"], ncomp=2, source_xy=(26, 24), fwhm=4, delta_rot=20, verbose=False)   # empty libraries
+    with pytest.raises(NotImplementedError):
+        pca(g["cube"], g["angles"], ncomp=(1, 3), source_xy=(34, 24), fwhm=4, verbose=False)

@@ -112,7 +112,7 @@ def _find_indices_adi_all(angle_list, thr, truncate=False, max_frames=200):
     prev = np.where(below.any(axis=1), below.argmax(axis=1), idx)
     above = (D > thr) & (idx[None, :] >= idx[:, None])           # candidates k >= j of the second scan
     foll = np.where(above.any(axis=1), above.argmax(axis=1), n)
-    lim = min(n - 1, max_frames)
+    lim = min(n - 1, max_frames) if truncate else n
     out = []
     for j in range(n):
         all_indices = np.concatenate([idx[:prev[j]], idx[foll[j]:]])

@@ -6,8 +6,9 @@ Same positional order (= ``PCA_Params`` field order), same kwargs (unknown kwarg
 ``rot_options``), same return tuples and shapes.  All array work runs on the MI355X through
 libvipmi.so; numpy in -> numpy out, cuda tensor in -> cuda tensors out (no host copies).
 
-Not accelerated (raise NotImplementedError, SURVEY.md 8(f) "next"): ``scale_list`` (mSDI), tuple/list
-``ncomp`` (pca_grid), ``source_xy``, ``batch`` (incremental PCA), ``left_eigv``, ``cube_sig``,
+Tuple/list ``ncomp`` (the ``pca_grid`` of final frames) and ``source_xy`` (PA-threshold frame rejection) are
+accelerated for 3-D cubes.  Not accelerated (raise NotImplementedError, SURVEY.md 8(f) "next"): ``scale_list``
+(mSDI), ``pca_grid`` scored by S/N (tuple ``ncomp`` + ``source_xy``), ``batch`` (incremental PCA), ``left_eigv``, ``cube_sig``,
 ``mask_rdi``, ``smooth``, ``imlib != 'vip-fft'``.
 """
 from dataclasses import dataclass
@@ -19,7 +20,9 @@ import numpy as np
 from .. import backend as B
 from ..config.paramenum import ALGO_KEY, Adimsdi, Collapse, Imlib, Interpolation, SvdMode
 from ..config.utils_param import separate_kwargs_dict, setup_parameters
+from ..preproc.derotation import _compute_pa_thresh, _find_indices_adi_all
 from ..preproc.parangles import check_pa_vector
+from ..var.coords import dist, frame_center
 from ..var.shapes import center_mask_u8
 from .svd import SVD_MODES, SVDecomposer
 
@@ -114,6 +117,115 @@ def _project_subtract(cube_t, cube_ref_t, ncomp, scaling, mask_center_px, svd_mo
     return res
 
 
+def _prepared_matrices(cube_t, cube_ref_t, scaling, mask_center_px):
+    """prepare_matrix(mode='fullfr') of the cube (and reference cube) on the device -> (M, ref or None)."""
+    n, y, x = cube_t.shape
+    mask = None
+    if mask_center_px:
+        mask = B.to_device_f32(center_mask_u8((y, x), mask_center_px).astype(np.float32)).to(B._torch().uint8)
+
+    def prep(c):
+        m = c.reshape(c.shape[0], -1)
+        if mask is not None:
+            m = B.apply_mask(m, mask.reshape(-1), 0.0)
+        if scaling is not None:
+            m = B.scale(m, scaling)
+        return m
+
+    return prep(cube_t), (prep(cube_ref_t) if cube_ref_t is not None else None)
+
+
+def _pca_grid(cube, angle_list, range_pcs, cube_ref, scaling, mask_center_px, svd_mode, collapse, weights,
+              full_output, verbose, mv_nan):
+    """Device version of ``pca_grid(mode='fullfr', source_xy=None)`` (reference psfsub/utils_pca.py:25-428,
+    called from pca_fullfr.py:1010-1035): ONE decomposition with the largest number of PCs, then for every entry of
+    the grid truncate -> subtract -> derotate -> collapse.  Returns ``cubeout`` (n_grid, y, x)[, pclist]."""
+    torch = B._torch()
+    n, y, x = cube.shape
+    if isinstance(range_pcs, list):
+        pclist = list(range_pcs)
+        pcmax = max(pclist)
+    else:
+        if len(range_pcs) == 2:
+            pcmin, pcmax = range_pcs
+            pcmax = min(pcmax, n)
+            step = 1
+        elif len(range_pcs) == 3:
+            pcmin, pcmax, step = range_pcs
+            pcmax = min(pcmax, n)
+        else:
+            raise TypeError("`range_pcs` must be None or a tuple, corresponding to (PC_INI, PC_MAX) or "
+                            "(PC_INI, PC_MAX, STEP)")
+        pclist = list(range(pcmin, pcmax + 1, step))
+    M, ref = _prepared_matrices(cube, cube_ref, scaling, mask_center_px)
+    ref_lib = M if ref is None else ref
+    if pcmax > min(ref_lib.shape):
+        msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
+        msg += " Increase the size of the patches or request less PCs"
+        raise RuntimeError(msg.format(pcmax, ref_lib.shape[0], ref_lib.shape[1]))
+    from .svd import _decompose
+    _sig, _E, V = _decompose(ref_lib, int(pcmax), want_pcs=True, leading_only=True)      # V: (pcmax, P)
+    coeff = B.cross_gram(M, V).to(torch.float32)                                        # M V^T: (n, pcmax)
+    ctx = B.get_context(cube.device.index)
+    P = y * x
+    frames = []
+    for pc in pclist:
+        C = coeff[:, :pc].contiguous()
+        R = B.empty((n, P), device=cube.device.index)
+        ctx.call("vipmi_subtract_gemm_f32", B.ptr(M), B.ptr(C), B.ptr(V), n, int(pc), P, B.ptr(R), None)
+        der = B.derotate(R.reshape(n, y, x), angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
+        frames.append(B.collapse(der, collapse, w=weights))
+    cubeout = torch.stack(frames)
+    if verbose:
+        print("Computed residual frames for PCs interval: {}".format(range_pcs))
+        print("Number of steps", len(pclist))
+    if full_output:
+        return cubeout, pclist
+    return cubeout
+
+
+def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scaling, mask_center_px, min_frames_pca,
+                      max_frames_pca, verbose):
+    """Device version of the ``source_xy`` branch (reference pca_fullfr.py:911-965 + the per-frame mode of
+    ``_project_subtract``, :1677-1713): frame j is modelled with the PCs of the frames that have rotated by more than
+    the PA threshold at ``source_xy``.  All n per-frame decompositions come from sub-blocks of ONE Gram matrix
+    (the identity used for annular PCA).  Returns (residuals (n, P), M (n, P), library sizes)."""
+    torch = B._torch()
+    n, y, x = cube.shape
+    if delta_rot is None or fwhm is None:
+        raise TypeError("Delta_rot or fwhm parameters missing. Needed forPA-based rejection of frames from the library")
+    yc, xc = frame_center(cube[0])
+    x1, y1 = source_xy
+    ann_center = dist(yc, xc, y1, x1)
+    pa_thr = _compute_pa_thresh(ann_center, fwhm, delta_rot)
+    truncate = max_frames_pca is not None
+    libs = _find_indices_adi_all(angle_list, pa_thr, truncate=truncate, max_frames=max_frames_pca)
+    msg = "{} frames comply to delta_rot condition < less than "
+    for li in libs:
+        if li.shape[0] < min_frames_pca:
+            raise RuntimeError((msg + "min_frames_pca ({}). Try decreasing delta_rot or min_frames_pca").format(
+                li.shape[0], min_frames_pca))
+        if li.shape[0] < ncomp:
+            raise RuntimeError((msg + "ncomp ({}). Try decreasing the parameter delta_rot or ncomp").format(
+                li.shape[0], ncomp))
+    M, _ = _prepared_matrices(cube, None, scaling, mask_center_px)
+    P = y * x
+    max_lib = max(li.shape[0] for li in libs)
+    idx = np.zeros((n, max_lib), dtype=np.int32)
+    ln = np.zeros(n, dtype=np.int32)
+    for j, li in enumerate(libs):
+        idx[j, :li.shape[0]] = li
+        ln[j] = li.shape[0]
+    idx_t = torch.from_numpy(idx).to(cube.device)
+    ln_t = torch.from_numpy(ln).to(cube.device)
+    R = B.empty((n, P), device=cube.device.index)
+    ctx = B.get_context(cube.device.index)
+    ctx.call("vipmi_annular_residuals_f32", B.ptr(M), n, P, B.ptr(idx_t), B.ptr(ln_t), int(max_lib), int(ncomp), B.ptr(R))
+    if verbose:
+        print("Size LIB: min={} max={} mean={:.1f}".format(int(ln.min()), int(ln.max()), float(ln.mean())))
+    return R, M, ln
+
+
 def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot, fwhm, scaling,
                  mask_center_px, svd_mode, imlib, interpolation, collapse, verbose, start_time, nproc,
                  full_output, weights=None, mask_rdi=None, cube_sig=None, left_eigv=False,
@@ -121,8 +233,6 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
     """ADI / ADI+RDI full-frame PCA on device tensors; returns device tensors."""
     if batch is not None:
         raise NotImplementedError("batch (incremental PCA) is outside the accelerated path")
-    if source_xy is not None:
-        raise NotImplementedError("source_xy (PA-threshold frame rejection) is not accelerated yet")
     if mask_rdi is not None or cube_sig is not None or left_eigv or smooth is not None:
         raise NotImplementedError("mask_rdi / cube_sig / left_eigv / smooth are outside the accelerated path")
     if _s(imlib) != "vip-fft":
@@ -133,10 +243,14 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         raise ValueError("`angle_list` vector has wrong length. It must equal the number of frames in the cube")
     if not np.isscalar(ncomp) and not isinstance(ncomp, (tuple, list)):
         raise TypeError("`ncomp` must be an int, float, tuple or list in the ADI case")
-    if not np.isscalar(ncomp):
-        raise NotImplementedError("tuple/list ncomp (pca_grid) is not accelerated yet")
+    grid = not np.isscalar(ncomp)
+    if grid and source_xy is not None:
+        raise NotImplementedError("pca_grid with source_xy needs the S/N metrics of vip_hci.metrics (CPU, outside "
+                                  "the accelerated path); run the grid without source_xy and score the frames there")
     nref = cube_ref.shape[0] if cube_ref is not None else n
-    if isinstance(ncomp, (int, np.integer)) and ncomp > nref:
+    if grid:
+        pass
+    elif isinstance(ncomp, (int, np.integer)) and ncomp > nref:
         ncomp = min(int(ncomp), nref)
         print("Number of PCs too high (max PCs={}), using {} PCs instead.".format(nref, ncomp))
     elif ncomp <= 0:
@@ -153,6 +267,31 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         raise TypeError("mode not recognized")
     if collapse == "wmean" and weights is None:
         raise ValueError("Weights have to be provided for weighted mean mode")
+
+    if grid:
+        return _pca_grid(cube, angle_list, ncomp, cube_ref, scaling, mask_center_px, svd_mode, collapse, weights,
+                         full_output, verbose, mv_nan)
+    if source_xy is not None:
+        if cube_ref is not None:
+            raise NotImplementedError("source_xy together with cube_ref is outside the accelerated path")
+        if not isinstance(ncomp, (int, np.integer)):
+            raise NotImplementedError("source_xy needs an integer ncomp on the device path")
+        R, M, _ln = _pca_pa_rejection(cube, angle_list, int(ncomp), source_xy, delta_rot, fwhm, scaling,
+                                      mask_center_px, min_frames_pca, max_frames_pca, verbose)
+        residuals_cube = R.reshape(n, y, x)
+        residuals_cube_ = B.derotate(residuals_cube, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
+        frame = B.collapse(residuals_cube_, collapse, w=weights)
+        if mask_center_px:
+            mask = B.to_device_f32(center_mask_u8((y, x), mask_center_px).astype(np.float32)).to(B._torch().uint8)
+            if full_output:
+                residuals_cube_ = B.apply_mask(residuals_cube_.reshape(n, -1), mask.reshape(-1), 0.0).reshape(n, y, x)
+            frame = B.apply_mask(frame.reshape(1, -1), mask.reshape(-1), 0.0).reshape(y, x)
+        if verbose:
+            print("Done de-rotating and combining")
+        if full_output:
+            recon_cube = (M - R).reshape(n, y, x)
+            return recon_cube, residuals_cube, residuals_cube_, frame
+        return frame
 
     fused_ok = (cube_ref is None and isinstance(ncomp, (int, np.integer)) and collapse in
                 ("median", "mean", "sum", "max", "absmean") and (bool(mask_center_px) != mv_nan))
@@ -303,6 +442,17 @@ def pca(*all_args: List, **all_kwargs: dict):
             raise TypeError("ref_strategy argument not recognized.Should be 'RDI' or 'ARDI'")
     fp = setup_parameters(algo_params, _adi_rdi_pca, cube=cube_t, cube_ref=cube_ref_t, **add)
     out = _adi_rdi_pca(**fp, **rot_options)
+    if isinstance(algo_params.ncomp, (tuple, list)):
+        # PCA grid (pca_fullfr.py:716-717,776-777,792-793): cube of final frames [, list of PCs]
+        cubeout, pclist = out if fo else (out, None)
+        if algo_params.med_of_npcs:
+            cubeout = B.collapse(cubeout, "median")
+        return (host(cubeout), pclist) if fo else host(cubeout)
+    if algo_params.source_xy is not None:
+        if fo:
+            recon_cube, residuals_cube, residuals_cube_, frame = out
+            return host(frame), host(recon_cube), host(residuals_cube), host(residuals_cube_)
+        return host(out)
     if fo:
         pcs, recon, residuals_cube, residuals_cube_, frame = out
         return host(frame), host(pcs), host(recon), host(residuals_cube), host(residuals_cube_)

@@ -15,13 +15,17 @@ SVD_MODES = ("lapack", "arpack", "eigen", "randsvd", "cupy", "eigencupy", "randc
              "eigenpytorch", "randpytorch")
 
 
-def _decompose(mat_t, ncomp, want_pcs=True):
+def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
     """mat_t: (n, P) float32 cuda tensor.  Returns (sigma[min(n,P)] f64, E[k, n] f64 rows = left
-    vectors, V[k,P])."""
+    vectors, V[k,P]).  ``leading_only``: only the first ``ncomp`` singular values are needed (lets the
+    library use the top-k eigensolver); sigma then has ``ncomp`` entries."""
     torch = B._torch()
     n, P = mat_t.shape
     G = B.gram(mat_t)
-    evals, evecs = B.eigh(G)
+    if leading_only:
+        evals, evecs = B.eigh_topk(G, ncomp)
+    else:
+        evals, evecs = B.eigh(G)
     sig_all = torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
     sig = sig_all[:ncomp]
     E = evecs[:ncomp]
