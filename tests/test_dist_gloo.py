@@ -62,6 +62,32 @@ def _worker(rank, world, port, q):
                 out[fr] = m[fr] - (m[fr] @ V.T) @ V
             return out
         res["cube_out"] = D.pca_annular_residuals(cube, angc, plan, resid).numpy()
+        # --- ONE cube sharded over the ranks: all_reduce of the Gram + two all_to_all exchanges (ragged splits:
+        #     11 frames / 23 rows over 2 ranks), numpy stand-ins for the device kernels
+        class NumpyOps:
+            def to_dev(self, a):
+                return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+            def gram(self, M):
+                m = M.numpy().astype(np.float64)
+                return torch.from_numpy(m @ m.T)
+
+            def leading(self, G, k):
+                w, v = np.linalg.eigh(G.numpy())
+                return torch.from_numpy(w[::-1][:k].copy()), torch.from_numpy(v[:, ::-1][:, :k].T.copy())
+
+            def residuals(self, M, ev, ec):
+                m = M.numpy().astype(np.float64)
+                E = ec.numpy()
+                return torch.from_numpy((m - E.T @ (E @ m)).astype(np.float32))
+
+            def derotate(self, frames, angles):
+                return torch.from_numpy(O.cube_derotate(frames.numpy(), np.asarray(angles)))
+
+            def collapse(self, cube, mode):
+                return torch.from_numpy(O.cube_collapse(cube.numpy(), mode)).reshape(-1)
+        cs, as_ = O.synth_adi(11, 23, seed=21)
+        res["single"] = D.pca_single_cube(cs, as_, 3, ops=NumpyOps()).numpy()
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -91,6 +117,12 @@ def test_world2_gloo():
     serial = np.stack([O.pca_fullframe(c, a, ncomp=2) for c, a in zip(cubes, angs)])
     for r in (r0, r1):
         assert np.array_equal(r["frames"], serial)
+    cs, as_ = O.synth_adi(11, 23, seed=21)
+    ref_single = O.pca_fullframe(cs, as_, ncomp=3)
+    for r in (r0, r1):
+        assert r["single"].shape == (23, 23)
+        assert np.nanmax(np.abs(r["single"] - ref_single)) < 2e-5
+    assert np.array_equal(r0["single"], r1["single"], equal_nan=True)
     c4 = np.stack([O.synth_adi(8, 24, seed=10 + i)[0] for i in range(3)])
     a4 = np.linspace(0, 70, 8)
     f4 = O.pca_4d(c4, a4, ncomp=2, full_output=True)

@@ -217,3 +217,16 @@ def test_pca_pa_rejection_errors():
         pca(g["cube"], g["angles"], ncomp=2, source_xy=(26, 24), fwhm=4, delta_rot=20, verbose=False)   # empty libraries
     with pytest.raises(NotImplementedError):
         pca(g["cube"], g["angles"], ncomp=(1, 3), source_xy=(34, 24), fwhm=4, verbose=False)
+
+
+def test_single_cube_sharded_path_world1():
+    """vip_amd.dist.pca_single_cube with the device kernels (one rank: the slab / exchange code paths degenerate to
+    local copies) reproduces pca()."""
+    from vip_amd import dist as D
+    from vip_amd.psfsub import pca
+    cube, ang = O.synth_adi(20, 64, seed=4)
+    ref = pca(cube, ang, ncomp=4, verbose=False)
+    got = D.pca_single_cube(cube, O.check_pa_vector(ang), 4).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-5
+    got_mean = D.pca_single_cube(cube, O.check_pa_vector(ang), 4, collapse="mean").cpu().numpy()
+    assert np.abs(got_mean - pca(cube, ang, ncomp=4, collapse="mean", verbose=False)).max() < 1e-5
