@@ -38,7 +38,8 @@ enum { VIPMI_SCALE_TEMP_MEAN = 1, VIPMI_SCALE_TEMP_STANDARD = 2,
        VIPMI_SCALE_SPAT_MEAN = 3, VIPMI_SCALE_SPAT_STANDARD = 4 };
 enum { VIPMI_COLLAPSE_MEDIAN = 0, VIPMI_COLLAPSE_MEAN = 1, VIPMI_COLLAPSE_SUM = 2,
        VIPMI_COLLAPSE_MAX = 3, VIPMI_COLLAPSE_ABSMEAN = 4, VIPMI_COLLAPSE_WMEAN = 5,
-       VIPMI_COLLAPSE_TRIMMEAN = 6 };
+       VIPMI_COLLAPSE_TRIMMEAN = 6,
+       VIPMI_COLLAPSE_STIM = 7 /* mean / population std over the frames, 0 where std == 0 (metrics/stim.py:24-44) */ };
 enum { VIPMI_ROT_AUTO = 0, VIPMI_ROT_DIRECT = 1, VIPMI_ROT_FFT = 2 };
 
 int vipmi_version(void);

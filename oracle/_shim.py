@@ -107,6 +107,7 @@ def load():
         from vip_hci.preproc.derotation import (_find_indices_adi, _define_annuli,
                                                 _compute_pa_thresh, rotate_fft)
         from vip_hci.preproc.cosmetics import frame_pad
+        from vip_hci.metrics.stim import stim_map, inverse_stim_map, normalized_stim_map
         from vip_hci.var import (prepare_matrix, matrix_scaling, mask_circle,
                                  get_annulus_segments, frame_center, reshape_matrix)
     ns = types.SimpleNamespace(
@@ -121,5 +122,6 @@ def load():
         frame_pad=frame_pad, prepare_matrix=prepare_matrix,
         matrix_scaling=matrix_scaling, mask_circle=mask_circle,
         get_annulus_segments=get_annulus_segments, frame_center=frame_center,
-        reshape_matrix=reshape_matrix)
+        reshape_matrix=reshape_matrix, median_sub=ps.median_sub, stim_map=stim_map,
+        inverse_stim_map=inverse_stim_map, normalized_stim_map=normalized_stim_map)
     return ns

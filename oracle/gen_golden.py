@@ -178,3 +178,20 @@ for tag, kw in (("rej_a", dict(ncomp=3, source_xy=(34, 24), fwhm=4, delta_rot=1,
     for nm, a in zip(("frame", "recon", "res", "resder"), fo):
         g["%s_%s" % (tag, nm)] = a
 save("g7_grid_rejection", **g)
+
+# ---- G8: median_sub (full-frame) and STIM maps --------------------------------------------------------------------
+cube, ang = O.synth_adi(16, 40, seed=13)
+g = {"cube": cube, "angles": ang}
+for tag, kw in (("a", dict()), ("b", dict(radius_int=4, collapse="mean")),
+                ("c", dict(cube_ref=O.synth_adi(9, 40, seed=14)[0], collapse_ref="median")),
+                ("d", dict(cube_ref=O.synth_adi(9, 40, seed=14)[0], collapse_ref="mean"))):
+    co, cd, fr_ = ref.median_sub(cube, ang, full_output=True, verbose=False, nproc=1, **kw)
+    g["ms_%s_out" % tag], g["ms_%s_der" % tag], g["ms_%s_frame" % tag] = co, cd, fr_
+g["cube_ref"] = O.synth_adi(9, 40, seed=14)[0]
+res = ref.pca(cube, ang, ncomp=3, full_output=True, verbose=False)
+g["res"], g["resder"] = res[3], res[4]
+g["stim"] = ref.stim_map(res[4])
+g["stim_inv"] = ref.inverse_stim_map(res[3], ang)
+g["stim_norm"] = ref.normalized_stim_map(res[3], ang)
+g["stim_norm_mask"] = ref.normalized_stim_map(res[3], ang, mask=5)
+save("g8_medsub_stim", **g)

@@ -534,6 +534,57 @@ def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scalin
     return frame
 
 
+def median_sub_fullfr(cube, angle_list, radius_int=0, collapse="median", cube_ref=None, collapse_ref="median",
+                      full_output=False):
+    """``median_sub(cube, angles, mode='fullfr')`` for a 3-D cube.  Ref: psfsub/medsub.py:226-229 (mask default),
+    :246-253 (reference frame), :279-281 (median model), :288-319 (full-frame), :376-387 (derotate, mask, collapse),
+    :516-519 (returns)."""
+    arr = cube.copy()
+    mask_val = 0 if radius_int else np.nan
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    if cube_ref is not None:
+        ref_frame = np.median(cube_ref, axis=0) if "median" in collapse_ref else np.mean(cube_ref, axis=0)
+        arr -= ref_frame
+    else:
+        arr -= np.median(arr, axis=0)
+    cube_out = arr
+    cube_der = cube_derotate(cube_out, angle_list, mask_val=mask_val)
+    if radius_int:
+        cube_out = mask_circle(cube_out, radius_int)
+        cube_der = mask_circle(cube_der, radius_int)
+    frame = cube_collapse(cube_der, mode=collapse)
+    if full_output:
+        return cube_out, cube_der, frame
+    return frame
+
+
+def stim_map(cube_der):
+    """Ref: metrics/stim.py:24-44 (+ var/shapes.py:389-398 get_circle)."""
+    t, n, _ = cube_der.shape
+    mu = np.mean(cube_der, axis=0)
+    sigma = np.sqrt(np.var(cube_der, axis=0))
+    det = np.divide(mu, sigma, out=np.zeros_like(mu), where=sigma != 0)
+    cy, cx = frame_center(det)
+    yy, xx = np.ogrid[:det.shape[0], :det.shape[1]]
+    return det * ((yy - cy) ** 2 + (xx - cx) ** 2 < int(np.round(n / 2.)) ** 2)
+
+
+def inverse_stim_map(cube, angle_list):
+    """Ref: metrics/stim.py:47-72."""
+    return stim_map(cube_derotate(cube, -np.asarray(angle_list)))
+
+
+def normalized_stim_map(cube, angle_list, mask=None):
+    """Ref: metrics/stim.py:75-118."""
+    inv = inverse_stim_map(cube, angle_list)
+    if mask is not None:
+        inv = mask_circle(inv, mask) if np.isscalar(mask) else inv * mask
+    max_inv = np.nanmax(inv)
+    if max_inv <= 0:
+        raise ValueError("The normalization value is found to be {}".format(max_inv))
+    return stim_map(cube_derotate(cube, angle_list)) / max_inv
+
+
 def pca_4d(cube, angle_list, ncomp=1, collapse_ifs="mean", full_output=False, **kw):
     """4-D cube, scale_list=None: per-channel full-frame PCA then spectral collapse.
     Ref: psfsub/pca_fullfr.py:544-658,770-774."""

@@ -230,3 +230,35 @@ def test_single_cube_sharded_path_world1():
     assert np.abs(got - ref).max() < 1e-5
     got_mean = D.pca_single_cube(cube, O.check_pa_vector(ang), 4, collapse="mean").cpu().numpy()
     assert np.abs(got_mean - pca(cube, ang, ncomp=4, collapse="mean", verbose=False)).max() < 1e-5
+
+
+# ---- median subtraction and STIM maps ------------------------------------------------------------
+
+@pytest.mark.parametrize("tag,kw", [("a", dict()), ("b", dict(radius_int=4, collapse="mean")),
+                                    ("c", dict(rdi=True, collapse_ref="median")), ("d", dict(rdi=True, collapse_ref="mean"))])
+def test_median_sub_golden(tag, kw):
+    from vip_amd.psfsub import median_sub
+    g = load_golden("g8_medsub_stim")
+    kw = dict(kw)
+    if kw.pop("rdi", False):
+        kw["cube_ref"] = g["cube_ref"]
+    co, cd, fr = median_sub(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    for nm, a, b in (("out", co, g["ms_%s_out" % tag]), ("der", cd, g["ms_%s_der" % tag]), ("frame", fr, g["ms_%s_frame" % tag])):
+        assert a.shape == b.shape and a.dtype == b.dtype, nm
+        assert np.abs(a - b).max() < TOL, (tag, nm, np.abs(a - b).max())
+    assert np.abs(median_sub(g["cube"], g["angles"], verbose=False, **kw) - g["ms_%s_frame" % tag]).max() < TOL
+    with pytest.raises(NotImplementedError):
+        median_sub(g["cube"], g["angles"], mode="annular", verbose=False)
+
+
+def test_stim_maps_golden():
+    from vip_amd.metrics import stim_map, inverse_stim_map, normalized_stim_map
+    g = load_golden("g8_medsub_stim")
+    s = stim_map(g["resder"])
+    assert s.shape == g["stim"].shape and np.abs(s - g["stim"]).max() < 1e-4
+    # the inverse / normalised maps divide by a per-pixel standard deviation: compare relative to the map's scale
+    for got, exp in ((inverse_stim_map(g["res"], g["angles"]), g["stim_inv"]),
+                     (normalized_stim_map(g["res"], g["angles"]), g["stim_norm"]),
+                     (normalized_stim_map(g["res"], g["angles"], mask=5), g["stim_norm_mask"])):
+        assert got.shape == exp.shape
+        assert np.abs(got - exp).max() < 2e-3 * max(1.0, np.abs(exp).max())

@@ -14,7 +14,7 @@ _ctx_cache = {}
 _ctx_lock = threading.Lock()
 
 SCALE_MODES = {None: 0, "temp-mean": 1, "temp-standard": 2, "spat-mean": 3, "spat-standard": 4}
-COLLAPSE_MODES = {"median": 0, "mean": 1, "sum": 2, "max": 3, "absmean": 4, "wmean": 5, "trimmean": 6}
+COLLAPSE_MODES = {"median": 0, "mean": 1, "sum": 2, "max": 3, "absmean": 4, "wmean": 5, "trimmean": 6, "stim": 7}
 ROT_METHODS = {"auto": 0, "direct": 1, "fft": 2}
 
 

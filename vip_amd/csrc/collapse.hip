@@ -141,11 +141,16 @@ __global__ void colreduce_kernel(const float* __restrict__ cube, int n, int64_t 
                                  const float* __restrict__ w, float* __restrict__ out) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
        p += (int64_t)gridDim.x * blockDim.x) {
-    double s = 0;
+    double s = 0, s2 = 0;
     float mx = -__builtin_inff();
     int cnt = 0;
     for (int f = 0; f < n; ++f) {
       const float v = cube[(int64_t)f * P + p];
+      if (mode == VIPMI_COLLAPSE_STIM) {          // np.mean / np.var semantics: NaN propagates
+        s += v;
+        s2 += (double)v * v;
+        continue;
+      }
       if (v == v) {
         ++cnt;
         if (mode == VIPMI_COLLAPSE_ABSMEAN) s += fabsf(v);
@@ -157,6 +162,15 @@ __global__ void colreduce_kernel(const float* __restrict__ cube, int n, int64_t 
     float r;
     const float nanv = __uint_as_float(0x7fc00000u);
     switch (mode) {
+      case VIPMI_COLLAPSE_STIM: {
+        const double mu = s / n;
+        double var = s2 / n - mu * mu;
+        if (var < 0) var = 0;
+        const float sig = (float)sqrt(var);
+        r = (sig != 0.f) ? (float)mu / sig : 0.f;
+        if (!(mu == mu)) r = nanv;
+        break;
+      }
       case VIPMI_COLLAPSE_MEAN:
       case VIPMI_COLLAPSE_ABSMEAN: r = cnt ? (float)(s / cnt) : nanv; break;
       case VIPMI_COLLAPSE_SUM:
@@ -228,6 +242,7 @@ int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mo
     case VIPMI_COLLAPSE_MEAN:
     case VIPMI_COLLAPSE_SUM:
     case VIPMI_COLLAPSE_MAX:
+    case VIPMI_COLLAPSE_STIM:
     case VIPMI_COLLAPSE_ABSMEAN: {
       int64_t b = cdiv(P, 256);
       hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, ctx->stream,

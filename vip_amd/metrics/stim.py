@@ -1,0 +1,70 @@
+"""STIM maps: drop-in for ``vip_hci.metrics.stim`` (reference metrics/stim.py:24-118).
+
+``stim_map`` is one pass of the column-reduction kernel (mean / population standard deviation over the frames,
+float64 accumulation) followed by the reference's ``get_circle`` mask; the inverse / normalised maps add the FFT
+derotation.  numpy in -> numpy out, cuda tensor in -> cuda tensor out.
+"""
+import numpy as np
+
+from .. import backend as B
+from ..var.coords import frame_center
+from ..var.shapes import mask_circle
+
+
+def _circle_keep_u8(n_y, n_x, radius):
+    """1 where ``get_circle`` zeroes the map: (y-cy)^2 + (x-cx)^2 >= radius^2 (var/shapes.py:389-398)."""
+    cy, cx = frame_center(np.zeros((n_y, n_x)))
+    yy, xx = np.ogrid[:n_y, :n_x]
+    inside = (yy - cy) ** 2 + (xx - cx) ** 2 < radius ** 2
+    return (~inside).astype(np.uint8)
+
+
+def _stim_dev(cube_t):
+    torch = B._torch()
+    t, n, nx = cube_t.shape
+    det = B.collapse(cube_t, "stim")
+    outside = torch.from_numpy(_circle_keep_u8(n, nx, int(np.round(n / 2.0)))).to(cube_t.device)
+    return B.apply_mask(det.reshape(1, -1), outside.reshape(-1), 0.0).reshape(n, nx)
+
+
+def _wrap(x, dev_in, like):
+    if dev_in:
+        return x
+    out = x.cpu().numpy()
+    return out.astype(like.dtype, copy=False) if like.dtype.kind == "f" else out.astype(np.float64)
+
+
+def stim_map(cube_der):
+    """mu / sigma over the frames of a de-rotated residual cube, inside the inscribed circle."""
+    if cube_der.ndim != 3:
+        raise TypeError("Input array is not a cube or 3d array")
+    dev_in = B.is_device_tensor(cube_der)
+    return _wrap(_stim_dev(B.to_device_f32(cube_der)), dev_in, cube_der)
+
+
+def inverse_stim_map(cube, angle_list, **rot_options):
+    """STIM map of the cube de-rotated with the opposite angles."""
+    if rot_options.get("imlib", "vip-fft") != "vip-fft":
+        raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
+    dev_in = B.is_device_tensor(cube)
+    t = B.to_device_f32(cube)
+    der = B.derotate(t, -np.asarray(angle_list, dtype=np.float64))
+    return _wrap(_stim_dev(der), dev_in, cube)
+
+
+def normalized_stim_map(cube, angle_list, mask=None, **rot_options):
+    """STIM map divided by the maximum of the inverse STIM map (optionally outside a central mask)."""
+    dev_in = B.is_device_tensor(cube)
+    t = B.to_device_f32(cube)
+    inv_map = inverse_stim_map(t, angle_list, **rot_options)
+    if mask is not None:
+        if np.isscalar(mask):
+            inv_map = mask_circle(inv_map, mask)
+        else:
+            inv_map = inv_map * B.to_device_f32(np.asarray(mask, dtype=np.float32))
+    torch = B._torch()
+    max_inv = float(torch.max(torch.nan_to_num(inv_map, nan=-np.inf)).item())
+    if max_inv <= 0:
+        raise ValueError("The normalization value is found to be {}".format(max_inv))
+    der = B.derotate(t, np.asarray(angle_list, dtype=np.float64))
+    return _wrap(_stim_dev(der) / max_inv, dev_in, cube)

@@ -16,7 +16,7 @@ def cube_collapse(cube, mode="median", n=50, w=None):
             raise ValueError("Weights have to be provided for weighted mean mode")
         if len(w) != cube.shape[0]:
             raise TypeError("Weights need same length as cube")
-    if mode not in B.COLLAPSE_MODES:
+    if mode not in B.COLLAPSE_MODES or mode == "stim":
         raise TypeError("mode not recognized")
     dev_in = B.is_device_tensor(cube)
     t = B.to_device_f32(cube)
