@@ -25,16 +25,48 @@ __device__ __forceinline__ float key2f(unsigned k) {
   return __uint_as_float(u);
 }
 
-// rank-k (0-based) order statistic of the wave's keys: 32-step bitwise bisection with wave ballots
+// Wave-wide minimum on DPP (xor butterflies inside a 16-lane row, then the four row minima through readlane); the
+// ds_bpermute-based __shfl_xor costs an LDS round trip per step.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = umin_(v, dpp_u32<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = umin_(v, dpp_u32<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = umin_(v, dpp_u32<0x141>(v));    // row_half_mirror
+  v = umin_(v, dpp_u32<0x140>(v));    // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return umin_(umin_(a, b), umin_(c, d));
+}
+
+// Wave-wide sum of a small per-lane count (0 .. RPL): one ballot per bit of the count.
+template <int RPL>
+__device__ __forceinline__ int wave_count(int c) {
+  int tot = __popcll(__ballot(c & 1));
+  if (RPL >= 2) tot += 2 * __popcll(__ballot(c & 2));
+  if (RPL >= 4) tot += 4 * __popcll(__ballot(c & 4));
+  if (RPL >= 8) tot += 8 * __popcll(__ballot(c & 8));
+  if (RPL >= 16) tot += 16 * __popcll(__ballot(c & 16));
+  if (RPL >= 32) tot += 32 * __popcll(__ballot(c & 32));
+  if (RPL >= 64) tot += 64 * __popcll(__ballot(c & 64));
+  return tot;
+}
+
+// rank-k (0-based) order statistic of the wave's keys: 32-step bitwise bisection.  The RPL comparisons of a step
+// are counted per lane on the vector ALU and summed across the wave with log2(RPL)+1 ballots (a ballot per key
+// serialises RPL VALU->SALU round trips per step, which made the median kernel latency bound).
 template <int RPL>
 __device__ __forceinline__ unsigned select_rank(const unsigned (&key)[RPL], int k) {
   unsigned ans = 0;
   for (int b = 31; b >= 0; --b) {
     const unsigned cand = ans | (1u << b);
-    int cnt = 0;
+    int c = 0;
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) cnt += __popcll(__ballot(key[r] < cand));
-    if (cnt <= k) ans = cand;
+    for (int r = 0; r < RPL; ++r) c += (key[r] < cand) ? 1 : 0;
+    if (wave_count<RPL>(c) <= k) ans = cand;
   }
   return ans;
 }
@@ -42,20 +74,49 @@ __device__ __forceinline__ unsigned select_rank(const unsigned (&key)[RPL], int 
 // TRIM = false: nanmedian.  TRIM = true: mean of sorted[t0 : t0+tn] (np.sort order, NaN last, then nanmean):
 // the reference's 'trimmean' (subsampling.py:87-96).
 template <int RPL, bool TRIM>
-__global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ cube, int n, int64_t P,
-                                                     int TP, float* __restrict__ out, int t0, int tn) {
+__global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ cube, int n, int64_t P,
+                                                     int TP, float* __restrict__ out, int t0, int tn, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // n x (TP+1)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
   const int ldt = TP + 1;
   const int64_t p0 = (int64_t)blockIdx.x * TP;
-  // stage: TP consecutive pixels of every frame
-  for (int e = threadIdx.x; e < n * TP; e += blockDim.x) {
-    const int f = e / TP, j = e % TP;
-    const int64_t p = p0 + j;
-    tile[f * ldt + j] = (p < P) ? cube[(int64_t)f * P + p] : 0.f;
+  // stage: TP consecutive pixels of every frame.  The kernel is bound by this load (400 row segments of 128 bytes,
+  // 1 MB apart), so each thread issues a batch of 16-byte loads (8 threads per segment, 32 frames per pass) before
+  // the first LDS write: ~13 requests in flight per thread instead of one.
+  if (TP == 32 && (P & 3) == 0) {
+    const int seg = threadIdx.x & 7, r0 = threadIdx.x >> 3, RPP = blockDim.x >> 3;   // rows per pass
+    const int64_t pc = p0 + 4 * seg;
+    const bool inb = pc < P;                                     // P % 4 == 0: the whole float4 is in range
+    constexpr int NB = 4;                                        // passes per batch
+    for (int fb = 0; fb < n; fb += RPP * NB) {
+      float4 v[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int f = fb + r0 + RPP * i;
+        v[i] = (inb && f < n) ? *reinterpret_cast<const float4*>(cube + (int64_t)f * P + pc) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int f = fb + r0 + RPP * i;
+        if (f < n) {
+          float* t = tile + f * ldt + 4 * seg;
+          t[0] = v[i].x;
+          t[1] = v[i].y;
+          t[2] = v[i].z;
+          t[3] = v[i].w;
+        }
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < n * TP; e += blockDim.x) {
+      const int f = e / TP, j = e % TP;
+      const int64_t p = p0 + j;
+      tile[f * ldt + j] = (p < P) ? cube[(int64_t)f * P + p] : 0.f;
+    }
   }
   __syncthreads();
+  if (dbg == 1) return;
   for (int j = wave; j < TP; j += nw) {
     const int64_t p = p0 + j;
     if (p >= P) break;
@@ -74,9 +135,7 @@ __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ c
       }
       key[r] = kk;
     }
-    int m = nvalid_lane;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) m += __shfl_xor(m, s, 64);
+    const int m = wave_count<RPL>(nvalid_lane);
     float res;
     if (TRIM) {
       int hi_end = t0 + tn;                    // slice [t0, hi_end) of the sorted samples, NaNs (rank >= m) dropped
@@ -124,11 +183,7 @@ __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ c
           cle += __popcll(__ballot(key[r] <= ans));
           if (key[r] > ans && key[r] < nxt) nxt = key[r];
         }
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-          unsigned o = __shfl_xor(nxt, s, 64);
-          nxt = o < nxt ? o : nxt;
-        }
+        nxt = wave_min_u32(nxt);
         const float hi = (cle >= k + 2) ? lo : key2f(nxt);
         res = (lo + hi) * 0.5f;
       }
@@ -189,7 +244,8 @@ int launch_median(vipmi_ctx* ctx, const float* cube, int n, int64_t P, float* ou
   auto kern = median_kernel<RPL, TRIM>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(256), lds, ctx->stream, cube, n, P, TP, out, t0, tn);
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(512), lds, ctx->stream, cube, n, P, TP, out, t0, tn,
+                     (int)ctx->opt("collapse_dbg", 0));
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -228,6 +284,7 @@ int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mo
       if (rpl <= 1) { VIPMI_MED(1); }
       if (rpl <= 2) { VIPMI_MED(2); }
       if (rpl <= 4) { VIPMI_MED(4); }
+      if (rpl <= 7) { VIPMI_MED(7); }      // 385..448 frames: one compare less per bisection step (VALU bound)
       if (rpl <= 8) { VIPMI_MED(8); }
       if (rpl <= 16) { VIPMI_MED(16); }
       if (rpl <= 32) { VIPMI_MED(32); }
