@@ -21,6 +21,7 @@
 //    by default -- the Gram matrix squares the condition number, so it is kept at f64 accuracy;
 //    option "gram_f32" selects v_mfma_f32_16x16x4_f32 (2x MFMA rate, f32 chains per slice).
 #include "common.h"
+#include <algorithm>
 
 namespace vipmi {
 
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel
   if (tile >= ntiles) return;
   const int slice = blockIdx.x;
   const int2 t = tiles[tile];
+  if (t.x < 0) return;                      // padding entry of the balanced tile order
   const int r = lane & 15, kq = lane >> 4;
   const int64_t kbeg = (int64_t)slice * klen;
   int64_t kend = kbeg + klen;
@@ -170,6 +172,7 @@ __global__ void gram_reduce_kernel(const void* __restrict__ partial_, const int2
     int blk = rem >> 8, idx = rem & 255;
     int bi = blk / TB, bj = blk % TB;
     int2 t = tiles[tile];
+    if (t.x < 0) continue;
     int gi = (t.x * TB + bi) * 16 + (idx >> 4);
     int gj = (t.y * TB + bj) * 16 + (idx & 15);
     if (gi >= na || gj >= nb) continue;
@@ -189,11 +192,50 @@ static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, in
   std::vector<int2> tiles;
   for (int i = 0; i < nta; ++i)
     for (int j = symmetric ? i : 0; j < ntb; ++j) tiles.push_back(int2{i, j});
-  const int ntiles = (int)tiles.size();
   // waves per workgroup: the accumulator tile caps TB>=3 kernels at 2 waves/SIMD
   const int max_waves = gram_max_waves<TB>();
-  int wpw = ntiles < max_waves ? ntiles : max_waves;
-  int ngroups = (int)cdiv(ntiles, wpw);
+  int wpw = (int)tiles.size() < max_waves ? (int)tiles.size() : max_waves;
+  int ngroups = (int)cdiv((int64_t)tiles.size(), wpw);
+  // Balance the MFMA work over the SIMDs: tiles differ (diagonal tiles skip their lower blocks, edge tiles their
+  // padding), a workgroup holds its CU until its busiest SIMD is done, and wave w runs on SIMD w % 4.  Longest-
+  // processing-time assignment of the tiles to (workgroup, SIMD) slots, slots sorted by load so that the four
+  // slots of a workgroup are alike; unfilled positions become (-1, -1) entries that exit at once.
+  if (wpw % 4 == 0 && ngroups >= 1 && (int)tiles.size() > 4) {
+    auto work = [&](const int2& t) {
+      int w = 0;
+      for (int i = 0; i < TB; ++i)
+        for (int j = 0; j < TB; ++j) {
+          if ((t.x * TB + i) >= nba || (t.y * TB + j) >= nbb) continue;
+          if (symmetric && t.x == t.y && j < i) continue;
+          ++w;
+        }
+      return w;
+    };
+    const int q = wpw / 4, nslots = ngroups * 4;
+    std::vector<int> order(tiles.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work(tiles[a]) > work(tiles[b]); });
+    std::vector<std::vector<int>> slot(nslots);
+    std::vector<int> load(nslots, 0);
+    for (int idx : order) {
+      int best = -1;
+      for (int sl = 0; sl < nslots; ++sl)
+        if ((int)slot[sl].size() < q && (best < 0 || load[sl] < load[best])) best = sl;
+      slot[best].push_back(idx);
+      load[best] += work(tiles[idx]);
+    }
+    std::vector<int> sorder(nslots);
+    for (int i = 0; i < nslots; ++i) sorder[i] = i;
+    std::stable_sort(sorder.begin(), sorder.end(), [&](int a, int b) { return load[a] > load[b]; });
+    std::vector<int2> balanced((size_t)ngroups * wpw, int2{-1, -1});
+    for (int si = 0; si < nslots; ++si) {
+      const int g = si / 4, simd = si % 4;
+      const std::vector<int>& members = slot[sorder[si]];
+      for (size_t pos = 0; pos < members.size(); ++pos) balanced[(size_t)g * wpw + simd + 4 * pos] = tiles[members[pos]];
+    }
+    tiles.swap(balanced);
+  }
+  const int ntiles = (int)tiles.size();
   // slices: ~2 workgroups per CU in total, slice length a multiple of 16, >= 64 pixels
   int64_t target = ctx->opt("gram_slices", 0);
   if (target <= 0) target = cdiv((int64_t)2 * ctx->num_cu, ngroups);
