@@ -554,7 +554,9 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
     wprev[c] = 0.0;
     pfull[c] = 0.0;
   }
-  __syncthreads();
+  // every workgroup has read row 0 (and its own rows) before any reflector is written over the input matrix
+  bar_target += W;
+  grid_barrier(bar, bar_target, W);
   double* vcur = vbuf0;
   double* vnext = vbuf1;
   // derive (v_{s+1}, beta, alpha, diagonal) from x = updated row s+1 held in cfull[c], c >= s+1 ; every wave
