@@ -390,6 +390,68 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2(const float* __restrict
   }
 }
 
+// ---- shear 2 without the LDS tile (one wave per line): every wave reads and writes its two columns directly,
+// eight bytes per lane and row.  A load instruction then touches 64 different 128-byte lines, but the 16 column pairs
+// that share those lines are consecutive tokens of one XCD queue, so they are processed by waves of the same XCD at
+// about the same time: one HBM fetch per line, the rest L2 hits; the partial stores merge in the L2 the same way.
+// What it buys: no workgroup barrier and no global <-> LDS staging phase in which all eight waves of a workgroup
+// wait (36 % of the tiled kernel) -- a wave's memory latency now hides behind the transforms of the other waves.
+template <class P>
+__global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __restrict__ A1r,
+                                                                const RotFrame* __restrict__ fr, RotGeom g,
+                                                                float* __restrict__ A2r, Aux aux, int f0, int nf,
+                                                                const cf* __restrict__ twtab,
+                                                                int* __restrict__ counters) {
+  static_assert(P::WPL == 1, "rs_shear2_direct: one wave per line");
+  VIPMI_SLOT_PROLOGUE();
+  Tasks<P, true> tasks;
+  tasks.init(counters, lds_all);
+  constexpr int HALF = P::L / 2;                  // column pairs per frame
+  constexpr int TPG = 16;                         // 16 pairs = 32 columns = one 128-byte line of every row
+  const int ntask = nf * HALF;
+  tasks.request();
+  for (int task = tasks.template take<TPG>(); task < ntask; task = tasks.template take<TPG>()) {
+    tasks.request();
+    const int fl = task / HALF, X1 = 2 * (task % HALF), X2 = X1 + 1, f = f0 + fl;
+    const RotFrame p = fr[f];
+    const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+    const float* src = A1r + (int64_t)fl * g.N * P::L + X1;
+    cf v[P::VL];
+#pragma unroll
+    for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+      for (int n1 = 0; n1 < P::R1; ++n1) {
+        cf val = mkcf(0.f, 0.f);
+        if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {     // compile-time window
+          const int yrel = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul) - r0;
+          if (yrel >= 0 && yrel < g.N) val = *reinterpret_cast<const cf*>(src + (int64_t)yrel * P::L);
+        }
+        v[ul * P::R1 + n1] = val;
+      }
+    const double s1 = p.b * (double)(X1 - g.c), s2 = p.b * (double)(X2 - g.c);
+    float alt1, alt2, sn1, sn2;
+    pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+    // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m
+    const float bfl = aux.bf[fl];
+    const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
+    const float k2c = sn2 * ((X2 & 1) ? -bfl : bfl);
+    float* dst = A2r + (int64_t)fl * g.N * P::L + X1;
+#pragma unroll
+    for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+      for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
+        const int m = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);      // off == M1*NLO
+        const float sg = ((g.off + m) & 1) ? -1.f : 1.f;
+        *reinterpret_cast<cf*>(dst + (int64_t)m * P::L) =
+            mkcf(v[ul * P::R1 + n1].x - sg * k1c, v[ul * P::R1 + n1].y - sg * k2c);
+      }
+    if (lane == 0) {
+      aux.gam[fl * P::L + X1] = ((X1 & 1) ? -sn1 : sn1) * alt1;
+      aux.gam[fl * P::L + X2] = ((X2 & 1) ? -sn2 : sn2) * alt2;
+    }
+  }
+}
+
 // Gam[f] = sum_X (-1)^X gamma_X  (fixed-order tree: deterministic)
 __global__ __launch_bounds__(256) void rs_gamma_kernel(Aux aux, int L) {
   __shared__ float sh[4];
@@ -541,8 +603,21 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     hipLaunchKernelGGL(ka, dim3(ga), blk, lds, ctx->stream, d_frames, g, aux, (int)f0, nf, twtab);
     ctx->toc("k_rot_aux");
     ctx->tic("k_rot_s2");
-    hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
-                       counters + 256);
+    if constexpr (P::WPL == 1) {
+      if (ctx->opt("rot_s2_tiled", 0) == 0) {
+        auto k2d = rs_shear2_direct<P>;
+        VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2d),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k2d, dim3(gr), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
+                           counters + 256);
+      } else {
+        hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
+                           counters + 256);
+      }
+    } else {
+      hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
+                         counters + 256);
+    }
     ctx->toc("k_rot_s2");
     ctx->tic("k_rot_aux");
     hipLaunchKernelGGL(rs_gamma_kernel, dim3(nf), dim3(256), 0, ctx->stream, aux, P::L);
