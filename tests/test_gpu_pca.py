@@ -262,3 +262,19 @@ def test_stim_maps_golden():
                      (normalized_stim_map(g["res"], g["angles"], mask=5), g["stim_norm_mask"])):
         assert got.shape == exp.shape
         assert np.abs(got - exp).max() < 2e-3 * max(1.0, np.abs(exp).max())
+
+
+def test_pca_many_matches_serial():
+    """Independent cubes issued through two streams in asynchronous mode give exactly the serial results."""
+    from vip_amd.psfsub import pca, pca_many
+    cubes, angs = zip(*[O.synth_adi(20 + 2 * i, 64, seed=30 + i) for i in range(5)])
+    serial = [pca(c, a, ncomp=3, verbose=False) for c, a in zip(cubes, angs)]
+    many = pca_many(list(cubes), list(angs), depth=2, ncomp=3)
+    assert len(many) == 5
+    for s_, m in zip(serial, many):
+        assert m.dtype == s_.dtype and np.array_equal(s_, m)
+    # a failing call must not leave the library in asynchronous mode
+    with pytest.raises(ValueError):
+        pca_many(list(cubes), list(angs), ncomp=0)
+    from vip_amd import backend
+    assert backend._async["on"] is False

@@ -457,3 +457,44 @@ def pca(*all_args: List, **all_kwargs: dict):
         pcs, recon, residuals_cube, residuals_cube_, frame = out
         return host(frame), host(pcs), host(recon), host(residuals_cube), host(residuals_cube_)
     return host(out)
+
+
+def pca_many(cubes, angle_lists, depth=2, **kwargs):
+    """``[pca(c, a, **kwargs) for c, a in zip(cubes, angle_lists)]`` for independent cubes (survey mode, the
+    contrast-curve / NEGFC loops of the reference, which it parallelises over processes with ``nproc``), issued
+    through ``depth`` streams in the library's asynchronous mode so that the eigensolver of one cube runs beside the
+    derotation of the previous one.  ``full_output`` is not supported; numpy cubes are uploaded
+    one ahead.  Returns a list of final frames (numpy in -> numpy out, cuda tensors in -> cuda tensors out)."""
+    if kwargs.get("full_output"):
+        raise NotImplementedError("pca_many returns final frames only")
+    kwargs = dict(kwargs, full_output=False, verbose=False)
+    torch = B.require_gpu()
+    n_items = len(cubes)
+    if n_items != len(angle_lists):
+        raise ValueError("cubes and angle_lists must have the same length")
+    depth = max(1, min(int(depth), n_items)) if n_items else 1
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    dev_in = [B.is_device_tensor(c) for c in cubes]
+    outs = [None] * n_items
+    B.set_async(True)
+    try:
+        cur = torch.cuda.current_stream()
+        for i, (c, a) in enumerate(zip(cubes, angle_lists)):
+            st = streams[i % depth]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                t = B.to_device_f32(c)
+                outs[i] = pca(t, a, **kwargs)
+        for st in streams:
+            st.synchronize()
+        B.check_deferred()
+    finally:
+        B.set_async(False)
+    res = []
+    for i, o in enumerate(outs):
+        if dev_in[i]:
+            res.append(o)
+        else:
+            c = cubes[i]
+            res.append(o.cpu().numpy().astype(c.dtype if c.dtype.kind == "f" else np.float64, copy=False))
+    return res
