@@ -125,6 +125,9 @@ int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals,
 bool eigh_topk_supported(int64_t n, int64_t k);
 int eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                   double* evals, double* evecs);
+// one larger problem (512 < n <= 2048): eigh_tri_large.hip
+bool eigh_large_supported(int64_t n, int64_t k);
+int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs);
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                  double* evals, double* evecs);
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,

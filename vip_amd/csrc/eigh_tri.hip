@@ -999,6 +999,8 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
                  double* evecs) {
   if (ctx->opt("eigh_method", 0) != 1 && eigh_topk_supported(n, k))
     return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs);
+  if (ctx->opt("eigh_method", 0) != 1 && !nact && batch <= 4 && eigh_large_supported(n, k))
+    return eigh_large_f64(ctx, G, batch, n, k, evals, evecs);
   return eigh_f64(ctx, G, batch, n, evals, evecs);
 }
 

@@ -1,0 +1,518 @@
+// eigh_tri_large.hip -- leading k eigenpairs of ONE larger symmetric float64 matrix (512 < n <= 2048, k <= 64):
+// the algorithm of eigh_tri.hip's multi-workgroup variant with the matrix left in global memory (a 2000 x 2000
+// float64 matrix is 32 MB: it no longer fits the LDS of the cooperating workgroups, but it does fit the L2s and the
+// Infinity Cache).  W = 64 workgroups own the rows cyclically (row r -> workgroup r mod W) and update them in place;
+// per Householder step a workgroup reads and writes its share of the trailing matrix once (all loads of a row issued
+// before the first use), then the same single counter barrier / redundant-reflector scheme as in eigh_tri.hip.
+// Afterwards workgroup c computes eigenvalue c, its eigenvector by inverse iteration (factors in LDS) and its
+// back-transformation; workgroup 0 finally orthonormalises the k vectors.
+//
+// Replaces, for C5-sized cubes (n = 2000 frames), the one-sided Jacobi kernel (140 ms) in the decomposition step of
+// svd_wrapper / get_eigenvectors (psfsub/svd.py:342-702).
+#include "common.h"
+#include "wave_util.h"
+
+namespace vipmi {
+
+namespace {
+
+constexpr int LNT = 512;            // threads per workgroup (256-VGPR budget)
+constexpr int LNW = LNT / 64;
+constexpr double LEPS = 2.220446049250313e-16;
+
+__device__ __forceinline__ double fast_rcp_l(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+
+__device__ __forceinline__ double hash_unit_l(unsigned a, unsigned b) {
+  unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  x *= 0x297A2D39u;
+  x ^= x >> 15;
+  return ((double)(x >> 8) + 0.5) * (2.0 / 16777216.0) - 1.0;
+}
+
+// Sturm count (product form, see eigh_tri.hip)
+__device__ __forceinline__ int sturm_count_l(const double* __restrict__ d, const double* __restrict__ e2, int n,
+                                             double sigma) {
+  double pm = 1.0, p = d[0] - sigma;
+  bool neg = p < 0.0 || p == 0.0;
+  if (p == 0.0) p = -1e-300;
+  int cnt = neg ? 1 : 0;
+  for (int i0 = 1; i0 < n; i0 += 16) {
+    double db[16], eb[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u;
+      db[u] = (i < n) ? d[i] : 0.0;
+      eb[u] = (i < n) ? e2[i - 1] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (i0 + u < n) {
+        const double t = eb[u] * pm;
+        double pn = fma(db[u] - sigma, p, -t);
+        if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
+        const bool nneg = pn < 0.0;
+        cnt += (nneg != neg) ? 1 : 0;
+        neg = nneg;
+        pm = p;
+        p = pn;
+      }
+    }
+    const int ex = ilogb(fabs(p) > fabs(pm) ? p : pm);
+    p = scalbn(p, -ex);
+    pm = scalbn(pm, -ex);
+  }
+  return cnt;
+}
+
+template <int RPL>
+__global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, int n, int k, double* __restrict__ evals,
+                                                        double* __restrict__ evecs, double* __restrict__ gb,
+                                                        unsigned* __restrict__ bar) {
+  extern __shared__ double sm[];
+  const int W = gridDim.x, wg = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // phase 1: six vectors of n ; later phases reuse the space (9 n doubles in total)
+  double* vbuf0 = sm;
+  double* vbuf1 = vbuf0 + n;
+  double* vprev = vbuf1 + n;
+  double* wprev = vprev + n;
+  double* pfull = wprev + n;
+  double* cfull = pfull + n;
+  double* Pb = gb;                 // [2][n]
+  double* Cb = gb + 2 * n;         // [2][n]
+  double* Db = gb + 4 * n;         // [n]
+  double* gd = gb + 5 * n;         // [n] diagonal of T       (written by workgroup 0)
+  double* ge = gb + 6 * n;         // [n] off-diagonal
+  double* gt = gb + 7 * n;         // [n] Householder scalars
+  unsigned bar_target = 0;
+  const int na = n;
+  const int kk = k < na ? k : na;
+
+  for (int c = tid; c < n; c += LNT) {
+    cfull[c] = A[c];               // row 0: input data
+    vprev[c] = 0.0;
+    wprev[c] = 0.0;
+    pfull[c] = 0.0;
+  }
+  __syncthreads();
+  bar_target += W;
+  grid_barrier(bar, bar_target, W);            // everybody has row 0 before reflectors overwrite the matrix
+  double* vcur = vbuf0;
+  double* vnext = vbuf1;
+  double beta_cur = 0.0;
+  // (v, beta, alpha, diagonal) from the updated row held in cfull[c], c >= s1 ; returns beta (uniform)
+  auto form_reflector = [&](int s1, double* vout) -> double {
+    double nrm2 = 0.0;
+    for (int c = s1 + 1 + lane; c < na; c += 64) {
+      const double x = cfull[c];
+      nrm2 += x * x;
+    }
+    nrm2 = wave_sum(nrm2);
+    const double x0 = cfull[s1 + 1];
+    const double nrm = sqrt(nrm2);
+    const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+    const double v0 = x0 - alpha;
+    double rest = nrm2 - x0 * x0;
+    if (rest < 0.0) rest = 0.0;
+    const double vv = rest + v0 * v0;
+    const double beta = (nrm2 > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
+    for (int c = s1 + 1 + tid; c < na; c += LNT) vout[c] = (c == s1 + 1) ? v0 : cfull[c];
+    if (wg == 0 && tid == 0) {
+      st_shared(&gd[s1], cfull[s1]);
+      st_shared(&ge[s1], (nrm2 > 0.0) ? alpha : 0.0);
+      st_shared(&gt[s1], beta);
+    }
+    return beta;
+  };
+  beta_cur = form_reflector(0, vcur);
+  __syncthreads();
+
+  // ---------------- 1. tridiagonalisation, matrix in global memory ----------------
+  for (int s = 0; s + 2 < na; ++s) {
+    const int par = s & 1;
+    const double beta = beta_cur;
+    if (s % W == wg)
+      for (int c = s + 1 + tid; c < na; c += LNT) st_shared(&A[(size_t)s * n + c], vcur[c]);
+    const int lr0 = (s + 1 - wg + W - 1) / W;
+    for (int lr = (lr0 > 0 ? lr0 : 0) + wave;; lr += LNW) {
+      const int r = lr * W + wg;
+      if (r >= na) break;
+      double* row = A + (size_t)r * n;
+      double a[RPL];
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int c = s + 1 + lane + 64 * ch;
+        a[ch] = (c < na) ? row[c] : 0.0;
+      }
+      const double vr = vprev[r], wr = wprev[r];
+      double acc = 0.0, cval = 0.0, dval = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int c = s + 1 + lane + 64 * ch;
+        if (c < na) {
+          const double t = a[ch] - vr * wprev[c] - wr * vprev[c];
+          row[c] = t;
+          acc += t * vcur[c];
+          if (ch == 0 && lane == 0) cval = t;
+          if (c == r) dval = t;
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        st_shared(&Pb[par * n + r], beta * acc);
+        st_shared(&Cb[par * n + r], cval);
+      }
+      if (s + 3 == na) {
+        const int dl = r - s - 1;
+        if (lane == (dl & 63)) st_shared(&Db[r], dval);
+      }
+    }
+    bar_target += W;
+    grid_barrier(bar, bar_target, W);
+    for (int c = s + 1 + tid; c < na; c += LNT) {
+      pfull[c] = ld_shared(&Pb[par * n + c]);
+      cfull[c] = ld_shared(&Cb[par * n + c]);
+    }
+    __syncthreads();
+    double kd = 0.0;
+    for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pfull[r];
+    const double K = 0.5 * beta * wave_sum(kd);
+    const double vs1 = vcur[s + 1], ws1 = pfull[s + 1] - K * vs1;
+    for (int r = s + 1 + tid; r < na; r += LNT) {
+      const double v = vcur[r];
+      const double w = pfull[r] - K * v;
+      wprev[r] = w;
+      vprev[r] = v;
+      cfull[r] = cfull[r] - vs1 * w - ws1 * v;
+    }
+    __syncthreads();
+    if (s + 3 < na) {
+      beta_cur = form_reflector(s + 1, vnext);
+      double* t = vcur;
+      vcur = vnext;
+      vnext = t;
+    }
+    __syncthreads();
+  }
+  if (wg == 0 && tid == 0) {
+    const int a = na - 2, b = na - 1;
+    st_shared(&gd[a], cfull[a]);
+    st_shared(&ge[a], cfull[b]);
+    st_shared(&gd[b], ld_shared(&Db[b]) - 2.0 * vprev[b] * wprev[b]);
+    st_shared(&ge[b], 0.0);
+  }
+  bar_target += W;
+  grid_barrier(bar, bar_target, W);
+
+  // ---------------- 2. T into LDS (scaled), eigenvalue of this workgroup's vector ----------------
+  double* dd = sm;                 // [n]
+  double* ee = dd + n;             // [n]
+  double* e2 = ee + n;             // [n]
+  double* lamv = e2 + n;           // [8]  (then the inverse-iteration arrays, 6 n)
+  double* U0 = lamv + 8;
+  double* U1 = U0 + n;
+  double* U2 = U1 + n;
+  double* Lm = U2 + n;
+  double* Ls = Lm + n;
+  double* Zl = Ls + n;
+  for (int i = tid; i < na; i += LNT) {
+    dd[i] = ld_shared(&gd[i]);
+    ee[i] = ld_shared(&ge[i]);
+  }
+  __syncthreads();
+  double scale = 0.0, glo = 0.0, ghi = 0.0;
+  {
+    double mx = 0.0;
+    for (int i = lane; i < na; i += 64) mx = fmax(mx, fmax(fabs(dd[i]), fabs(ee[i])));
+    scale = wave_max(mx);
+  }
+  const double iscale = scale > 0.0 ? 1.0 / scale : 0.0;
+  __syncthreads();
+  for (int i = tid; i < na; i += LNT) {
+    const double e = ee[i] * iscale;
+    dd[i] *= iscale;
+    ee[i] = e;
+    e2[i] = e * e;
+  }
+  __syncthreads();
+  {
+    double lo = 1e300, hi = -1e300;
+    for (int i = lane; i < na; i += 64) {
+      const double rad = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i + 1 < na ? fabs(ee[i]) : 0.0);
+      lo = fmin(lo, dd[i] - rad);
+      hi = fmax(hi, dd[i] + rad);
+    }
+    glo = -wave_max(-lo);
+    ghi = wave_max(hi);
+    const double margin = 4.0 * LEPS * (double)na + 1e-290;
+    glo -= margin;
+    ghi += margin;
+  }
+  const bool mine = wg < kk;                    // vector c = wg (the host launches W >= k workgroups)
+  const int c = wg;
+  if (mine && wave == 0) {
+    const int target = na - 1 - c;
+    double a = glo, b = ghi;
+    for (int sweep = 0; sweep < 14; ++sweep) {
+      const double h = (b - a) * (1.0 / 65.0);
+      const double sigma = a + h * (double)(lane + 1);
+      const int cnt = sturm_count_l(dd, e2, na, sigma);
+      const int L = __popcll(__ballot(cnt <= target));
+      const double na_ = (L == 0) ? a : a + h * (double)L;
+      const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
+      a = na_;
+      b = nb_;
+      if (b - a <= 2.0 * LEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
+    }
+    if (lane == 0) lamv[0] = 0.5 * (a + b);
+  }
+  __syncthreads();
+
+  // ---------------- 3. inverse iteration (one thread; factors in LDS) ----------------
+  if (mine && tid == 0) {
+    const double lc = lamv[0] - (double)(c + 1) * 4.0 * LEPS;
+    const double ptiny = 1e-3 * LEPS;
+    double p = dd[0] - lc, q = (na > 1) ? ee[0] : 0.0, r = 0.0;
+    double yc = hash_unit_l(0u, (unsigned)c);
+    for (int i = 0; i + 1 < na; ++i) {
+      const double sub = ee[i], nd = dd[i + 1] - lc, nu = (i + 2 < na) ? ee[i + 1] : 0.0;
+      const double yn = hash_unit_l((unsigned)(i + 1), (unsigned)c);
+      double inv, u1, u2, yi, m, sw;
+      if (fabs(sub) > fabs(p) && fabs(sub) >= ptiny) {
+        inv = fast_rcp_l(sub);
+        u1 = nd; u2 = nu;
+        m = p * inv;
+        sw = 1.0;
+        yi = yn;
+        yc = yc - m * yn;
+        p = q - m * nd;
+        q = r - m * nu;
+        r = 0.0;
+      } else {
+        if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+        inv = fast_rcp_l(p);
+        u1 = q; u2 = r;
+        m = sub * inv;
+        sw = 0.0;
+        yi = yc;
+        yc = yn - m * yc;
+        p = nd - m * q;
+        q = nu - m * r;
+        r = 0.0;
+      }
+      U0[i] = inv;
+      U1[i] = u1;
+      U2[i] = u2;
+      Lm[i] = m;
+      Ls[i] = sw;
+      Zl[i] = yi;
+    }
+    if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+    const double invlast = fast_rcp_l(p);
+    double rs = 1.0;
+    for (int it = 0; it < 2; ++it) {
+      if (it > 0) {
+        yc = Zl[0] * rs;
+        for (int i = 0; i + 1 < na; ++i) {
+          const double yn = Zl[i + 1] * rs;
+          const double m = Lm[i];
+          const bool sw = Ls[i] != 0.0;
+          const double yi = sw ? yn : yc;
+          yc = sw ? (yc - m * yn) : (yn - m * yc);
+          Zl[i] = yi;
+        }
+      }
+      double x1 = yc * invlast, x2 = 0.0;
+      Zl[na - 1] = x1;
+      double acc = x1 * x1;
+      for (int i = na - 2; i >= 0; --i) {
+        const double x = (Zl[i] - U1[i] * x1 - U2[i] * x2) * U0[i];
+        Zl[i] = x;
+        acc += x * x;
+        x2 = x1;
+        x1 = x;
+      }
+      rs = acc > 0.0 ? 1.0 / sqrt(acc) : 1.0;
+    }
+    lamv[1] = rs;
+  }
+  __syncthreads();
+
+  // ---------------- 4. back-transformation of this workgroup's vector: rows split over the 8 waves ----------------
+  // z lives in LDS (Zl); every reflector needs one dot product over the whole vector: waves reduce their slices,
+  // partial sums through LDS.  Reflectors are staged in blocks of RB rows.
+  {
+    constexpr int RB = 4;
+    double* stage = U0;                         // [RB][n] over U0..Lm (dead)
+    double* part = Zl + n;                      // [2][LNW] partial dots
+    if (mine) {
+      const double rs = lamv[1];
+      for (int i = tid; i < na; i += LNT) {
+        Zl[i] *= rs;
+        dd[i] = ld_shared(&gt[i]);              // Householder scalars (dd is dead)
+      }
+      for (int jb = na - 3; jb >= 0; jb -= RB) {
+        __syncthreads();
+        for (int e = tid; e < RB * n; e += LNT) {
+          const int q = e / n, i = e - q * n, j = jb - q;
+          stage[e] = (j >= 0 && i > j && i < na) ? ld_shared(&A[(size_t)j * n + i]) : 0.0;
+        }
+        __syncthreads();
+        for (int q = 0; q < RB; ++q) {
+          const int j = jb - q;
+          if (j < 0) break;
+          const double beta = dd[j];
+          // every thread owns the same elements i = tid + LNT m in all steps: no cross-thread hazard on Zl
+          double sdot = 0.0;
+          for (int i = tid; i < na; i += LNT) sdot += stage[q * n + i] * Zl[i];      // stage is 0 for i <= j
+          sdot = wave_sum(sdot);
+          if (lane == 0) part[wave + (q & 1) * LNW] = sdot;
+          __syncthreads();
+          double tot = 0.0;
+#pragma unroll
+          for (int w = 0; w < LNW; ++w) tot += part[w + (q & 1) * LNW];
+          tot *= beta;
+          for (int i = tid; i < na; i += LNT) Zl[i] -= tot * stage[q * n + i];
+        }
+      }
+    }
+    __syncthreads();
+    if (mine) {
+      for (int i = tid; i < n; i += LNT) st_shared(&evecs[(size_t)c * n + i], (i < na) ? Zl[i] : 0.0);
+      if (tid == 0) st_shared(&evals[c], lamv[0] * scale);
+    }
+  }
+  bar_target += W;
+  grid_barrier(bar, bar_target, W);
+  if (wg != 0) return;
+
+  // ---------------- 5. workgroup 0: modified Gram-Schmidt in place (vectors in global / L2), sign convention ---------
+  double* qv = sm;                               // [n] pivot vector
+  for (int cp = 0; cp < kk; ++cp) {
+    // normalise vector cp (all threads)
+    double sq = 0.0;
+    for (int i = tid; i < na; i += LNT) {
+      const double x = ld_shared(&evecs[(size_t)cp * n + i]);
+      qv[i] = x;
+      sq += x * x;
+    }
+    sq = wave_sum(sq);
+    __syncthreads();                             // qv complete ; reuse part area for the block reduction
+    double* red = sm + n;
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < LNW; ++w) tot += red[w];
+    const double inv = tot > 0.0 ? 1.0 / sqrt(tot) : 0.0;
+    __syncthreads();
+    for (int i = tid; i < na; i += LNT) {
+      const double x = qv[i] * inv;
+      qv[i] = x;
+      st_shared(&evecs[(size_t)cp * n + i], x);
+    }
+    __syncthreads();
+    // remove its component from the later vectors: one wave per vector
+    for (int c2 = cp + 1 + wave; c2 < kk; c2 += LNW) {
+      double x[RPL], sdot = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        x[rr] = (i < na) ? ld_shared(&evecs[(size_t)c2 * n + i]) : 0.0;
+        sdot += (i < na) ? x[rr] * qv[i] : 0.0;
+      }
+      sdot = wave_sum(sdot);
+#pragma unroll
+      for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        if (i < na) st_shared(&evecs[(size_t)c2 * n + i], x[rr] - sdot * qv[i]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // sign convention: largest-magnitude component positive ; one wave per vector
+  for (int c2 = wave; c2 < k; c2 += LNW) {
+    double x[RPL];
+    double best = -1.0, bval = 0.0;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      const int i = lane + 64 * rr;
+      x[rr] = (c2 < kk && i < na) ? ld_shared(&evecs[(size_t)c2 * n + i]) : 0.0;
+      const double a = fabs(x[rr]);
+      if (i < na && a > best) {
+        best = a;
+        bval = x[rr];
+        bidx = i;
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double ob = __shfl_xor(best, m, 64), ovv = __shfl_xor(bval, m, 64);
+      const int oi = __shfl_xor(bidx, m, 64);
+      if (ob > best || (ob == best && oi < bidx)) {
+        best = ob;
+        bval = ovv;
+        bidx = oi;
+      }
+    }
+    const double sg = (c2 < kk) ? (bval < 0.0 ? -1.0 : 1.0) : 0.0;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      const int i = lane + 64 * rr;
+      if (i < n) evecs[(size_t)c2 * n + i] = (i < na) ? x[rr] * sg : 0.0;
+    }
+    if (lane == 0 && c2 >= kk) evals[c2] = 0.0;
+  }
+}
+
+template <int RPL>
+int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double* evecs) {
+  const int W = 64;                                    // >= k: workgroup c owns vector c
+  double* gbuf = nullptr;
+  unsigned* bars = nullptr;
+  VIPMI_TRY(ws(ctx, "eigh_large_gbuf", (size_t)8 * n, &gbuf));
+  VIPMI_TRY(ws(ctx, "eigh_large_bar", (size_t)1, &bars));
+  VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned), ctx->stream));
+  const size_t lds = ((size_t)9 * n + 8 + 2 * LNW + 16) * sizeof(double);
+  VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(large): LDS budget exceeded (%zu)", lds);
+  auto kern = tri_large_kernel<RPL>;
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+  hipLaunchKernelGGL(kern, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, bars);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+}  // namespace
+
+bool eigh_large_supported(int64_t n, int64_t k) { return n > 512 && n <= 2048 && k >= 1 && k <= 64; }
+
+// one problem (batch entries are solved one after the other)
+int eigh_large_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs) {
+  VIPMI_REQUIRE(A && evals && evecs, "eigh_large: null pointer");
+  VIPMI_REQUIRE(batch > 0 && eigh_large_supported(n, k), "eigh_large: unsupported sizes n=%ld k=%ld", (long)n, (long)k);
+  StageScope sc(ctx, "eigh");
+  for (int64_t p = 0; p < batch; ++p) {
+    double* Ap = A + (size_t)p * n * n;
+    double* ev = evals + (size_t)p * n;
+    double* ec = evecs + (size_t)p * n * n;
+    if (n <= 1024) {
+      VIPMI_TRY(launch_large<16>(ctx, Ap, (int)n, (int)k, ev, ec));
+    } else {
+      VIPMI_TRY(launch_large<32>(ctx, Ap, (int)n, (int)k, ev, ec));
+    }
+  }
+  return VIPMI_OK;
+}
+
+}  // namespace vipmi
