@@ -102,6 +102,11 @@ int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* 
 int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                         double* evals, double* evecs);
 
+/* All n eigenvalues (descending) and the leading k eigenvectors: what SVDecomposer.get_cevr (psfsub/svd.py:216-339) and
+ * svd_wrapper(..., full_output=True) in the 'eigen' modes (svd.py:454-462) need.  Same layout as vipmi_eigh_f64. */
+int vipmi_eigh_spectrum_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals,
+                            double* evecs);
+
 /* ---- _project_subtract: psfsub/pca_fullfr.py:1727-1731 ---- */
 /* B[k,P] = W[k,n] (float32) * M[n,P];  row c optionally scaled by rowscale[c] (may be NULL). */
 int vipmi_rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n,

@@ -474,3 +474,19 @@ def test_eigh_topk_large(B, n, k):
     G = M @ M.T
     ev, ec = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), k)
     _topk_check(G, ev.cpu().numpy(), ec.cpu().numpy(), k)
+
+
+@pytest.mark.parametrize("n,k", [(40, 3), (200, 8), (400, 20), (700, 5)])
+def test_eigh_spectrum(B, n, k):
+    """All eigenvalues + leading k vectors (what CEVR / svd_wrapper(full_output) need) from the tridiagonal solvers:
+    single-workgroup, LDS-resident multi-workgroup and global-memory variants."""
+    import torch
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 20)) * (2.0 ** (-np.arange(n + 20) / 30.0))
+    G = M @ M.T
+    ev, ec = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), k, all_evals=True)
+    ev, ec = ev.cpu().numpy(), ec.cpu().numpy()
+    w = np.linalg.eigvalsh(G)[::-1]
+    assert ev.shape == (n,) and ec.shape == (k, n)
+    np.testing.assert_allclose(ev, w, atol=1e-12 * w[0])
+    _topk_check(G, ev[:k], ec, k)

@@ -224,9 +224,10 @@ def eigh(G):
     return (evals[0], evecs[0]) if single else (evals, evecs)
 
 
-def eigh_topk(G, k, nact=None):
+def eigh_topk(G, k, nact=None, all_evals=False):
     """Leading k eigenpairs of G: (batch, n, n) or (n, n) float64 cuda tensor (destroyed).  Returns
-    (evals (.., k) descending, evecs (.., k, n) rows).  nact: optional int32 cuda tensor of active sizes."""
+    (evals (.., k) descending -- all n of them with ``all_evals`` --, evecs (.., k, n) rows).  nact: optional int32
+    cuda tensor of active sizes (not with ``all_evals``)."""
     torch = _torch()
     ctx = get_context(G.device.index)
     single = G.dim() == 2
@@ -234,8 +235,12 @@ def eigh_topk(G, k, nact=None):
     batch, n, _ = Gb.shape
     evals = torch.zeros((batch, n), dtype=torch.float64, device=G.device)
     evecs = torch.zeros((batch, n, n), dtype=torch.float64, device=G.device)
-    ctx.call("vipmi_eigh_topk_f64", ptr(Gb), batch, n, int(k), ptr(nact), ptr(evals), ptr(evecs))
-    ev, ec = evals[:, :k], evecs[:, :k, :]
+    if all_evals:
+        ctx.call("vipmi_eigh_spectrum_f64", ptr(Gb), batch, n, int(k), ptr(evals), ptr(evecs))
+        ev, ec = evals, evecs[:, :k, :]
+    else:
+        ctx.call("vipmi_eigh_topk_f64", ptr(Gb), batch, n, int(k), ptr(nact), ptr(evals), ptr(evecs))
+        ev, ec = evals[:, :k], evecs[:, :k, :]
     return (ev[0], ec[0]) if single else (ev, ec)
 
 

@@ -337,6 +337,15 @@ int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int
   return eigh_leading(ctx, G, batch, n, k, nact, evals, evecs);
 }
 
+int vipmi_eigh_spectrum_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals,
+                            double* evecs) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(G && evals && evecs, "eigh_spectrum: null pointer");
+  VIPMI_REQUIRE(batch > 0 && n > 0 && k > 0 && k <= n, "eigh_spectrum: bad sizes batch=%ld n=%ld k=%ld", (long)batch,
+                (long)n, (long)k);
+  return eigh_leading(ctx, G, batch, n, k, nullptr, evals, evecs, true);
+}
+
 int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs) {
   CTX_GUARD();
   return eigh_f64(ctx, G, batch, n, evals, evecs);

@@ -124,12 +124,13 @@ int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals,
 // option "eigh_method" == 1.  nact: optional device array with the active size of each (zero padded) problem.
 bool eigh_topk_supported(int64_t n, int64_t k);
 int eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
-                  double* evals, double* evecs);
+                  double* evals, double* evecs, bool all_evals = false);
 // one larger problem (512 < n <= 2048): eigh_tri_large.hip
 bool eigh_large_supported(int64_t n, int64_t k);
-int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs);
+int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,
+                   bool all_evals = false);
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
-                 double* evals, double* evecs);
+                 double* evals, double* evecs, bool all_evals = false);
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,
                       const float* rowscale, float* B);
 int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,

@@ -86,7 +86,7 @@ template <int RPL>
 __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
                                                       const int32_t* __restrict__ nact, double* __restrict__ evals_all,
                                                       double* __restrict__ evecs_all, double* __restrict__ scratch_all,
-                                                      int kp) {
+                                                      int kp, int all_evals) {
   extern __shared__ double sm[];
   double* vcur = sm;             // [n] Householder vector of the current step (indexed by absolute row)
   double* vprev = vcur + n;      // [n] pending rank-2 update  A -= v w^T + w v^T
@@ -276,6 +276,24 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
     }
     if (lane == 0) lam[i] = 0.5 * (a + b);
   }
+  if (all_evals) {                         // the rest of the spectrum (values only), straight to the output
+    for (int i = kk + wave; i < na; i += TNW) {
+      const int target = na - 1 - i;
+      double a = glo, b = ghi;
+      for (int sweep = 0; sweep < 14; ++sweep) {
+        const double h = (b - a) * (1.0 / 65.0);
+        const int cnt = sturm_count(dd, e2, na, a + h * (double)(lane + 1));
+        const int L = __popcll(__ballot(cnt <= target));
+        const double na_ = (L == 0) ? a : a + h * (double)L;
+        const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
+        a = na_;
+        b = nb_;
+        if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
+      }
+      if (lane == 0) evals[i] = 0.5 * (a + b) * scale;
+    }
+    for (int i = na + tid; i < n; i += TNT) evals[i] = 0.0;
+  }
   __syncthreads();
 
   const long long t_2 = wall_clock64();
@@ -456,7 +474,7 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
   }
 
   const long long t_5 = wall_clock64();
-  if (tid == 0 && n >= k + 8) {       // phase durations (100 MHz ticks) in the unused tail of evals: profiling aid
+  if (tid == 0 && n >= k + 8 && !all_evals) {       // phase durations (100 MHz ticks) in the unused tail of evals: profiling aid
     evals[n - 1] = (double)(t_1 - t_0);
     evals[n - 2] = (double)(t_2 - t_1);
     evals[n - 3] = (double)(t_3 - t_2);
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
 // Afterwards every workgroup computes the eigenvalues / inverse iterations / back-transformations of ITS vectors
 // (vector c belongs to workgroup c mod W, all scratch in LDS), one more barrier, and workgroup 0 orthonormalises.
 template <int RPL>
-__global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aall, int n, int k, int RW, int VW, int rows_d,
+__global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aall, int n, int k, int RW, int VW, int rows_d, int all_evals,
                                                         double* __restrict__ evals_all, double* __restrict__ evecs_all,
                                                         double* __restrict__ gbuf_all, unsigned* __restrict__ bars) {
   extern __shared__ double sm[];
@@ -704,6 +722,23 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
       if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
     }
     if (lane == 0) lam[j] = 0.5 * (a + b);
+  }
+  if (all_evals) {                         // the rest of the spectrum (values only), spread over all waves
+    for (int i = kk + wg * TNW + wave; i < na; i += W * TNW) {
+      const int target = na - 1 - i;
+      double a = glo, b = ghi;
+      for (int sweep = 0; sweep < 14; ++sweep) {
+        const double h = (b - a) * (1.0 / 65.0);
+        const int cnt = sturm_count(dd, e2, na, a + h * (double)(lane + 1));
+        const int L = __popcll(__ballot(cnt <= target));
+        const double na_ = (L == 0) ? a : a + h * (double)L;
+        const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
+        a = na_;
+        b = nb_;
+        if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
+      }
+      if (lane == 0) evals[i] = 0.5 * (a + b) * scale;
+    }
   }
   __syncthreads();
 
@@ -929,7 +964,8 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
 }
 
 template <int RPL>
-int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, double* evals, double* evecs) {
+int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, double* evals, double* evecs,
+                     int all_evals) {
   const int W = n <= 256 ? 8 : (n <= 448 ? 16 : 32);
   const int RW = (int)cdiv(n, W);
   double* gbuf = nullptr;
@@ -950,7 +986,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
   for (int64_t p0 = 0; p0 < batch; p0 += per_launch) {
     const int64_t nb = batch - p0 < per_launch ? batch - p0 : per_launch;
-    hipLaunchKernelGGL(kern, dim3(W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW, (int)rows_d,
+    hipLaunchKernelGGL(kern, dim3(W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW, (int)rows_d, all_evals,
                        evals + (size_t)p0 * n, evecs + (size_t)p0 * n * n, gbuf + (size_t)p0 * 5 * n, bars + p0);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
@@ -959,7 +995,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
 
 template <int RPL>
 int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int32_t* nact, double* evals,
-               double* evecs) {
+               double* evecs, int all_evals) {
   const int kp = (int)cdiv(k, 16) * 16;
   double* scratch = nullptr;
   VIPMI_TRY(ws(ctx, "eigh_tri_scratch", (size_t)batch * 6 * n * kp, &scratch));
@@ -967,7 +1003,8 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   auto kern = tri_eig_kernel<RPL>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(TNT), lds, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp);
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(TNT), lds, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
+                     all_evals);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -979,28 +1016,28 @@ bool eigh_topk_supported(int64_t n, int64_t k) { return n >= 1 && n <= 512 && k 
 // Leading k eigenpairs of `batch` symmetric n x n matrices (destroyed).  evals[p*n + c], evecs[p*n*n + c*n + i] for
 // c < k (other entries are not written).  nact (device, optional): active leading size of every problem.
 int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k, const int32_t* nact, double* evals,
-                  double* evecs) {
+                  double* evecs, bool all_evals) {
   VIPMI_REQUIRE(A && evals && evecs, "eigh_topk: null pointer");
   VIPMI_REQUIRE(batch > 0 && eigh_topk_supported(n, k), "eigh_topk: unsupported sizes n=%ld k=%ld", (long)n, (long)k);
   StageScope sc(ctx, "eigh");
   // a few larger problems: spread each over several CUs (LDS-resident matrix); many problems: one CU each
   const bool multi = !nact && n >= 96 && batch <= 8 && ctx->opt("eigh_multi", 1) != 0;
   if (multi) {
-    if (n <= 128) return launch_tri_multi<2>(ctx, A, batch, (int)n, (int)k, evals, evecs);
-    if (n <= 256) return launch_tri_multi<4>(ctx, A, batch, (int)n, (int)k, evals, evecs);
-    return launch_tri_multi<8>(ctx, A, batch, (int)n, (int)k, evals, evecs);
+    if (n <= 128) return launch_tri_multi<2>(ctx, A, batch, (int)n, (int)k, evals, evecs, all_evals);
+    if (n <= 256) return launch_tri_multi<4>(ctx, A, batch, (int)n, (int)k, evals, evecs, all_evals);
+    return launch_tri_multi<8>(ctx, A, batch, (int)n, (int)k, evals, evecs, all_evals);
   }
-  if (n <= 128) return launch_tri<2>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
-  if (n <= 256) return launch_tri<4>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
-  return launch_tri<8>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs);
+  if (n <= 128) return launch_tri<2>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs, all_evals);
+  if (n <= 256) return launch_tri<4>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs, all_evals);
+  return launch_tri<8>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs, all_evals);
 }
 
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact, double* evals,
-                 double* evecs) {
+                 double* evecs, bool all_evals) {
   if (ctx->opt("eigh_method", 0) != 1 && eigh_topk_supported(n, k))
-    return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs);
+    return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs, all_evals);
   if (ctx->opt("eigh_method", 0) != 1 && !nact && batch <= 4 && eigh_large_supported(n, k))
-    return eigh_large_f64(ctx, G, batch, n, k, evals, evecs);
+    return eigh_large_f64(ctx, G, batch, n, k, evals, evecs, all_evals);
   return eigh_f64(ctx, G, batch, n, evals, evecs);
 }
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ int sturm_count_l(const double* __restrict__ d, const
 template <int RPL>
 __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, int n, int k, double* __restrict__ evals,
                                                         double* __restrict__ evecs, double* __restrict__ gb,
-                                                        unsigned* __restrict__ bar) {
+                                                        unsigned* __restrict__ bar, int all_evals) {
   extern __shared__ double sm[];
   const int W = gridDim.x, wg = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,6 +273,23 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
       if (b - a <= 2.0 * LEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
     }
     if (lane == 0) lamv[0] = 0.5 * (a + b);
+  }
+  if (all_evals) {                         // the rest of the spectrum (values only): waves 1.. of every workgroup
+    for (int i = kk + wg * (LNW - 1) + (wave - 1); wave > 0 && i < na; i += W * (LNW - 1)) {
+      const int target = na - 1 - i;
+      double a = glo, b = ghi;
+      for (int sweep = 0; sweep < 14; ++sweep) {
+        const double h = (b - a) * (1.0 / 65.0);
+        const int cnt = sturm_count_l(dd, e2, na, a + h * (double)(lane + 1));
+        const int L = __popcll(__ballot(cnt <= target));
+        const double na_ = (L == 0) ? a : a + h * (double)L;
+        const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
+        a = na_;
+        b = nb_;
+        if (b - a <= 2.0 * LEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
+      }
+      if (lane == 0) evals[i] = 0.5 * (a + b) * scale;
+    }
   }
   __syncthreads();
 
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
 }
 
 template <int RPL>
-int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double* evecs) {
+int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double* evecs, int all_evals) {
   const int W = 64;                                    // >= k: workgroup c owns vector c
   double* gbuf = nullptr;
   unsigned* bars = nullptr;
@@ -488,7 +505,7 @@ int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double*
   auto kern = tri_large_kernel<RPL>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-  hipLaunchKernelGGL(kern, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, bars);
+  hipLaunchKernelGGL(kern, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, bars, all_evals);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -498,7 +515,8 @@ int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double*
 bool eigh_large_supported(int64_t n, int64_t k) { return n > 512 && n <= 2048 && k >= 1 && k <= 64; }
 
 // one problem (batch entries are solved one after the other)
-int eigh_large_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs) {
+int eigh_large_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,
+                   bool all_evals) {
   VIPMI_REQUIRE(A && evals && evecs, "eigh_large: null pointer");
   VIPMI_REQUIRE(batch > 0 && eigh_large_supported(n, k), "eigh_large: unsupported sizes n=%ld k=%ld", (long)n, (long)k);
   StageScope sc(ctx, "eigh");
@@ -507,9 +525,9 @@ int eigh_large_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t 
     double* ev = evals + (size_t)p * n;
     double* ec = evecs + (size_t)p * n * n;
     if (n <= 1024) {
-      VIPMI_TRY(launch_large<16>(ctx, Ap, (int)n, (int)k, ev, ec));
+      VIPMI_TRY(launch_large<16>(ctx, Ap, (int)n, (int)k, ev, ec, all_evals));
     } else {
-      VIPMI_TRY(launch_large<32>(ctx, Ap, (int)n, (int)k, ev, ec));
+      VIPMI_TRY(launch_large<32>(ctx, Ap, (int)n, (int)k, ev, ec, all_evals));
     }
   }
   return VIPMI_OK;

@@ -2,8 +2,8 @@
 
 Every ``svd_mode`` of the reference is an alternative back-end of the same mathematical object (the
 top-k right singular vectors of the n x P matrix).  Here all of them map onto ONE deterministic device
-algorithm: Gram matrix on the matrix cores (float64 accumulation) + one-sided block Jacobi
-eigensolver (float64) + back-projection, i.e. the arithmetic of the reference's ``'eigen'`` mode at
+algorithm: Gram matrix on the matrix cores (float64 accumulation) + a float64 eigensolver (Householder
+tridiagonalisation / multisection / inverse iteration; block Jacobi beyond n = 2048) + back-projection, i.e. the arithmetic of the reference's ``'eigen'`` mode at
 LAPACK-class accuracy.  PCs are defined up to a per-row sign (sign convention: see DESIGN.md).
 """
 import numpy as np
@@ -24,6 +24,8 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
     G = B.gram(mat_t)
     if leading_only:
         evals, evecs = B.eigh_topk(G, ncomp)
+    elif n <= 2048 and 0 < ncomp <= 64:
+        evals, evecs = B.eigh_topk(G, ncomp, all_evals=True)       # whole spectrum, leading vectors
     else:
         evals, evecs = B.eigh(G)
     sig_all = torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
@@ -115,7 +117,11 @@ class SVDecomposer:
         if not hasattr(self, "matrix"):
             self.generate_matrix()
         t = B.to_device_f32(self.matrix)
-        evals, _ = B.eigh(B.gram(t))
+        G = B.gram(t)
+        if G.shape[0] <= 2048:
+            evals, _ = B.eigh_topk(G, 1, all_evals=True)     # values only: tridiagonalisation + multisection
+        else:
+            evals, _ = B.eigh(G)
         self.s = B._torch().sqrt(B._torch().clamp(evals, min=0)).cpu().numpy()
 
     def get_cevr(self, ncomp_list=None, plot=False, **_):
