@@ -75,7 +75,7 @@ __device__ __forceinline__ unsigned select_rank(const unsigned (&key)[RPL], int 
 // the reference's 'trimmean' (subsampling.py:87-96).
 template <int RPL, bool TRIM>
 __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ cube, int n, int64_t P,
-                                                     int TP, float* __restrict__ out, int t0, int tn, int dbg) {
+                                                     int TP, float* __restrict__ out, int t0, int tn) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // n x (TP+1)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
@@ -116,7 +116,6 @@ __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ c
     }
   }
   __syncthreads();
-  if (dbg == 1) return;
   for (int j = wave; j < TP; j += nw) {
     const int64_t p = p0 + j;
     if (p >= P) break;
@@ -244,8 +243,7 @@ int launch_median(vipmi_ctx* ctx, const float* cube, int n, int64_t P, float* ou
   auto kern = median_kernel<RPL, TRIM>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(512), lds, ctx->stream, cube, n, P, TP, out, t0, tn,
-                     (int)ctx->opt("collapse_dbg", 0));
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(512), lds, ctx->stream, cube, n, P, TP, out, t0, tn);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }

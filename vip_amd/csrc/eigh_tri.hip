@@ -18,6 +18,7 @@
 // component positive.  Zero-padded problems (annular PCA: library sizes differ per frame) pass their active size.
 #include "common.h"
 #include "wave_util.h"
+#include "tri_common.h"
 
 namespace vipmi {
 
@@ -25,62 +26,10 @@ namespace {
 
 constexpr int TNT = 1024;           // threads per workgroup
 constexpr int TNW = TNT / 64;       // waves
-constexpr double TEPS = 2.220446049250313e-16;
-
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = r * (2.0 - x * r);
-  r = r * (2.0 - x * r);
-  return r;
-}
-
-// number of eigenvalues of the (scaled, max-norm 1) tridiagonal (d, e2 = e^2) strictly below sigma: sign changes of
-// the Sturm sequence p_i = (d_i - sigma) p_{i-1} - e_{i-1}^2 p_{i-2} (one dependent FMA per step instead of a
-// float64 division); the pair (p_i, p_{i-1}) is renormalised every 16 steps (|growth| <= 4 per step).  A zero term
-// counts as a sign change and is given the opposite sign, as LAPACK dstebz does with its pivmin clamp.
-__device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n,
-                                           double sigma) {
-  double pm = 1.0, p = d[0] - sigma;
-  bool neg = p < 0.0 || p == 0.0;          // effective sign of p_i (true = negative); p_0 = 1 is positive
-  if (p == 0.0) p = -1e-300;
-  int cnt = neg ? 1 : 0;
-  for (int i0 = 1; i0 < n; i0 += 16) {
-    double db[16], eb[16];                 // operands of 16 steps fetched from LDS up front (uniform addresses)
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = i0 + u;
-      db[u] = (i < n) ? d[i] : 0.0;
-      eb[u] = (i < n) ? e2[i - 1] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      if (i0 + u < n) {
-        const double t = eb[u] * pm;
-        double pn = fma(db[u] - sigma, p, -t);
-        if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
-        const bool nneg = pn < 0.0;
-        cnt += (nneg != neg) ? 1 : 0;
-        neg = nneg;
-        pm = p;
-        p = pn;
-      }
-    }
-    const int ex = ilogb(fabs(p) > fabs(pm) ? p : pm);
-    p = scalbn(p, -ex);
-    pm = scalbn(pm, -ex);
-  }
-  return cnt;
-}
-
-__device__ __forceinline__ double hash_unit(unsigned a, unsigned b) {   // deterministic pseudo-random in (-1, 1)
-  unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
-  x ^= x >> 15;
-  x *= 0x2C1B3C6Du;
-  x ^= x >> 12;
-  x *= 0x297A2D39u;
-  x ^= x >> 15;
-  return ((double)(x >> 8) + 0.5) * (2.0 / 16777216.0) - 1.0;
-}
+constexpr double TEPS = tri::EPS;
+using tri::fast_rcp;
+using tri::hash_unit;
+using tri::sturm_count;
 
 template <int RPL>
 __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
@@ -112,7 +61,6 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
     vcur[i] = 0.0;
   }
   __syncthreads();
-  const long long t_0 = wall_clock64();
 
   // ---------------- 1. tridiagonalisation ----------------
   // Per step: ONE global round trip (the trailing pass).  Its first batch of loads is issued before the
@@ -229,7 +177,6 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
   }
   __syncthreads();
 
-  const long long t_1 = wall_clock64();
   // ---------------- 2. leading eigenvalues of T (scaled to max-norm 1) ----------------
   double scale = 0.0, glo = 0.0, ghi = 0.0;
   {
@@ -261,42 +208,19 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
   }
   for (int i = wave; i < kk; i += TNW) {
     const int target = na - 1 - i;         // ascending index of the i-th largest eigenvalue
-    double a = glo, b = ghi;
-    for (int sweep = 0; sweep < 14; ++sweep) {
-      const double h = (b - a) * (1.0 / 65.0);
-      const double sigma = a + h * (double)(lane + 1);
-      const int cnt = sturm_count(dd, e2, na, sigma);
-      const unsigned long long below = __ballot(cnt <= target);    // sigma_l <= lambda_target
-      const int L = __popcll(below);
-      const double na_ = (L == 0) ? a : a + h * (double)L;
-      const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
-      a = na_;
-      b = nb_;
-      if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
-    }
-    if (lane == 0) lam[i] = 0.5 * (a + b);
+    const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
+    if (lane == 0) lam[i] = lam_;
   }
   if (all_evals) {                         // the rest of the spectrum (values only), straight to the output
     for (int i = kk + wave; i < na; i += TNW) {
       const int target = na - 1 - i;
-      double a = glo, b = ghi;
-      for (int sweep = 0; sweep < 14; ++sweep) {
-        const double h = (b - a) * (1.0 / 65.0);
-        const int cnt = sturm_count(dd, e2, na, a + h * (double)(lane + 1));
-        const int L = __popcll(__ballot(cnt <= target));
-        const double na_ = (L == 0) ? a : a + h * (double)L;
-        const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
-        a = na_;
-        b = nb_;
-        if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
-      }
-      if (lane == 0) evals[i] = 0.5 * (a + b) * scale;
+      const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
+      if (lane == 0) evals[i] = lam_ * scale;
     }
     for (int i = na + tid; i < n; i += TNT) evals[i] = 0.0;
   }
   __syncthreads();
 
-  const long long t_2 = wall_clock64();
   // ---------------- 3. eigenvectors of T: inverse iteration, one lane per vector ----------------
   double* __restrict__ U0 = scr;                       // [n][kp] reciprocal pivots
   double* __restrict__ U1 = scr + (size_t)n * kp;      // first superdiagonal of U
@@ -379,7 +303,6 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
   }
   __syncthreads();
 
-  const long long t_3 = wall_clock64();
   // ---------------- 3b. modified Gram-Schmidt, one wave per vector (registers), pivot vector through LDS -------------
   constexpr int VPW = 4;                    // vectors per wave: c = wave + 16 v
   double z[VPW][RPL];
@@ -434,7 +357,6 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
     __syncthreads();
   }
 
-  const long long t_4 = wall_clock64();
   // ---------------- 4. back-transformation: reflectors staged through LDS in blocks, one wave per vector ------------
   {
     constexpr int RB = 6;                             // reflectors per block: RB * n doubles of LDS (vcur..ee reused;
@@ -473,14 +395,6 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
     }
   }
 
-  const long long t_5 = wall_clock64();
-  if (tid == 0 && n >= k + 8 && !all_evals) {       // phase durations (100 MHz ticks) in the unused tail of evals: profiling aid
-    evals[n - 1] = (double)(t_1 - t_0);
-    evals[n - 2] = (double)(t_2 - t_1);
-    evals[n - 3] = (double)(t_3 - t_2);
-    evals[n - 4] = (double)(t_4 - t_3);
-    evals[n - 5] = (double)(t_5 - t_4);
-  }
   // ---------------- output: sign convention of eigh.hip, zero padding ----------------
 #pragma unroll
   for (int v = 0; v < VPW; ++v) {
@@ -709,35 +623,14 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   for (int j = wave; j < nmine; j += TNW) {
     const int c = wg + W * j;
     const int target = na - 1 - c;
-    double a = glo, b = ghi;
-    for (int sweep = 0; sweep < 14; ++sweep) {
-      const double h = (b - a) * (1.0 / 65.0);
-      const double sigma = a + h * (double)(lane + 1);
-      const int cnt = sturm_count(dd, e2, na, sigma);
-      const int L = __popcll(__ballot(cnt <= target));
-      const double na_ = (L == 0) ? a : a + h * (double)L;
-      const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
-      a = na_;
-      b = nb_;
-      if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
-    }
-    if (lane == 0) lam[j] = 0.5 * (a + b);
+    const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
+    if (lane == 0) lam[j] = lam_;
   }
   if (all_evals) {                         // the rest of the spectrum (values only), spread over all waves
     for (int i = kk + wg * TNW + wave; i < na; i += W * TNW) {
       const int target = na - 1 - i;
-      double a = glo, b = ghi;
-      for (int sweep = 0; sweep < 14; ++sweep) {
-        const double h = (b - a) * (1.0 / 65.0);
-        const int cnt = sturm_count(dd, e2, na, a + h * (double)(lane + 1));
-        const int L = __popcll(__ballot(cnt <= target));
-        const double na_ = (L == 0) ? a : a + h * (double)L;
-        const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
-        a = na_;
-        b = nb_;
-        if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
-      }
-      if (lane == 0) evals[i] = 0.5 * (a + b) * scale;
+      const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
+      if (lane == 0) evals[i] = lam_ * scale;
     }
   }
   __syncthreads();

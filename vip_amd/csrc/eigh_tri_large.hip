@@ -11,6 +11,7 @@
 // svd_wrapper / get_eigenvectors (psfsub/svd.py:342-702).
 #include "common.h"
 #include "wave_util.h"
+#include "tri_common.h"
 
 namespace vipmi {
 
@@ -18,59 +19,7 @@ namespace {
 
 constexpr int LNT = 512;            // threads per workgroup (256-VGPR budget)
 constexpr int LNW = LNT / 64;
-constexpr double LEPS = 2.220446049250313e-16;
-
-__device__ __forceinline__ double fast_rcp_l(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = r * (2.0 - x * r);
-  r = r * (2.0 - x * r);
-  return r;
-}
-
-__device__ __forceinline__ double hash_unit_l(unsigned a, unsigned b) {
-  unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
-  x ^= x >> 15;
-  x *= 0x2C1B3C6Du;
-  x ^= x >> 12;
-  x *= 0x297A2D39u;
-  x ^= x >> 15;
-  return ((double)(x >> 8) + 0.5) * (2.0 / 16777216.0) - 1.0;
-}
-
-// Sturm count (product form, see eigh_tri.hip)
-__device__ __forceinline__ int sturm_count_l(const double* __restrict__ d, const double* __restrict__ e2, int n,
-                                             double sigma) {
-  double pm = 1.0, p = d[0] - sigma;
-  bool neg = p < 0.0 || p == 0.0;
-  if (p == 0.0) p = -1e-300;
-  int cnt = neg ? 1 : 0;
-  for (int i0 = 1; i0 < n; i0 += 16) {
-    double db[16], eb[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = i0 + u;
-      db[u] = (i < n) ? d[i] : 0.0;
-      eb[u] = (i < n) ? e2[i - 1] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      if (i0 + u < n) {
-        const double t = eb[u] * pm;
-        double pn = fma(db[u] - sigma, p, -t);
-        if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
-        const bool nneg = pn < 0.0;
-        cnt += (nneg != neg) ? 1 : 0;
-        neg = nneg;
-        pm = p;
-        p = pn;
-      }
-    }
-    const int ex = ilogb(fabs(p) > fabs(pm) ? p : pm);
-    p = scalbn(p, -ex);
-    pm = scalbn(pm, -ex);
-  }
-  return cnt;
-}
+constexpr double LEPS = tri::EPS;
 
 template <int RPL>
 __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, int n, int k, double* __restrict__ evals,
@@ -260,35 +209,14 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
   const int c = wg;
   if (mine && wave == 0) {
     const int target = na - 1 - c;
-    double a = glo, b = ghi;
-    for (int sweep = 0; sweep < 14; ++sweep) {
-      const double h = (b - a) * (1.0 / 65.0);
-      const double sigma = a + h * (double)(lane + 1);
-      const int cnt = sturm_count_l(dd, e2, na, sigma);
-      const int L = __popcll(__ballot(cnt <= target));
-      const double na_ = (L == 0) ? a : a + h * (double)L;
-      const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
-      a = na_;
-      b = nb_;
-      if (b - a <= 2.0 * LEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
-    }
-    if (lane == 0) lamv[0] = 0.5 * (a + b);
+    const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
+    if (lane == 0) lamv[0] = lam_;
   }
   if (all_evals) {                         // the rest of the spectrum (values only): waves 1.. of every workgroup
     for (int i = kk + wg * (LNW - 1) + (wave - 1); wave > 0 && i < na; i += W * (LNW - 1)) {
       const int target = na - 1 - i;
-      double a = glo, b = ghi;
-      for (int sweep = 0; sweep < 14; ++sweep) {
-        const double h = (b - a) * (1.0 / 65.0);
-        const int cnt = sturm_count_l(dd, e2, na, a + h * (double)(lane + 1));
-        const int L = __popcll(__ballot(cnt <= target));
-        const double na_ = (L == 0) ? a : a + h * (double)L;
-        const double nb_ = (L == 64) ? b : a + h * (double)(L + 1);
-        a = na_;
-        b = nb_;
-        if (b - a <= 2.0 * LEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
-      }
-      if (lane == 0) evals[i] = 0.5 * (a + b) * scale;
+      const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
+      if (lane == 0) evals[i] = lam_ * scale;
     }
   }
   __syncthreads();
@@ -298,13 +226,13 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
     const double lc = lamv[0] - (double)(c + 1) * 4.0 * LEPS;
     const double ptiny = 1e-3 * LEPS;
     double p = dd[0] - lc, q = (na > 1) ? ee[0] : 0.0, r = 0.0;
-    double yc = hash_unit_l(0u, (unsigned)c);
+    double yc = tri::hash_unit(0u, (unsigned)c);
     for (int i = 0; i + 1 < na; ++i) {
       const double sub = ee[i], nd = dd[i + 1] - lc, nu = (i + 2 < na) ? ee[i + 1] : 0.0;
-      const double yn = hash_unit_l((unsigned)(i + 1), (unsigned)c);
+      const double yn = tri::hash_unit((unsigned)(i + 1), (unsigned)c);
       double inv, u1, u2, yi, m, sw;
       if (fabs(sub) > fabs(p) && fabs(sub) >= ptiny) {
-        inv = fast_rcp_l(sub);
+        inv = tri::fast_rcp(sub);
         u1 = nd; u2 = nu;
         m = p * inv;
         sw = 1.0;
@@ -315,7 +243,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
         r = 0.0;
       } else {
         if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
-        inv = fast_rcp_l(p);
+        inv = tri::fast_rcp(p);
         u1 = q; u2 = r;
         m = sub * inv;
         sw = 0.0;
@@ -333,7 +261,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
       Zl[i] = yi;
     }
     if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
-    const double invlast = fast_rcp_l(p);
+    const double invlast = tri::fast_rcp(p);
     double rs = 1.0;
     for (int it = 0; it < 2; ++it) {
       if (it > 0) {
