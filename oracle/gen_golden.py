@@ -195,3 +195,10 @@ g["stim_inv"] = ref.inverse_stim_map(res[3], ang)
 g["stim_norm"] = ref.normalized_stim_map(res[3], ang)
 g["stim_norm_mask"] = ref.normalized_stim_map(res[3], ang, mask=5)
 save("g8_medsub_stim", **g)
+
+# ---- G9: pca_annular on a 4-D cube without scale_list (per-channel loop) -----------------------------------------
+c4 = np.stack([O.synth_adi(12, 40, seed=40 + i)[0] for i in range(3)])
+a4 = np.linspace(0, 80, 12)
+co, cd, fr_ = ref.pca_annular(c4, a4, asize=8, ncomp=2, fwhm=4, delta_rot=(0.1, 1), full_output=True, verbose=False,
+                              nproc=1)
+save("g9_annular_4d", cube=c4, angles=a4, cube_out=co, cube_der=cd, frame=fr_)

@@ -278,3 +278,18 @@ def test_pca_many_matches_serial():
         pca_many(list(cubes), list(angs), ncomp=0)
     from vip_amd import backend
     assert backend._async["on"] is False
+
+
+def test_pca_annular_4d_golden():
+    """4-D cube without scale_list: per-channel annular PCA, then the spectral collapse (pca_local.py:279-325)."""
+    from vip_amd.psfsub import pca_annular
+    g = load_golden("g9_annular_4d")
+    co, cd, fr = pca_annular(g["cube"], g["angles"], asize=8, ncomp=2, fwhm=4, delta_rot=(0.1, 1), full_output=True,
+                             verbose=False)
+    assert co.shape == g["cube_out"].shape and cd.shape == g["cube_der"].shape and fr.shape == g["frame"].shape
+    assert fr.dtype == g["frame"].dtype
+    assert np.abs(co - g["cube_out"]).max() < TOL
+    assert np.abs(cd - g["cube_der"]).max() < TOL
+    assert np.abs(fr - g["frame"]).max() < TOL
+    assert np.abs(pca_annular(g["cube"], g["angles"], asize=8, ncomp=[2, 2, 2], fwhm=4, delta_rot=(0.1, 1),
+                              verbose=False) - g["frame"]).max() < TOL

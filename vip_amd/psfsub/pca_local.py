@@ -7,7 +7,8 @@ segment matrix.  Here each segment matrix is gathered once on the device, its Gr
 the matrix cores, and every frame's library PCA is obtained from the corresponding Gram sub-block
 (SURVEY.md 8(a-ann)): residual_j = x_j - M_lib^T (E_k L_k^-1 E_k^T) G[lib, j], batched over frames.
 
-Not accelerated (NotImplementedError): 4-D input, ``cube_ref``, ``cube_sig``, ``left_eigv``,
+4-D cubes without ``scale_list`` run the same path per spectral channel.  Not accelerated
+(NotImplementedError): ``scale_list`` (mSDI), ``cube_ref``, ``cube_sig``, ``left_eigv``,
 ``ncomp='auto'``, list ``ncomp``.
 """
 from dataclasses import dataclass
@@ -206,9 +207,9 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
     cube = algo_params.cube
     if not (isinstance(cube, np.ndarray) or B.is_device_tensor(cube)):
         raise TypeError("`cube` must be a numpy ndarray")
-    if cube.ndim == 4 or algo_params.scale_list is not None:
-        raise NotImplementedError("4-D / mSDI annular PCA is not accelerated yet (SURVEY 8(f))")
-    if cube.ndim != 3:
+    if algo_params.scale_list is not None:
+        raise NotImplementedError("ADI+mSDI annular PCA (scale_list) is not accelerated yet (SURVEY 8(f))")
+    if cube.ndim not in (3, 4):
         raise TypeError("Input array is not a cube or 3d array")
     dev_in = B.is_device_tensor(cube)
     out_dtype = None if dev_in else (cube.dtype if cube.dtype.kind == "f" else np.float64)
@@ -216,7 +217,34 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
     def host(t):
         return t if dev_in else t.cpu().numpy().astype(out_dtype, copy=False)
 
+    def host4(t):          # the reference builds the per-channel frames in a float64 array (pca_local.py:281)
+        return t if dev_in else t.cpu().numpy().astype(np.float64, copy=False)
+
     cube_t = B.to_device_f32(cube)
+    if cube.ndim == 4:
+        # 4-D cube without scale_list: one annular ADI PCA per spectral channel, then collapse_ifs
+        # (pca_local.py:279-325); ncomp / fwhm broadcast per channel
+        torch = B._torch()
+        nch = cube.shape[0]
+        ncomp = algo_params.ncomp
+        if not isinstance(ncomp, list) or len(ncomp) != nch:
+            ncomp = [ncomp] * nch
+        fwhm = algo_params.fwhm
+        if np.isscalar(fwhm):
+            fwhm = [fwhm] * nch
+        if algo_params.cube_ref is not None:
+            raise NotImplementedError("cube_ref is outside the accelerated annular path")
+        outs = []
+        for ch in range(nch):
+            fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t[ch], fwhm=fwhm[ch], ncomp=ncomp[ch],
+                                  full_output=True)
+            outs.append(_pca_adi_rdi(**fp, **rot_options))
+        ifs = torch.stack([o[2] for o in outs])
+        frame = B.collapse(ifs, _s(algo_params.collapse_ifs)) if algo_params.collapse_ifs is not None else ifs
+        if algo_params.full_output:
+            return (host(torch.stack([o[0] for o in outs])), host(torch.stack([o[1] for o in outs])),
+                    host4(frame))
+        return host4(frame)
     fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t, full_output=True)
     cube_out, cube_der, frame = _pca_adi_rdi(**fp, **rot_options)
     if algo_params.full_output:
