@@ -115,6 +115,15 @@ int vipmi_rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int6
 int vipmi_subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B,
                             int64_t n, int64_t k, int64_t P, float* R, float* recon);
 
+/* ---- FFT zoom of the spectral channels (ADI+mSDI): scale_fft / frame_rescaling(imlib='vip-fft') /
+ * cube_rescaling_wavelengths, preproc/rescaling.py:1114-1217, 636-672, 427-475 ----
+ * The zoom is a separable linear map Y = Re(E X E^T); E (dout x din, complex, one per scale factor, reflect padding and
+ * crops folded in) is built on the host.  out[b] (dout x dout) = Er[c] X[b] Er[c]^T - Ei[c] X[b] Ei[c]^T with
+ * c = chan[b]; X[b] is din x din.  Er / Ei: [nchan][dout][ldk] row-major with ldk = din rounded up to 4 (zero
+ * padded); X: [nb][din][din]; work: float32 scratch of nb * 2 * dout * ldk (device). */
+int vipmi_zoom_frames_f32(vipmi_ctx* ctx, const float* X, int64_t nb, int64_t din, const float* Er, const float* Ei,
+                          const int32_t* chan, int64_t dout, int64_t ldk, float* work, float* out);
+
 /* ---- cube_derotate / frame_rotate(imlib='vip-fft'): preproc/derotation.py:51-328,331-399,542-640 ----
  * out[n,N,N] = frames of in[n,N,N] rotated by -angles_host[i] degrees with the reference's 3-shear
  * FFT rotation (1.5x then 4x zero padding, rot90 pre-step, complex field carried between shears).

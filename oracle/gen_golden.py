@@ -202,3 +202,27 @@ a4 = np.linspace(0, 80, 12)
 co, cd, fr_ = ref.pca_annular(c4, a4, asize=8, ncomp=2, fwhm=4, delta_rot=(0.1, 1), full_output=True, verbose=False,
                               nproc=1)
 save("g9_annular_4d", cube=c4, angles=a4, cube_out=co, cube_der=cd, frame=fr_)
+
+# ---- G10: ADI+mSDI (4-D cube + scale_list): rescaling of the channels, double- and single-pass PCA ----------------
+z_, n_, N_ = 5, 8, 32
+c4 = np.stack([O.synth_adi(n_, N_, seed=50 + i)[0] for i in range(z_)]).astype(np.float32)
+a4 = np.linspace(0, 60, n_)
+sc = np.linspace(1.0, 1.25, z_)[::-1].copy()
+g = {"cube": c4, "angles": a4, "scale_list": sc}
+from vip_hci.preproc import cube_rescaling_wavelengths as _scw          # noqa: E402
+r = _scw(c4[:, 0].astype(np.float64), sc, imlib="vip-fft")
+g["scw_cube"], g["scw_frame"] = r[0], r[1]
+ri = _scw(r[0], sc, full_output=True, inverse=True, y_in=N_, x_in=N_, imlib="vip-fft", collapse="mean")
+g["scw_inv_cube"], g["scw_inv_frame"] = ri[0], ri[1]
+for tag, kw in (("d22", dict(ncomp=(2, 2))), ("dN2", dict(ncomp=(None, 2))), ("d2N", dict(ncomp=(2, None))),
+                ("dmask", dict(ncomp=(2, 2), mask_center_px=3, scaling="temp-mean", collapse_ifs="median")),
+                ("drange", dict(ncomp=(2, 2), ifs_collapse_range=(1, 4)))):
+    fo = ref.pca(c4, a4, scale_list=sc, adimsdi="double", full_output=True, verbose=False, nproc=1, **kw)
+    for nm, a in zip(("frame", "rcc", "rcc_der"), fo):
+        g["%s_%s" % (tag, nm)] = np.asarray(a)
+for tag, kw in (("s3", dict(ncomp=3)), ("s3nocrop", dict(ncomp=3, crop_ifs=False)),
+                ("s2mask", dict(ncomp=2, mask_center_px=3, scaling="temp-standard"))):
+    fo = ref.pca(c4, a4, scale_list=sc, adimsdi="single", full_output=True, verbose=False, nproc=1, **kw)
+    for nm, a in zip(("frame", "allfr", "desc", "adi"), fo):
+        g["%s_%s" % (tag, nm)] = np.asarray(a)
+save("g10_msdi", **g)

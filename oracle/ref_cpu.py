@@ -585,6 +585,220 @@ def normalized_stim_map(cube, angle_list, mask=None):
     return stim_map(cube_derotate(cube, angle_list)) / max_inv
 
 
+# --------------------------------------------------------------------------------------
+# ADI+mSDI: FFT rescaling of the spectral channels and the single / double pass PCA
+# --------------------------------------------------------------------------------------
+def scale_fft(array, scale, ori_dim=False):
+    """FFT zoom of an even square frame.  Ref: preproc/rescaling.py:1114-1217."""
+    if scale == 1:
+        return array
+    dim = array.shape[0]
+    kd_array = np.arange(dim / 2 + 1, dtype=int)
+    yy = dim / 2 * (scale - 1) + kd_array.astype(float) * scale
+    kf_array = np.round(yy).astype(int)
+    imin = np.nanargmin(np.abs(yy - kf_array))
+    kd_io, kf_io = kd_array[imin], kf_array[imin]
+    dim_p = int(dim + 2 * kd_io)
+    tmp = np.zeros((dim_p, dim_p), dtype=array.dtype.kind)
+    tmp[kd_io:kd_io + dim, kd_io:kd_io + dim] = array
+    array_f = np.fft.fftshift(np.fft.fft2(tmp))
+    dim_pp = int(dim + 2 * kf_io)
+    if dim_pp > dim_p:
+        tmp = np.zeros((dim_pp, dim_pp), dtype=complex)
+        lo, hi = (dim_pp - dim_p) // 2, (dim_pp + dim_p) // 2
+        tmp[lo:hi, lo:hi] = array_f
+    else:
+        tmp = array_f[kd_io - kf_io:kd_io - kf_io + dim_pp, kd_io - kf_io:kd_io - kf_io + dim_pp]
+    array_resc = np.fft.ifft2(np.fft.fftshift(tmp)).real
+    dim_resc = int(round(scale * dim))
+    if dim_resc > dim and dim_resc % 2 != dim % 2:
+        dim_resc += 1
+    elif dim_resc < dim and dim_resc % 2 != dim % 2:
+        dim_resc -= 1
+    if not ori_dim and dim_pp > dim_resc:
+        lo, hi = (dim_pp - dim_resc) // 2, (dim_pp + dim_resc) // 2
+        array_resc = array_resc[lo:hi, lo:hi]
+    elif not ori_dim and dim_pp <= dim_resc:
+        out = np.zeros((dim_resc, dim_resc))
+        lo, hi = (dim_resc - dim_pp) // 2, (dim_resc + dim_pp) // 2
+        out[lo:hi, lo:hi] = array_resc
+        array_resc = out
+    elif dim_pp > dim:
+        array_resc = array_resc[kf_io:kf_io + dim, kf_io:kf_io + dim]
+    elif dim_pp <= dim:
+        scaled = array * 0
+        scaled[-kf_io:-kf_io + dim_pp, -kf_io:-kf_io + dim_pp] = array_resc
+        array_resc = scaled
+    return array_resc
+
+
+def frame_rescaling_fft(array, scale):
+    """frame_rescaling(imlib='vip-fft') about the frame centre, NaN-free input.
+    Ref: preproc/rescaling.py:560-575 (centre check), :636-672 (vip-fft branch, odd frames embedded at [1:, 1:])."""
+    if scale is None:
+        scale = 1.0
+    if array.shape[0] != array.shape[1]:
+        raise ValueError("FFT scaling only supports square input arrays")
+    if array.shape[0] % 2:
+        even = np.zeros([array.shape[0] + 1, array.shape[1] + 1])
+        even[1:, 1:] = array
+        return scale_fft(even, scale, ori_dim=True)[1:, 1:]
+    return scale_fft(array, scale, ori_dim=True)
+
+
+def get_square(array, size, y, x):
+    """Ref: var/shapes.py:290-352 (force=False)."""
+    size_init = array.shape[0]
+    if size >= array.shape[0] and size >= array.shape[1]:
+        raise ValueError("`Size` is equal to or bigger than the initial frame size")
+    if size_init % 2 == 0:
+        if size % 2 != 0:
+            size += 1
+    elif size % 2 == 0:
+        size += 1
+    wing = (size - 1) / 2
+    y0, y1 = int(y - wing), int(y + wing + 1)
+    x0, x1 = int(x - wing), int(x + wing + 1)
+    if y0 < 0 or x0 < 0 or y1 > array.shape[0] or x1 > array.shape[1]:
+        raise RuntimeError("square cannot be obtained with size={}, y={}, x={}".format(size, y, x))
+    return array[y0:y1, x0:x1].copy()
+
+
+def cube_crop_frames(array, size):
+    """Centre crop of the frames of a 3-D cube.  Ref: preproc/cosmetics.py:66-109 (xy=None, force=False)."""
+    fr = array[0]
+    if fr.shape[0] == size and fr.shape[1] == size:
+        return array
+    cy, cx = frame_center(fr)
+    wing = ((size + (1 if (fr.shape[0] % 2 == 0) != (size % 2 == 0) else 0)) - 1) / 2
+    y0, x0 = int(cy - wing), int(cx - wing)
+    if fr.shape[0] % 2 == 0:
+        if size % 2 != 0:
+            size += 1
+    elif size % 2 == 0:
+        size += 1
+    return array[:, y0:y0 + size, x0:x0 + size]
+
+
+def cube_rescaling_wavelengths(cube, scal_list, full_output=True, inverse=False, y_in=None, x_in=None,
+                               collapse="median", pad_mode="reflect"):
+    """Ref: preproc/rescaling.py:427-475 (imlib='vip-fft')."""
+    n, y, x = cube.shape
+    scal_list = np.asarray(scal_list, dtype=float)
+    max_sc = np.amax(scal_list)
+    if not inverse and max_sc > 1:
+        new_y, new_x = int(np.ceil(max_sc * y)), int(np.ceil(max_sc * x))
+        if (new_y - y) % 2 != 0:
+            new_y += 1
+        if (new_x - x) % 2 != 0:
+            new_x += 1
+        py, px = (new_y - y) // 2, (new_x - x) // 2
+        big_cube = np.pad(cube, ((0, 0), (py, py), (px, px)), pad_mode)
+    else:
+        big_cube = cube.copy()
+    n, y, x = big_cube.shape
+    cy, cx = frame_center(big_cube[0])
+    if inverse:
+        scal_list = 1.0 / scal_list
+        cy, cx = frame_center(cube[0])
+    out = np.array([frame_rescaling_fft(big_cube[i], scal_list[i]) for i in range(n)])
+    frame = cube_collapse(out, collapse)
+    if inverse and max_sc > 1:
+        if y_in is None or x_in is None:
+            raise ValueError("Provide y_in and x_in when inverse=True")
+        siz = max(y_in, x_in)
+        if frame.shape[0] > siz:
+            frame = get_square(frame, siz, cy, cx)
+        if full_output and out.shape[-1] > siz:
+            old = out.copy()
+            out = np.zeros([old.shape[0], siz, siz])
+            for zz in range(old.shape[0]):
+                out[zz] = get_square(old[zz], siz, cy, cx)
+    if full_output:
+        return out, frame, y, x, cy, cx
+    return frame
+
+
+def pca_adimsdi_double(cube, angle_list, scale_list, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
+                       collapse="median", collapse_ifs="mean", ifs_collapse_range="all", weights=None,
+                       full_output=False):
+    """``pca(cube4d, angles, scale_list=..., adimsdi='double', ncomp=(k_ifs, k_adi))``.
+    Ref: psfsub/pca_fullfr.py:412-415 (mask default), :478-508 (routing), :1263-1549 (_adimsdi_doublepca and
+    _adimsdi_doublepca_ifs), :726-731 (returns)."""
+    z, n, y_in, x_in = cube.shape
+    if not isinstance(ncomp, tuple):
+        raise TypeError("`ncomp` must be a tuple when a double pass PCA is performed")
+    ncomp_ifs, ncomp_adi = ncomp
+    mask_val = 0 if mask_center_px else np.nan
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    scale_list = np.asarray(scale_list, dtype=float)
+    if type(scaling) is not tuple:
+        scaling = (scaling, scaling)
+    if ncomp_ifs is not None and ncomp_ifs > z:
+        ncomp_ifs = min(ncomp_ifs, z)
+    i0, i1 = (0, z) if ifs_collapse_range == "all" else ifs_collapse_range
+    res = []
+    for fr in range(n):
+        ms = cube[:, fr]
+        if ncomp_ifs is None:
+            frame_i = cube_collapse(ms[i0:i1])
+        else:
+            cube_resc = cube_rescaling_wavelengths(ms, scale_list)[0]
+            residuals = project_subtract(cube_resc, ncomp_ifs, scaling[0], mask_center_px, svd_mode)
+            frame_i = cube_rescaling_wavelengths(residuals[i0:i1], scale_list[i0:i1], full_output=False, inverse=True,
+                                                 y_in=y_in, x_in=x_in, collapse=collapse_ifs)
+            if mask_center_px:
+                frame_i = mask_circle(frame_i, mask_center_px)
+        res.append(frame_i)
+    res_cube_channels = np.array(res)
+    if ncomp_adi is None:
+        der = cube_derotate(res_cube_channels[:n], angle_list, mask_val=mask_val)
+    else:
+        if ncomp_adi > n:
+            ncomp_adi = n
+        res_ifs_adi = project_subtract(res_cube_channels, ncomp_adi, scaling[1], mask_center_px, svd_mode)
+        der = cube_derotate(res_ifs_adi, angle_list, mask_val=mask_val)
+    frame = cube_collapse(der, mode=collapse, w=weights)
+    if full_output:
+        return frame, res_cube_channels, der
+    return frame
+
+
+def pca_adimsdi_single(cube, angle_list, scale_list, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
+                       collapse="median", collapse_ifs="mean", ifs_collapse_range="all", crop_ifs=True, weights=None,
+                       full_output=False):
+    """``pca(cube4d, angles, scale_list=..., adimsdi='single', ncomp=<int>)``.
+    Ref: psfsub/pca_fullfr.py:1038-1216 (_adimsdi_singlepca), :736-742 (returns)."""
+    z, n, y_in, x_in = cube.shape
+    mask_val = 0 if mask_center_px else np.nan
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    scale_list = np.asarray(scale_list, dtype=float)
+    big = []
+    for i in range(n):
+        cr = cube_rescaling_wavelengths(cube[:, i], scale_list)[0]
+        if crop_ifs:
+            cr = cube_crop_frames(cr, y_in)
+        big.append(cr)
+    big = np.array(big)
+    big = big.reshape(z * n, big.shape[2], big.shape[3])
+    res_cube = project_subtract(big, ncomp, scaling, mask_center_px, svd_mode)
+    resadi = np.zeros((n, y_in, x_in))
+    i0, i1 = (0, z) if ifs_collapse_range == "all" else ifs_collapse_range
+    desc = np.zeros_like(cube[i0:i1])
+    for i in range(n):
+        r = cube_rescaling_wavelengths(res_cube[i * z + i0:i * z + i1], scale_list[i0:i1], full_output=True,
+                                       inverse=True, y_in=y_in, x_in=x_in, collapse=collapse_ifs)
+        desc[:, i] = r[0]
+        resadi[i] = r[1]
+    der = cube_derotate(resadi, angle_list, mask_val=mask_val)
+    if mask_center_px:
+        der = mask_circle(der, mask_center_px)
+    frame = cube_collapse(der, mode=collapse, w=weights)
+    if full_output:
+        return frame, res_cube, desc, resadi
+    return frame
+
+
 def pca_4d(cube, angle_list, ncomp=1, collapse_ifs="mean", full_output=False, **kw):
     """4-D cube, scale_list=None: per-channel full-frame PCA then spectral collapse.
     Ref: psfsub/pca_fullfr.py:544-658,770-774."""

@@ -135,8 +135,13 @@ def test_argument_errors_raise_before_touching_the_gpu():
         pca(np.zeros((8, 8), np.float32), np.zeros(4), verbose=False)
     with pytest.raises(TypeError):
         pca([1, 2, 3], np.zeros(4), verbose=False)
-    with pytest.raises(NotImplementedError):
-        pca(cube, np.zeros(4), scale_list=np.ones(4), verbose=False)
+    with pytest.raises(TypeError):
+        pca(cube, np.zeros(4), scale_list=np.ones(4), verbose=False)                 # mSDI needs a 4-D cube
+    with pytest.raises(TypeError):
+        pca(np.zeros((3, 4, 8, 8), np.float32), np.zeros(4), scale_list=np.ones(3), adimsdi="double", ncomp=2,
+            verbose=False)
+    with pytest.raises(ValueError):
+        pca(np.zeros((3, 4, 8, 8), np.float32), np.zeros(4), scale_list=np.ones(5), verbose=False)
     with pytest.raises(ValueError):
         pca(cube, np.zeros(4), svd_mode="nope", verbose=False)
     with pytest.raises(NotImplementedError):
@@ -148,7 +153,7 @@ def test_argument_errors_raise_before_touching_the_gpu():
     with pytest.raises(ValueError):
         svd_wrapper(np.zeros((4, 10)), "nope", 2, False)
     with pytest.raises(NotImplementedError):
-        pca_annular(np.zeros((2, 4, 8, 8), np.float32), np.zeros(4), verbose=False)
+        pca_annular(np.zeros((2, 4, 8, 8), np.float32), np.zeros(4), scale_list=np.ones(2), verbose=False)
 
 
 def test_find_indices_adi_all_matches_per_frame_scan():

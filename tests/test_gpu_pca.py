@@ -293,3 +293,60 @@ def test_pca_annular_4d_golden():
     assert np.abs(fr - g["frame"]).max() < TOL
     assert np.abs(pca_annular(g["cube"], g["angles"], asize=8, ncomp=[2, 2, 2], fwhm=4, delta_rot=(0.1, 1),
                               verbose=False) - g["frame"]).max() < TOL
+
+
+# ---- ADI+mSDI -------------------------------------------------------------------------------------
+
+def test_rescaling_wavelengths_golden():
+    from vip_amd.preproc.rescaling import cube_rescaling_wavelengths
+    g = load_golden("g10_msdi")
+    r = cube_rescaling_wavelengths(g["cube"][:, 0], g["scale_list"])
+    assert r[0].shape == g["scw_cube"].shape and r[2:4] == (40, 40)
+    assert np.abs(r[0] - g["scw_cube"]).max() < 2e-5
+    assert np.abs(r[1] - g["scw_frame"]).max() < 2e-5
+    ri = cube_rescaling_wavelengths(g["scw_cube"], g["scale_list"], full_output=True, inverse=True, y_in=32, x_in=32,
+                                    collapse="mean")
+    assert ri[0].shape == g["scw_inv_cube"].shape
+    assert np.abs(ri[0] - g["scw_inv_cube"]).max() < 2e-5
+    assert np.abs(ri[1] - g["scw_inv_frame"]).max() < 2e-5
+    fr = cube_rescaling_wavelengths(g["scw_cube"], g["scale_list"], full_output=False, inverse=True, y_in=32, x_in=32,
+                                    collapse="mean")
+    assert np.abs(fr - g["scw_inv_frame"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("tag,kw", [("d22", dict(ncomp=(2, 2))), ("dN2", dict(ncomp=(None, 2))), ("d2N", dict(ncomp=(2, None))),
+                                    ("dmask", dict(ncomp=(2, 2), mask_center_px=3, scaling="temp-mean", collapse_ifs="median")),
+                                    ("drange", dict(ncomp=(2, 2), ifs_collapse_range=(1, 4)))])
+def test_msdi_double_golden(tag, kw):
+    from vip_amd.psfsub import pca
+    g = load_golden("g10_msdi")
+    out = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", full_output=True, verbose=False, **kw)
+    assert len(out) == 3
+    for nm, a in zip(("frame", "rcc", "rcc_der"), out):
+        b = g["%s_%s" % (tag, nm)]
+        assert a.shape == b.shape and a.dtype == b.dtype, (nm, a.dtype, b.dtype)
+        assert np.abs(a - b).max() < TOL, (tag, nm, np.abs(a - b).max())
+    fr = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", verbose=False, **kw)
+    assert np.abs(fr - g[tag + "_frame"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag,kw", [("s3", dict(ncomp=3)), ("s3nocrop", dict(ncomp=3, crop_ifs=False)),
+                                    ("s2mask", dict(ncomp=2, mask_center_px=3, scaling="temp-standard"))])
+def test_msdi_single_golden(tag, kw):
+    from vip_amd.psfsub import pca
+    g = load_golden("g10_msdi")
+    out = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="single", full_output=True, verbose=False, **kw)
+    assert len(out) == 4
+    for nm, a in zip(("frame", "allfr", "desc", "adi"), out):
+        b = g["%s_%s" % (tag, nm)]
+        assert a.shape == b.shape, (nm, a.shape, b.shape)
+        assert np.abs(a - b).max() < TOL, (tag, nm, np.abs(a - b).max())
+
+
+def test_msdi_errors():
+    from vip_amd.psfsub import pca
+    g = load_golden("g10_msdi")
+    with pytest.raises(TypeError):
+        pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", ncomp=2, verbose=False)
+    with pytest.raises(ValueError):
+        pca(g["cube"], g["angles"], scale_list=g["scale_list"][:3], adimsdi="double", ncomp=(1, 1), verbose=False)

@@ -40,6 +40,8 @@ _SIGS = {
                             ctypes.c_int),
     "vipmi_rowspace_gemm_f32": ([c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p], True, ctypes.c_int),
     "vipmi_subtract_gemm_f32": ([c_f32p, c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p], True, ctypes.c_int),
+    "vipmi_zoom_frames_f32": ([c_f32p, i64, i64, c_f32p, c_f32p, ctypes.c_void_p, i64, i64, c_f32p, c_f32p], True,
+                              ctypes.c_int),
     "vipmi_derotate_f32": ([c_f32p, ctypes.c_void_p, i64, i64, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int],
                            True, ctypes.c_int),
     "vipmi_collapse_f32": ([c_f32p, i64, i64, ctypes.c_int, c_f32p, i64, c_f32p], True, ctypes.c_int),

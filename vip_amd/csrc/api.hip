@@ -337,6 +337,29 @@ int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int
   return eigh_leading(ctx, G, batch, n, k, nact, evals, evecs);
 }
 
+int vipmi_zoom_frames_f32(vipmi_ctx* ctx, const float* X, int64_t nb, int64_t din, const float* Er, const float* Ei,
+                          const int32_t* chan, int64_t dout, int64_t ldk, float* work, float* out) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(X && Er && Ei && chan && work && out, "zoom_frames: null pointer");
+  VIPMI_REQUIRE(nb > 0 && din > 0 && dout > 0 && ldk >= din, "zoom_frames: bad sizes");
+  // U = E X^T  (dout x din, per frame, real and imaginary operators) ...
+  float* Ur = work;
+  float* Ui = work + (size_t)nb * dout * ldk;
+  for (int64_t b0 = 0; b0 < nb; b0 += 32768) {
+    const int64_t cnt = nb - b0 < 32768 ? nb - b0 : 32768;
+    const float* Xb = X + (size_t)b0 * din * din;
+    VIPMI_TRY(bgemm_abt_f32(ctx, Er, Xb, nullptr, nullptr, chan + b0, nullptr, cnt, dout, din, din, ldk, din, ldk,
+                            dout * ldk, din * din, dout * ldk, Ur + (size_t)b0 * dout * ldk));
+    VIPMI_TRY(bgemm_abt_f32(ctx, Ei, Xb, nullptr, nullptr, chan + b0, nullptr, cnt, dout, din, din, ldk, din, ldk,
+                            dout * ldk, din * din, dout * ldk, Ui + (size_t)b0 * dout * ldk));
+    // ... Y = Er Ur^T - Ei Ui^T  (dout x dout)
+    VIPMI_TRY(bgemm_abt_f32(ctx, Er, Ur + (size_t)b0 * dout * ldk, Ei, Ui + (size_t)b0 * dout * ldk, chan + b0, nullptr,
+                            cnt, dout, dout, din, ldk, ldk, dout, dout * ldk, dout * ldk, dout * dout,
+                            out + (size_t)b0 * dout * dout));
+  }
+  return VIPMI_OK;
+}
+
 int vipmi_eigh_spectrum_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals,
                             double* evecs) {
   CTX_GUARD();

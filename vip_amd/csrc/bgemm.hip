@@ -1,0 +1,134 @@
+// bgemm.hip -- batched small products in "A B^T" form on the f32 matrix cores:
+//     C[b] (M x N) = A0[ia[b]] (M x K) * B0[ib[b]]^T (N x K)   [ - A1[ia[b]] * B1[ib[b]]^T ]
+// every operand row-major with the contraction index K contiguous.  It carries the FFT zoom of the ADI+mSDI path:
+// the reference rescales every spectral channel of every frame with scale_fft (preproc/rescaling.py:1114-1217:
+// zero-pad -> fft2 -> crop / pad the spectrum -> ifft2 -> real part -> crop / pad), which is a separable LINEAR map
+//     Y = Re(E X E^T) = Er X Er^T - Ei X Ei^T
+// with one small complex matrix E per scale factor (the reflect padding of cube_rescaling_wavelengths and the final
+// crops fold into E as well).  With U = E X^T (an "A B^T" product) the result is Y = Er Ur^T - Ei Ui^T (another one),
+// so a frame costs four real products of the frame size instead of two 2-D FFTs of awkward (non power-of-two) sizes.
+//
+// One wave owns a 32 x 32 output tile (2 x 2 blocks of v_mfma_f32_16x16x4_f32); operands are read straight from
+// global memory in MFMA fragment layout (lane (r = lane & 15, kq = lane >> 4) reads row r, columns k0 + 4 kq .. + 3;
+// component c feeds MFMA number c -- the same k permutation on both operands, so no LDS staging), as in gram.hip.
+#include "common.h"
+
+namespace vipmi {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 ldfrag(const float* __restrict__ row, bool ok, int off, int K) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!ok) return v;
+  if (VEC && off + 4 <= K) {
+    v = *reinterpret_cast<const f32x4*>(row + off);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (off + c < K) v[c] = row[off + c];
+  }
+  return v;
+}
+
+struct BgemmArgs {
+  const float* A0;
+  const float* B0;
+  const float* A1;      // may be null
+  const float* B1;
+  const int32_t* ia;    // per-batch index into the A arrays (null: b)
+  const int32_t* ib;    // per-batch index into the B arrays (null: b)
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int64_t sa, sb, sc;   // strides between matrices
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bgemm_abt_kernel(BgemmArgs g, int tiles_n, int ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int b = blockIdx.y;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t oa = (int64_t)(g.ia ? g.ia[b] : b) * g.sa, ob = (int64_t)(g.ib ? g.ib[b] : b) * g.sb;
+  const int nprod = g.A1 ? 2 : 1;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  for (int p = 0; p < nprod; ++p) {
+    const float* A = (p ? g.A1 : g.A0) + oa;
+    const float* B = (p ? g.B1 : g.B0) + ob;
+    const float sign = p ? -1.f : 1.f;
+    const float* pa[2];
+    const float* pb[2];
+    bool oka[2], okb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = tm * 32 + i * 16 + r, rb = tn * 32 + i * 16 + r;
+      oka[i] = ra < g.M;
+      okb[i] = rb < g.N;
+      pa[i] = A + (int64_t)(oka[i] ? ra : 0) * g.lda;
+      pb[i] = B + (int64_t)(okb[i] ? rb : 0) * g.ldb;
+    }
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = ldfrag<VEC>(pa[i], oka[i], k0 + 4 * kq, g.K);
+        fb[i] = ldfrag<VEC>(pb[i], okb[i], k0 + 4 * kq, g.K);
+        fa[i] *= sign;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* C = g.C + (int64_t)b * g.sc;
+  const int col = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = tm * 32 + i * 16 + (lane >> 4) * 4 + q;      // f32 16x16x4: row = (lane>>4)*4 + q
+        const int cc = tn * 32 + j * 16 + col;
+        if (row < g.M && cc < g.N) C[(int64_t)row * g.ldc + cc] = acc[i][j][q];
+      }
+}
+
+}  // namespace
+
+int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float* A1, const float* B1,
+                  const int32_t* ia, const int32_t* ib, int64_t nbatch, int64_t M, int64_t N, int64_t K, int64_t lda,
+                  int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc, float* C) {
+  VIPMI_REQUIRE(A0 && B0 && C, "bgemm: null pointer");
+  VIPMI_REQUIRE((A1 == nullptr) == (B1 == nullptr), "bgemm: second product needs both operands");
+  VIPMI_REQUIRE(nbatch > 0 && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc >= N, "bgemm: bad sizes");
+  VIPMI_REQUIRE(nbatch <= 65535, "bgemm: more than 65535 matrices per call");
+  StageScope scope(ctx, "bgemm");
+  BgemmArgs g{A0, B0, A1, B1, ia, ib, C, (int)M, (int)N, (int)K, (int)lda, (int)ldb, (int)ldc, sa, sb, sc};
+  const int tiles_m = (int)cdiv(M, 32), tiles_n = (int)cdiv(N, 32), ntiles = tiles_m * tiles_n;
+  auto aligned = [](const float* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = lda % 4 == 0 && ldb % 4 == 0 && sa % 4 == 0 && sb % 4 == 0 && aligned(A0) && aligned(B0) &&
+                   aligned(A1) && aligned(B1);
+  dim3 grid((unsigned)cdiv(ntiles, 4), (unsigned)nbatch), block(256);
+  if (vec)
+    hipLaunchKernelGGL(bgemm_abt_kernel<true>, grid, block, 0, ctx->stream, g, tiles_n, ntiles);
+  else
+    hipLaunchKernelGGL(bgemm_abt_kernel<false>, grid, block, 0, ctx->stream, g, tiles_n, ntiles);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+}  // namespace vipmi

@@ -125,6 +125,10 @@ int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals,
 bool eigh_topk_supported(int64_t n, int64_t k);
 int eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                   double* evals, double* evecs, bool all_evals = false);
+// batched C[b] = A0[ia[b]] B0[ib[b]]^T - A1[ia[b]] B1[ib[b]]^T (bgemm.hip)
+int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float* A1, const float* B1,
+                  const int32_t* ia, const int32_t* ib, int64_t nbatch, int64_t M, int64_t N, int64_t K, int64_t lda,
+                  int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc, float* C);
 // one larger problem (512 < n <= 2048): eigh_tri_large.hip
 bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,

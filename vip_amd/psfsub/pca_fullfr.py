@@ -361,10 +361,25 @@ def pca(*all_args: List, **all_kwargs: dict):
         raise TypeError("`cube` must be a 3 or 4d numpy ndarray")
     if algo_params.left_eigv:
         raise NotImplementedError("left_eigv is outside the accelerated path")
-    if algo_params.scale_list is not None:
-        raise NotImplementedError("scale_list (ADI+mSDI) is not accelerated yet (SURVEY 8(f))")
     if _s(algo_params.svd_mode) not in SVD_MODES:
         raise ValueError("The SVD `mode` is not recognized")
+    if algo_params.scale_list is not None:
+        # argument checks of the ADI+mSDI path before anything touches the GPU
+        if cube.ndim != 4:
+            raise TypeError("`scale_list` needs a 4d (channels, frames, y, x) cube")
+        for name in ("cube_ref", "source_xy", "mask_rdi", "cube_sig", "smooth_first_pass"):
+            if getattr(algo_params, name, None) is not None:
+                raise NotImplementedError("{} is outside the accelerated ADI+mSDI path".format(name))
+        if _s(algo_params.imlib) != "vip-fft" or _s(algo_params.imlib2) != "vip-fft":
+            raise NotImplementedError("vip_amd implements imlib='vip-fft' / imlib2='vip-fft' only")
+        if _s(algo_params.adimsdi) not in ("double", "single"):
+            raise ValueError("`adimsdi` mode not recognized")
+        if _s(algo_params.adimsdi) == "double" and not isinstance(algo_params.ncomp, tuple):
+            raise TypeError("`ncomp` must be a tuple when a double pass PCA is performed")
+        if np.asarray(algo_params.scale_list).ndim > 1:
+            raise ValueError("Scaling factors vector is not 1d")
+        if np.asarray(algo_params.scale_list).shape[0] != cube.shape[0]:
+            raise ValueError("Scaling factors vector has wrong length")
     cond_mask = algo_params.mask_rdi is not None
     if cond_mask and algo_params.ref_strategy in ("ARDI", "ARSDI"):
         raise TypeError("mask for data imputation detected. This mode can only run with a pure RDI strategy, "
@@ -386,6 +401,43 @@ def pca(*all_args: List, **all_kwargs: dict):
         return t.cpu().numpy().astype(dtype or out_dtype, copy=False)
 
     cube_t = B.to_device_f32(cube)
+    if algo_params.scale_list is not None:
+        # ADI+mSDI (pca_fullfr.py:478-540): 4-D cube, channels rescaled by scale_list
+        from .pca_msdi import adimsdi_double, adimsdi_single
+        mask_val = rot_options.get("mask_val", np.nan)
+        mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
+        if not mv_nan and mask_val != 0:
+            raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
+        collapse = _s(algo_params.collapse)
+        if collapse not in B.COLLAPSE_MODES or collapse == "stim":
+            raise TypeError("mode not recognized")
+        mode = _s(algo_params.adimsdi)
+        if mode == "double":
+            rcc, rcc_, frame = adimsdi_double(cube_t, algo_params.angle_list, algo_params.scale_list,
+                                              algo_params.ncomp, algo_params.scaling, algo_params.mask_center_px,
+                                              collapse, algo_params.collapse_ifs, algo_params.ifs_collapse_range,
+                                              algo_params.weights, mv_nan, algo_params.verbose)
+            # the reference's scale_fft returns float32 when it crops the spectrum (down-scaling) and float64 when it
+            # pads it or leaves a channel untouched (scale 1): mirror the resulting dtype of the collapsed frames
+            dt = None
+            if algo_params.ncomp[0] is not None:
+                z_ = cube.shape[0]
+                r0, r1 = (0, z_) if algo_params.ifs_collapse_range == "all" else algo_params.ifs_collapse_range
+                sl = np.asarray(algo_params.scale_list, dtype=np.float64)[r0:r1]
+                dt = np.float64 if np.any(sl <= 1) else np.float32
+            if algo_params.full_output:
+                return host(frame, dt), host(rcc, dt), host(rcc_, dt)
+            return host(frame, dt)
+        if mode == "single":
+            allfr, desc, adi, frame = adimsdi_single(cube_t, algo_params.angle_list, algo_params.scale_list,
+                                                     algo_params.ncomp, _s(algo_params.scaling),
+                                                     algo_params.mask_center_px, collapse, algo_params.collapse_ifs,
+                                                     algo_params.ifs_collapse_range, algo_params.crop_ifs,
+                                                     algo_params.weights, mv_nan, algo_params.verbose)
+            if algo_params.full_output:
+                return host(frame, np.float64), host(allfr, np.float64), host(desc), host(adi, np.float64)
+            return host(frame, np.float64)
+        raise ValueError("`adimsdi` mode not recognized")
     cube_ref_t = None
     if algo_params.cube_ref is not None:
         cube_ref_t = B.to_device_f32(algo_params.cube_ref)

@@ -1,0 +1,161 @@
+"""ADI+mSDI full-frame PCA (4-D cube + ``scale_list``): device versions of ``_adimsdi_doublepca`` /
+``_adimsdi_doublepca_ifs`` (reference psfsub/pca_fullfr.py:1263-1549) and ``_adimsdi_singlepca`` (:1038-1216).
+
+The spectral channels are rescaled with the matrix-core zoom of ``vip_amd.preproc.rescaling`` (all frames of all
+channels in one call), the PCA stages reuse the full-frame kernels, the de-scaled channels are collapsed with the
+collapse kernel.  Not accelerated (NotImplementedError): ``cube_ref``, ``source_xy``, ``batch``, ``mask_rdi``,
+``smooth_first_pass``, tuple / list ``ncomp`` in single-pass mode (grid), ``imlib2`` other than 'vip-fft'.
+"""
+import numpy as np
+
+from .. import backend as B
+from ..preproc.parangles import check_pa_vector
+from ..preproc.rescaling import channel_operators, zoom_frames
+from ..var.shapes import center_mask_u8
+
+
+def _s(x):
+    return str(getattr(x, "value", x)) if x is not None else None
+
+
+def _prep(M3, scaling, mask_center_px):
+    """prepare_matrix(mode='fullfr') of a device cube (nf, y, x) -> (nf, P)."""
+    nf, y, x = M3.shape
+    m = M3.reshape(nf, -1)
+    if mask_center_px:
+        mask = B.to_device_f32(center_mask_u8((y, x), mask_center_px).astype(np.float32)).to(B._torch().uint8)
+        m = B.apply_mask(m, mask.reshape(-1), 0.0)
+    if scaling is not None:
+        m = B.scale(m, scaling)
+    return m
+
+
+def _residuals(M3, ncomp, scaling, mask_center_px):
+    """_project_subtract(cube, None, ncomp, scaling, mask_center_px, ...) -> residual cube (nf, y, x)."""
+    nf, y, x = M3.shape
+    M = _prep(M3, scaling, mask_center_px)
+    if ncomp > min(M.shape):
+        msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
+        msg += " Increase the size of the patches or request less PCs"
+        raise RuntimeError(msg.format(ncomp, M.shape[0], M.shape[1]))
+    res = B.pca_project(M, int(ncomp))[0]
+    return res.reshape(nf, y, x)
+
+
+def _check(cube, angle_list, scale_list):
+    z, n, y_in, x_in = cube.shape
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
+    if not angle_list.shape[0] == n:
+        raise ValueError("Angle list vector has wrong length. It must equal the number frames in the cube")
+    if scale_list is None:
+        raise ValueError("Scaling factors vector must be provided")
+    scale_list = np.asarray(scale_list, dtype=np.float64)
+    if scale_list.ndim > 1:
+        raise ValueError("Scaling factors vector is not 1d")
+    if not scale_list.shape[0] == z:
+        raise ValueError("Scaling factors vector has wrong length")
+    if y_in != x_in:
+        raise ValueError("FFT scaling only supports square input arrays")
+    return angle_list, scale_list
+
+
+def _frame_major(cube4):
+    """(z, n, y, x) -> (n*z, y, x) with index f*z + c, the order of the reference's ``big_cube``."""
+    z, n, y, x = cube4.shape
+    return cube4.permute(1, 0, 2, 3).reshape(n * z, y, x).contiguous()
+
+
+def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px, collapse, collapse_ifs,
+                   ifs_collapse_range, weights, mv_nan, verbose):
+    """Returns (res_cube_channels (n, y, x), residuals_cube_channels_ (n, y, x), frame) as device tensors."""
+    torch = B._torch()
+    z, n, y_in, x_in = cube.shape
+    if not isinstance(ncomp, tuple):
+        raise TypeError("`ncomp` must be a tuple when a double pass PCA is performed")
+    ncomp_ifs, ncomp_adi = ncomp
+    angle_list, scale_list = _check(cube, angle_list, scale_list)
+    if type(scaling) is not tuple:
+        scaling = (scaling, scaling)
+    if verbose:
+        print("{} spectral channels in IFS cube".format(z))
+    if ncomp_ifs is not None and ncomp_ifs > z:
+        ncomp_ifs = min(ncomp_ifs, z)
+        print("Number of PCs too high (max PCs={}), using {} PCs instead".format(z, ncomp_ifs))
+    i0, i1 = (0, z) if ifs_collapse_range == "all" else ifs_collapse_range
+    zc = i1 - i0
+    if ncomp_ifs is None:
+        # first stage skipped: median of the channels of every multispectral frame (pca_fullfr.py:1479-1480)
+        per = cube[i0:i1].permute(1, 0, 2, 3).contiguous()               # (n, zc, y, x)
+        res_cube_channels = torch.stack([B.collapse(per[f], "median") for f in range(n)])
+    else:
+        # 1. rescale every channel of every frame (reflect padded to the largest scale), frame-major order
+        E = channel_operators(y_in, scale_list)
+        big = E.shape[1]
+        resc = zoom_frames(_frame_major(cube), E, np.tile(np.arange(z), n))          # (n*z, big, big)
+        # 2. per multispectral frame: PCA over the z channels
+        res_all = B.empty((n, zc, big, big), device=cube.device.index)
+        for f in range(n):
+            r = _residuals(resc[f * z:(f + 1) * z], int(ncomp_ifs), scaling[0], mask_center_px)
+            res_all[f] = r[i0:i1]
+        # 3. de-scale, crop back to the input size, collapse the channels
+        Einv = channel_operators(big, scale_list[i0:i1], inverse=True, out_size=max(y_in, x_in))
+        desc = zoom_frames(res_all.reshape(n * zc, big, big), Einv, np.tile(np.arange(zc), n))
+        ys = desc.shape[1]
+        desc = desc.reshape(n, zc, ys, ys)
+        res_cube_channels = torch.stack([B.collapse(desc[f], _s(collapse_ifs)) for f in range(n)])
+        if mask_center_px:
+            mask = B.to_device_f32(center_mask_u8((ys, ys), mask_center_px).astype(np.float32)).to(torch.uint8)
+            res_cube_channels = B.apply_mask(res_cube_channels.reshape(n, -1), mask.reshape(-1), 0.0).reshape(n, ys, ys)
+    if ncomp_adi is None:
+        if verbose:
+            print("{} ADI frames".format(n))
+            print("De-rotating and combining frames (skipping PCA)")
+        src = res_cube_channels
+    else:
+        if ncomp_adi > n:
+            ncomp_adi = n
+            print("Number of PCs too high, using  maximum of {} PCs instead".format(n))
+        if verbose:
+            print("{} ADI frames".format(n))
+            print("Second PCA stage exploiting rotational variability")
+        src = _residuals(res_cube_channels, int(ncomp_adi), scaling[1], mask_center_px)
+    der = B.derotate(src, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
+    frame = B.collapse(der, _s(collapse), w=weights)
+    return res_cube_channels, der, frame
+
+
+def adimsdi_single(cube, angle_list, scale_list, ncomp, scaling, mask_center_px, collapse, collapse_ifs,
+                   ifs_collapse_range, crop_ifs, weights, mv_nan, verbose):
+    """Returns (cube_allfr_residuals (z*n, Y, X), cube_desc_residuals (zc, n, y, x), cube_adi_residuals (n, y, x),
+    frame) as device tensors."""
+    torch = B._torch()
+    z, n, y_in, x_in = cube.shape
+    angle_list, scale_list = _check(cube, angle_list, scale_list)
+    if not np.isscalar(ncomp):
+        raise NotImplementedError("tuple / list ncomp (grid) in single-pass ADI+mSDI is not accelerated")
+    if isinstance(ncomp, (float, np.floating)):
+        raise NotImplementedError("float ncomp (CEVR) in single-pass ADI+mSDI is not accelerated")
+    if verbose:
+        print("Rescaling the spectral channels to align the speckles")
+    E = channel_operators(y_in, scale_list, crop_to=y_in if crop_ifs else None)
+    big_cube = zoom_frames(_frame_major(cube), E, np.tile(np.arange(z), n))           # (n*z, Y, Y)
+    Y = big_cube.shape[1]
+    if verbose:
+        print("{} total frames".format(n * z))
+        print("Performing single-pass PCA")
+    res_cube = _residuals(big_cube, int(ncomp), scaling, mask_center_px)
+    i0, i1 = (0, z) if ifs_collapse_range == "all" else ifs_collapse_range
+    zc = i1 - i0
+    sel = res_cube.reshape(n, z, Y, Y)[:, i0:i1].reshape(n * zc, Y, Y).contiguous()
+    Einv = channel_operators(Y, scale_list[i0:i1], inverse=True, out_size=max(y_in, x_in))
+    desc = zoom_frames(sel, Einv, np.tile(np.arange(zc), n))
+    ys = desc.shape[1]
+    desc = desc.reshape(n, zc, ys, ys)
+    resadi = torch.stack([B.collapse(desc[f], _s(collapse_ifs)) for f in range(n)])
+    cube_desc = desc.permute(1, 0, 2, 3).contiguous()
+    der = B.derotate(resadi, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
+    if mask_center_px:
+        mask = B.to_device_f32(center_mask_u8((ys, ys), mask_center_px).astype(np.float32)).to(torch.uint8)
+        der = B.apply_mask(der.reshape(n, -1), mask.reshape(-1), 0.0).reshape(n, ys, ys)
+    frame = B.collapse(der, _s(collapse), w=weights)
+    return res_cube, cube_desc, resadi, frame
