@@ -11,6 +11,8 @@ padding of ``cube_rescaling_wavelengths`` and the final crops folded in) and the
 all channels with four real matrix-core products per frame (``vipmi_zoom_frames_f32``).  The reference evaluates
 its forward FFT in float32 (numpy >= 2 keeps the input precision), so agreement is at the 1e-6 level, not 1e-15.
 """
+import functools
+
 import numpy as np
 
 from .. import backend as B
@@ -27,22 +29,29 @@ def _kd_kf(dim, scale):
     return int(kd_array[imin]), int(kf_array[imin])
 
 
+@functools.lru_cache(maxsize=512)
 def _zoom_operator_even(dim, scale):
-    """Complex E (dim x dim) with ``scale_fft(X, scale, ori_dim=True) == Re(E X E^T)`` for an even ``dim``."""
+    """Complex E (dim x dim) with ``scale_fft(X, scale, ori_dim=True) == Re(E X E^T)`` for an even ``dim``.
+
+    Per axis: y[m] = (1/N'') sum_{k=-K/2}^{K/2-1} e^{2 pi i k m / N''} sum_j x[j] e^{-2 pi i k (j + kd) / N'}, K = min(N', N'')
+    (the frequencies that survive the crop / zero padding of the shifted spectrum).  The sum over k is a geometric
+    series: with theta = m/N'' - (j + kd)/N' it equals e^{-i pi theta} sin(pi K theta) / sin(pi theta)."""
     if scale == 1:
         return np.eye(dim, dtype=complex)
     kd, kf = _kd_kf(dim, scale)
     dim_p, dim_pp = dim + 2 * kd, dim + 2 * kf
     K = min(dim_p, dim_pp)
-    ks = np.arange(-K // 2, K // 2)                      # frequencies that survive the crop / zero padding
-    w_out = np.exp(2j * np.pi * np.outer(np.arange(dim_pp), ks) / dim_pp) / dim_pp
-    w_in = np.exp(-2j * np.pi * np.outer(ks, np.arange(dim) + kd) / dim_p)
-    full = w_out @ w_in                                   # (dim_pp, dim)
+    theta = np.arange(dim_pp)[:, None] / dim_pp - (np.arange(dim)[None, :] + kd) / dim_p
+    den = np.sin(np.pi * theta)
+    small = np.abs(den) < 1e-12
+    ratio = np.where(small, float(K), np.sin(np.pi * K * theta) / np.where(small, 1.0, den))
+    full = np.exp(-1j * np.pi * theta) * ratio / dim_pp            # (dim_pp, dim)
     E = np.zeros((dim, dim), dtype=complex)
     if dim_pp > dim:
         E[:] = full[kf:kf + dim]
     else:
         E[-kf:-kf + dim_pp] = full
+    E.setflags(write=False)
     return E
 
 
@@ -56,15 +65,15 @@ def zoom_operator(dim, scale):
     return _zoom_operator_even(dim, float(scale))
 
 
-def _reflect_matrix(size, pad):
-    """R (size + 2 pad, size) with R X R^T == np.pad(X, pad, 'reflect')."""
-    big = size + 2 * pad
-    idx = np.arange(big) - pad
-    idx = np.where(idx < 0, -idx, idx)
-    idx = np.where(idx >= size, 2 * (size - 1) - idx, idx)
-    R = np.zeros((big, size))
-    R[np.arange(big), idx] = 1.0
-    return R
+def _fold_reflect(A, size, pad):
+    """A @ R for the reflect-padding matrix R ((size + 2 pad) x size, R X R^T == np.pad(X, pad, 'reflect')): the
+    padded columns of A are folded back onto the columns they mirror."""
+    if pad == 0:
+        return np.array(A)
+    E = np.array(A[:, pad:pad + size])
+    E[:, 1:pad + 1] += A[:, pad - 1::-1][:, :pad]                       # padded column i (< pad) mirrors column pad - i
+    E[:, size - 1 - pad:size - 1] += A[:, :pad + size - 1:-1][:, :pad]  # column pad+size+t mirrors column size-2-t
+    return E
 
 
 def padded_size(size, scal_list):
@@ -90,6 +99,12 @@ def _square_crop(size_in, size, cy):
 
 
 def channel_operators(size, scal_list, inverse=False, out_size=None, crop_to=None):
+    return _channel_operators(int(size), tuple(float(v) for v in np.asarray(scal_list, dtype=float)), bool(inverse),
+                              None if out_size is None else int(out_size), None if crop_to is None else int(crop_to))
+
+
+@functools.lru_cache(maxsize=16)
+def _channel_operators(size, scal_list, inverse, out_size, crop_to):
     """Per-channel complex operators of ``cube_rescaling_wavelengths``.
 
     forward (``inverse=False``): frames of ``size`` -> reflect pad to ``padded_size`` -> zoom by s_c [-> centre crop to
@@ -100,13 +115,12 @@ def channel_operators(size, scal_list, inverse=False, out_size=None, crop_to=Non
     ops = []
     if not inverse:
         big = padded_size(size, scal_list)
-        R = _reflect_matrix(size, (big - size) // 2) if big != size else np.eye(size)
         y0, dout = 0, big
         if crop_to is not None and crop_to != big:
             cy, _ = frame_center(np.zeros((big, big)))
             y0, dout = _square_crop(big, int(crop_to), cy)
         for s in scal_list:
-            E = zoom_operator(big, s) @ R
+            E = _fold_reflect(zoom_operator(big, s), size, (big - size) // 2)
             ops.append(E[y0:y0 + dout])
     else:
         y0, dout = 0, size
