@@ -115,6 +115,10 @@ int vipmi_rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int6
 int vipmi_subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B,
                             int64_t n, int64_t k, int64_t P, float* R, float* recon);
 
+/* out = a*x + b*y (y may be NULL: out = a*x), float32, `total` elements: the elementwise glue of the reference's
+ * numpy expressions (reconstructed = matrix - residuals, pca_fullfr.py:1731; STIM normalisation, metrics/stim.py:118). */
+int vipmi_lincomb_f32(vipmi_ctx* ctx, const float* x, const float* y, float a, float b, int64_t total, float* out);
+
 /* ---- FFT zoom of the spectral channels (ADI+mSDI): scale_fft / frame_rescaling(imlib='vip-fft') /
  * cube_rescaling_wavelengths, preproc/rescaling.py:1114-1217, 636-672, 427-475 ----
  * The zoom is a separable linear map Y = Re(E X E^T); E (dout x din, complex, one per scale factor, reflect padding and

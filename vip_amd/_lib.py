@@ -40,6 +40,7 @@ _SIGS = {
                             ctypes.c_int),
     "vipmi_rowspace_gemm_f32": ([c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p], True, ctypes.c_int),
     "vipmi_subtract_gemm_f32": ([c_f32p, c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p], True, ctypes.c_int),
+    "vipmi_lincomb_f32": ([c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, i64, c_f32p], True, ctypes.c_int),
     "vipmi_zoom_frames_f32": ([c_f32p, i64, i64, c_f32p, c_f32p, ctypes.c_void_p, i64, i64, c_f32p, c_f32p], True,
                               ctypes.c_int),
     "vipmi_derotate_f32": ([c_f32p, ctypes.c_void_p, i64, i64, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int],

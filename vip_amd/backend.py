@@ -191,6 +191,16 @@ def apply_mask(M, mask_u8, fill=0.0, out=None):
     return out
 
 
+def lincomb(x, y=None, a=1.0, b=1.0):
+    """a*x + b*y (y optional) elementwise on float32 cuda tensors of equal shape."""
+    ctx = get_context(x.device.index)
+    x = x.contiguous()
+    yy = None if y is None else y.contiguous()
+    out = empty(tuple(x.shape), device=x.device.index)
+    ctx.call("vipmi_lincomb_f32", ptr(x), ptr(yy), ctypes.c_float(a), ctypes.c_float(b), x.numel(), ptr(out))
+    return out
+
+
 def gram(M):
     torch = _torch()
     ctx = get_context(M.device.index)

@@ -337,6 +337,11 @@ int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int
   return eigh_leading(ctx, G, batch, n, k, nact, evals, evecs);
 }
 
+int vipmi_lincomb_f32(vipmi_ctx* ctx, const float* x, const float* y, float a, float b, int64_t total, float* out) {
+  CTX_GUARD();
+  return lincomb_f32(ctx, x, y, a, b, total, out);
+}
+
 int vipmi_zoom_frames_f32(vipmi_ctx* ctx, const float* X, int64_t nb, int64_t din, const float* Er, const float* Ei,
                           const int32_t* chan, int64_t dout, int64_t ldk, float* work, float* out) {
   CTX_GUARD();

@@ -156,6 +156,12 @@ __global__ void scale_rows_kernel(const float* __restrict__ in, const float* __r
     out[e] = in[e] * rs[e / P];
 }
 
+__global__ void lincomb_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b,
+                               int64_t total, float* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = y ? a * x[e] + b * y[e] : a * x[e];
+}
+
 int grid_for(int64_t total, int cap) {
   int64_t b = cdiv(total, 256);
   return (int)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -223,6 +229,13 @@ int convert_evecs(vipmi_ctx* ctx, const double* evecs, const double* evals, int6
   const int nld = (int)cdiv(n, 32) * 32, kld = (int)cdiv(k, 32) * 32;
   hipLaunchKernelGGL(convert_evecs_kernel, dim3(grid_for((int64_t)kld * nld, 1024)), dim3(256), 0,
                      ctx->stream, evecs, evals, (int)n, (int)k, Ekn, nld, Enk, kld, inv_sigma);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+int lincomb_f32(vipmi_ctx* ctx, const float* x, const float* y, float a, float b, int64_t total, float* out) {
+  VIPMI_REQUIRE(x && out && total > 0, "lincomb: bad arguments");
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, ctx->stream, x, y, a, b, total, out);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }

@@ -61,10 +61,13 @@ def normalized_stim_map(cube, angle_list, mask=None, **rot_options):
         if np.isscalar(mask):
             inv_map = mask_circle(inv_map, mask)
         else:
-            inv_map = inv_map * B.to_device_f32(np.asarray(mask, dtype=np.float32))
-    torch = B._torch()
-    max_inv = float(torch.max(torch.nan_to_num(inv_map, nan=-np.inf)).item())
+            # binary mask (ones where the maximum may be taken): zero the rest
+            torch = B._torch()
+            off = torch.from_numpy((np.asarray(mask) == 0).astype(np.uint8)).to(inv_map.device)
+            inv_map = B.apply_mask(inv_map.reshape(1, -1), off.reshape(-1), 0.0).reshape(inv_map.shape)
+    # np.nanmax over the map = NaN-aware 'max' collapse of the pixels seen as a one-pixel cube
+    max_inv = float(B.collapse(inv_map.reshape(-1, 1, 1), "max").item())
     if max_inv <= 0:
         raise ValueError("The normalization value is found to be {}".format(max_inv))
     der = B.derotate(t, np.asarray(angle_list, dtype=np.float64))
-    return _wrap(_stim_dev(der) / max_inv, dev_in, cube)
+    return _wrap(B.lincomb(_stim_dev(der), None, 1.0 / max_inv), dev_in, cube)

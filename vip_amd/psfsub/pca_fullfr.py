@@ -289,7 +289,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         if verbose:
             print("Done de-rotating and combining")
         if full_output:
-            recon_cube = (M - R).reshape(n, y, x)
+            recon_cube = B.lincomb(M, R, 1.0, -1.0).reshape(n, y, x)
             return recon_cube, residuals_cube, residuals_cube_, frame
         return frame
 
