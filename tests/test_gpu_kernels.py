@@ -354,6 +354,28 @@ def test_rotate_masks_and_cube_direct(B):
     assert np.abs(got - g["derot_128"]).max() < 5e-5
 
 
+@pytest.mark.parametrize("N", [21, 101, 200, 301])
+def test_derotate_generic_sizes_vs_oracle(B, N):
+    """Non-power-of-two padded lengths take the real-split direct path (rot_variant 0) -- every rot90 quadrant, angles
+    whose shears land next to integer shifts, NaN mask -- and the complex-field correlation (rot_variant 1) agrees."""
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(N)
+    angles = np.array([10.0, 50.0, 100.0, 200.0, 300.0, 359.0, -44.9, 45.1, 180.0, 0.0])
+    n = len(angles) if N < 300 else 5
+    cube = rng.standard_normal((n, N, N)).astype(np.float32)
+    cube[1, 3:6, 4] = np.nan
+    ref = O.cube_derotate(cube, angles[:n])
+    ctx = B.get_context()
+    try:
+        for variant in ((0, 1) if N <= 200 else (0,)):
+            ctx.set_option("rot_variant", variant)
+            got = cube_derotate(cube, angles[:n], method="direct")
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            assert np.nanmax(np.abs(got - ref)) < (2e-5 if variant == 0 else 5e-5), variant
+    finally:
+        ctx.set_option("rot_variant", 0)
+
+
 @pytest.mark.parametrize("N", [80, 81])
 def test_cube_derotate_reference_roundtrip(B, N):
     # reference tests/pre_3_10/test_preproc_rotation.py:21-69: 24 successive derotations of ones

@@ -184,6 +184,8 @@ int derotate_fft(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, cons
 bool derotate_fft_supported(const RotGeom& g);
 int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
                   float* out, int mask_nan, int mask_zero);  // derotate_fft2.hip (real-split, default)
+int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
+                     float* out, int mask_nan, int mask_zero);  // derotate_direct2.hip (real-split correlations)
 
 // host-side geometry / angle split (derotation.py:154-158, cosmetics.py:210-215, derotation.py:577-602)
 static void rot_geometry(int N, RotGeom& g) {
@@ -249,7 +251,9 @@ int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int
     if (ctx->opt("rot_variant", 0) == 1) return derotate_fft(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     return derotate_fft2(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
   }
-  return derotate_direct(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+  // any other padded length: real-split correlations (rot_variant 1: the complex-field correlation of this file)
+  if (ctx->opt("rot_variant", 0) == 1) return derotate_direct(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+  return derotate_direct2(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
 }
 
 }  // namespace vipmi

@@ -1,0 +1,412 @@
+// derotate_direct2.hip -- "real-split" DIRECT derotation: the generic path for padded lengths that are not a power of
+// two (odd frame sizes -- the usual case in practice: 101 px -> Le = 402 = 2*3*67, 201 px -> Le = 802 = 2*401 --
+// and even sizes such as 200 px -> Le = 800).
+//
+// Same decomposition as derotate_fft2.hip (three passes of REAL circular sinc shifts plus rank-one Nyquist
+// corrections, formulas in that file's header; re-validated against the reference for odd and even frame sizes and
+// all quadrants to 1e-15 in float64), but every real shift is evaluated as the correlation it is,
+//     (R_s x)[m] = sum_j x[j] r(m - j - s),      r(t) = sin(pi t) cos(pi t / Le) / (Le sin(pi t / Le))
+// using the zero structure of the problem (N of Le inputs or outputs are live in every pass): 12 N^3 real
+// multiply-adds per frame, against 44 N^3 for the complex-field correlation of derotate.hip, and with
+//   * one LINEAR table of kernel values per line in LDS, T[u] = r(u + shift) for u in [-nin, nout): since
+//     sin(pi (d - s)) = -(-1)^d sin(pi s), an entry costs one float32 sincos instead of three float64 ones;
+//   * a register-blocked Toeplitz product: a lane owns 4 consecutive outputs, inputs are consumed 4 at a time, so one
+//     step is 2 aligned 16-byte LDS reads (4 inputs broadcast + 4 new table entries; the other 4 table entries are
+//     the previous step's) for 16 FMAs;
+//   * the column pass works on 16-column tiles staged through LDS (64-byte row segments).
+// K = sum_X R_{s_X} beta (the one term that couples all columns) is evaluated in the frequency domain with explicit
+// DFT sums over an LDS table of the Le-th roots of unity (8 N^2 complex multiply-adds per frame).
+#include "common.h"
+#include "rot_common.h"
+
+namespace vipmi {
+
+namespace {
+
+struct AuxD {          // per-batch auxiliary arrays (device), as in derotate_fft2.hip
+  float* beta;         // [nf][N]
+  float* bf;           // [nf]
+  float* kv;           // [nf][N]
+  float* gam;          // [nf][Le]   (-1)^X gamma_X
+  float* gsum;         // [nf]
+};
+
+__device__ __forceinline__ float sin_pi_d(double s) {     // sin(pi s), argument reduced in float64
+  // reduce to [-1/2, 1/2] (NOT [-1, 1]: float32 would lose the distance to the zero at +-1, and the table divides
+  // this by an equally small sine, so the relative error matters): sin(pi s) = (-1)^n sin(pi (s - n))
+  const double n = rint(s);
+  const float v = sinpif((float)(s - n));
+  return (((long long)n) & 1) ? -v : v;
+}
+
+// T[u + OFF] = r(u + d0 - s) for u in [-OFF, nout_pad): d0 = (first output index) - (first input index).
+// r(t) = sin(pi t) cos(pi t/Le) / (Le sin(pi t/Le)), with sin(pi (d - s)) = -(-1)^d sin(pi s) for integer d.
+__device__ __forceinline__ void fill_table(float* __restrict__ T, int OFF, int nout_pad, int d0, double s, int Le,
+                                           int tid, int nthreads) {
+  const float sps = sin_pi_d(s);
+  const float invLe = 1.0f / (float)Le;
+  const double dLe = 1.0 / (double)Le;
+  for (int e = tid; e < OFF + nout_pad; e += nthreads) {
+    const int d = e - OFF + d0;                    // integer offset m - j
+    const double delta = (double)d - s;
+    double th = delta * dLe;                       // turns of pi: angle = pi * th
+    th -= rint(th);                                // cot has period pi: reduce to [-1/2, 1/2], where float32 keeps the
+                                                   // distance to the only pole (th = 0) to full relative precision
+    float sn, cs;
+    sincospif((float)th, &sn, &cs);
+    float r;
+    if (fabsf(sn) < 1e-9f) {
+      // t = delta is a multiple of Le (r = 1) -- or float32 lost the angle: the limit sin(pi t)/(pi t) -> handled as 1
+      r = (fabs(delta - (double)Le * rint(delta * dLe)) < 1e-6) ? 1.0f : 0.0f;
+    } else {
+      const float sgn = (d & 1) ? 1.0f : -1.0f;    // -(-1)^d
+      r = sgn * sps * cs * invLe / sn;
+    }
+    T[e] = r;
+  }
+}
+
+// Register-blocked Toeplitz product of one line:  y[m0 + o] = sum_j x[j] T[(m0 + o) - j + OFF],  o = 0..3
+// x: nin_pad floats (zero padded to a multiple of 4, 16-byte aligned); T: 16-byte aligned, OFF multiple of 4;
+// m0 multiple of 4 (relative output index).
+__device__ __forceinline__ void toeplitz4(const float* __restrict__ x, int nin_pad, const float* __restrict__ T,
+                                          int OFF, int m0, float (&acc)[4]) {
+  acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+  int base = m0 + OFF;                              // index of T for (o = 0, j = 4q)
+  float4 tB = *reinterpret_cast<const float4*>(T + base);
+  for (int q = 0; q < nin_pad; q += 4) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + q);
+    const float4 tA = *reinterpret_cast<const float4*>(T + base - 4);
+    // t[o - i] for o, i in 0..3: indices -3..3 = (tA.y, tA.z, tA.w, tB.x, tB.y, tB.z, tB.w)
+    acc[0] += xv.x * tB.x + xv.y * tA.w + xv.z * tA.z + xv.w * tA.y;
+    acc[1] += xv.x * tB.y + xv.y * tB.x + xv.z * tA.w + xv.w * tA.z;
+    acc[2] += xv.x * tB.z + xv.y * tB.y + xv.z * tB.x + xv.w * tA.w;
+    acc[3] += xv.x * tB.w + xv.y * tB.z + xv.z * tB.y + xv.w * tB.x;
+    tB = tA;
+    base -= 4;
+  }
+}
+
+__device__ __forceinline__ void src_map_d(int q, int Y, const RotGeom& g, int& base, int& stride) {
+  switch (q) {
+    case 1: stride = g.N; base = -g.off * g.N + (g.Lc - Y - g.off); break;
+    case 2: stride = -1; base = (g.Lc - Y - g.off) * g.N + (g.Lc - g.off); break;
+    case 3: stride = -g.N; base = (g.Lc - g.off) * g.N + (Y - g.off); break;
+    default: stride = 1; base = (Y - g.off) * g.N - g.off; break;
+  }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {      // sum over the workgroup (<= 16 waves)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < nw; ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+// ---- shear 1: one workgroup per data row; N inputs -> Le outputs ----
+__global__ __launch_bounds__(1024) void ds_shear1(const float* __restrict__ in, const RotFrame* __restrict__ fr,
+                                                  RotGeom g, float* __restrict__ A1r, AuxD aux, int f0, int Npad,
+                                                  int Lpad) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* x = smem;                       // [Npad]
+  float* T = smem + Npad;                // [Npad + Lpad]
+  float* red = T + Npad + Lpad;          // [16]
+  const int fl = blockIdx.y, f = f0 + fl, yrel = blockIdx.x;
+  const RotFrame p = fr[f];
+  const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+  const int c0 = (p.q == 2 || p.q == 3) ? g.alt0 : g.off;
+  const int Y = r0 + yrel;
+  const double s = p.a * (double)(Y - g.c);
+  int b, st;
+  src_map_d(p.q, Y, g, b, st);
+  const float* frame = in + (int64_t)f * g.N * g.N;
+  float alt = 0.f;
+  for (int j = threadIdx.x; j < Npad; j += blockDim.x) {
+    float v = 0.f;
+    if (j < g.N) {
+      const float t = frame[b + (c0 + j) * st];
+      v = (t == t) ? t : 0.f;
+    }
+    x[j] = v;
+    alt += ((c0 + j) & 1) ? -v : v;
+  }
+  // outputs X = 0 .. Le-1, inputs at canvas columns c0 + j: d = X - (c0 + j) -> d0 = -c0
+  fill_table(T, Npad, Lpad, -c0, s, g.Le, threadIdx.x, blockDim.x);
+  alt = block_sum(alt, red);            // contains the barrier that publishes x and T
+  float* orow = A1r + ((int64_t)fl * g.N + yrel) * g.Le;
+  for (int m0 = 4 * threadIdx.x; m0 < g.Le; m0 += 4 * blockDim.x) {
+    float acc[4];
+    toeplitz4(x, Npad, T, Npad, m0, acc);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (m0 + o < g.Le) orow[m0 + o] = acc[o];
+  }
+  if (threadIdx.x == 0) aux.beta[fl * g.N + yrel] = sin_pi_d(s) * alt / (float)g.Le;
+}
+
+// Bf[f] = sum_Y (-1)^Y beta_Y
+__global__ __launch_bounds__(256) void ds_bf(const RotFrame* __restrict__ fr, RotGeom g, AuxD aux, int f0) {
+  __shared__ float red[16];
+  const int fl = blockIdx.x;
+  const RotFrame p = fr[f0 + fl];
+  const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+  float s = 0.f;
+  for (int y = threadIdx.x; y < g.N; y += blockDim.x) {
+    const float b = aux.beta[fl * g.N + y];
+    s += ((r0 + y) & 1) ? -b : b;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) aux.bf[fl] = s;
+}
+
+// K[m] = Re sum_k Bhat[k] g[k] e^{2 pi i k (off + m)/Le},  Bhat[k] = sum_y beta[y] e^{-2 pi i k (r0 + y)/Le},
+// g(k) = sum_X exp(-2 pi i ks b (X - c)/Le)/Le in closed form (ks = signed frequency; Nyquist: real part).
+__global__ __launch_bounds__(1024) void ds_aux_k(const RotFrame* __restrict__ fr, RotGeom g, AuxD aux, int f0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* root = reinterpret_cast<float2*>(smem);          // [Le] e^{+2 pi i t/Le}
+  float2* H = root + g.Le;                                  // [Le]
+  float* beta = reinterpret_cast<float*>(H + g.Le);         // [N]
+  const int fl = blockIdx.x;
+  const RotFrame p = fr[f0 + fl];
+  const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+  const int Le = g.Le;
+  for (int t = threadIdx.x; t < Le; t += blockDim.x) {
+    float sn, cs;
+    sincospif(2.0f * (float)t / (float)Le, &sn, &cs);
+    root[t] = make_float2(cs, sn);
+  }
+  for (int y = threadIdx.x; y < g.N; y += blockDim.x) beta[y] = aux.beta[fl * g.N + y];
+  __syncthreads();
+  for (int k = threadIdx.x; k < Le; k += blockDim.x) {
+    float re = 0.f, im = 0.f;
+    int idx = (int)(((long long)k * r0) % Le);             // k (r0 + y) mod Le, advanced by k per step
+    for (int y = 0; y < g.N; ++y) {
+      const float2 w = root[idx];
+      re += beta[y] * w.x;                                  // e^{-i phi} = (cos, -sin)
+      im -= beta[y] * w.y;
+      idx += k;
+      if (idx >= Le) idx -= Le;
+    }
+    const int ks = (k < Le / 2) ? k : k - Le;
+    const double kbv = (double)ks * p.b;
+    const double den = sinpi(kbv / (double)Le);
+    const double ratio = (fabs(den) < 1e-300) ? (double)Le : sinpi(kbv) / den;
+    double sn, cs;
+    sincospi(-2.0 * kbv * (0.5 * (double)(Le - 1) - (double)g.c) / (double)Le, &sn, &cs);
+    float gre = (float)(ratio * cs / (double)Le), gim = (float)(ratio * sn / (double)Le);
+    if (k == Le / 2) gim = 0.f;
+    H[k] = make_float2(re * gre - im * gim, re * gim + im * gre);
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m < g.N; m += blockDim.x) {
+    const int Yo = g.off + m;
+    float re = 0.f;
+    int idx = 0;
+    for (int k = 0; k < Le; ++k) {
+      const float2 w = root[idx], h = H[k];
+      re += h.x * w.x - h.y * w.y;
+      idx += Yo;
+      if (idx >= Le) idx -= Le;
+    }
+    aux.kv[fl * g.N + m] = re;
+  }
+}
+
+// ---- shear 2: one workgroup per 16-column tile; N live input rows -> N output rows (crop window) ----
+template <int CT>          // columns per tile (16 = one 64-byte segment per row; fewer for large frames: LDS)
+__global__ __launch_bounds__(1024) void ds_shear2(const float* __restrict__ A1r, const RotFrame* __restrict__ fr,
+                                                  RotGeom g, float* __restrict__ A2r, AuxD aux, int f0, int Npad) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int CS = Npad + 4;                           // column stride in LDS (16-byte aligned, spreads the banks)
+  float* xin = smem;                                 // [CT][CS]   column-major copy of the tile
+  float* T = xin + CT * CS;                          // [CT][2 Npad]
+  float* yout = T + CT * 2 * Npad;                   // [CT][CS]
+  float* alts = yout + CT * CS;                      // [CT]
+  float* sps = alts + CT;                            // [CT]
+  const int fl = blockIdx.y, f = f0 + fl, X0 = blockIdx.x * CT;
+  const RotFrame p = fr[f];
+  const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+  const int ncol = (g.Le - X0 < CT) ? (g.Le - X0) : CT;
+  const float* src = A1r + (int64_t)fl * g.N * g.Le + X0;
+  // tile in: 64-byte row segments, transposed into LDS
+  for (int e = threadIdx.x; e < Npad * CT; e += blockDim.x) {
+    const int row = e / CT, c = e % CT;
+    xin[c * CS + row] = (row < g.N && c < ncol) ? src[(int64_t)row * g.Le + c] : 0.f;
+  }
+  // kernel tables: outputs at canvas rows off + m, inputs at rows r0 + y: d0 = off - r0
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int c = wave; c < CT; c += nw) {
+    const double s = p.b * (double)(X0 + c - g.c);
+    fill_table(T + c * 2 * Npad, Npad, Npad, g.off - r0, s, g.Le, lane, 64);
+    if (lane == 0) sps[c] = sin_pi_d(s) / (float)g.Le;
+  }
+  __syncthreads();
+  // alternating sums of the columns (gamma) -- one wave per column
+  for (int c = wave; c < CT; c += nw) {
+    float a = 0.f;
+    for (int y = lane; y < g.N; y += 64) {
+      const float v = xin[c * CS + y];
+      a += ((r0 + y) & 1) ? -v : v;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) alts[c] = a;
+  }
+  // Toeplitz products: tasks = (column, block of 4 outputs)
+  const int nblk = Npad / 4;
+  for (int t = threadIdx.x; t < CT * nblk; t += blockDim.x) {
+    const int c = t / nblk, m0 = 4 * (t % nblk);
+    float acc[4];
+    toeplitz4(xin + c * CS, Npad, T + c * 2 * Npad, Npad, m0, acc);
+    *reinterpret_cast<float4*>(yout + c * CS + m0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  // tile out with the rank-one correction  - sin(pi s_X) (-1)^X Bf/Le (-1)^Y
+  const float bfl = aux.bf[fl];
+  float* dst = A2r + (int64_t)fl * g.N * g.Le + X0;
+  for (int e = threadIdx.x; e < g.N * CT; e += blockDim.x) {
+    const int m = e / CT, c = e % CT;
+    if (c < ncol) {
+      const int X = X0 + c;
+      const float kc = sps[c] * ((X & 1) ? -bfl : bfl);
+      const float sg = ((g.off + m) & 1) ? -1.f : 1.f;
+      dst[(int64_t)m * g.Le + c] = yout[c * CS + m] - sg * kc;
+    }
+  }
+  if (threadIdx.x < ncol) {
+    const int X = X0 + threadIdx.x;
+    const float sn = sps[threadIdx.x];
+    aux.gam[fl * g.Le + X] = ((X & 1) ? -sn : sn) * alts[threadIdx.x];
+  }
+}
+
+// Gam[f] = sum_X (-1)^X gamma_X
+__global__ __launch_bounds__(256) void ds_gamma(AuxD aux, int Le) {
+  __shared__ float red[16];
+  const int fl = blockIdx.x;
+  float s = 0.f;
+  for (int x = threadIdx.x; x < Le; x += blockDim.x) s += aux.gam[fl * Le + x];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) aux.gsum[fl] = s;
+}
+
+// ---- shear 3: one workgroup per output row; Le inputs -> N outputs, corrections, mask restore ----
+__global__ __launch_bounds__(256) void ds_shear3(const float* __restrict__ A2r, const RotFrame* __restrict__ fr,
+                                                 RotGeom g, const float* __restrict__ in, float* __restrict__ out,
+                                                 AuxD aux, int f0, int mask_nan, int mask_zero, int Npad, int Lpad) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* x = smem;                       // [Lpad]
+  float* T = smem + Lpad;                // [Lpad + Npad]
+  const int fl = blockIdx.y, f = f0 + fl, m = blockIdx.x;
+  const RotFrame p = fr[f];
+  const int Y = g.off + m;
+  const double s = p.a * (double)(Y - g.c);
+  const float* irow = A2r + ((int64_t)fl * g.N + m) * g.Le;
+  for (int j = threadIdx.x; j < Lpad; j += blockDim.x) x[j] = (j < g.Le) ? irow[j] : 0.f;
+  // outputs at canvas columns off + jo, inputs at columns 0..Le-1: d0 = off
+  fill_table(T, Lpad, Npad, g.off, s, g.Le, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const float gs = aux.gsum[fl];
+  const float c1 = sin_pi_d(s) / (float)g.Le * (aux.kv[fl * g.N + m] + ((Y & 1) ? -gs : gs));
+  const int64_t ob = ((int64_t)f * g.N + m) * g.N;
+  for (int m0 = 4 * threadIdx.x; m0 < g.N; m0 += 4 * blockDim.x) {
+    float acc[4];
+    toeplitz4(x, Lpad, T, Lpad, m0, acc);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int j = m0 + o;
+      if (j < g.N) {
+        const float sg = ((g.off + j) & 1) ? -1.f : 1.f;
+        float re = acc[o] - sg * c1;
+        const float srcv = in[ob + j];
+        if (mask_nan && !(srcv == srcv)) re = __uint_as_float(0x7fc00000u);
+        if (mask_zero && srcv == 0.f) re = 0.f;
+        out[ob + j] = re;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n, float* out,
+                     int mask_nan, int mask_zero) {
+  const int Npad = (int)cdiv(g.N, 4) * 4, Lpad = (int)cdiv(g.Le, 4) * 4;
+  const int64_t per_frame = (int64_t)g.N * g.Le;
+  int64_t chunk = ctx->opt("rot_batch", 0);
+  if (chunk <= 0) {
+    const int64_t budget = ctx->opt("rot_ws_mb", 2048) * (int64_t)(1 << 20);
+    chunk = budget / (2 * per_frame * (int64_t)sizeof(float));
+  }
+  if (chunk < 1) chunk = 1;
+  if (chunk > n) chunk = n;
+  if (chunk > 65535) chunk = 65535;
+  float *A1r = nullptr, *A2r = nullptr;
+  VIPMI_TRY(ws(ctx, "rot_a1", (size_t)(chunk * per_frame), &A1r));
+  VIPMI_TRY(ws(ctx, "rot_a2", (size_t)(chunk * per_frame), &A2r));
+  AuxD aux;
+  VIPMI_TRY(ws(ctx, "rot_beta", (size_t)(chunk * g.N), &aux.beta));
+  VIPMI_TRY(ws(ctx, "rot_bf", (size_t)chunk, &aux.bf));
+  VIPMI_TRY(ws(ctx, "rot_kv", (size_t)(chunk * g.N), &aux.kv));
+  VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * g.Le), &aux.gam));
+  VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
+  const size_t lds1 = (size_t)(2 * Npad + Lpad + 16) * sizeof(float);
+  const size_t ldsk = (size_t)(4 * g.Le + g.N) * sizeof(float);
+  int CT = 16;
+  auto lds2_for = [&](int ct) { return (size_t)(ct * (4 * Npad + 8) + 2 * ct) * sizeof(float); };
+  while (CT > 2 && lds2_for(CT) > 150 * 1024) CT >>= 1;
+  const size_t lds2 = lds2_for(CT);
+  const size_t lds3 = (size_t)(2 * Lpad + Npad) * sizeof(float);
+  VIPMI_REQUIRE(lds1 <= 160 * 1024 && ldsk <= 160 * 1024 && lds2 <= 160 * 1024 && lds3 <= 160 * 1024,
+                "derotate(direct): frame size %d too large for the LDS-resident tables", g.N);
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ds_shear1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds1));
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ds_aux_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)ldsk));
+  const void* k2 = CT == 16  ? reinterpret_cast<const void*>(ds_shear2<16>)
+                   : CT == 8 ? reinterpret_cast<const void*>(ds_shear2<8>)
+                   : CT == 4 ? reinterpret_cast<const void*>(ds_shear2<4>)
+                             : reinterpret_cast<const void*>(ds_shear2<2>);
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ds_shear3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds3));
+  // threads: one lane per block of 4 outputs
+  auto threads_for = [](int nout, int cap) {
+    int t = (int)cdiv(cdiv(nout, 4), 64) * 64;
+    return t < 64 ? 64 : (t > cap ? cap : t);
+  };
+  const int t1 = threads_for(g.Le, 1024), t3 = threads_for(g.N, 256);
+  int t2 = (int)cdiv((int64_t)CT * (Npad / 4), 64) * 64;
+  if (t2 > 1024) t2 = 1024;
+  if (t2 < 256) t2 = 256;
+  for (int64_t f0 = 0; f0 < n; f0 += chunk) {
+    const unsigned nf = (unsigned)((n - f0) < chunk ? (n - f0) : chunk);
+    hipLaunchKernelGGL(ds_shear1, dim3(g.N, nf), dim3(t1), lds1, ctx->stream, in, d_frames, g, A1r, aux, (int)f0, Npad,
+                       Lpad);
+    hipLaunchKernelGGL(ds_bf, dim3(nf), dim3(256), 0, ctx->stream, d_frames, g, aux, (int)f0);
+    hipLaunchKernelGGL(ds_aux_k, dim3(nf), dim3(1024), ldsk, ctx->stream, d_frames, g, aux, (int)f0);
+    {
+      const dim3 grid2((unsigned)cdiv(g.Le, CT), nf);
+      if (CT == 16)
+        hipLaunchKernelGGL(ds_shear2<16>, grid2, dim3(t2), lds2, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, Npad);
+      else if (CT == 8)
+        hipLaunchKernelGGL(ds_shear2<8>, grid2, dim3(t2), lds2, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, Npad);
+      else if (CT == 4)
+        hipLaunchKernelGGL(ds_shear2<4>, grid2, dim3(t2), lds2, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, Npad);
+      else
+        hipLaunchKernelGGL(ds_shear2<2>, grid2, dim3(t2), lds2, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, Npad);
+    }
+    hipLaunchKernelGGL(ds_gamma, dim3(nf), dim3(256), 0, ctx->stream, aux, g.Le);
+    hipLaunchKernelGGL(ds_shear3, dim3(g.N, nf), dim3(t3), lds3, ctx->stream, A2r, d_frames, g, in, out, aux, (int)f0,
+                       mask_nan, mask_zero, Npad, Lpad);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  return VIPMI_OK;
+}
+
+}  // namespace vipmi
