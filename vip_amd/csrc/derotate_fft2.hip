@@ -157,6 +157,29 @@ struct Tasks {
   }
 };
 
+// ---- blocked intermediates (plans with one wave per line) ----
+// A wave of a row kernel holds a PAIR of rows as one complex line, a wave of the column kernel a pair of columns;
+// with row-major intermediates the column kernel touches 8 bytes of a different 128-byte line with every lane, and
+// every such request moves a whole line between L2 and L1 (measured: 1.3 ms for the loads and 1.2 ms for the stores of
+// shear 2 at C2, the transforms hidden behind them).  Any two lines may share a transform, so the pairs are chosen
+// 64 apart -- rows (Y, Y+64), columns (X, X+64) -- and the intermediates are stored as 2x2 blocks
+//     blk[t][u] = (Y1@X1, Y2@X1, Y1@X2, Y2@X2),  Y1 = off + 128 (t/64) + t%64,  X1 = 128 (u/64) + u%64:
+// element j of a line lives in lane j%64, so both rows of a block are registers of the SAME lane of the column
+// kernel and both columns registers of the same lane of the row kernels -- every access is one float4 with no
+// shuffle: 16 bytes per scattered request in shear 2 (half the requests), 1 KB contiguous per instruction in shears
+// 1 and 3.  Block rows per frame: N/2 + 1 (the last one only holds canvas row off + N, live when the rot90
+// pre-step moves the data down by one row).
+template <class P>
+struct Blk {
+  static constexpr int N = P::L / 4, OFF = 3 * P::L / 8;
+  static constexpr int NB = N / 2 + 1;          // block rows per frame
+  static constexpr int NBC = P::L / 2;          // block columns
+  static constexpr int NG = N / 128;            // groups of 64 block rows
+  // register of line element jb + lane (jb a multiple of 64)
+  static constexpr int reg(int jb) { return ((jb % P::M1) / 64) * P::R1 + jb / P::M1; }
+  static_assert(N % 128 == 0 && OFF % 64 == 0, "blocked layout needs N = L/4 a multiple of 128");
+};
+
 // affine source map of canvas'(Y, X) -> frame[base + X*stride] (rot90 folded in)
 __device__ __forceinline__ void src_map(int q, int Y, const RotGeom& g, int& base, int& stride) {
   switch (q) {
@@ -178,7 +201,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
                                // source frame's 64-byte sectors when the rot90 pre-step makes the gather column-wise
   Tasks<P, PW> tasks;
   tasks.init(counters, lds_all);
-  const int half = g.N / 2;
+  constexpr bool BLK = P::WPL == 1;             // blocked intermediates, rows paired 64 apart
+  const int half = BLK ? Blk<P>::NB : g.N / 2;
   const int npairs = nf * half;
   constexpr int PPT = 4;                        // line pairs per token of a wave (keeps the atomics under ~25 per us)
   const int ntask = PW ? (npairs + PPT - 1) / PPT : (npairs + P::LPB - 1) / P::LPB;
@@ -190,11 +214,16 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
     const bool live = pr < npairs;
     if (PW && !live) break;
     if (!live) pr = npairs - 1;
-    const int fl = pr / half, yrel = 2 * (pr % half), f = f0 + fl;
+    const int fl = pr / half, f = f0 + fl;
     const RotFrame p = fr[f];
     const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
     const int c0 = (p.q == 2 || p.q == 3) ? g.alt0 : g.off;
-    const int Y1 = r0 + yrel, Y2 = Y1 + 1;
+    const int tb = pr % half;                                       // block row (BLK)
+    const int Y1 = BLK ? g.off + 128 * (tb / 64) + (tb % 64) : r0 + 2 * tb;
+    const int Y2 = BLK ? Y1 + 64 : Y1 + 1;
+    const int yrel = Y1 - r0;
+    const bool lv1 = Y1 >= r0 && Y1 < r0 + g.N, lv2 = Y2 >= r0 && Y2 < r0 + g.N;   // always true unless BLK
+    if (BLK && !(live && (lv1 || lv2))) continue;                   // (one wave per line: no barrier inside)
     const float* frame = in + (int64_t)f * g.N * g.N;
     int b1, st1, b2, st2;
     src_map(p.q, Y1, g, b1, st1);
@@ -208,7 +237,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
         if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {       // compile-time window
           const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
           if (X >= c0 && X < c0 + g.N) {
-            const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
+            const float t1 = lv1 ? frame[b1 + X * st1] : 0.f, t2 = lv2 ? frame[b2 + X * st2] : 0.f;
             x1 = (t1 == t1) ? t1 : 0.f;
             x2 = (t2 == t2) ? t2 : 0.f;
           }
@@ -218,7 +247,19 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
     const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
     float alt1, alt2, sn1, sn2;
     pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
-    if (live) {
+    if constexpr (BLK) {
+      using B = Blk<P>;
+      float4* o = reinterpret_cast<float4*>(A1r) + ((int64_t)fl * B::NB + tb) * B::NBC + lane;
+#pragma unroll
+      for (int gq = 0; gq < P::L / 128; ++gq) {
+        const cf a = v[B::reg(128 * gq)], b = v[B::reg(128 * gq + 64)];
+        o[64 * gq] = make_float4(a.x, a.y, b.x, b.y);
+      }
+      if (lane == 0) {
+        if (lv1) aux.beta[fl * g.N + yrel] = sn1 * alt1;
+        if (lv2) aux.beta[fl * g.N + yrel + 64] = sn2 * alt2;
+      }
+    } else if (live) {
       float* o1 = A1r + ((int64_t)fl * g.N + yrel) * P::L;
       float* o2 = o1 + P::L;
 #pragma unroll
@@ -390,12 +431,15 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2(const float* __restrict
   }
 }
 
-// ---- shear 2 without the LDS tile (one wave per line): every wave reads and writes its two columns directly,
-// eight bytes per lane and row.  A load instruction then touches 64 different 128-byte lines, but the 16 column pairs
-// that share those lines are consecutive tokens of one XCD queue, so they are processed by waves of the same XCD at
-// about the same time: one HBM fetch per line, the rest L2 hits; the partial stores merge in the L2 the same way.
-// What it buys: no workgroup barrier and no global <-> LDS staging phase in which all eight waves of a workgroup
-// wait (36 % of the tiled kernel) -- a wave's memory latency now hides behind the transforms of the other waves.
+// ---- shear 2 without the LDS tile (one wave per line, blocked intermediates -- see Blk): every wave reads and writes
+// its two columns (X, X + 64) directly, one 2x2 block = 16 bytes per lane.  A load instruction then touches 64 different
+// 128-byte lines, but the 8 block columns that share those lines are consecutive tokens of one XCD queue, so they are
+// processed by waves of the same XCD at about the same time: one HBM fetch per line, the rest L2 hits; the partial
+// stores merge in the L2 the same way.  No workgroup barrier and no global <-> LDS staging phase in which all eight
+// waves of a workgroup wait (36 % of the tiled kernel).  Measured at C2 (400 x 512^2, 2.6 ms): transforms alone
+// 2.2 ms, loads alone 0.9 ms, stores alone 0.9 ms (with 8-byte row-major accesses: 1.3 + 1.2 ms) -- the kernel is bound
+// by the transforms' instruction stream (2443 VALU instructions per line pair, 69 % of them packed FP32 arithmetic,
+// issued at 75 % of the SIMD rate with two waves per SIMD), not by memory.
 template <class P>
 __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __restrict__ A1r,
                                                                 const RotFrame* __restrict__ fr, RotGeom g,
@@ -403,31 +447,32 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
                                                                 const cf* __restrict__ twtab,
                                                                 int* __restrict__ counters) {
   static_assert(P::WPL == 1, "rs_shear2_direct: one wave per line");
+  using B = Blk<P>;
   VIPMI_SLOT_PROLOGUE();
   Tasks<P, true> tasks;
   tasks.init(counters, lds_all);
-  constexpr int HALF = P::L / 2;                  // column pairs per frame
-  constexpr int TPG = 16;                         // 16 pairs = 32 columns = one 128-byte line of every row
-  const int ntask = nf * HALF;
+  constexpr int TPG = 8;                          // 8 block columns = one 128-byte line of every block row
+  const int ntask = nf * B::NBC;
   tasks.request();
   for (int task = tasks.template take<TPG>(); task < ntask; task = tasks.template take<TPG>()) {
     tasks.request();
-    const int fl = task / HALF, X1 = 2 * (task % HALF), X2 = X1 + 1, f = f0 + fl;
+    const int fl = task / B::NBC, u = task % B::NBC, f = f0 + fl;
+    const int X1 = 128 * (u / 64) + (u % 64), X2 = X1 + 64;
     const RotFrame p = fr[f];
     const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
-    const float* src = A1r + (int64_t)fl * g.N * P::L + X1;
+    const float4* src = reinterpret_cast<const float4*>(A1r) + (int64_t)fl * B::NB * B::NBC + u;
     cf v[P::VL];
 #pragma unroll
-    for (int ul = 0; ul < P::U1L; ++ul)
+    for (int i = 0; i < P::VL; ++i) v[i] = mkcf(0.f, 0.f);
 #pragma unroll
-      for (int n1 = 0; n1 < P::R1; ++n1) {
-        cf val = mkcf(0.f, 0.f);
-        if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {     // compile-time window
-          const int yrel = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul) - r0;
-          if (yrel >= 0 && yrel < g.N) val = *reinterpret_cast<const cf*>(src + (int64_t)yrel * P::L);
-        }
-        v[ul * P::R1 + n1] = val;
-      }
+    for (int G = 0; G <= B::NG; ++G) {
+      const int Y1 = B::OFF + 128 * G + lane, Y2 = Y1 + 64;
+      const bool lv1 = Y1 >= r0 && Y1 < r0 + B::N, lv2 = (G < B::NG) && Y2 >= r0 && Y2 < r0 + B::N;
+      float4 blk = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lv1 || lv2) blk = src[(int64_t)(64 * G + lane) * B::NBC];
+      v[B::reg(B::OFF + 128 * G)] = lv1 ? mkcf(blk.x, blk.z) : mkcf(0.f, 0.f);
+      if (G < B::NG) v[B::reg(B::OFF + 128 * G + 64)] = lv2 ? mkcf(blk.y, blk.w) : mkcf(0.f, 0.f);
+    }
     const double s1 = p.b * (double)(X1 - g.c), s2 = p.b * (double)(X2 - g.c);
     float alt1, alt2, sn1, sn2;
     pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
@@ -435,16 +480,14 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
     const float bfl = aux.bf[fl];
     const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
     const float k2c = sn2 * ((X2 & 1) ? -bfl : bfl);
-    float* dst = A2r + (int64_t)fl * g.N * P::L + X1;
+    float4* dst = reinterpret_cast<float4*>(A2r) + (int64_t)fl * B::NB * B::NBC + u;
 #pragma unroll
-    for (int ul = 0; ul < P::U1L; ++ul)
-#pragma unroll
-      for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
-        const int m = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);      // off == M1*NLO
-        const float sg = ((g.off + m) & 1) ? -1.f : 1.f;
-        *reinterpret_cast<cf*>(dst + (int64_t)m * P::L) =
-            mkcf(v[ul * P::R1 + n1].x - sg * k1c, v[ul * P::R1 + n1].y - sg * k2c);
-      }
+    for (int G = 0; G < B::NG; ++G) {
+      const cf a = v[B::reg(B::OFF + 128 * G)], b = v[B::reg(B::OFF + 128 * G + 64)];
+      const float sg = ((B::OFF + lane) & 1) ? -1.f : 1.f;           // rows Y and Y + 64 (+128 G): same parity
+      dst[(int64_t)(64 * G + lane) * B::NBC] =
+          make_float4(a.x - sg * k1c, b.x - sg * k1c, a.y - sg * k2c, b.y - sg * k2c);
+    }
     if (lane == 0) {
       aux.gam[fl * P::L + X1] = ((X1 & 1) ? -sn1 : sn1) * alt1;
       aux.gam[fl * P::L + X2] = ((X2 & 1) ? -sn2 : sn2) * alt2;
@@ -476,6 +519,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
   constexpr bool PW = P::WPL == 1;
   Tasks<P, PW> tasks;
   tasks.init(counters, lds_all);
+  constexpr bool BLK = P::WPL == 1;             // blocked intermediates, rows paired 64 apart
   const int half = g.N / 2;
   const int npairs = nf * half;
   constexpr int PPT = 4;                        // line pairs per token of a wave (keeps the atomics under ~25 per us)
@@ -488,27 +532,39 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
     const bool live = pr < npairs;
     if (PW && !live) break;
     if (!live) pr = npairs - 1;
-    const int fl = pr / half, m = 2 * (pr % half), f = f0 + fl;
+    const int fl = pr / half, tb = pr % half, f = f0 + fl;
+    const int m = BLK ? 128 * (tb / 64) + (tb % 64) : 2 * tb, dm = BLK ? 64 : 1;     // output rows m, m + dm
     const RotFrame p = fr[f];
-    const int Y1 = g.off + m, Y2 = Y1 + 1;
-    const float* i1 = A2r + ((int64_t)fl * g.N + m) * P::L;
-    const float* i2 = i1 + P::L;
+    const int Y1 = g.off + m, Y2 = Y1 + dm;
     cf v[P::VL];
+    if constexpr (BLK) {
+      using B = Blk<P>;
+      const float4* ib = reinterpret_cast<const float4*>(A2r) + ((int64_t)fl * B::NB + tb) * B::NBC + lane;
 #pragma unroll
-    for (int ul = 0; ul < P::U1L; ++ul)
-#pragma unroll
-      for (int n1 = 0; n1 < P::R1; ++n1) {
-        const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
-        v[ul * P::R1 + n1] = mkcf(i1[X], i2[X]);
+      for (int gq = 0; gq < P::L / 128; ++gq) {
+        const float4 blk = ib[64 * gq];
+        v[B::reg(128 * gq)] = mkcf(blk.x, blk.y);
+        v[B::reg(128 * gq + 64)] = mkcf(blk.z, blk.w);
       }
+    } else {
+      const float* i1 = A2r + ((int64_t)fl * g.N + m) * P::L;
+      const float* i2 = i1 + P::L;
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = 0; n1 < P::R1; ++n1) {
+          const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
+          v[ul * P::R1 + n1] = mkcf(i1[X], i2[X]);
+        }
+    }
     const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
     float alt1, alt2, sn1, sn2;
     pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
     if (live) {
       const float gs = aux.gsum[fl];
       const float c1 = sn1 * (aux.kv[fl * g.N + m] + ((Y1 & 1) ? -gs : gs));
-      const float c2 = sn2 * (aux.kv[fl * g.N + m + 1] + ((Y2 & 1) ? -gs : gs));
-      const int64_t ob1 = ((int64_t)f * g.N + m) * g.N, ob2 = ob1 + g.N;
+      const float c2 = sn2 * (aux.kv[fl * g.N + m + dm] + ((Y2 & 1) ? -gs : gs));
+      const int64_t ob1 = ((int64_t)f * g.N + m) * g.N, ob2 = ob1 + (int64_t)dm * g.N;
 #pragma unroll
       for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
@@ -533,7 +589,9 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
 template <class P>
 int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n, float* out,
               int mask_nan, int mask_zero) {
-  const int64_t per_frame = (int64_t)g.N * P::L;            // floats per intermediate per frame
+  constexpr bool BLK = P::WPL == 1;                         // blocked intermediates (see Blk)
+  VIPMI_REQUIRE(4 * g.N == P::L && 8 * g.off == 3 * P::L, "derotate(fft2): unexpected canvas geometry");
+  const int64_t per_frame = (int64_t)(BLK ? g.N + 2 : g.N) * P::L;     // floats per intermediate per frame
   int64_t chunk = ctx->opt("rot_batch", 0);
   if (chunk <= 0) {
     int64_t budget = ctx->opt("rot_ws_mb", 2048) * (int64_t)(1 << 20);
@@ -581,7 +639,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   const dim3 blk(64 * P::WPB);
   for (int64_t f0 = 0; f0 < n; f0 += chunk) {
     const int nf = (int)((n - f0) < chunk ? (n - f0) : chunk);
-    const int64_t npairs = (int64_t)nf * (g.N / 2);
+    const int64_t npairs = (int64_t)nf * (g.N / 2 + (BLK ? 1 : 0));
     int gr = (int)cdiv(npairs, P::LPB);
     if (gr > maxwg) gr = maxwg;
     if (gr < 8) gr = 8;
@@ -604,16 +662,11 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     ctx->toc("k_rot_aux");
     ctx->tic("k_rot_s2");
     if constexpr (P::WPL == 1) {
-      if (ctx->opt("rot_s2_tiled", 0) == 0) {
-        auto k2d = rs_shear2_direct<P>;
-        VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2d),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k2d, dim3(gr), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
-                           counters + 256);
-      } else {
-        hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
-                           counters + 256);
-      }
+      auto k2d = rs_shear2_direct<P>;
+      VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2d),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k2d, dim3(gr), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
+                         counters + 256);
     } else {
       hipLaunchKernelGGL(k2, dim3(gc), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
                          counters + 256);
@@ -637,7 +690,9 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
                   float* out, int mask_nan, int mask_zero) {
   switch (g.Le) {
     case 512: return run_plan2<Plan512>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-    case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 1024:
+      if (ctx->opt("rot_wpb", 8) == 4) return run_plan2<Plan1024w4>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     case 2048:
       // rot_wpb = waves per workgroup: 8 (default) = one wave per line, 2 waves/SIMD with a 256-VGPR budget;
       // 12 / 16 = two waves per line (more waves, but workgroup barriers and 1.5x the instructions per line)
