@@ -1,0 +1,50 @@
+"""Fixtures added after the first set (G11 ...): same rules as oracle/gen_golden.py -- outputs of the REAL reference
+(imported read-only through oracle/_shim.py) frozen as data under tests/golden/; runs only in the build container:
+
+    python oracle/gen_golden_more.py
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _shim, ref_cpu as O  # noqa: E402
+
+warnings.simplefilter("ignore")
+ref = _shim.load()
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# ---- G11: cube_sig (estimated-signal cube: PCs learnt from / projection of cube - cube_sig, model subtracted from
+# the cube; reference pca_fullfr.py:1652-1662,1717-1731) in the whole-matrix, RDI and source_xy branches ------------
+n, N = 14, 36
+cube, ang = O.synth_adi(n, N, seed=60)
+ang = np.linspace(0, 70, n)
+yy, xx = np.mgrid[:N, :N]
+sig = np.zeros_like(cube)
+for i, a in enumerate(np.deg2rad(ang)):          # a faint companion moving with the parallactic angle
+    cy, cx = N // 2 + 9 * np.sin(a), N // 2 + 9 * np.cos(a)
+    sig[i] = 0.8 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.7 ** 2))
+cube = (cube + sig).astype(np.float32)
+sig = (0.9 * sig).astype(np.float32)             # an imperfect estimate of it
+cref = O.synth_adi(9, N, seed=61)[0]
+g = {"cube": cube, "angles": ang, "cube_sig": sig, "cube_ref": cref}
+for tag, kw in (("plain", dict(ncomp=3)), ("scaled", dict(ncomp=2, scaling="temp-mean", mask_center_px=3)),
+                ("rdi", dict(ncomp=3, cube_ref=cref))):
+    fo = ref.pca(cube, ang, cube_sig=sig, full_output=True, verbose=False, nproc=1, **kw)
+    for nm, a in zip(("frame", "pcs", "recon", "res", "resder"), fo):
+        g["%s_%s" % (tag, nm)] = np.asarray(a)
+fo = ref.pca(cube, ang, ncomp=2, cube_sig=sig, source_xy=(N // 2 + 9, N // 2), fwhm=4, delta_rot=1, min_frames_pca=3,
+             full_output=True, verbose=False, nproc=1)
+for nm, a in zip(("frame", "recon", "res", "resder"), fo):
+    g["sxy_%s" % nm] = np.asarray(a)
+save("g11_cube_sig", **g)

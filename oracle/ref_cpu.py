@@ -177,17 +177,21 @@ def cevr_to_ncomp(cube, cevr, scaling=None, svd_mode="lapack"):
 
 
 def project_subtract(cube, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
-                     cube_ref=None, full_output=False, seed=0):
-    """Whole-matrix branch of ``_project_subtract``.  Ref: psfsub/pca_fullfr.py:1649-1737."""
+                     cube_ref=None, full_output=False, seed=0, cube_sig=None):
+    """Whole-matrix branch of ``_project_subtract``.  Ref: psfsub/pca_fullfr.py:1649-1737.
+    ``cube_sig`` (estimated signal, :1652-1662): the PCs are learnt from and the projection is taken of the
+    "empty" matrix ``matrix - reshape(cube_sig)`` (cube_sig is neither masked nor scaled), but the model is
+    subtracted from ``matrix`` itself (:1717-1731)."""
     n, y, x = cube.shape
     if isinstance(ncomp, (float, np.floating)):
         if not 1 > ncomp > 0:
             raise ValueError("if `ncomp` is float, it must lie in the interval (0,1]")
         ncomp = cevr_to_ncomp(cube, ncomp, scaling, svd_mode)
     matrix = prepare_matrix(cube, scaling, mask_center_px)
-    ref_lib = matrix if cube_ref is None else prepare_matrix(cube_ref, scaling, mask_center_px)
+    matrix_emp = matrix if cube_sig is None else matrix - np.reshape(cube_sig, (cube_sig.shape[0], -1))
+    ref_lib = matrix_emp if cube_ref is None else prepare_matrix(cube_ref, scaling, mask_center_px)
     V = svd_wrapper(ref_lib, svd_mode, ncomp, seed=seed)
-    transformed = V @ matrix.T
+    transformed = V @ matrix_emp.T
     reconstructed = transformed.T @ V
     residuals = (matrix - reconstructed).reshape(n, y, x)
     if full_output:
@@ -420,7 +424,7 @@ def get_annulus_segments(shape, inner_radius, width, nsegm=1, theta_init=0):
 
 def pca_fullframe(cube, angle_list, ncomp=1, svd_mode="lapack", scaling=None,
                   mask_center_px=None, collapse="median", cube_ref=None, weights=None,
-                  full_output=False, seed=0, rot_options=None):
+                  full_output=False, seed=0, rot_options=None, cube_sig=None):
     """3-D ADI / RDI branch of ``pca``.  Ref: psfsub/pca_fullfr.py:412-415,661-701,
     801-1007,759-793."""
     if cube.ndim != 3:
@@ -440,7 +444,7 @@ def pca_fullframe(cube, angle_list, ncomp=1, svd_mode="lapack", scaling=None,
     elif ncomp <= 0:
         raise ValueError("Number of PCs too low. It should be > 0.")
     res, recon, V = project_subtract(cube, ncomp, scaling, mask_center_px, svd_mode,
-                                     cube_ref=cube_ref, full_output=True, seed=seed)
+                                     cube_ref=cube_ref, full_output=True, seed=seed, cube_sig=cube_sig)
     y, x = cube.shape[1:]
     pcs = V.reshape(V.shape[0], y, x)
     recon = recon.reshape(n, y, x)
@@ -494,7 +498,7 @@ def pca_grid_frames(cube, angle_list, range_pcs, scaling=None, mask_center_px=No
 
 def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scaling=None, mask_center_px=None,
                      min_frames_pca=10, max_frames_pca=None, collapse="median", svd_mode="lapack", weights=None,
-                     full_output=False, seed=0):
+                     full_output=False, seed=0, cube_sig=None):
     """``pca(cube, angles, ncomp=<int>, source_xy=(x, y), fwhm=..., delta_rot=...)``: every frame is modelled with
     the PCs of the frames that rotated by more than the PA threshold at ``source_xy``.
     Ref: psfsub/pca_fullfr.py:911-965 (threshold, per-frame loop), :1677-1713 (_project_subtract with indices/frame),
@@ -508,11 +512,12 @@ def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scalin
     pa_thr = compute_pa_thresh(ann_center, fwhm, delta_rot)
     truncate = max_frames_pca is not None
     matrix = prepare_matrix(cube, scaling, mask_center_px)
+    matrix_emp = matrix if cube_sig is None else matrix - np.reshape(cube_sig, (n, -1))     # :1652-1662
     residuals = np.zeros_like(matrix)
     recon = np.zeros_like(matrix)
     for fr in range(n):
         ind = find_indices_adi(angle_list, fr, pa_thr, truncate=truncate, max_frames=max_frames_pca)
-        ref_lib = matrix[ind]
+        ref_lib = matrix_emp[ind]
         if ref_lib.shape[0] < min_frames_pca:
             raise RuntimeError("{} frames comply to delta_rot condition < less than min_frames_pca ({})".format(
                 ref_lib.shape[0], min_frames_pca))
@@ -520,7 +525,7 @@ def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scalin
             raise RuntimeError("{} frames comply to delta_rot condition < less than ncomp ({})".format(
                 ref_lib.shape[0], ncomp))
         V = svd_wrapper(ref_lib, svd_mode, ncomp, seed=seed)
-        transformed = np.dot(matrix[fr], V.T)
+        transformed = np.dot(matrix_emp[fr], V.T)
         recon[fr] = np.dot(transformed.T, V)
         residuals[fr] = matrix[fr] - recon[fr]
     res_cube = residuals.reshape(n, y, x)

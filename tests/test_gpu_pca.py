@@ -208,6 +208,43 @@ def test_pca_pa_rejection_golden(tag, kw):
     assert np.abs(fr - g[tag + "_frame"]).max() < TOL
 
 
+@pytest.mark.parametrize("tag,kw", [("plain", dict(ncomp=3)), ("scaled", dict(ncomp=2, scaling="temp-mean", mask_center_px=3)),
+                                    ("rdi", dict(ncomp=3, rdi=True))])
+def test_cube_sig_golden(tag, kw):
+    """cube_sig (reference pca_fullfr.py:1652-1662,1717-1731) against the reference's outputs."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g11_cube_sig")
+    kw = dict(kw)
+    if kw.pop("rdi", False):
+        kw["cube_ref"] = g["cube_ref"]
+    out = pca(g["cube"], g["angles"], cube_sig=g["cube_sig"], full_output=True, verbose=False, **kw)
+    assert len(out) == 5
+    for nm, a in zip(("frame", "pcs", "recon", "res", "resder"), out):
+        b = g["%s_%s" % (tag, nm)]
+        assert a.shape == b.shape and a.dtype == b.dtype, nm
+        if nm == "pcs":
+            a = sign_align(a, b)
+        assert np.abs(a - b).max() < TOL, (tag, nm, np.abs(a - b).max())
+    fr = pca(g["cube"], g["angles"], cube_sig=g["cube_sig"], verbose=False, **kw)
+    assert np.abs(fr - g[tag + "_frame"]).max() < TOL
+
+
+def test_cube_sig_pa_rejection_golden():
+    from vip_amd.psfsub import pca
+    g = load_golden("g11_cube_sig")
+    N = g["cube"].shape[1]
+    out = pca(g["cube"], g["angles"], ncomp=2, cube_sig=g["cube_sig"], source_xy=(N // 2 + 9, N // 2), fwhm=4,
+              delta_rot=1, min_frames_pca=3, full_output=True, verbose=False)
+    for nm, a in zip(("frame", "recon", "res", "resder"), out):
+        b = g["sxy_%s" % nm]
+        assert a.shape == b.shape and a.dtype == b.dtype, nm
+        assert np.abs(a - b).max() < (5e-4 if nm == "recon" else TOL), (nm, np.abs(a - b).max())
+    with pytest.raises(TypeError):
+        pca(g["cube"], g["angles"], ncomp=2, cube_sig=g["cube_sig"][:-1], verbose=False)
+    with pytest.raises(NotImplementedError):
+        pca(g["cube"], g["angles"], ncomp=(1, 3), cube_sig=g["cube_sig"], verbose=False)
+
+
 def test_pca_pa_rejection_errors():
     from vip_amd.psfsub import pca
     g = load_golden("g7_grid_rejection")

@@ -6,10 +6,10 @@ Same positional order (= ``PCA_Params`` field order), same kwargs (unknown kwarg
 ``rot_options``), same return tuples and shapes.  All array work runs on the MI355X through
 libvipmi.so; numpy in -> numpy out, cuda tensor in -> cuda tensors out (no host copies).
 
-Tuple/list ``ncomp`` (the ``pca_grid`` of final frames) and ``source_xy`` (PA-threshold frame rejection) are
-accelerated for 3-D cubes.  Not accelerated (raise NotImplementedError, SURVEY.md 8(f) "next"): ``scale_list``
-(mSDI), ``pca_grid`` scored by S/N (tuple ``ncomp`` + ``source_xy``), ``batch`` (incremental PCA), ``left_eigv``, ``cube_sig``,
-``mask_rdi``, ``smooth``, ``imlib != 'vip-fft'``.
+Tuple/list ``ncomp`` (the ``pca_grid`` of final frames), ``source_xy`` (PA-threshold frame rejection), ``cube_ref``
+(RDI / ARDI), ``cube_sig`` and 4-D cubes with ``scale_list`` (ADI+mSDI, psfsub/pca_msdi.py) are accelerated.  Not
+accelerated (raise NotImplementedError): ``pca_grid`` scored by S/N (tuple ``ncomp`` + ``source_xy``), ``batch``
+(incremental PCA), ``left_eigv``, ``mask_rdi``, ``smooth``, ``imlib != 'vip-fft'``.
 """
 from dataclasses import dataclass
 from enum import Enum
@@ -75,9 +75,14 @@ def _is_array(x):
     return isinstance(x, np.ndarray) or B.is_device_tensor(x)
 
 
-def _project_subtract(cube_t, cube_ref_t, ncomp, scaling, mask_center_px, svd_mode, verbose, full_output):
+def _project_subtract(cube_t, cube_ref_t, ncomp, scaling, mask_center_px, svd_mode, verbose, full_output,
+                      cube_sig_t=None):
     """Device version of the whole-matrix branch of the reference's ``_project_subtract``.
-    cube_t / cube_ref_t: float32 cuda tensors (n, y, x).  Returns device tensors."""
+    cube_t / cube_ref_t / cube_sig_t: float32 cuda tensors (n, y, x).  Returns device tensors.
+
+    ``cube_sig`` (reference :1652-1662,1717-1731): PCs and projection come from the "empty" matrix
+    ``M_emp = M - S`` (S = cube_sig, neither masked nor scaled) while the model is subtracted from ``M``; since
+    ``M - proj(M_emp) = (M_emp - proj(M_emp)) + S`` this is the ordinary path on ``M_emp`` plus ``S`` added back."""
     n, y, x = cube_t.shape
     if not isinstance(ncomp, (int, np.integer, float, np.floating)):
         raise TypeError("Type not recognized for ncomp, should be int or float")
@@ -102,6 +107,10 @@ def _project_subtract(cube_t, cube_ref_t, ncomp, scaling, mask_center_px, svd_mo
         return m
 
     M = prep(cube_t)
+    S = None
+    if cube_sig_t is not None:
+        S = cube_sig_t.reshape(cube_sig_t.shape[0], -1)
+        M = B.lincomb(M, S, 1.0, -1.0)
     ref = prep(cube_ref_t) if cube_ref_t is not None else None
     nref = M.shape[0] if ref is None else ref.shape[0]
     if ncomp > min(nref, M.shape[1]):
@@ -109,8 +118,10 @@ def _project_subtract(cube_t, cube_ref_t, ncomp, scaling, mask_center_px, svd_mo
         msg += " Increase the size of the patches or request less PCs"
         raise RuntimeError(msg.format(ncomp, nref, M.shape[1]))
     res, recon, pcs, _ = B.pca_project(M, ncomp, ref=ref, want_recon=full_output, want_pcs=full_output)
+    if S is not None:
+        res = B.lincomb(res, S, 1.0, 1.0)
     if verbose:
-        print("Done PCA on MI355X (Gram + block-Jacobi + MFMA projection)")
+        print("Done PCA on MI355X (Gram + eigensolver + MFMA projection)")
     res = res.reshape(n, y, x)
     if full_output:
         return res, recon, pcs
@@ -185,7 +196,7 @@ def _pca_grid(cube, angle_list, range_pcs, cube_ref, scaling, mask_center_px, sv
 
 
 def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scaling, mask_center_px, min_frames_pca,
-                      max_frames_pca, verbose):
+                      max_frames_pca, verbose, cube_sig=None):
     """Device version of the ``source_xy`` branch (reference pca_fullfr.py:911-965 + the per-frame mode of
     ``_project_subtract``, :1677-1713): frame j is modelled with the PCs of the frames that have rotated by more than
     the PA threshold at ``source_xy``.  All n per-frame decompositions come from sub-blocks of ONE Gram matrix
@@ -209,6 +220,10 @@ def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scali
             raise RuntimeError((msg + "ncomp ({}). Try decreasing the parameter delta_rot or ncomp").format(
                 li.shape[0], ncomp))
     M, _ = _prepared_matrices(cube, None, scaling, mask_center_px)
+    S = None
+    if cube_sig is not None:                      # libraries and projections from M - S (see _project_subtract)
+        S = cube_sig.reshape(n, -1)
+        M_full, M = M, B.lincomb(M, S, 1.0, -1.0)
     P = y * x
     max_lib = max(li.shape[0] for li in libs)
     idx = np.zeros((n, max_lib), dtype=np.int32)
@@ -221,6 +236,9 @@ def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scali
     R = B.empty((n, P), device=cube.device.index)
     ctx = B.get_context(cube.device.index)
     ctx.call("vipmi_annular_residuals_f32", B.ptr(M), n, P, B.ptr(idx_t), B.ptr(ln_t), int(max_lib), int(ncomp), B.ptr(R))
+    if S is not None:
+        R = B.lincomb(R, S, 1.0, 1.0)
+        M = M_full
     if verbose:
         print("Size LIB: min={} max={} mean={:.1f}".format(int(ln.min()), int(ln.max()), float(ln.mean())))
     return R, M, ln
@@ -233,8 +251,10 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
     """ADI / ADI+RDI full-frame PCA on device tensors; returns device tensors."""
     if batch is not None:
         raise NotImplementedError("batch (incremental PCA) is outside the accelerated path")
-    if mask_rdi is not None or cube_sig is not None or left_eigv or smooth is not None:
-        raise NotImplementedError("mask_rdi / cube_sig / left_eigv / smooth are outside the accelerated path")
+    if mask_rdi is not None or left_eigv or smooth is not None:
+        raise NotImplementedError("mask_rdi / left_eigv / smooth are outside the accelerated path")
+    if cube_sig is not None and tuple(cube_sig.shape) != tuple(cube.shape):
+        raise TypeError("`cube_sig` must have the shape of `cube`")
     if _s(imlib) != "vip-fft":
         raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
     n, y, x = cube.shape
@@ -269,6 +289,8 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         raise ValueError("Weights have to be provided for weighted mean mode")
 
     if grid:
+        if cube_sig is not None:
+            raise NotImplementedError("cube_sig with a grid of ncomp is outside the accelerated path")
         return _pca_grid(cube, angle_list, ncomp, cube_ref, scaling, mask_center_px, svd_mode, collapse, weights,
                          full_output, verbose, mv_nan)
     if source_xy is not None:
@@ -277,7 +299,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         if not isinstance(ncomp, (int, np.integer)):
             raise NotImplementedError("source_xy needs an integer ncomp on the device path")
         R, M, _ln = _pca_pa_rejection(cube, angle_list, int(ncomp), source_xy, delta_rot, fwhm, scaling,
-                                      mask_center_px, min_frames_pca, max_frames_pca, verbose)
+                                      mask_center_px, min_frames_pca, max_frames_pca, verbose, cube_sig=cube_sig)
         residuals_cube = R.reshape(n, y, x)
         residuals_cube_ = B.derotate(residuals_cube, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
         frame = B.collapse(residuals_cube_, collapse, w=weights)
@@ -293,7 +315,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
             return recon_cube, residuals_cube, residuals_cube_, frame
         return frame
 
-    fused_ok = (cube_ref is None and isinstance(ncomp, (int, np.integer)) and collapse in
+    fused_ok = (cube_ref is None and cube_sig is None and isinstance(ncomp, (int, np.integer)) and collapse in
                 ("median", "mean", "sum", "max", "absmean") and (bool(mask_center_px) != mv_nan))
     if fused_ok:
         # one call into the C ABI: mask/scale -> Gram -> eigh -> project -> derotate -> collapse
@@ -309,7 +331,8 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
             return pcs, recon, residuals_cube, residuals_cube_, frame
         return out
 
-    res = _project_subtract(cube, cube_ref, ncomp, scaling, mask_center_px, svd_mode, verbose, full_output)
+    res = _project_subtract(cube, cube_ref, ncomp, scaling, mask_center_px, svd_mode, verbose, full_output,
+                            cube_sig_t=cube_sig)
     if full_output:
         residuals_cube, recon, pcs = res
         pcs = pcs.reshape(pcs.shape[0], y, x)
@@ -444,6 +467,12 @@ def pca(*all_args: List, **all_kwargs: dict):
 
     fo = bool(algo_params.full_output)
     add = {"start_time": None, "full_output": fo}
+    if algo_params.cube_sig is not None:
+        if cube.ndim == 4:
+            raise NotImplementedError("cube_sig with a 4-D cube is outside the accelerated path")
+        if not _is_array(algo_params.cube_sig) or tuple(algo_params.cube_sig.shape) != tuple(cube.shape):
+            raise TypeError("`cube_sig` must be an array with the shape of `cube`")
+        add["cube_sig"] = B.to_device_f32(algo_params.cube_sig)
 
     if cube.ndim == 4:
         torch = B._torch()
