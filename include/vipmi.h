@@ -150,6 +150,11 @@ int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, 
 int vipmi_annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
                                 const int32_t* lib_idx, const int32_t* lib_len, int64_t max_lib,
                                 int64_t ncomp, float* residuals);
+/* Same with a LIST of truncation ranks (pca_local.py:665-668,892-902: one decomposition with max(ncomp), one
+ * residual matrix per V[:k]): ncomps_host is a HOST array of nk ranks, residuals is [nk][n][npx] (device). */
+int vipmi_annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
+                                      const int32_t* lib_idx, const int32_t* lib_len, int64_t max_lib,
+                                      const int32_t* ncomps_host, int64_t nk, float* residuals);
 /* gather / scatter of annulus pixels: A[n,npx] = cube[n, pix[j]] and back. */
 int vipmi_gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
                      int64_t npx, float* A);

@@ -48,3 +48,15 @@ fo = ref.pca(cube, ang, ncomp=2, cube_sig=sig, source_xy=(N // 2 + 9, N // 2), f
 for nm, a in zip(("frame", "recon", "res", "resder"), fo):
     g["sxy_%s" % nm] = np.asarray(a)
 save("g11_cube_sig", **g)
+
+# ---- G12: pca_annular with a LIST of ncomp (several truncations of one decomposition; pca_local.py:665-668,892-902) --
+cube, _ = O.synth_adi(16, 40, seed=70)
+ang = np.linspace(0, 85, 16)
+g = {"cube": cube, "angles": ang}
+for tag, kw in (("a", dict(ncomp=[1, 3, 6], asize=8, fwhm=4, delta_rot=(0.1, 1))),
+                ("b", dict(ncomp=[2, 4], asize=5, fwhm=4, delta_rot=0.5, n_segments=2, radius_int=5,
+                           scaling="temp-standard", collapse="mean"))):
+    co, cd, fr_ = ref.pca_annular(cube, ang, full_output=True, verbose=False, nproc=1, **kw)
+    g[tag + "_out"], g[tag + "_der"], g[tag + "_frames"] = co.astype(np.float32), cd.astype(np.float32), np.stack(fr_)
+    g[tag + "_dtypes"] = np.array([str(co.dtype), str(cd.dtype), str(fr_[0].dtype)])
+save("g12_annular_list", **g)

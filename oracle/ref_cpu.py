@@ -825,8 +825,10 @@ def pca_annular(cube, angle_list, radius_int=0, fwhm=4, asize=4, n_segments=1,
                 delta_rot=(0.1, 1), ncomp=1, svd_mode="lapack", min_frames_lib=2,
                 max_frames_lib=200, scaling=None, collapse="median", theta_init=0,
                 weights=None, full_output=False, rot_options=None):
-    """3-D ADI annular PCA (int / per-annulus tuple ncomp).  Ref: psfsub/pca_local.py:
-    228-278,594-827 and do_pca_patch :830-909; get_eigenvectors svd.py:694-700."""
+    """3-D ADI annular PCA (int / per-annulus tuple ncomp / LIST of ncomp: one decomposition with max(ncomp) per
+    frame and segment, residuals for every V[:k] -> 4-D float64 cube_out / cube_der and a list of frames).
+    Ref: psfsub/pca_local.py:228-278,594-827 (list: :665-668,744-749,799-807) and do_pca_patch :830-909
+    (list: :892-902); get_eigenvectors svd.py:694-700."""
     if cube.ndim != 3:
         raise TypeError("Input array is not a cube or 3d array")
     if cube.shape[0] != np.asarray(angle_list).shape[0]:
@@ -851,11 +853,16 @@ def pca_annular(cube, angle_list, radius_int=0, fwhm=4, asize=4, n_segments=1,
             ang = np.rad2deg(2 * np.arctan(ld / (2 * i * asize)))
             n_segments.append(int(np.ceil(360 / ang)))
     cube_out = np.zeros_like(cube)
+    is_list = isinstance(ncomp, list)
+    if is_list:
+        cube_out = np.zeros([len(ncomp), n, y, x])
     for ann in range(n_annuli):
         if isinstance(ncomp, (tuple, np.ndarray)):
             if len(ncomp) != n_annuli:
                 raise TypeError("If `ncomp` is a tuple, its length must match the number of annuli")
             k_ann = ncomp[ann]
+        elif is_list:
+            k_ann = max(ncomp)
         else:
             k_ann = ncomp
         pa_thr, inner_radius, _ = define_annuli(angle_list, ann, n_annuli, fwhm, radius_int,
@@ -875,7 +882,20 @@ def pca_annular(cube, angle_list, radius_int=0, fwhm=4, asize=4, n_segments=1,
                 k = min(k_ann, min(lib.shape))
                 V = svd_wrapper(lib, svd_mode, k)
                 cur = m[fr]
-                cube_out[fr][yy, xx] = cur - (cur @ V.T) @ V
+                if is_list:
+                    for nn, kk in enumerate(ncomp):
+                        cube_out[nn, fr][yy, xx] = cur - (cur @ V[:kk].T) @ V[:kk]
+                else:
+                    cube_out[fr][yy, xx] = cur - (cur @ V.T) @ V
+    if is_list:
+        cube_der = np.zeros_like(cube_out)
+        frame = []
+        for nn in range(len(ncomp)):
+            cube_der[nn] = cube_derotate(cube_out[nn], angle_list, mask_val=mask_val)
+            frame.append(cube_collapse(cube_der[nn], mode=collapse, w=weights))
+        if full_output:
+            return cube_out, cube_der, frame
+        return frame
     cube_der = cube_derotate(cube_out, angle_list, mask_val=mask_val)
     frame = cube_collapse(cube_der, mode=collapse, w=weights)
     if full_output:

@@ -152,6 +152,28 @@ def test_pca_annular_golden(tag, kw):
     assert np.abs(fr - g[tag + "_frame"]).max() < TOL
 
 
+@pytest.mark.parametrize("tag,kw", [("a", dict(ncomp=[1, 3, 6], asize=8, fwhm=4, delta_rot=(0.1, 1))),
+                                    ("b", dict(ncomp=[2, 4], asize=5, fwhm=4, delta_rot=0.5, n_segments=2, radius_int=5,
+                                               scaling="temp-standard", collapse="mean"))])
+def test_pca_annular_list_ncomp_golden(tag, kw):
+    """list ncomp (reference pca_local.py:665-668,892-902) against the reference's outputs; each entry also equals
+    the single-ncomp run."""
+    from vip_amd.psfsub import pca_annular
+    g = load_golden("g12_annular_list")
+    co, cd, frames = pca_annular(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    assert isinstance(frames, list) and len(frames) == len(kw["ncomp"])
+    assert [str(co.dtype), str(cd.dtype), str(frames[0].dtype)] == list(g[tag + "_dtypes"])
+    assert co.shape == g[tag + "_out"].shape and cd.shape == g[tag + "_der"].shape
+    assert np.abs(co - g[tag + "_out"]).max() < TOL
+    assert np.nanmax(np.abs(cd - g[tag + "_der"])) < TOL
+    assert np.abs(np.stack(frames) - g[tag + "_frames"]).max() < TOL
+    only = pca_annular(g["cube"], g["angles"], verbose=False, **kw)
+    assert isinstance(only, list) and np.abs(np.stack(only) - g[tag + "_frames"]).max() < TOL
+    kw1 = dict(kw, ncomp=kw["ncomp"][1])
+    single = pca_annular(g["cube"], g["angles"], verbose=False, **kw1)
+    assert np.abs(single - frames[1]).max() < 2e-5
+
+
 def test_pca_annular_scaling_and_errors():
     from vip_amd.psfsub import pca_annular
     cube, ang = O.synth_adi(20, 48, seed=4)

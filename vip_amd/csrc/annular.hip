@@ -69,11 +69,19 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
 
 }  // namespace
 
-int annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
-                          const int32_t* lib_len, int64_t max_lib, int64_t ncomp, float* residuals) {
-  VIPMI_REQUIRE(A && lib_idx && lib_len && residuals, "annular_residuals: null pointer");
-  VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && ncomp > 0, "annular_residuals: bad sizes");
+// ncomps: HOST array of nk truncation ranks (the reference's list `ncomp`, pca_local.py:665-668,892-902: one
+// decomposition with max(ncomp), residuals for every V[:k]); residuals: [nk][n][npx].
+int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                                const int32_t* lib_len, int64_t max_lib, const int32_t* ncomps, int64_t nk,
+                                float* residuals) {
+  VIPMI_REQUIRE(A && lib_idx && lib_len && residuals && ncomps, "annular_residuals: null pointer");
+  VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && nk > 0, "annular_residuals: bad sizes");
   VIPMI_REQUIRE(max_lib <= n, "annular_residuals: max_lib > n");
+  int64_t kmax = 0;
+  for (int64_t i = 0; i < nk; ++i) {
+    VIPMI_REQUIRE(ncomps[i] > 0, "annular_residuals: ncomp must be positive");
+    if (ncomps[i] > kmax) kmax = ncomps[i];
+  }
   const int m = (int)max_lib;
   double *G = nullptr, *H = nullptr, *evals = nullptr, *evecs = nullptr;
   float* C = nullptr;
@@ -86,14 +94,24 @@ int annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx
   hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, G, (int)n, lib_idx, lib_len,
                      (int)max_lib, m, H);
   VIPMI_CHECK_HIP(hipGetLastError());
-  VIPMI_TRY(eigh_leading(ctx, H, n, m, ncomp < m ? ncomp : m, lib_len, evals, evecs));
-  VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
-  const size_t shm = (size_t)(m + ncomp + 8) * sizeof(double);
-  hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
-                     (int)max_lib, m, evals, evecs, (int)ncomp, (int)npx, C);
-  VIPMI_CHECK_HIP(hipGetLastError());
-  // residuals = A - C * A   (projection GEMM on the matrix cores: "components" are the n frames)
-  return subtract_gemm_f32(ctx, A, C, A, n, n, npx, residuals, nullptr);
+  VIPMI_TRY(eigh_leading(ctx, H, n, m, kmax < m ? kmax : m, lib_len, evals, evecs));
+  const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
+  for (int64_t i = 0; i < nk; ++i) {
+    VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
+    hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
+                       (int)max_lib, m, evals, evecs, (int)ncomps[i], (int)npx, C);
+    VIPMI_CHECK_HIP(hipGetLastError());
+    // residuals = A - C * A   (projection GEMM on the matrix cores: "components" are the n frames)
+    VIPMI_TRY(subtract_gemm_f32(ctx, A, C, A, n, n, npx, residuals + (size_t)i * n * npx, nullptr));
+  }
+  return VIPMI_OK;
+}
+
+int annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                          const int32_t* lib_len, int64_t max_lib, int64_t ncomp, float* residuals) {
+  VIPMI_REQUIRE(ncomp > 0, "annular_residuals: bad sizes");
+  const int32_t k = (int32_t)ncomp;
+  return annular_residuals_multi_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, &k, 1, residuals);
 }
 
 }  // namespace vipmi

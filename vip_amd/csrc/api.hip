@@ -422,6 +422,13 @@ int vipmi_annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
   return annular_residuals_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, ncomp, residuals);
 }
 
+int vipmi_annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
+                                      const int32_t* lib_idx, const int32_t* lib_len, int64_t max_lib,
+                                      const int32_t* ncomps_host, int64_t nk, float* residuals) {
+  CTX_GUARD();
+  return annular_residuals_multi_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, ncomps_host, nk, residuals);
+}
+
 // PCs / residuals of M[n,P] with respect to the top-k principal components of ref[nref,P]
 // (ref == M for ADI).  Internal building block of vipmi_pca_fullframe_f32 and of the RDI path.
 int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float* ref, int64_t nref,

@@ -7,10 +7,12 @@ segment matrix.  Here each segment matrix is gathered once on the device, its Gr
 the matrix cores, and every frame's library PCA is obtained from the corresponding Gram sub-block
 (SURVEY.md 8(a-ann)): residual_j = x_j - M_lib^T (E_k L_k^-1 E_k^T) G[lib, j], batched over frames.
 
-4-D cubes without ``scale_list`` run the same path per spectral channel.  Not accelerated
-(NotImplementedError): ``scale_list`` (mSDI), ``cube_ref``, ``cube_sig``, ``left_eigv``,
-``ncomp='auto'``, list ``ncomp``.
+``ncomp``: int, per-annulus tuple, or a list (several truncations of one decomposition -> 4-D ``cube_out`` /
+``cube_der`` and a list of frames).  4-D cubes without ``scale_list`` run the same path per spectral channel.
+Not accelerated (NotImplementedError): ``scale_list`` (mSDI), ``cube_ref``, ``cube_sig``, ``left_eigv``,
+``ncomp='auto'``.
 """
+import ctypes
 from dataclasses import dataclass
 from enum import Enum
 from typing import List, Tuple, Union
@@ -138,20 +140,26 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         raise TypeError("Input vector or parallactic angles has wrong length")
     if cube_ref is not None or cube_sig is not None or left_eigv:
         raise NotImplementedError("cube_ref / cube_sig / left_eigv are outside the accelerated annular path")
-    if isinstance(ncomp, list) or isinstance(ncomp, str):
-        raise NotImplementedError("list / 'auto' ncomp is outside the accelerated annular path")
+    if isinstance(ncomp, str):
+        raise NotImplementedError("ncomp='auto' is outside the accelerated annular path")
+    ks = None
+    if isinstance(ncomp, list):          # several truncations of one decomposition (pca_local.py:665-668,892-902)
+        ks = np.asarray([int(k) for k in ncomp], dtype=np.int32)
+        if ks.size == 0 or ks.min() <= 0:
+            raise ValueError("every ncomp of the list must be a positive integer")
     if _s(imlib) != "vip-fft":
         raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
     n, y, x = cube.shape
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
-    plan = annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot, ncomp,
-                        min_frames_lib, max_frames_lib, theta_init)
+    plan = annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot,
+                        ncomp if ks is None else int(ks.max()), min_frames_lib, max_frames_lib, theta_init)
     if verbose:
         print("N annuli = {}, FWHM = {:.3f}".format(int((y / 2 - radius_int) / asize), fwhm))
     ctx = B.get_context(cube.device.index)
     dev = cube.device.index
     P = y * x
-    cube_out = torch.zeros_like(cube)
+    cube_out = torch.zeros_like(cube) if ks is None else torch.zeros((len(ks),) + tuple(cube.shape), dtype=cube.dtype,
+                                                                     device=cube.device)
     scaling = _s(scaling)
     lib_cache = {}
     for seg in plan:
@@ -171,14 +179,30 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             idx, ln, max_lib = _pack_libs(seg["libs"])
             lib_cache[key] = (torch.from_numpy(idx).to(cube.device), torch.from_numpy(ln).to(cube.device), max_lib)
         idx_t, ln_t, max_lib = lib_cache[key]
-        R = B.empty((n, npx), device=dev)
-        ctx.call("vipmi_annular_residuals_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
-                 int(seg["ncomp"]), B.ptr(R))
-        ctx.call("vipmi_scatter_f32", B.ptr(R), n, P, B.ptr(pix), npx, B.ptr(cube_out))
+        if ks is None:
+            R = B.empty((n, npx), device=dev)
+            ctx.call("vipmi_annular_residuals_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
+                     int(seg["ncomp"]), B.ptr(R))
+            ctx.call("vipmi_scatter_f32", B.ptr(R), n, P, B.ptr(pix), npx, B.ptr(cube_out))
+        else:
+            R = B.empty((len(ks), n, npx), device=dev)
+            ctx.call("vipmi_annular_residuals_multi_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
+                     ks.ctypes.data_as(ctypes.c_void_p), len(ks), B.ptr(R))
+            for nn in range(len(ks)):
+                ctx.call("vipmi_scatter_f32", B.ptr(R[nn]), n, P, B.ptr(pix), npx, B.ptr(cube_out[nn]))
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
     if not mv_nan and mask_val != 0:
         raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
+    if ks is not None:
+        cube_der = torch.stack([B.derotate(cube_out[nn], angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
+                                for nn in range(len(ks))])
+        frames = [B.collapse(cube_der[nn], _s(collapse), w=weights) for nn in range(len(ks))]
+        if verbose:
+            print("Done derotating and combining.")
+        if full_output:
+            return cube_out, cube_der, frames
+        return frames
     cube_der = B.derotate(cube_out, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
     frame = B.collapse(cube_der, _s(collapse), w=weights)
     if verbose:
@@ -236,6 +260,8 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
             raise NotImplementedError("cube_ref is outside the accelerated annular path")
         outs = []
         for ch in range(nch):
+            if isinstance(ncomp[ch], list):
+                raise NotImplementedError("a list of ncomp per channel is outside the accelerated annular path")
             fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t[ch], fwhm=fwhm[ch], ncomp=ncomp[ch],
                                   full_output=True)
             outs.append(_pca_adi_rdi(**fp, **rot_options))
@@ -247,6 +273,12 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
         return host4(frame)
     fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t, full_output=True)
     cube_out, cube_der, frame = _pca_adi_rdi(**fp, **rot_options)
+    if isinstance(frame, list):
+        # list ncomp: the reference allocates cube_out / cube_der with np.zeros (float64, pca_local.py:666-668,800)
+        frames = [host4(f) for f in frame]
+        if algo_params.full_output:
+            return host4(cube_out), host4(cube_der), frames
+        return frames
     if algo_params.full_output:
         return host(cube_out), host(cube_der), host(frame)
     return host(frame)
