@@ -105,6 +105,24 @@ def set_async(on=True, reserve_cus=16):
             c.lib.vipmi_set_gate(c.handle, gate)
 
 
+def is_async():
+    return bool(_async["on"])
+
+
+_side_streams = {}
+
+
+def side_streams(depth, device=None):
+    """``depth`` cached torch streams of the device (independent sub-problems of ONE call -- spectral channels --
+    are issued round-robin on them in asynchronous mode, see psfsub/pca_fullfr.py)."""
+    torch = require_gpu()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    lst = _side_streams.setdefault(dev, [])
+    while len(lst) < depth:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:depth]
+
+
 def check_deferred():
     """Synchronise every context and raise if a deferred error (eigensolver non-convergence) was latched."""
     with _ctx_lock:

@@ -487,20 +487,40 @@ def pca(*all_args: List, **all_kwargs: dict):
         fwhm = algo_params.fwhm
         fwhms = [fwhm] * nch if np.isscalar(fwhm) else fwhm
         outs = []
-        for ch in range(nch):
-            ref_ch = None
-            if cube_ref_t is not None:
-                if cube_ref_t.ndim != 4:
-                    raise TypeError("Ref cube has wrong format for 4d input cube")
-                if algo_params.ref_strategy == "RDI":
-                    ref_ch = cube_ref_t[ch]
-                elif algo_params.ref_strategy == "ARDI":
-                    ref_ch = torch.cat((cube_t[ch], cube_ref_t[ch]))
-                else:
-                    raise TypeError("ref_strategy argument not recognized.Should be 'RDI' or 'ARDI'")
-            fp = setup_parameters(algo_params, _adi_rdi_pca, cube=cube_t[ch], cube_ref=ref_ch,
-                                  ncomp=ncomps[ch], fwhm=fwhms[ch], **add)
-            outs.append(_adi_rdi_pca(**fp, **rot_options))
+        # the channels are independent: issue them round-robin on two streams in asynchronous mode, so that the
+        # latency-bound eigensolver of one channel runs beside the derotation of the previous one (unless the
+        # caller already pipelines whole calls itself)
+        pipelined = nch > 1 and not B.is_async()
+        cur = torch.cuda.current_stream()
+        streams = B.side_streams(2, cube_t.device.index) if pipelined else [cur]
+        if pipelined:
+            B.set_async(True)
+        try:
+            for ch in range(nch):
+                st = streams[ch % len(streams)]
+                if pipelined and ch < len(streams):
+                    st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    ref_ch = None
+                    if cube_ref_t is not None:
+                        if cube_ref_t.ndim != 4:
+                            raise TypeError("Ref cube has wrong format for 4d input cube")
+                        if algo_params.ref_strategy == "RDI":
+                            ref_ch = cube_ref_t[ch]
+                        elif algo_params.ref_strategy == "ARDI":
+                            ref_ch = torch.cat((cube_t[ch], cube_ref_t[ch]))
+                        else:
+                            raise TypeError("ref_strategy argument not recognized.Should be 'RDI' or 'ARDI'")
+                    fp = setup_parameters(algo_params, _adi_rdi_pca, cube=cube_t[ch], cube_ref=ref_ch,
+                                          ncomp=ncomps[ch], fwhm=fwhms[ch], **add)
+                    outs.append(_adi_rdi_pca(**fp, **rot_options))
+            if pipelined:
+                for st in streams:
+                    cur.wait_stream(st)
+                B.check_deferred()
+        finally:
+            if pipelined:
+                B.set_async(False)
         ifs = torch.stack([o[4] if fo else o for o in outs])
         frame = B.collapse(ifs, _s(algo_params.collapse_ifs))
         if fo:

@@ -259,12 +259,30 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
         if algo_params.cube_ref is not None:
             raise NotImplementedError("cube_ref is outside the accelerated annular path")
         outs = []
-        for ch in range(nch):
-            if isinstance(ncomp[ch], list):
-                raise NotImplementedError("a list of ncomp per channel is outside the accelerated annular path")
-            fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t[ch], fwhm=fwhm[ch], ncomp=ncomp[ch],
-                                  full_output=True)
-            outs.append(_pca_adi_rdi(**fp, **rot_options))
+        # independent channels: two streams in asynchronous mode (see the 4-D loop of psfsub/pca_fullfr.py)
+        pipelined = nch > 1 and not B.is_async()
+        cur = torch.cuda.current_stream()
+        streams = B.side_streams(2, cube_t.device.index) if pipelined else [cur]
+        if pipelined:
+            B.set_async(True)
+        try:
+            for ch in range(nch):
+                if isinstance(ncomp[ch], list):
+                    raise NotImplementedError("a list of ncomp per channel is outside the accelerated annular path")
+                st = streams[ch % len(streams)]
+                if pipelined and ch < len(streams):
+                    st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t[ch], fwhm=fwhm[ch], ncomp=ncomp[ch],
+                                          full_output=True)
+                    outs.append(_pca_adi_rdi(**fp, **rot_options))
+            if pipelined:
+                for st in streams:
+                    cur.wait_stream(st)
+                B.check_deferred()
+        finally:
+            if pipelined:
+                B.set_async(False)
         ifs = torch.stack([o[2] for o in outs])
         frame = B.collapse(ifs, _s(algo_params.collapse_ifs)) if algo_params.collapse_ifs is not None else ifs
         if algo_params.full_output:
