@@ -31,11 +31,16 @@ using tri::fast_rcp;
 using tri::hash_unit;
 using tri::sturm_count;
 
-template <int RPL>
-__global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
-                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
-                                                      double* __restrict__ evecs_all, double* __restrict__ scratch_all,
-                                                      int kp, int all_evals) {
+// NT = threads per workgroup: 1024 for a handful of problems; 512 once there are more problems than CUs (annular
+// PCA: 400 problems of 200 x 200 per annulus), so that two problems share a CU -- a problem is bound by the latency
+// of its ~n dependent steps (7.6 us each at n = 200), not by throughput: 400 problems take 2.7 ms, one takes 1.5 ms.
+// The Gram-Schmidt stage holds 4 vectors per wave: k <= NT/16.
+template <int RPL, int NT>
+__global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
+                                                     const int32_t* __restrict__ nact, double* __restrict__ evals_all,
+                                                     double* __restrict__ evecs_all, double* __restrict__ scratch_all,
+                                                     int kp, int all_evals) {
+  constexpr int TNT = NT, TNW = NT / 64;          // (shadow the file-scope values used by tri_multi_kernel)
   extern __shared__ double sm[];
   double* vcur = sm;             // [n] Householder vector of the current step (indexed by absolute row)
   double* vprev = vcur + n;      // [n] pending rank-2 update  A -= v w^T + w v^T
@@ -63,12 +68,18 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
   __syncthreads();
 
   // ---------------- 1. tridiagonalisation ----------------
-  // Per step: ONE global round trip (the trailing pass).  Its first batch of loads is issued before the
-  // Householder vector of the step is formed, and row s itself arrives through LDS (`nrow`, written by the wave
-  // that updated it in the previous pass) instead of being re-read from L2.
+  // Per step: ONE global round trip (the trailing pass) over the LOWER triangle of the trailing matrix only (the
+  // batch is bound by the traffic of these passes: 400 problems of 200 x 200 move 2/3 n^3 * 8 B each).  Element
+  // (r, c), c <= r, is updated once and used twice: in the dot product of row r with v (wave reduction) and, for
+  // c < r, in the column sum  sum_r A[r][c] v[r]  that a lane accumulates in registers for its columns; the column
+  // sums of the waves are combined through LDS in a fixed order (deterministic).  The first batch of loads is
+  // issued before the Householder vector of the step is formed; column s+1 of the updated matrix (the next
+  // Householder column) is handed over through LDS (`nrow`) instead of being re-read.
   constexpr int RQ = 4;                                // rows per wave and batch
-  double* nrow = e2;                                   // [n] row s of the updated matrix (e2 is not yet in use)
-  for (int c = tid; c < na; c += TNT) nrow[c] = A[c];  // row 0
+  double* nrow = e2;                                   // [n] column s of the updated matrix (e2 is not yet in use)
+  double* prow = lam + 72;                             // [n] row parts of A v
+  double* pcolw = prow + n;                            // [TNW][n] per-wave column parts of A v
+  for (int c = tid; c < na; c += TNT) nrow[c] = A[(size_t)c * n];  // column 0
   __syncthreads();
   for (int s = 0; s + 2 < na; ++s) {
     // first batch of the trailing pass: rows r0 .. r0+RQ-1 of this wave (independent of the new Householder vector)
@@ -79,10 +90,10 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
 #pragma unroll
       for (int ch = 0; ch < RPL; ++ch) {
         const int c = s + 1 + lane + 64 * ch, r = rfirst + q;
-        a[q][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
+        a[q][ch] = (r < na && c <= r) ? A[(size_t)r * n + c] : 0.0;
       }
     if (wave == 0) {
-      // row s (already updated): its tail is the next Householder column
+      // column s below the diagonal (already updated) is the next Householder vector
       double nrm2 = 0.0;
       for (int c = s + 1 + lane; c < na; c += 64) {
         const double x = nrow[c];
@@ -106,10 +117,14 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
         tau[s] = beta;
       }
       __builtin_amdgcn_wave_barrier();
-      for (int c = s + 1 + lane; c < na; c += 64) A[(size_t)s * n + c] = vcur[c];   // kept for the back-transform
+      // kept for the back-transform, in the (otherwise unused) upper triangle: row s, columns > s
+      for (int c = s + 1 + lane; c < na; c += 64) A[(size_t)s * n + c] = vcur[c];
     }
     __syncthreads();
     const double beta = tau[s];
+    double colacc[RPL];
+#pragma unroll
+    for (int ch = 0; ch < RPL; ++ch) colacc[ch] = 0.0;
     for (int r0 = rfirst; r0 < na; r0 += RQ * TNW) {
       if (r0 != rfirst) {
 #pragma unroll
@@ -117,39 +132,45 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
 #pragma unroll
           for (int ch = 0; ch < RPL; ++ch) {
             const int c = s + 1 + lane + 64 * ch, r = r0 + q;
-            a[q][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
+            a[q][ch] = (r < na && c <= r) ? A[(size_t)r * n + c] : 0.0;
           }
       }
 #pragma unroll
       for (int q = 0; q < RQ; ++q) {
         const int r = r0 + q;
         if (r < na) {
-          const double vr = vprev[r], wr = wprev[r];
+          const double vr = vprev[r], wr = wprev[r], vcr = vcur[r];
           double acc = 0.0;
 #pragma unroll
           for (int ch = 0; ch < RPL; ++ch) {
             const int c = s + 1 + lane + 64 * ch;
-            if (c < na) {
+            if (c <= r) {
               const double t = a[q][ch] - vr * wprev[c] - wr * vprev[c];
               A[(size_t)r * n + c] = t;
-              a[q][ch] = t;
               acc += t * vcur[c];
+              if (c < r) colacc[ch] += t * vcr;
+              if (ch == 0 && lane == 0) nrow[r] = t;     // column s+1 (without the still pending update of this step)
             }
           }
           acc = wave_sum(acc);
-          if (lane == 0) pcur[r] = beta * acc;
-        }
-      }
-      if (r0 == s + 1) {            // this wave holds row s+1: stash it (without the still pending update) for the next step
-#pragma unroll
-        for (int ch = 0; ch < RPL; ++ch) {
-          const int c = s + 1 + lane + 64 * ch;
-          if (c < na) nrow[c] = a[0][ch];
+          if (lane == 0) prow[r] = acc;
         }
       }
     }
+#pragma unroll
+    for (int ch = 0; ch < RPL; ++ch) {
+      const int c = s + 1 + lane + 64 * ch;
+      if (c < na) pcolw[wave * n + c] = colacc[ch];
+    }
     __syncthreads();
-    // K = beta/2 v.p (every wave computes it: no second barrier) ; w = p - K v becomes the pending update
+    for (int r = s + 1 + tid; r < na; r += TNT) {
+      double t = prow[r];
+#pragma unroll 4
+      for (int w = 0; w < TNW; ++w) t += pcolw[w * n + r];
+      pcur[r] = beta * t;
+    }
+    __syncthreads();
+    // K = beta/2 v.p (every wave computes it: no further barrier) ; w = p - K v becomes the pending update
     double kd = 0.0;
     for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pcur[r];
     const double K = 0.5 * beta * wave_sum(kd);
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
       const double w = pcur[r] - K * v;
       wprev[r] = w;
       vprev[r] = v;
-      nrow[r] = nrow[r] - vs1 * w - ws1 * v;      // row s+1 with its own step's update: ready for the next step
+      nrow[r] = nrow[r] - vs1 * w - ws1 * v;      // column s+1 with its own step's update: ready for the next step
     }
     __syncthreads();
   }
@@ -167,7 +188,7 @@ __global__ __launch_bounds__(TNT) void tri_eig_kernel(double* __restrict__ Aall,
     if (na >= 2) {
       const int a = na - 2, b = na - 1;
       dd[a] = A[(size_t)a * n + a] - 2.0 * vprev[a] * wprev[a];
-      ee[a] = A[(size_t)a * n + b] - vprev[a] * wprev[b] - wprev[a] * vprev[b];
+      ee[a] = A[(size_t)b * n + a] - vprev[a] * wprev[b] - wprev[a] * vprev[b];
       dd[b] = A[(size_t)b * n + b] - 2.0 * vprev[b] * wprev[b];
       ee[b] = 0.0;
     } else if (na == 1) {
@@ -892,12 +913,24 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   const int kp = (int)cdiv(k, 16) * 16;
   double* scratch = nullptr;
   VIPMI_TRY(ws(ctx, "eigh_tri_scratch", (size_t)batch * 6 * n * kp, &scratch));
-  const size_t lds = ((size_t)8 * n + 64 + 8) * sizeof(double);
-  auto kern = tri_eig_kernel<RPL>;
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(TNT), lds, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
-                     all_evals);
+  // workgroup size: several problems per CU once there are more problems than CUs (option eigh_nt overrides)
+  int nt = (int)ctx->opt("eigh_nt", 0);
+  if (nt != 256 && nt != 512 && nt != 1024) nt = batch > ctx->num_cu ? 512 : 1024;   // measured: 256 never wins
+  while (nt < 1024 && k > nt / 16) nt *= 2;
+  const size_t lds = ((size_t)(9 + nt / 64) * n + 64 + 8) * sizeof(double);     // + prow[n], pcolw[waves][n]
+  const void* kern = nt == 256   ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 256>)
+                     : nt == 512 ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 512>)
+                                 : reinterpret_cast<const void*>(tri_eig_kernel<RPL, 1024>);
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (nt == 256)
+    hipLaunchKernelGGL((tri_eig_kernel<RPL, 256>), dim3((unsigned)batch), dim3(256), lds, ctx->stream, A, n, k, nact,
+                       evals, evecs, scratch, kp, all_evals);
+  else if (nt == 512)
+    hipLaunchKernelGGL((tri_eig_kernel<RPL, 512>), dim3((unsigned)batch), dim3(512), lds, ctx->stream, A, n, k, nact,
+                       evals, evecs, scratch, kp, all_evals);
+  else
+    hipLaunchKernelGGL((tri_eig_kernel<RPL, 1024>), dim3((unsigned)batch), dim3(1024), lds, ctx->stream, A, n, k, nact,
+                       evals, evecs, scratch, kp, all_evals);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }

@@ -13,6 +13,7 @@ Not accelerated (NotImplementedError): ``scale_list`` (mSDI), ``cube_ref``, ``cu
 ``ncomp='auto'``.
 """
 import ctypes
+from collections import OrderedDict
 from dataclasses import dataclass
 from enum import Enum
 from typing import List, Tuple, Union
@@ -116,6 +117,40 @@ def annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, delta_r
     return plan
 
 
+# The plan is pure index arithmetic on (frame shape, angles, geometry parameters), but it costs tens of milliseconds
+# of host time (n_annuli x n library selections) -- as much as the device work of a C3-sized call.  Callers such as
+# contrast curves or fake-companion loops repeat the same geometry hundreds of times, so the last few plans are kept,
+# together with the device copies of their pixel / library index arrays.
+_PLAN_CACHE = OrderedDict()
+_PLAN_CACHE_SIZE = 8
+
+
+def _freeze(v):
+    if isinstance(v, np.ndarray):
+        return ("nd", v.shape, v.dtype.str, v.tobytes())
+    if isinstance(v, (list, tuple)):
+        return (type(v).__name__,) + tuple(_freeze(x) for x in v)
+    return v
+
+
+def cached_annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, delta_rot, ncomp, min_frames_lib,
+                        max_frames_lib, theta_init=0):
+    """``annulus_plan`` through a small LRU cache; returns (plan, dev) where ``dev`` is a dict the caller may use to
+    keep device-side copies that belong to this plan."""
+    key = _freeze((tuple(shape), np.ascontiguousarray(angle_list, dtype=np.float64), radius_int, fwhm, asize, n_segments,
+                   delta_rot, ncomp, min_frames_lib, max_frames_lib, theta_init))
+    hit = _PLAN_CACHE.get(key)
+    if hit is None:
+        hit = (annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, delta_rot, ncomp, min_frames_lib,
+                            max_frames_lib, theta_init), {})
+        _PLAN_CACHE[key] = hit
+        while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+            _PLAN_CACHE.popitem(last=False)
+    else:
+        _PLAN_CACHE.move_to_end(key)
+    return hit
+
+
 def _pack_libs(libs):
     n = len(libs)
     max_lib = max(len(li) for li in libs)
@@ -151,8 +186,9 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
     n, y, x = cube.shape
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
-    plan = annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot,
-                        ncomp if ks is None else int(ks.max()), min_frames_lib, max_frames_lib, theta_init)
+    plan, plan_dev = cached_annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot,
+                                         ncomp if ks is None else int(ks.max()), min_frames_lib, max_frames_lib,
+                                         theta_init)
     if verbose:
         print("N annuli = {}, FWHM = {:.3f}".format(int((y / 2 - radius_int) / asize), fwhm))
     ctx = B.get_context(cube.device.index)
@@ -161,14 +197,18 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     cube_out = torch.zeros_like(cube) if ks is None else torch.zeros((len(ks),) + tuple(cube.shape), dtype=cube.dtype,
                                                                      device=cube.device)
     scaling = _s(scaling)
-    lib_cache = {}
-    for seg in plan:
-        pix_h = seg["pix"]
-        # pad to a multiple of 4 columns (-1 = zero column) so rows are 16-byte aligned; zero columns change
-        # neither the Gram matrix nor temporal statistics (spatial scaling needs the exact row length)
-        if pix_h.size % 4 and scaling not in ("spat-mean", "spat-standard"):
-            pix_h = np.concatenate([pix_h, np.full(4 - pix_h.size % 4, -1, dtype=np.int32)])
-        pix = torch.from_numpy(pix_h).to(cube.device)
+    pad_ok = scaling not in ("spat-mean", "spat-standard")
+    lib_cache = plan_dev.setdefault(("libs", dev), {})
+    pix_cache = plan_dev.setdefault(("pix", dev, pad_ok), {})
+    for si, seg in enumerate(plan):
+        pix = pix_cache.get(si)
+        if pix is None:
+            pix_h = seg["pix"]
+            # pad to a multiple of 4 columns (-1 = zero column) so rows are 16-byte aligned; zero columns change
+            # neither the Gram matrix nor temporal statistics (spatial scaling needs the exact row length)
+            if pix_h.size % 4 and pad_ok:
+                pix_h = np.concatenate([pix_h, np.full(4 - pix_h.size % 4, -1, dtype=np.int32)])
+            pix = pix_cache[si] = torch.from_numpy(pix_h).to(cube.device)
         npx = int(pix.numel())
         A = B.empty((n, npx), device=dev)
         ctx.call("vipmi_gather_f32", B.ptr(cube), n, P, B.ptr(pix), npx, B.ptr(A))
