@@ -1,0 +1,76 @@
+"""GPU parity at BASELINE.json's full C2 size (400 x 512 x 512, ncomp = 20), where the oracle is too slow to run on the
+whole cube: size-independent properties of the path (orthonormal PCs, residuals orthogonal to them, recon + residuals
+= data, linearity of the derotation, exact quarter turns), plus the oracle on a handful of frames / pixel rows."""
+import numpy as np
+import pytest
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+N_FR, N_PX, K = 400, 512, 20
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import torch
+    from vip_amd.psfsub import pca
+    from vip_amd.synth import synth_adi
+    cube, ang = synth_adi(N_FR, N_PX, seed=0)
+    cube_t = torch.from_numpy(cube).cuda()
+    out = pca(cube_t, ang, ncomp=K, full_output=True, verbose=False, check_memory=False)
+    return cube, ang, cube_t, out
+
+
+def test_c2_projection_properties(c2):
+    import torch
+    cube, ang, cube_t, (frame, pcs, recon, res, res_der) = c2
+    P = N_PX * N_PX
+    V = pcs.reshape(K, P).double()
+    M = cube_t.reshape(N_FR, P)
+    R = res.reshape(N_FR, P)
+    assert (V @ V.T - torch.eye(K, dtype=torch.float64, device=V.device)).abs().max().item() < 2e-5   # orthonormal PCs
+    # reconstructed + residuals = data (float32 round-off of one subtraction)
+    assert (recon.reshape(N_FR, P) + R - M).abs().max().item() < 4e-6
+    # residuals are orthogonal to the PCs: |V r| small against |r|
+    c = (R.double() @ V.T).abs().max().item()
+    assert c < 1e-3 * R.double().norm(dim=1).max().item() / np.sqrt(K)
+    # the model lives in the row space of the data: recon = (M V^T) V
+    coeff = M.double() @ V.T
+    assert ((coeff @ V).float() - recon.reshape(N_FR, P)).abs().max().item() < 1e-4
+    # idempotence: projecting the residuals again removes nothing more
+    again = R.double() - (R.double() @ V.T) @ V
+    assert (again.float() - R).abs().max().item() < 1e-4
+
+
+def test_c2_derotation_and_median_against_oracle_samples(c2):
+    cube, ang, cube_t, (frame, pcs, recon, res, res_der) = c2
+    ang_c = O.check_pa_vector(ang)
+    for i in (0, 57, 199, 266, 399):                 # derotation angles in several rot90 quadrants
+        exp = O.frame_rotate_fft(res[i].cpu().numpy().astype(np.float64), -ang_c[i])
+        got = res_der[i].cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert np.nanmax(np.abs(got - exp)) < 1e-4, i
+    rows = slice(200, 216)
+    exp = np.nanmedian(res_der[:, rows].cpu().numpy(), axis=0)
+    assert np.array_equal(frame[rows].cpu().numpy(), exp)          # median collapse: bit-exact
+
+
+def test_c2_derotation_linearity_and_quarter_turns():
+    import torch
+    from vip_amd import backend as B
+    rng = np.random.default_rng(5)
+    n = 24
+    a = torch.from_numpy(rng.standard_normal((n, N_PX, N_PX)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.standard_normal((n, N_PX, N_PX)).astype(np.float32)).cuda()
+    angles = np.linspace(-170, 190, n)
+    da, db, dab = B.derotate(a, angles), B.derotate(b, angles), B.derotate(a + 2 * b, angles)
+    assert (da + 2 * db - dab).abs().max().item() < 1e-4
+    # quarter turns are exact re-indexings (rot90 about pixel N//2 through the odd embedding): no interpolation error
+    for ang, k in ((-90.0, 1), (-180.0, 2), (-270.0, 3), (90.0, 3)):
+        got = B.derotate(a[:2], np.array([ang, ang]))[0].cpu().numpy()
+        src = a[0].cpu().numpy()
+        emb = np.zeros((N_PX + 1, N_PX + 1), np.float32)
+        emb[:N_PX, :N_PX] = src
+        exp = np.rot90(emb, k)[:N_PX, :N_PX]
+        assert np.abs(got - exp).max() < 2e-5, ang
