@@ -170,8 +170,13 @@ def to_device_f32(x, device=None):
     if isinstance(x, torch.Tensor):
         t = x.to(device=dev, dtype=torch.float32)
     else:
-        a = np.ascontiguousarray(x, dtype=np.float32)
-        t = torch.from_numpy(a).to(dev)
+        a = np.ascontiguousarray(x)
+        if a.dtype in (np.float64, np.float16, np.int32, np.int64, np.int16, np.uint8):
+            # convert on the device: a float64 cube of C2 size costs 60 ms in numpy's astype, 15 ms to upload as is
+            # (same round-to-nearest-even conversion)
+            t = torch.from_numpy(a).to(dev).to(torch.float32)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     return t.contiguous()
 
 
