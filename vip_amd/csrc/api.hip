@@ -443,10 +443,8 @@ int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float
   VIPMI_TRY(ws(ctx, "pca_evals", (size_t)nref, &evals));
   VIPMI_TRY(ws(ctx, "pca_evecs", (size_t)nref * nref, &evecs));
   VIPMI_TRY(gram_f32(ctx, ref, nref, ref, nref, P, P, G));
-  if (evals_out)      // the caller wants the whole spectrum
-    VIPMI_TRY(eigh_f64(ctx, G, 1, nref, evals, evecs));
-  else
-    VIPMI_TRY(eigh_leading(ctx, G, 1, nref, k, nullptr, evals, evecs));
+  // evals_out: the caller wants the whole spectrum (values only beyond the k leading pairs)
+  VIPMI_TRY(eigh_leading(ctx, G, 1, nref, k, nullptr, evals, evecs, evals_out != nullptr));
   VIPMI_TRY(ctx->gate_enter());
   const int nld = (int)cdiv(nref, 32) * 32, kld = (int)cdiv(k, 32) * 32;
   float *Ekn = nullptr, *Enk = nullptr, *isig = nullptr;
