@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvipmi.so")
+LIB_PATH = os.environ.get("VIPMI_LIB_PATH") or os.path.join(_HERE, "libvipmi.so")   # (override: A/B builds)
 
 c_f32p = ctypes.c_void_p
 i64 = ctypes.c_int64
