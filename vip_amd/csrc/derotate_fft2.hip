@@ -157,6 +157,55 @@ struct Tasks {
   }
 };
 
+// Workgroup-wide task sequence WITHOUT a workgroup barrier (one wave per line): all waves of a workgroup walk the same
+// dynamic sequence of tasks (their line pairs are adjacent rows -- that is what makes the rot90-folded gather of
+// shear 1 efficient), but each at its own pace, so that one wave's loads overlap the other waves' transforms instead of
+// all eight waiting in the same phase.  The sequence lives in a 4-entry LDS ring: the first wave to need token i claims
+// it (LDS compare-and-swap), fetches it from the XCD queue and publishes it; a wave may run at most 4 tokens ahead
+// of the slowest one.  All waves see the same tokens, hence leave the loop at the same index.
+// LDS words (the barrier counters of Twiddles, unused when WPL == 1): ring [0..3], ready [4], claim [5],
+// consumed [8 + wave].
+template <class P>
+struct RingTasks {
+  static_assert(P::WPL == 1 && P::WPB <= 8, "RingTasks: one wave per line, at most 8 waves");
+  int* ctr;
+  volatile int* w;
+  int xcd, i, wave;
+  __device__ __forceinline__ void init(int* counters, cf* lds_all, int wave_) {
+    xcd = blockIdx.x & 7;
+    ctr = counters + xcd * 32;
+    w = reinterpret_cast<volatile int*>(lds_all + P::LPB * P::LDS_ELEMS + Twiddles<P>::PER_LANE * 64);   // zeroed by tw.init
+    i = 0;
+    wave = wave_;
+  }
+  __device__ __forceinline__ int next() {
+    int t = 0;
+    if ((threadIdx.x & 63) == 0) {
+      for (;;) {
+        if (i < w[4]) {
+          t = w[i & 3];
+          break;
+        }
+        if (atomicCAS(const_cast<int*>(&w[5]), i, i + 1) == i) {
+          if (i >= 4)
+            for (int k = 0; k < P::WPB; ++k)
+              while (w[8 + k] < i - 3) __builtin_amdgcn_s_sleep(1);
+          t = atomicAdd(ctr, 1);
+          w[i & 3] = t;
+          __threadfence_block();
+          w[4] = i + 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      w[8 + wave] = i + 1;
+    }
+    ++i;
+    t = __builtin_amdgcn_readfirstlane(t);
+    return t * 8 + xcd;
+  }
+};
+
 // ---- blocked intermediates (plans with one wave per line) ----
 // A wave of a row kernel holds a PAIR of rows as one complex line, a wave of the column kernel a pair of columns;
 // with row-major intermediates the column kernel touches 8 bytes of a different 128-byte line with every lane, and
@@ -199,16 +248,26 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
   VIPMI_SLOT_PROLOGUE();
   constexpr bool PW = false;   // one token per workgroup: its LPB line pairs are adjacent rows, which share the
                                // source frame's 64-byte sectors when the rot90 pre-step makes the gather column-wise
-  Tasks<P, PW> tasks;
-  tasks.init(counters, lds_all);
   constexpr bool BLK = P::WPL == 1;             // blocked intermediates, rows paired 64 apart
+  // one wave per line: barrier-free workgroup sequence (RingTasks); else one token per workgroup and barrier
+  using TaskSource = typename std::conditional<BLK, RingTasks<P>, Tasks<P, PW>>::type;
+  TaskSource tasks;
+  if constexpr (BLK) tasks.init(counters, lds_all, wave); else tasks.init(counters, lds_all);
   const int half = BLK ? Blk<P>::NB : g.N / 2;
   const int npairs = nf * half;
   constexpr int PPT = 4;                        // line pairs per token of a wave (keeps the atomics under ~25 per us)
   const int ntask = PW ? (npairs + PPT - 1) / PPT : (npairs + P::LPB - 1) / P::LPB;
-  tasks.request();
-  for (int task = tasks.template take<1>(); task < ntask; task = tasks.template take<1>()) {
-    tasks.request();
+  auto next_task = [&]() {
+    if constexpr (BLK) {
+      return tasks.next();
+    } else {
+      const int t = tasks.template take<1>();
+      tasks.request();
+      return t;
+    }
+  };
+  if constexpr (!BLK) tasks.request();
+  for (int task = next_task(); task < ntask; task = next_task()) {
    for (int sub_task = 0; sub_task < (PW ? PPT : 1); ++sub_task) {
     int pr = PW ? task * PPT + sub_task : task * P::LPB + slot;
     const bool live = pr < npairs;
