@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void shear3_direct(const float2* __restrict__ 
 int derotate_direct(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
                     float* out, int mask_nan, int mask_zero) {
   const int64_t per_frame = (int64_t)g.N * g.Le;          // float2 elements per intermediate
-  int64_t budget = ctx->opt("rot_ws_mb", 2048) * (int64_t)(1 << 20);
+  int64_t budget = ctx->opt("rot_ws_mb", 4096) * (int64_t)(1 << 20);
   int64_t chunk = budget / (2 * per_frame * (int64_t)sizeof(float2));
   if (chunk < 1) chunk = 1;
   if (chunk > n) chunk = n;

@@ -653,7 +653,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   const int64_t per_frame = (int64_t)(BLK ? g.N + 2 : g.N) * P::L;     // floats per intermediate per frame
   int64_t chunk = ctx->opt("rot_batch", 0);
   if (chunk <= 0) {
-    int64_t budget = ctx->opt("rot_ws_mb", 2048) * (int64_t)(1 << 20);
+    int64_t budget = ctx->opt("rot_ws_mb", 4096) * (int64_t)(1 << 20);
     chunk = budget / (2 * per_frame * (int64_t)sizeof(float));
   }
   if (chunk < 1) chunk = 1;
