@@ -408,6 +408,24 @@ def test_derotate_fft_vs_oracle_and_direct(B, N):
         assert np.nanmax(np.abs(got - alt)) < 2e-5
 
 
+@pytest.mark.parametrize("N", [128, 256])
+def test_derotate_batching_is_bit_identical(B, N):
+    """The derotation works through the cube in batches sized by the workspace option; results must not depend on
+    the batch size (deterministic kernels, blocked intermediates indexed by the frame's position in its batch)."""
+    import torch
+    rng = np.random.default_rng(N)
+    ang = np.array([3.0, -47.5, 95.0, 200.1, 333.3, 135.0, 44.999, 270.0, 181.0, 91.0, -1.0])
+    cube = torch.from_numpy(rng.standard_normal((len(ang), N, N)).astype(np.float32)).cuda()
+    ctx = B.get_context()
+    ref = B.derotate(cube, ang).cpu().numpy()
+    try:
+        for rb in (1, 3, 4):
+            ctx.set_option("rot_batch", rb)
+            assert np.array_equal(B.derotate(cube, ang).cpu().numpy(), ref), rb
+    finally:
+        ctx.set_option("rot_batch", 0)
+
+
 def test_derotate_fft_golden_128(B):
     from vip_amd.preproc import cube_derotate
     g = load_golden("g3_rotate")
