@@ -83,6 +83,10 @@ int vipmi_scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int6
 int vipmi_apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
                          const uint8_t* mask, float fill);
 
+/* `batch` Gram matrices of equal shape in one launch: M is [batch][n][P], G is [batch][n][n] (float64).  Used for
+ * the first pass of ADI+mSDI (pca_fullfr.py:1482-1520: one spectral PCA per multispectral frame). */
+int vipmi_gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, int64_t P, double* G);
+
 /* ---- svd_wrapper mode 'eigen'/'lapack' arithmetic: psfsub/svd.py:447-475 ---- */
 /* G[n,n] (float64, symmetric) = M[n,P] * M^T, M row-major with leading dimension ld (floats). */
 int vipmi_gram_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double* G);

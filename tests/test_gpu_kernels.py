@@ -55,6 +55,18 @@ def test_gram_tile_variants(B):
     ctx.set_option("gram_tb", 0)
 
 
+@pytest.mark.parametrize("batch,n,P", [(7, 39, 1089), (3, 12, 4096), (5, 30, 333), (2, 70, 2500)])
+def test_gram_batched(B, batch, n, P):
+    """One launch for a stack of equally shaped Gram problems (ADI+mSDI first pass); odd row lengths included."""
+    rng = np.random.default_rng(batch * 100 + n)
+    M = (rng.standard_normal((batch, n, P)) * 2 + 0.3).astype(np.float32)
+    G = B.gram_batched(dev(B, M)).cpu().numpy()
+    ref = np.einsum("bip,bjp->bij", M.astype(np.float64), M.astype(np.float64))
+    assert G.shape == (batch, n, n)
+    assert np.abs(G - ref).max() < 1e-9 * np.abs(ref).max()
+    assert np.array_equal(G, G.transpose(0, 2, 1))
+
+
 def test_cross_gram(B):
     rng = np.random.default_rng(6)
     A = rng.standard_normal((37, 3000)).astype(np.float32)

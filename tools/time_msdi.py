@@ -17,3 +17,9 @@ for mode, nc in (("double", (3, 10)),):
         fr = pca(ct, ang, scale_list=sc, adimsdi=mode, ncomp=nc, verbose=False, check_memory=False)
         torch.cuda.synchronize()
         print(mode, nc, "%.1f ms" % ((time.perf_counter() - t) * 1e3), bool(torch.isfinite(fr).all()), "peak GB %.1f" % (torch.cuda.max_memory_allocated() / 1e9))
+from vip_amd import backend as B
+ctx = B.get_context(); ctx.set_option("timing", 1); ctx.reset_timers()
+torch.cuda.synchronize(); t = time.perf_counter()
+fr = pca(ct, ang, scale_list=sc, adimsdi="double", ncomp=(3, 10), verbose=False, check_memory=False)
+torch.cuda.synchronize()
+print("with stage timing: %.1f ms" % ((time.perf_counter() - t) * 1e3), {s: (round(ctx.stage_ms(s), 2), ctx.stage_count(s)) for s in ("scale", "gram", "eigh", "project", "derotate", "collapse")})

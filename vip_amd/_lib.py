@@ -33,6 +33,7 @@ _SIGS = {
     "vipmi_scale_f32": ([c_f32p, c_f32p, i64, i64, ctypes.c_int], True, ctypes.c_int),
     "vipmi_apply_mask_f32": ([c_f32p, c_f32p, i64, i64, ctypes.c_void_p, ctypes.c_float], True, ctypes.c_int),
     "vipmi_gram_f32": ([c_f32p, i64, i64, i64, ctypes.c_void_p], True, ctypes.c_int),
+    "vipmi_gram_batched_f32": ([c_f32p, i64, i64, i64, ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_cross_gram_f32": ([c_f32p, i64, c_f32p, i64, i64, i64, ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_eigh_f64": ([ctypes.c_void_p, i64, i64, ctypes.c_void_p, ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_eigh_spectrum_f64": ([ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p], True, ctypes.c_int),

@@ -224,6 +224,17 @@ def lincomb(x, y=None, a=1.0, b=1.0):
     return out
 
 
+def gram_batched(M3):
+    """M3: (batch, n, P) float32 cuda tensor -> (batch, n, n) float64 Gram matrices, one launch."""
+    torch = _torch()
+    M3 = M3.contiguous()
+    ctx = get_context(M3.device.index)
+    b, n, P = M3.shape
+    G = empty((b, n, n), torch.float64, M3.device.index)
+    ctx.call("vipmi_gram_batched_f32", ptr(M3), b, n, P, ptr(G))
+    return G
+
+
 def gram(M):
     torch = _torch()
     ctx = get_context(M.device.index)

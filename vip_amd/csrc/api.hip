@@ -322,6 +322,11 @@ int vipmi_gram_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t
   return gram_f32(ctx, M, n, M, n, P, ld, G);
 }
 
+int vipmi_gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, int64_t P, double* G) {
+  CTX_GUARD();
+  return gram_batched_f32(ctx, M, batch, n, P, G);
+}
+
 int vipmi_cross_gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb,
                          int64_t P, int64_t ld, double* C) {
   CTX_GUARD();

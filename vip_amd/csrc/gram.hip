@@ -52,7 +52,10 @@ template <int TB, bool ACC64, bool VEC>
 __global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel(
     const float* __restrict__ A, const float* __restrict__ B, int na, int nb, int64_t P, int64_t ld,
     const int2* __restrict__ tiles, int ntiles, int waves_per_wg, int64_t klen, int symmetric,
-    void* __restrict__ partial_) {
+    void* __restrict__ partial_, int64_t batch_stride, int nslices) {
+  // blockIdx.z = problem of a batch (same shapes; operands batch_stride elements apart)
+  A += (int64_t)blockIdx.z * batch_stride;
+  B += (int64_t)blockIdx.z * batch_stride;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int tile = blockIdx.y * waves_per_wg + wave;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel
 
   using sc_t = typename std::conditional<ACC64, double, float>::type;
   sc_t* partial = reinterpret_cast<sc_t*>(partial_) +
-                  ((int64_t)slice * ntiles + tile) * (int64_t)(TB * TB * 256);
+                  (((int64_t)blockIdx.z * nslices + slice) * ntiles + tile) * (int64_t)(TB * TB * 256);
   const int col = lane & 15;
 #pragma unroll
   for (int i = 0; i < TB; ++i)
@@ -162,9 +165,10 @@ __global__ void gram_reduce_kernel(const void* __restrict__ partial_, const int2
                                    int ntiles, int nslices, int na, int nb, int symmetric,
                                    double* __restrict__ G) {
   using sc_t = typename std::conditional<ACC64, double, float>::type;
-  const sc_t* partial = reinterpret_cast<const sc_t*>(partial_);
   const int64_t per_tile = TB * TB * 256;
   const int64_t total = (int64_t)ntiles * per_tile;
+  const sc_t* partial = reinterpret_cast<const sc_t*>(partial_) + (int64_t)blockIdx.y * nslices * total;   // batch
+  G += (int64_t)blockIdx.y * na * nb;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     int tile = (int)(e / per_tile);
@@ -186,7 +190,7 @@ __global__ void gram_reduce_kernel(const void* __restrict__ partial_, const int2
 
 template <int TB, bool ACC64>
 static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb, int64_t P,
-                  int64_t ld, double* G, bool symmetric) {
+                  int64_t ld, double* G, bool symmetric, int64_t batch = 1) {
   const int nba = (int)cdiv(na, 16), nbb = (int)cdiv(nb, 16);
   const int nta = (int)cdiv(nba, TB), ntb = (int)cdiv(nbb, TB);
   std::vector<int2> tiles;
@@ -239,6 +243,10 @@ static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, in
   // slices: ~2 workgroups per CU in total, slice length a multiple of 16, >= 64 pixels
   int64_t target = ctx->opt("gram_slices", 0);
   if (target <= 0) target = cdiv((int64_t)2 * ctx->num_cu, ngroups);
+  if (batch > 1) {                         // many small problems: ~8 waves per CU in total
+    target = cdiv((int64_t)8 * ctx->num_cu, batch * ngroups * wpw);
+    if (target < 1) target = 1;
+  }
   int64_t klen = cdiv(cdiv(P, target), 16) * 16;
   if (klen < 64) klen = 64;
   int nslices = (int)cdiv(P, klen);
@@ -257,22 +265,25 @@ static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, in
   }
   const size_t esz = ACC64 ? 8 : 4;
   void* partial = nullptr;
-  VIPMI_TRY(ctx->get("gram_partial", (size_t)nslices * ntiles * TB * TB * 256 * esz, &partial));
+  VIPMI_TRY(ctx->get("gram_partial", (size_t)batch * nslices * ntiles * TB * TB * 256 * esz, &partial));
   // blocks that are skipped (out of range / lower triangle) are never read by the reducer
   const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  dim3 grid(nslices, ngroups), block(64 * wpw);
+  VIPMI_REQUIRE(batch <= 65535, "gram: batch too large");
+  dim3 grid(nslices, ngroups, (unsigned)batch), block(64 * wpw);
+  const int64_t bstride = na * ld;          // (batched: A == B, problems stacked row-wise)
   if (vec)
     hipLaunchKernelGGL((gram_partial_kernel<TB, ACC64, true>), grid, block, 0, ctx->stream, A, B,
-                       (int)na, (int)nb, P, ld, d_tiles, ntiles, wpw, klen, (int)symmetric, partial);
+                       (int)na, (int)nb, P, ld, d_tiles, ntiles, wpw, klen, (int)symmetric, partial, bstride, nslices);
   else
     hipLaunchKernelGGL((gram_partial_kernel<TB, ACC64, false>), grid, block, 0, ctx->stream, A, B,
-                       (int)na, (int)nb, P, ld, d_tiles, ntiles, wpw, klen, (int)symmetric, partial);
+                       (int)na, (int)nb, P, ld, d_tiles, ntiles, wpw, klen, (int)symmetric, partial, bstride, nslices);
   VIPMI_CHECK_HIP(hipGetLastError());
   int64_t total = (int64_t)ntiles * TB * TB * 256;
   int rb = (int)cdiv(total, 256);
   if (rb > 4096) rb = 4096;
-  hipLaunchKernelGGL((gram_reduce_kernel<TB, ACC64>), dim3(rb), dim3(256), 0, ctx->stream, partial,
+  if (batch > 1 && rb > 64) rb = 64;
+  hipLaunchKernelGGL((gram_reduce_kernel<TB, ACC64>), dim3(rb, (unsigned)batch), dim3(256), 0, ctx->stream, partial,
                      d_tiles, ntiles, nslices, (int)na, (int)nb, (int)symmetric, G);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
@@ -305,6 +316,24 @@ int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t
     case 3: return launch<3, true>(ctx, A, na, B, nb, P, ld, G, symmetric);
     default: return launch<4, true>(ctx, A, na, B, nb, P, ld, G, symmetric);
   }
+}
+
+// `batch` symmetric Gram matrices of equal shape: M is [batch][n][P] (row length ld = P), G is [batch][n][n].
+// One launch for all of them (ADI+mSDI: one 39 x 39 spectral Gram matrix per multispectral frame).
+int gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, int64_t P, double* G) {
+  VIPMI_REQUIRE(M && G, "gram_batched: null pointer");
+  VIPMI_REQUIRE(batch > 0 && n > 0 && P > 0 && n < (1 << 20), "gram_batched: bad sizes batch=%ld n=%ld P=%ld", (long)batch,
+                (long)n, (long)P);
+  StageScope sc(ctx, "gram");
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb_ = (batch - b0) < 65535 ? (batch - b0) : 65535;
+    const float* Mb = M + (size_t)b0 * n * P;
+    double* Gb = G + (size_t)b0 * n * n;
+    if (n <= 16) VIPMI_TRY((launch<1, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
+    else if (n <= 32) VIPMI_TRY((launch<2, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
+    else VIPMI_TRY((launch<4, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
+  }
+  return VIPMI_OK;
 }
 
 }  // namespace vipmi

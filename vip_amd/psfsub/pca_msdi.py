@@ -42,6 +42,37 @@ def _residuals(M3, ncomp, scaling, mask_center_px):
     return res.reshape(nf, y, x)
 
 
+def _residuals_batched(M4, ncomp, scaling, mask_center_px):
+    """``_residuals`` for a stack of equally shaped cubes, M4 = (batch, nf, y, x): the batch of small decompositions
+    (one spectral PCA per multispectral frame in the first pass of ADI+mSDI, pca_fullfr.py:1482-1520) shares ONE Gram
+    launch and ONE eigensolver launch (a workgroup per problem); only the two projection products stay per cube."""
+    torch = B._torch()
+    nb, nf, y, x = M4.shape
+    P = y * x
+    if ncomp > min(nf, P):
+        msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
+        msg += " Increase the size of the patches or request less PCs"
+        raise RuntimeError(msg.format(ncomp, nf, P))
+    if scaling is None and not mask_center_px:
+        M = M4.reshape(nb, nf, P)
+    else:
+        M = torch.stack([_prep(M4[b], scaling, mask_center_px) for b in range(nb)])
+    G = B.gram_batched(M)
+    ev, ec = B.eigh_topk(G, int(ncomp))                                   # (nb, k), (nb, k, nf)
+    keep = (ev > ev[:, :1] * 1e-12).to(torch.float32)
+    E = (ec.to(torch.float32) * keep[:, :, None]).contiguous()            # rows = leading eigenvectors
+    Ct = E.transpose(1, 2).contiguous()                                   # (nb, nf, k)
+    k = E.shape[1]
+    dev = M.device.index
+    ctx = B.get_context(dev)
+    T = B.empty((k, P), device=dev)
+    R = B.empty((nb, nf, P), device=dev)
+    for b in range(nb):
+        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(E[b]), B.ptr(M[b]), k, nf, P, None, B.ptr(T))
+        ctx.call("vipmi_subtract_gemm_f32", B.ptr(M[b]), B.ptr(Ct[b]), B.ptr(T), nf, k, P, B.ptr(R[b]), None)
+    return R.reshape(nb, nf, y, x)
+
+
 def _check(cube, angle_list, scale_list):
     z, n, y_in, x_in = cube.shape
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
@@ -93,10 +124,9 @@ def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
         big = E.shape[1]
         resc = zoom_frames(_frame_major(cube), E, np.tile(np.arange(z), n))          # (n*z, big, big)
         # 2. per multispectral frame: PCA over the z channels
-        res_all = B.empty((n, zc, big, big), device=cube.device.index)
-        for f in range(n):
-            r = _residuals(resc[f * z:(f + 1) * z], int(ncomp_ifs), scaling[0], mask_center_px)
-            res_all[f] = r[i0:i1]
+        res_all = _residuals_batched(resc.reshape(n, z, big, big), int(ncomp_ifs), scaling[0], mask_center_px)
+        if (i0, i1) != (0, z):
+            res_all = res_all[:, i0:i1].contiguous()
         # 3. de-scale, crop back to the input size, collapse the channels
         Einv = channel_operators(big, scale_list[i0:i1], inverse=True, out_size=max(y_in, x_in))
         desc = zoom_frames(res_all.reshape(n * zc, big, big), Einv, np.tile(np.arange(zc), n))
