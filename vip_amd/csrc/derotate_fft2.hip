@@ -168,6 +168,7 @@ struct Tasks {
 template <class P>
 struct RingTasks {
   static_assert(P::WPL == 1 && P::WPB <= 8, "RingTasks: one wave per line, at most 8 waves");
+  static constexpr int TPG = 8;
   int* ctr;
   volatile int* w;
   int xcd, i, wave;
@@ -202,7 +203,7 @@ struct RingTasks {
     }
     ++i;
     t = __builtin_amdgcn_readfirstlane(t);
-    return t * 8 + xcd;
+    return ((t / TPG) * 8 + xcd) * TPG + (t % TPG);      // TPG consecutive tasks (adjacent rows) stay on one XCD / L2
   }
 };
 
