@@ -4,6 +4,7 @@ PyTorch is plumbing only (allocation, H2D/D2H, streams); all arithmetic happens 
 ``vip_amd/csrc``.  One ``Context`` (vipmi_ctx) per (device, stream) is cached.
 """
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -40,6 +41,10 @@ class Context:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         st = self.lib.vipmi_create(self.device, ctypes.c_void_p(stream), ctypes.byref(self.handle))
         _lib.raise_for_status(st, "vipmi_create")
+        # VIPMI_OPTS="key=value,key=value": integer tuning options applied to every new context (A/B measurements)
+        for kv in filter(None, os.environ.get("VIPMI_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), int(v))
 
     def bind_stream(self):
         torch = _torch()

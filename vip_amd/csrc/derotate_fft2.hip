@@ -751,12 +751,15 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
   switch (g.Le) {
     case 512: return run_plan2<Plan512>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     case 1024:
+      // rot_wpb=4: 4-wave workgroups (three per CU at <= 168 VGPRs); a stand-alone derotation gains 4 % (shear 1: 12 %),
+      // but with two calls in flight (4-D cubes, pca_many) the other call's eigensolver finds no free CU: C4 +11 %
       if (ctx->opt("rot_wpb", 8) == 4) return run_plan2<Plan1024w4>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
       return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     case 2048:
       // rot_wpb = waves per workgroup: 8 (default) = one wave per line, 2 waves/SIMD with a 256-VGPR budget;
       // 12 / 16 = two waves per line (more waves, but workgroup barriers and 1.5x the instructions per line)
-      if (ctx->opt("rot_wpb", 8) == 8) return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      if (ctx->opt("rot_wpb", 8) == 8 || ctx->opt("rot_wpb", 8) == 4)
+        return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
       if (ctx->opt("rot_wpb", 8) == 12) return run_plan2<Plan2048w12>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
       return run_plan2<Plan2048>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     case 4096:
