@@ -92,15 +92,17 @@ def _gate():
     return _async["gate"]
 
 
-def set_async(on=True, reserve_cus=16):
+def set_async(on=True, reserve_cus=None):
     """Asynchronous (pipelined) mode: calls enqueue all work on the current torch stream and never
     synchronise (the eigensolver's convergence check is latched on the device and read by
     ``check_deferred()``).  Each (device, stream) pair gets its own vipmi_ctx / workspace, so independent
     calls issued on two streams overlap: the latency-bound Jacobi eigensolver of one cube (13 workgroups)
-    runs beside the FFT derotation of the previous one, for which ``reserve_cus`` CUs are left free.  All
+    runs beside the FFT derotation of the previous one (``reserve_cus`` CUs can be kept free for it; measured best: 0).  All
     contexts share a gate that runs the chip-filling half of the calls one at a time in issue order (otherwise
     identical calls drift into lock step and the chip idles while every stream sits in its eigensolver)."""
     _async["on"] = bool(on)
+    if reserve_cus is None:          # default 0: since the shear kernels take their work from dynamic queues, a CU that is
+        reserve_cus = int(os.environ.get("VIPMI_RESERVE_CUS", "0"))   # busy with the other call's eigensolver costs nothing
     _async["reserve_cus"] = int(reserve_cus) if on else 0
     gate = _gate() if on else None
     with _ctx_lock:

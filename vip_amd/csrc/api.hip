@@ -136,7 +136,7 @@ int vipmi_ctx::gate_leave() {
 }
 
 void vipmi_ctx::tic(const char* stage) {
-  if (!timing) return;
+  if (!timing || (timing == 2 && strcmp(stage, "k_rot_s2") != 0)) return;
   StageTimer& t = timers[stage];
   if (t.open) return;
   if (t.used == (int)t.ev.size()) {
@@ -150,7 +150,7 @@ void vipmi_ctx::tic(const char* stage) {
 }
 
 void vipmi_ctx::toc(const char* stage) {
-  if (!timing) return;
+  if (!timing || (timing == 2 && strcmp(stage, "k_rot_s2") != 0)) return;
   StageTimer& t = timers[stage];
   if (!t.open) return;
   (void)hipEventRecord(t.ev[t.used].second, stream);
@@ -223,7 +223,7 @@ int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
-  if (strcmp(key, "timing") == 0) ctx->timing = value != 0;
+  if (strcmp(key, "timing") == 0) ctx->timing = (int)value;
   ctx->options[key] = value;
   return VIPMI_OK;
 }

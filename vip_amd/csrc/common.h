@@ -76,7 +76,7 @@ struct vipmi_ctx {
   std::map<std::string, std::vector<PinnedSlot>> pinned;   // small rings of pinned staging buffers
   std::map<std::string, int> pinned_next;
   int num_cu = 256;
-  bool timing = false;
+  int timing = 0;                 // 0 off, 1 every stage / kernel, 2 only the roofline kernel (k_rot_s2)
 
   // returns a device buffer of at least `bytes` (contents undefined)
   int get(const char* name, size_t bytes, void** out);
