@@ -29,6 +29,7 @@ struct AuxD {          // per-batch auxiliary arrays (device), as in derotate_ff
   float* kv;           // [nf][N]
   float* gam;          // [nf][Le]   (-1)^X gamma_X
   float* gsum;         // [nf]
+  const float* cotab;  // [Le] cot(pi m/Le)
 };
 
 __device__ __forceinline__ float sin_pi_d(double s) {     // sin(pi s), argument reduced in float64
@@ -39,30 +40,65 @@ __device__ __forceinline__ float sin_pi_d(double s) {     // sin(pi s), argument
   return (((long long)n) & 1) ? -v : v;
 }
 
+// cotab[m] = cot(pi m / Le), m = 1 .. Le-1 (cotab[0] unused): filled once per call in float64 arithmetic.
+__global__ void ds_cotab_kernel(float* __restrict__ cotab, int Le) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Le) return;
+  double sn, cs;
+  sincospi((double)m / (double)Le, &sn, &cs);
+  cotab[m] = (m == 0) ? 0.f : (float)(cs / sn);
+}
+
 // T[u + OFF] = r(u + d0 - s) for u in [-OFF, nout_pad): d0 = (first output index) - (first input index).
-// r(t) = sin(pi t) cos(pi t/Le) / (Le sin(pi t/Le)), with sin(pi (d - s)) = -(-1)^d sin(pi s) for integer d.
+// r(t) = sin(pi t) cos(pi t/Le) / (Le sin(pi t/Le)) at t = d - s, d integer.  With s = n + f (n = rint(s), |f| <= 1/2)
+// and m = d - n:  sin(pi (d - s)) = -(-1)^m sin(pi f)  and  cot(pi (m - f)/Le) = cot(alpha + beta), alpha = pi m/Le on
+// the grid of `cotab`, beta = -pi f/Le tiny, so an entry is
+//     r = -(-1)^m sin(pi f)/Le * (cot(alpha) - tan(beta)) / (1 + cot(alpha) tan(beta))        (m != 0 mod Le)
+//     r = -sin(pi f)/(Le tan(beta))  (m = 0 mod Le: the pole, -> 1 as f -> 0)
+// -- two FMAs and one reciprocal per entry, the two transcendental values once per line (an entry used to cost a
+// float64 argument reduction, a sincos and a full division: as much as the Toeplitz product itself at 300 px).
+// No cancellation: |alpha| >= pi/Le > 2 |beta| away from the pole; where cot(alpha) ~ tan(beta) the entry is ~ 0.
 __device__ __forceinline__ void fill_table(float* __restrict__ T, int OFF, int nout_pad, int d0, double s, int Le,
-                                           int tid, int nthreads) {
-  const float sps = sin_pi_d(s);
-  const float invLe = 1.0f / (float)Le;
-  const double dLe = 1.0 / (double)Le;
-  for (int e = tid; e < OFF + nout_pad; e += nthreads) {
-    const int d = e - OFF + d0;                    // integer offset m - j
-    const double delta = (double)d - s;
-    double th = delta * dLe;                       // turns of pi: angle = pi * th
-    th -= rint(th);                                // cot has period pi: reduce to [-1/2, 1/2], where float32 keeps the
-                                                   // distance to the only pole (th = 0) to full relative precision
-    float sn, cs;
-    sincospif((float)th, &sn, &cs);
+                                           int tid, int nthreads, const float* __restrict__ cotab) {
+  const double ns = rint(s);
+  const double f = s - ns;                           // exact
+  const float sf = sinpif((float)f);
+  float tsn, tcs;
+  sincospif((float)(f / (double)Le), &tsn, &tcs);
+  const float tb = -tsn / tcs;                       // tan(beta)
+  const float scale = sf / (float)Le;
+  const bool integer_shift = (f == 0.0);
+  const int total = OFF + nout_pad;
+  // m = d - n for entry e = tid:  (tid - OFF + d0 - n) mod Le, then advanced by nthreads per iteration
+  const int m0 = tid - OFF + d0 - (int)ns;           // |m0| < 2 Le for every pass (|s| < Le/2, |d| < Le)
+  int mm = m0;
+  while (mm < 0) mm += Le;
+  while (mm >= Le) mm -= Le;
+  int par = m0 & 1;                                  // parity of m (two's complement: valid for negatives)
+  int step = nthreads;
+  while (step >= Le) step -= Le;
+  const int pstep = nthreads & 1;
+  for (int e = tid; e < total; e += nthreads) {
     float r;
-    if (fabsf(sn) < 1e-9f) {
-      // t = delta is a multiple of Le (r = 1) -- or float32 lost the angle: the limit sin(pi t)/(pi t) -> handled as 1
-      r = (fabs(delta - (double)Le * rint(delta * dLe)) < 1e-6) ? 1.0f : 0.0f;
+    if (integer_shift) {
+      r = (mm == 0) ? 1.0f : 0.0f;
     } else {
-      const float sgn = (d & 1) ? 1.0f : -1.0f;    // -(-1)^d
-      r = sgn * sps * cs * invLe / sn;
+      float cotv;
+      if (mm == 0) {
+        cotv = 1.0f / tb;
+      } else {
+        const float ca = cotab[mm];
+        const float den = fmaf(ca, tb, 1.0f);
+        float rc = __builtin_amdgcn_rcpf(den);
+        rc = rc * fmaf(-den, rc, 2.0f);               // one Newton step
+        cotv = (ca - tb) * rc;
+      }
+      r = (par ? scale : -scale) * cotv;              // -(-1)^m
     }
     T[e] = r;
+    mm += step;
+    if (mm >= Le) mm -= Le;
+    par ^= pstep;
   }
 }
 
@@ -136,7 +172,7 @@ __global__ __launch_bounds__(1024) void ds_shear1(const float* __restrict__ in, 
     alt += ((c0 + j) & 1) ? -v : v;
   }
   // outputs X = 0 .. Le-1, inputs at canvas columns c0 + j: d = X - (c0 + j) -> d0 = -c0
-  fill_table(T, Npad, Lpad, -c0, s, g.Le, threadIdx.x, blockDim.x);
+  fill_table(T, Npad, Lpad, -c0, s, g.Le, threadIdx.x, blockDim.x, aux.cotab);
   alt = block_sum(alt, red);            // contains the barrier that publishes x and T
   float* orow = A1r + ((int64_t)fl * g.N + yrel) * g.Le;
   for (int m0 = 4 * threadIdx.x; m0 < g.Le; m0 += 4 * blockDim.x) {
@@ -242,7 +278,7 @@ __global__ __launch_bounds__(1024) void ds_shear2(const float* __restrict__ A1r,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int c = wave; c < CT; c += nw) {
     const double s = p.b * (double)(X0 + c - g.c);
-    fill_table(T + c * 2 * Npad, Npad, Npad, g.off - r0, s, g.Le, lane, 64);
+    fill_table(T + c * 2 * Npad, Npad, Npad, g.off - r0, s, g.Le, lane, 64, aux.cotab);
     if (lane == 0) sps[c] = sin_pi_d(s) / (float)g.Le;
   }
   __syncthreads();
@@ -309,7 +345,7 @@ __global__ __launch_bounds__(256) void ds_shear3(const float* __restrict__ A2r, 
   const float* irow = A2r + ((int64_t)fl * g.N + m) * g.Le;
   for (int j = threadIdx.x; j < Lpad; j += blockDim.x) x[j] = (j < g.Le) ? irow[j] : 0.f;
   // outputs at canvas columns off + jo, inputs at columns 0..Le-1: d0 = off
-  fill_table(T, Lpad, Npad, g.off, s, g.Le, threadIdx.x, blockDim.x);
+  fill_table(T, Lpad, Npad, g.off, s, g.Le, threadIdx.x, blockDim.x, aux.cotab);
   __syncthreads();
   const float gs = aux.gsum[fl];
   const float c1 = sin_pi_d(s) / (float)g.Le * (aux.kv[fl * g.N + m] + ((Y & 1) ? -gs : gs));
@@ -355,6 +391,10 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
   VIPMI_TRY(ws(ctx, "rot_kv", (size_t)(chunk * g.N), &aux.kv));
   VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * g.Le), &aux.gam));
   VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
+  float* cotab = nullptr;
+  VIPMI_TRY(ws(ctx, "rot_cotab", (size_t)g.Le, &cotab));
+  hipLaunchKernelGGL(ds_cotab_kernel, dim3((unsigned)cdiv(g.Le, 256)), dim3(256), 0, ctx->stream, cotab, g.Le);
+  aux.cotab = cotab;
   const size_t lds1 = (size_t)(2 * Npad + Lpad + 16) * sizeof(float);
   const size_t ldsk = (size_t)(4 * g.Le + g.N) * sizeof(float);
   int CT = 16;
