@@ -40,6 +40,12 @@ __device__ __forceinline__ float sin_pi_d(double s) {     // sin(pi s), argument
   return (((long long)n) & 1) ? -v : v;
 }
 
+// LDS position of kernel-table entry idx: one 16-byte pad after every 16 entries.  The lanes of the Toeplitz product
+// read 16-byte table blocks 64 bytes apart (a lane pair owns 16 consecutive outputs); unpadded, those addresses fall
+// on 4 of the 16 bank groups (8-way conflict), padded (80 bytes apart) they cover all of them (2-way, the minimum
+// for 32 distinct 16-byte blocks).  Aligned blocks of 4 entries stay contiguous.
+__device__ __host__ __forceinline__ int tsw(int idx) { return idx + ((idx >> 4) << 2); }
+
 // cotab[m] = cot(pi m / Le), m = 1 .. Le-1 (cotab[0] unused): filled once per call in float64 arithmetic.
 __global__ void ds_cotab_kernel(float* __restrict__ cotab, int Le) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,32 +101,59 @@ __device__ __forceinline__ void fill_table(float* __restrict__ T, int OFF, int n
       }
       r = (par ? scale : -scale) * cotv;              // -(-1)^m
     }
-    T[e] = r;
+    T[tsw(e)] = r;
     mm += step;
     if (mm >= Le) mm -= Le;
     par ^= pstep;
   }
 }
 
-// Register-blocked Toeplitz product of one line:  y[m0 + o] = sum_j x[j] T[(m0 + o) - j + OFF],  o = 0..3
-// x: nin_pad floats (zero padded to a multiple of 4, 16-byte aligned); T: 16-byte aligned, OFF multiple of 4;
-// m0 multiple of 4 (relative output index).
-__device__ __forceinline__ void toeplitz4(const float* __restrict__ x, int nin_pad, const float* __restrict__ T,
-                                          int OFF, int m0, float (&acc)[4]) {
-  acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
-  int base = m0 + OFF;                              // index of T for (o = 0, j = 4q)
-  float4 tB = *reinterpret_cast<const float4*>(T + base);
-  for (int q = 0; q < nin_pad; q += 4) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + q);
-    const float4 tA = *reinterpret_cast<const float4*>(T + base - 4);
-    // t[o - i] for o, i in 0..3: indices -3..3 = (tA.y, tA.z, tA.w, tB.x, tB.y, tB.z, tB.w)
-    acc[0] += xv.x * tB.x + xv.y * tA.w + xv.z * tA.z + xv.w * tA.y;
-    acc[1] += xv.x * tB.y + xv.y * tB.x + xv.z * tA.w + xv.w * tA.z;
-    acc[2] += xv.x * tB.z + xv.y * tB.y + xv.z * tB.x + xv.w * tA.w;
-    acc[3] += xv.x * tB.w + xv.y * tB.z + xv.z * tB.y + xv.w * tB.x;
-    tB = tA;
-    base -= 4;
+// Register-blocked Toeplitz product of one line on packed FP32:  y[m] = sum_j x[j] T[m - j + OFF].
+// A lane owns the TNA outputs m = M + 2a + p (a < TNA; M a multiple of 2 TNA, p the lane's parity class) and consumes the
+// inputs in PAIRS, so that one v_pk_fma_f32 performs two multiply-adds whose operands are both aligned register pairs:
+//   p = 1:  pairs (x[k], x[k+1]);      p = 0:  pairs (x[k-1], x[k]) = aligned pairs of the shifted copy xo[k] = x[k-1];
+// in both cases the kernel values of output a and pair k are the aligned pair T[i], T[i+1], i = M + 2a - k + OFF, taken
+// in swapped order (op_sel) -- the parity split is what keeps every table pair aligned (owning consecutive outputs,
+// half of the pairs straddle two registers and cost a move each).  The lanes keep two partial sums per output.
+// One step = 4 inputs x TNA outputs: 2 TNA packed FMAs for 2 aligned 16-byte LDS reads (4 inputs broadcast + the 4 new
+// table entries; the others are the previous steps').  X: x (p = 1) or xo (p = 0), nin_pad floats, zero padded (at least one
+// zero after the last input), 16-byte aligned; T: OFF == nin_pad, entries up to OFF + M + 2 TNA - 1 valid.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int TNA = 8;                   // outputs per lane: 4 inputs x 8 outputs = 16 packed FMAs per 2 LDS reads (with 4
+                                         // outputs per lane the passes were bound by LDS bandwidth, not by the FMAs)
+template <int NA>
+__device__ __forceinline__ void toeplitz_par(const float* __restrict__ X, int nin_pad, const float* __restrict__ T,
+                                             int OFF, int M, float (&out)[NA], int k_begin = 0, int k_end = -1) {
+  if (k_end < 0) k_end = nin_pad;                    // [k_begin, k_end): multiples of 4 (partial sums over the inputs)
+  f2 acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = f2{0.f, 0.f};
+  int b = M + OFF - k_begin;                         // multiple of 4
+  float4 w[NA / 2];                                 // w[i] = T[b + 4 i .. b + 4 i + 3]
+#pragma unroll
+  for (int i = 0; i < NA / 2; ++i) w[i] = *reinterpret_cast<const float4*>(T + tsw(b + 4 * i));
+  for (int k = k_begin; k < k_end; k += 4) {
+    const float4 wm = *reinterpret_cast<const float4*>(T + tsw(b - 4));
+    const float4 xv = *reinterpret_cast<const float4*>(X + k);
+    const f2 x0 = f2{xv.x, xv.y}, x1 = f2{xv.z, xv.w};
+    // swapped table pairs P(j) = (T[b + 2 j + 1], T[b + 2 j]), j = -1 .. NA - 1
+    f2 P[NA + 1];
+    P[0] = f2{wm.w, wm.z};
+#pragma unroll
+    for (int i = 0; i < NA / 2; ++i) {
+      P[1 + 2 * i] = f2{w[i].y, w[i].x};
+      P[2 + 2 * i] = f2{w[i].w, w[i].z};
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      acc[a] = __builtin_elementwise_fma(x1, P[a], __builtin_elementwise_fma(x0, P[a + 1], acc[a]));
+#pragma unroll
+    for (int i = NA / 2 - 1; i > 0; --i) w[i] = w[i - 1];
+    w[0] = wm;
+    b -= 4;
   }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) out[a] = acc[a].x + acc[a].y;
 }
 
 __device__ __forceinline__ void src_map_d(int q, int Y, const RotGeom& g, int& base, int& stride) {
@@ -150,8 +183,9 @@ __global__ __launch_bounds__(1024) void ds_shear1(const float* __restrict__ in, 
                                                   int Lpad) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* x = smem;                       // [Npad]
-  float* T = smem + Npad;                // [Npad + Lpad]
-  float* red = T + Npad + Lpad;          // [16]
+  float* xo = x + Npad;                  // [Npad + 8]  xo[k] = x[k-1]
+  float* T = xo + Npad + 8;              // [tsw(Npad + Lpad)]
+  float* red = T + tsw(Npad + Lpad);     // [16]
   const int fl = blockIdx.y, f = f0 + fl, yrel = blockIdx.x;
   const RotFrame p = fr[f];
   const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
@@ -169,18 +203,21 @@ __global__ __launch_bounds__(1024) void ds_shear1(const float* __restrict__ in, 
       v = (t == t) ? t : 0.f;
     }
     x[j] = v;
+    xo[j + 1] = v;
     alt += ((c0 + j) & 1) ? -v : v;
   }
+  if (threadIdx.x == 0) xo[0] = 0.f;
   // outputs X = 0 .. Le-1, inputs at canvas columns c0 + j: d = X - (c0 + j) -> d0 = -c0
   fill_table(T, Npad, Lpad, -c0, s, g.Le, threadIdx.x, blockDim.x, aux.cotab);
   alt = block_sum(alt, red);            // contains the barrier that publishes x and T
   float* orow = A1r + ((int64_t)fl * g.N + yrel) * g.Le;
-  for (int m0 = 4 * threadIdx.x; m0 < g.Le; m0 += 4 * blockDim.x) {
-    float acc[4];
-    toeplitz4(x, Npad, T, Npad, m0, acc);
+  for (int t = threadIdx.x; 2 * TNA * (t >> 1) < g.Le; t += blockDim.x) {
+    const int M = 2 * TNA * (t >> 1), par = t & 1;
+    float acc[TNA];
+    toeplitz_par(par ? x : xo, Npad, T, Npad, M, acc);
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
-      if (m0 + o < g.Le) orow[m0 + o] = acc[o];
+    for (int a = 0; a < TNA; ++a)
+      if (M + 2 * a + par < g.Le) orow[M + 2 * a + par] = acc[a];
   }
   if (threadIdx.x == 0) aux.beta[fl * g.N + yrel] = sin_pi_d(s) * alt / (float)g.Le;
 }
@@ -258,10 +295,12 @@ template <int CT>          // columns per tile (16 = one 64-byte segment per row
 __global__ __launch_bounds__(1024) void ds_shear2(const float* __restrict__ A1r, const RotFrame* __restrict__ fr,
                                                   RotGeom g, float* __restrict__ A2r, AuxD aux, int f0, int Npad) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int CS = Npad + 4;                           // column stride in LDS (16-byte aligned, spreads the banks)
+  const int CS = Npad + 8;                           // column stride in LDS (16-byte aligned, spreads the banks)
   float* xin = smem;                                 // [CT][CS]   column-major copy of the tile
-  float* T = xin + CT * CS;                          // [CT][2 Npad]
-  float* yout = T + CT * 2 * Npad;                   // [CT][CS]
+  float* xsh = xin + CT * CS;                        // [CT][CS]   the same shifted by one row: xsh[k] = xin[k-1]
+  const int TS = tsw(2 * Npad);                      // table stride per column
+  float* T = xsh + CT * CS;                          // [CT][TS]
+  float* yout = T + CT * TS;                         // [CT][CS]
   float* alts = yout + CT * CS;                      // [CT]
   float* sps = alts + CT;                            // [CT]
   const int fl = blockIdx.y, f = f0 + fl, X0 = blockIdx.x * CT;
@@ -272,13 +311,16 @@ __global__ __launch_bounds__(1024) void ds_shear2(const float* __restrict__ A1r,
   // tile in: 64-byte row segments, transposed into LDS
   for (int e = threadIdx.x; e < Npad * CT; e += blockDim.x) {
     const int row = e / CT, c = e % CT;
-    xin[c * CS + row] = (row < g.N && c < ncol) ? src[(int64_t)row * g.Le + c] : 0.f;
+    const float v = (row < g.N && c < ncol) ? src[(int64_t)row * g.Le + c] : 0.f;
+    xin[c * CS + row] = v;
+    xsh[c * CS + row + 1] = v;
   }
+  if (threadIdx.x < CT) xsh[threadIdx.x * CS] = 0.f;
   // kernel tables: outputs at canvas rows off + m, inputs at rows r0 + y: d0 = off - r0
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int c = wave; c < CT; c += nw) {
     const double s = p.b * (double)(X0 + c - g.c);
-    fill_table(T + c * 2 * Npad, Npad, Npad, g.off - r0, s, g.Le, lane, 64, aux.cotab);
+    fill_table(T + c * TS, Npad, Npad, g.off - r0, s, g.Le, lane, 64, aux.cotab);
     if (lane == 0) sps[c] = sin_pi_d(s) / (float)g.Le;
   }
   __syncthreads();
@@ -294,12 +336,14 @@ __global__ __launch_bounds__(1024) void ds_shear2(const float* __restrict__ A1r,
     if (lane == 0) alts[c] = a;
   }
   // Toeplitz products: tasks = (column, block of 4 outputs)
-  const int nblk = Npad / 4;
+  const int nblk = Npad / TNA;
   for (int t = threadIdx.x; t < CT * nblk; t += blockDim.x) {
-    const int c = t / nblk, m0 = 4 * (t % nblk);
-    float acc[4];
-    toeplitz4(xin + c * CS, Npad, T + c * 2 * Npad, Npad, m0, acc);
-    *reinterpret_cast<float4*>(yout + c * CS + m0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    const int c = t / nblk, tt = t % nblk;
+    const int M = 2 * TNA * (tt >> 1), par = tt & 1;
+    float acc[TNA];
+    toeplitz_par((par ? xin : xsh) + c * CS, Npad, T + c * TS, Npad, M, acc);
+#pragma unroll
+    for (int a = 0; a < TNA; ++a) yout[c * CS + M + 2 * a + par] = acc[a];
   }
   __syncthreads();
   // tile out with the rank-one correction  - sin(pi s_X) (-1)^X Bf/Le (-1)^Y
@@ -332,39 +376,58 @@ __global__ __launch_bounds__(256) void ds_gamma(AuxD aux, int Le) {
 }
 
 // ---- shear 3: one workgroup per output row; Le inputs -> N outputs, corrections, mask restore ----
-__global__ __launch_bounds__(256) void ds_shear3(const float* __restrict__ A2r, const RotFrame* __restrict__ fr,
+template <int NA>           // outputs per lane: 8 for long rows, 4 where N / 8 lanes would leave most of a wave idle
+__global__ __launch_bounds__(1024) void ds_shear3(const float* __restrict__ A2r, const RotFrame* __restrict__ fr,
                                                  RotGeom g, const float* __restrict__ in, float* __restrict__ out,
                                                  AuxD aux, int f0, int mask_nan, int mask_zero, int Npad, int Lpad) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* x = smem;                       // [Lpad]
-  float* T = smem + Lpad;                // [Lpad + Npad]
+  float* xo = x + Lpad;                  // [Lpad + 8]  xo[k] = x[k-1]
+  float* T = xo + Lpad + 8;              // [tsw(Lpad + Npad)]
+  float* part = T + tsw(Lpad + Npad);    // [groups][Npad] partial sums
   const int fl = blockIdx.y, f = f0 + fl, m = blockIdx.x;
   const RotFrame p = fr[f];
   const int Y = g.off + m;
   const double s = p.a * (double)(Y - g.c);
   const float* irow = A2r + ((int64_t)fl * g.N + m) * g.Le;
-  for (int j = threadIdx.x; j < Lpad; j += blockDim.x) x[j] = (j < g.Le) ? irow[j] : 0.f;
+  for (int j = threadIdx.x; j < Lpad; j += blockDim.x) {
+    const float v = (j < g.Le) ? irow[j] : 0.f;
+    x[j] = v;
+    xo[j + 1] = v;
+  }
+  if (threadIdx.x == 0) xo[0] = 0.f;
   // outputs at canvas columns off + jo, inputs at columns 0..Le-1: d0 = off
   fill_table(T, Lpad, Npad, g.off, s, g.Le, threadIdx.x, blockDim.x, aux.cotab);
   __syncthreads();
   const float gs = aux.gsum[fl];
   const float c1 = sin_pi_d(s) / (float)g.Le * (aux.kv[fl * g.N + m] + ((Y & 1) ? -gs : gs));
   const int64_t ob = ((int64_t)f * g.N + m) * g.N;
-  for (int m0 = 4 * threadIdx.x; m0 < g.N; m0 += 4 * blockDim.x) {
-    float acc[4];
-    toeplitz4(x, Lpad, T, Lpad, m0, acc);
+  // Le inputs -> only N outputs: a row has work for Npad / NA lanes (one wave at 511 px), so the INPUTS are split over
+  // the lane groups of the workgroup (each group covers every output for its share of the inputs) and the partial
+  // sums are added through LDS in a fixed order
+  const int lg = Npad / NA;                                  // lanes that cover the outputs (Npad: multiple of 16)
+  const int lgp = (lg + 63) / 64 * 64;                        // ... padded to whole waves
+  const int ngrp = blockDim.x / lgp > 0 ? blockDim.x / lgp : 1;
+  const int grp = threadIdx.x / lgp, tl = threadIdx.x % lgp;
+  const int kq = (Lpad / 4 + ngrp - 1) / ngrp * 4;            // inputs per group (multiple of 4)
+  if (grp < ngrp && tl < lg) {
+    const int M = 2 * NA * (tl >> 1), par = tl & 1;
+    const int k0 = (grp * kq < Lpad) ? grp * kq : Lpad, k1 = (k0 + kq < Lpad) ? k0 + kq : Lpad;   // may be empty
+    float acc[NA];
+    toeplitz_par(par ? x : xo, Lpad, T, Lpad, M, acc, k0, k1);
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int j = m0 + o;
-      if (j < g.N) {
-        const float sg = ((g.off + j) & 1) ? -1.f : 1.f;
-        float re = acc[o] - sg * c1;
-        const float srcv = in[ob + j];
-        if (mask_nan && !(srcv == srcv)) re = __uint_as_float(0x7fc00000u);
-        if (mask_zero && srcv == 0.f) re = 0.f;
-        out[ob + j] = re;
-      }
-    }
+    for (int o = 0; o < NA; ++o) part[grp * Npad + M + 2 * o + par] = acc[o];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < g.N; j += blockDim.x) {
+    float re = 0.f;
+    for (int w = 0; w < ngrp; ++w) re += part[w * Npad + j];
+    const float sg = ((g.off + j) & 1) ? -1.f : 1.f;
+    re -= sg * c1;
+    const float srcv = in[ob + j];
+    if (mask_nan && !(srcv == srcv)) re = __uint_as_float(0x7fc00000u);
+    if (mask_zero && srcv == 0.f) re = 0.f;
+    out[ob + j] = re;
   }
 }
 
@@ -372,7 +435,8 @@ __global__ __launch_bounds__(256) void ds_shear3(const float* __restrict__ A2r, 
 
 int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n, float* out,
                      int mask_nan, int mask_zero) {
-  const int Npad = (int)cdiv(g.N, 4) * 4, Lpad = (int)cdiv(g.Le, 4) * 4;
+  // paddings: multiples of 2 TNA (a lane pair owns 2 TNA outputs) with at least one zero after the last input
+  const int Npad = (int)cdiv(g.N + 1, 2 * TNA) * 2 * TNA, Lpad = (int)cdiv(g.Le + 1, 2 * TNA) * 2 * TNA;
   const int64_t per_frame = (int64_t)g.N * g.Le;
   int64_t chunk = ctx->opt("rot_batch", 0);
   if (chunk <= 0) {
@@ -395,13 +459,16 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
   VIPMI_TRY(ws(ctx, "rot_cotab", (size_t)g.Le, &cotab));
   hipLaunchKernelGGL(ds_cotab_kernel, dim3((unsigned)cdiv(g.Le, 256)), dim3(256), 0, ctx->stream, cotab, g.Le);
   aux.cotab = cotab;
-  const size_t lds1 = (size_t)(2 * Npad + Lpad + 16) * sizeof(float);
+  const size_t lds1 = (size_t)(2 * Npad + 8 + tsw(Npad + Lpad) + 16) * sizeof(float);
   const size_t ldsk = (size_t)(4 * g.Le + g.N) * sizeof(float);
   int CT = 16;
-  auto lds2_for = [&](int ct) { return (size_t)(ct * (4 * Npad + 8) + 2 * ct) * sizeof(float); };
+  auto lds2_for = [&](int ct) { return (size_t)(ct * (3 * Npad + 24 + tsw(2 * Npad)) + 2 * ct) * sizeof(float); };
   while (CT > 2 && lds2_for(CT) > 150 * 1024) CT >>= 1;
   const size_t lds2 = lds2_for(CT);
-  const size_t lds3 = (size_t)(2 * Lpad + Npad) * sizeof(float);
+  const int na3 = g.N >= 256 ? 8 : 4;                          // outputs per lane in shear 3
+  const int lg3 = (int)cdiv(Npad / na3, 64) * 64;             // lanes covering the outputs of one row in shear 3
+  const int t3 = lg3 >= 256 ? lg3 : 256 / lg3 * lg3;          // lane groups splitting the inputs (256 threads)
+  const size_t lds3 = (size_t)(2 * Lpad + 8 + tsw(Lpad + Npad) + (t3 / lg3) * Npad) * sizeof(float);
   VIPMI_REQUIRE(lds1 <= 160 * 1024 && ldsk <= 160 * 1024 && lds2 <= 160 * 1024 && lds3 <= 160 * 1024,
                 "derotate(direct): frame size %d too large for the LDS-resident tables", g.N);
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ds_shear1), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -413,23 +480,28 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
                    : CT == 4 ? reinterpret_cast<const void*>(ds_shear2<4>)
                              : reinterpret_cast<const void*>(ds_shear2<2>);
   VIPMI_CHECK_HIP(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ds_shear3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds3));
-  // threads: one lane per block of 4 outputs
+  const void* k3 = na3 == 8 ? reinterpret_cast<const void*>(ds_shear3<8>) : reinterpret_cast<const void*>(ds_shear3<4>);
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+  // threads: one lane per TNA outputs
   auto threads_for = [](int nout, int cap) {
-    int t = (int)cdiv(cdiv(nout, 4), 64) * 64;
+    int t = (int)cdiv(cdiv(nout, TNA), 64) * 64;
     return t < 64 ? 64 : (t > cap ? cap : t);
   };
-  const int t1 = threads_for(g.Le, 1024), t3 = threads_for(g.N, 256);
-  int t2 = (int)cdiv((int64_t)CT * (Npad / 4), 64) * 64;
+  const int t1 = threads_for(g.Le, 1024);
+  int t2 = (int)cdiv((int64_t)CT * (Npad / TNA), 64) * 64;
   if (t2 > 1024) t2 = 1024;
   if (t2 < 256) t2 = 256;
   for (int64_t f0 = 0; f0 < n; f0 += chunk) {
     const unsigned nf = (unsigned)((n - f0) < chunk ? (n - f0) : chunk);
+    ctx->tic("k_rot_s1");
     hipLaunchKernelGGL(ds_shear1, dim3(g.N, nf), dim3(t1), lds1, ctx->stream, in, d_frames, g, A1r, aux, (int)f0, Npad,
                        Lpad);
+    ctx->toc("k_rot_s1");
+    ctx->tic("k_rot_aux");
     hipLaunchKernelGGL(ds_bf, dim3(nf), dim3(256), 0, ctx->stream, d_frames, g, aux, (int)f0);
     hipLaunchKernelGGL(ds_aux_k, dim3(nf), dim3(1024), ldsk, ctx->stream, d_frames, g, aux, (int)f0);
+    ctx->toc("k_rot_aux");
+    ctx->tic("k_rot_s2");
     {
       const dim3 grid2((unsigned)cdiv(g.Le, CT), nf);
       if (CT == 16)
@@ -441,9 +513,16 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
       else
         hipLaunchKernelGGL(ds_shear2<2>, grid2, dim3(t2), lds2, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, Npad);
     }
+    ctx->toc("k_rot_s2");
     hipLaunchKernelGGL(ds_gamma, dim3(nf), dim3(256), 0, ctx->stream, aux, g.Le);
-    hipLaunchKernelGGL(ds_shear3, dim3(g.N, nf), dim3(t3), lds3, ctx->stream, A2r, d_frames, g, in, out, aux, (int)f0,
-                       mask_nan, mask_zero, Npad, Lpad);
+    ctx->tic("k_rot_s3");
+    if (na3 == 8)
+      hipLaunchKernelGGL(ds_shear3<8>, dim3(g.N, nf), dim3(t3), lds3, ctx->stream, A2r, d_frames, g, in, out, aux,
+                         (int)f0, mask_nan, mask_zero, Npad, Lpad);
+    else
+      hipLaunchKernelGGL(ds_shear3<4>, dim3(g.N, nf), dim3(t3), lds3, ctx->stream, A2r, d_frames, g, in, out, aux,
+                         (int)f0, mask_nan, mask_zero, Npad, Lpad);
+    ctx->toc("k_rot_s3");
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   return VIPMI_OK;
