@@ -29,6 +29,12 @@ def test_library_exports_every_header_symbol():
     assert lib.vipmi_version() >= 100
 
 
+def test_integration_doc_lists_every_symbol():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in _header_symbols() if s not in doc]
+    assert not missing, missing
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
