@@ -8,7 +8,7 @@
 // crops fold into E as well).  With U = E X^T (an "A B^T" product) the result is Y = Er Ur^T - Ei Ui^T (another one),
 // so a frame costs four real products of the frame size instead of two 2-D FFTs of awkward (non power-of-two) sizes.
 //
-// One wave owns a 32 x 32 output tile (2 x 2 blocks of v_mfma_f32_16x16x4_f32); operands are read straight from
+// One wave owns a 64 x 64 (or 32 x 32) output tile of 16 x 16 v_mfma_f32_16x16x4_f32 blocks; operands are read straight from
 // global memory in MFMA fragment layout (lane (r = lane & 15, kq = lane >> 4) reads row r, columns k0 + 4 kq .. + 3;
 // component c feeds MFMA number c -- the same k permutation on both operands, so no LDS staging), as in gram.hip.
 #include "common.h"
@@ -46,7 +46,7 @@ struct BgemmArgs {
   int64_t sa, sb, sc;   // strides between matrices
 };
 
-template <bool VEC>
+template <bool VEC, int TB>       // TB x TB blocks of 16 x 16 per wave
 __global__ __launch_bounds__(256) void bgemm_abt_kernel(BgemmArgs g, int tiles_n, int ntiles) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x * 4 + wave;
@@ -56,53 +56,76 @@ __global__ __launch_bounds__(256) void bgemm_abt_kernel(BgemmArgs g, int tiles_n
   const int r = lane & 15, kq = lane >> 4;
   const int64_t oa = (int64_t)(g.ia ? g.ia[b] : b) * g.sa, ob = (int64_t)(g.ib ? g.ib[b] : b) * g.sb;
   const int nprod = g.A1 ? 2 : 1;
-  f32x4 acc[2][2];
+  f32x4 acc[TB][TB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int j = 0; j < TB; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  bool blka[TB], blkb[TB];            // wave-uniform: the block has rows inside the matrix (edge tiles skip the rest)
+#pragma unroll
+  for (int i = 0; i < TB; ++i) {
+    blka[i] = (tm * TB + i) * 16 < g.M;
+    blkb[i] = (tn * TB + i) * 16 < g.N;
+  }
   for (int p = 0; p < nprod; ++p) {
     const float* A = (p ? g.A1 : g.A0) + oa;
     const float* B = (p ? g.B1 : g.B0) + ob;
     const float sign = p ? -1.f : 1.f;
-    const float* pa[2];
-    const float* pb[2];
-    bool oka[2], okb[2];
+    const float* pa[TB];
+    const float* pb[TB];
+    bool oka[TB], okb[TB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ra = tm * 32 + i * 16 + r, rb = tn * 32 + i * 16 + r;
+    for (int i = 0; i < TB; ++i) {
+      const int ra = (tm * TB + i) * 16 + r, rb = (tn * TB + i) * 16 + r;
       oka[i] = ra < g.M;
       okb[i] = rb < g.N;
       pa[i] = A + (int64_t)(oka[i] ? ra : 0) * g.lda;
       pb[i] = B + (int64_t)(okb[i] ? rb : 0) * g.ldb;
     }
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-      f32x4 fa[2], fb[2];
+    // the fragments of step k0 + 16 are requested before the MFMAs of step k0 are issued
+    f32x4 fa[TB], fb[TB];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = ldfrag<VEC>(pa[i], oka[i], k0 + 4 * kq, g.K);
-        fb[i] = ldfrag<VEC>(pb[i], okb[i], k0 + 4 * kq, g.K);
-        fa[i] *= sign;
+    for (int i = 0; i < TB; ++i) {
+      fa[i] = ldfrag<VEC>(pa[i], oka[i], 4 * kq, g.K);
+      fb[i] = ldfrag<VEC>(pb[i], okb[i], 4 * kq, g.K);
+    }
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+      f32x4 na[TB], nb[TB];
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        na[i] = ldfrag<VEC>(pa[i], oka[i] && k0 + 16 < g.K, k0 + 16 + 4 * kq, g.K);
+        nb[i] = ldfrag<VEC>(pb[i], okb[i] && k0 + 16 < g.K, k0 + 16 + 4 * kq, g.K);
       }
+#pragma unroll
+      for (int i = 0; i < TB; ++i) fa[i] *= sign;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TB; ++i) {
+          if (!blka[i]) continue;
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TB; ++j) {
+            if (!blkb[j]) continue;
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        fa[i] = na[i];
+        fb[i] = nb[i];
+      }
     }
   }
   float* C = g.C + (int64_t)b * g.sc;
   const int col = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TB; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = tm * 32 + i * 16 + (lane >> 4) * 4 + q;      // f32 16x16x4: row = (lane>>4)*4 + q
-        const int cc = tn * 32 + j * 16 + col;
+        const int row = (tm * TB + i) * 16 + (lane >> 4) * 4 + q;      // f32 16x16x4: row = (lane>>4)*4 + q
+        const int cc = (tn * TB + j) * 16 + col;
         if (row < g.M && cc < g.N) C[(int64_t)row * g.ldc + cc] = acc[i][j][q];
       }
 }
@@ -118,15 +141,21 @@ int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float*
   VIPMI_REQUIRE(nbatch <= 65535, "bgemm: more than 65535 matrices per call");
   StageScope scope(ctx, "bgemm");
   BgemmArgs g{A0, B0, A1, B1, ia, ib, C, (int)M, (int)N, (int)K, (int)lda, (int)ldb, (int)ldc, sa, sb, sc};
-  const int tiles_m = (int)cdiv(M, 32), tiles_n = (int)cdiv(N, 32), ntiles = tiles_m * tiles_n;
+  // 64 x 64 tiles per wave (64 MFMAs per 8 fragment loads) once a matrix has enough of them, else 32 x 32
+  const int tb = (M >= 128 && N >= 128 && ctx->opt("bgemm_tb", 4) == 4) ? 4 : 2;
+  const int tiles_m = (int)cdiv(M, 16 * tb), tiles_n = (int)cdiv(N, 16 * tb), ntiles = tiles_m * tiles_n;
   auto aligned = [](const float* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = lda % 4 == 0 && ldb % 4 == 0 && sa % 4 == 0 && sb % 4 == 0 && aligned(A0) && aligned(B0) &&
                    aligned(A1) && aligned(B1);
   dim3 grid((unsigned)cdiv(ntiles, 4), (unsigned)nbatch), block(256);
-  if (vec)
-    hipLaunchKernelGGL(bgemm_abt_kernel<true>, grid, block, 0, ctx->stream, g, tiles_n, ntiles);
+  if (vec && tb == 4)
+    hipLaunchKernelGGL((bgemm_abt_kernel<true, 4>), grid, block, 0, ctx->stream, g, tiles_n, ntiles);
+  else if (vec)
+    hipLaunchKernelGGL((bgemm_abt_kernel<true, 2>), grid, block, 0, ctx->stream, g, tiles_n, ntiles);
+  else if (tb == 4)
+    hipLaunchKernelGGL((bgemm_abt_kernel<false, 4>), grid, block, 0, ctx->stream, g, tiles_n, ntiles);
   else
-    hipLaunchKernelGGL(bgemm_abt_kernel<false>, grid, block, 0, ctx->stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((bgemm_abt_kernel<false, 2>), grid, block, 0, ctx->stream, g, tiles_n, ntiles);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
