@@ -85,6 +85,14 @@ def test_pca_4d_golden():
     assert np.abs(resd - g["resder"]).max() < TOL
     assert np.abs(ifs - g["ifs"]).max() < TOL
     assert np.abs(pca(g["cube"], g["angles"], ncomp=2, verbose=False) - g["frame"]).max() < TOL
+    # frame-only calls take the batched path (one Gram / eigensolver / derotation launch for all channels): it must
+    # agree with the per-channel loop that full_output=True runs
+    for kw in (dict(scaling="temp-mean"), dict(mask_center_px=3, collapse="mean"), dict(collapse_ifs="median", ncomp=3),
+               dict(scaling="spat-standard", collapse="sum")):
+        kw = dict(dict(ncomp=2), **kw)
+        loop = pca(g["cube"], g["angles"], full_output=True, verbose=False, **kw)[0]
+        fast = pca(g["cube"], g["angles"], verbose=False, **kw)
+        assert fast.dtype == np.float64 and np.abs(fast - loop).max() < 2e-5, kw
 
 
 def test_device_tensor_api_and_algo_params():

@@ -243,8 +243,10 @@ static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, in
   // slices: ~2 workgroups per CU in total, slice length a multiple of 16, >= 64 pixels
   int64_t target = ctx->opt("gram_slices", 0);
   if (target <= 0) target = cdiv((int64_t)2 * ctx->num_cu, ngroups);
-  if (batch > 1) {                         // many small problems: ~8 waves per CU in total
-    target = cdiv((int64_t)8 * ctx->num_cu, batch * ngroups * wpw);
+  if (batch > 1 && ctx->opt("gram_slices", 0) <= 0) {
+    // many small problems: ~6 workgroups per CU in total, so that the hardware dispatcher evens out workgroups of
+    // different weight (the tile groups of one problem are not alike)
+    target = cdiv((int64_t)6 * ctx->num_cu, batch * ngroups);
     if (target < 1) target = 1;
   }
   int64_t klen = cdiv(cdiv(P, target), 16) * 16;

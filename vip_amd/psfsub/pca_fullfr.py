@@ -353,6 +353,51 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
     return frame
 
 
+def _adi_pca_channels_batched(cube4, angle_list, ncomp, scaling, mask_center_px, collapse, weights, mv_nan):
+    """Plain ADI PCA of every spectral channel of a 4-D cube (same integer ``ncomp``, no reference cube, final frames
+    only) with the small per-channel stages batched: ONE Gram launch and ONE eigensolver launch for all channels (a
+    workgroup per channel), ONE derotation call over all nch * n residual frames; only the projection products and the
+    collapses stay per channel.  Same arithmetic as the per-channel loop of ``pca`` (reference pca_fullfr.py:544-658).
+    Returns the per-channel final frames (nch, y, x) as a device tensor."""
+    torch = B._torch()
+    nch, n, y, x = cube4.shape
+    P = y * x
+    k = int(ncomp)
+    mask = None
+    if mask_center_px:
+        mask = B.to_device_f32(center_mask_u8((y, x), mask_center_px).astype(np.float32)).to(torch.uint8)
+    if mask is None and scaling is None:
+        M = cube4.reshape(nch, n, P)
+    else:
+        mats = []
+        for c in range(nch):
+            m = cube4[c].reshape(n, P)
+            if mask is not None:
+                m = B.apply_mask(m, mask.reshape(-1), 0.0)
+            if scaling is not None:
+                m = B.scale(m, scaling)
+            mats.append(m)
+        M = torch.stack(mats)
+    G = B.gram_batched(M)
+    ev, ec = B.eigh_topk(G, k)                                            # (nch, k), (nch, k, n)
+    keep = (ev > ev[:, :1] * 1e-12).to(torch.float32)
+    E = (ec.to(torch.float32) * keep[:, :, None]).contiguous()
+    Ct = E.transpose(1, 2).contiguous()
+    dev = cube4.device.index
+    ctx = B.get_context(dev)
+    T = B.empty((k, P), device=dev)
+    R = B.empty((nch, n, P), device=dev)
+    for c in range(nch):
+        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(E[c]), B.ptr(M[c]), k, n, P, None, B.ptr(T))
+        ctx.call("vipmi_subtract_gemm_f32", B.ptr(M[c]), B.ptr(Ct[c]), B.ptr(T), n, k, P, B.ptr(R[c]), None)
+    der = B.derotate(R.reshape(nch * n, y, x), np.tile(angle_list, nch), mask_nan=mv_nan, mask_zero=not mv_nan)
+    der = der.reshape(nch, n, y, x)
+    frames = torch.stack([B.collapse(der[c], collapse, w=weights) for c in range(nch)])
+    if mask is not None:
+        frames = B.apply_mask(frames.reshape(nch, -1), mask.reshape(-1), 0.0).reshape(nch, y, x)
+    return frames
+
+
 def pca(*all_args: List, **all_kwargs: dict):
     """Full-frame PCA (ADI, ADI+RDI, 4-D per-channel) on the MI355X.  See the reference docstring
     (psfsub/pca_fullfr.py:137-395) for the meaning of every parameter; returns
@@ -486,6 +531,24 @@ def pca(*all_args: List, **all_kwargs: dict):
             ncomps = ncomp
         fwhm = algo_params.fwhm
         fwhms = [fwhm] * nch if np.isscalar(fwhm) else fwhm
+        # fast path: plain ADI, one integer ncomp for all channels, final frame only -> batched small stages
+        mask_val = rot_options.get("mask_val", np.nan)
+        mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
+        same_k = all(isinstance(kc, (int, np.integer)) and kc == ncomps[0] for kc in ncomps)
+        if (not fo and same_k and cube_ref_t is None and algo_params.source_xy is None and algo_params.batch is None
+                and algo_params.mask_rdi is None and algo_params.smooth is None and not algo_params.left_eigv
+                and _s(algo_params.imlib) == "vip-fft" and (mv_nan or mask_val == 0)
+                and rot_options.get("edge_blend") in (None, "") and 0 < int(ncomps[0]) <= min(64, nz) and nz <= 512
+                and _s(algo_params.collapse) in B.COLLAPSE_MODES
+                and not (_s(algo_params.collapse) == "wmean" and algo_params.weights is None)):
+            angles = check_pa_vector(np.asarray(algo_params.angle_list, dtype=np.float64))
+            if angles.shape[0] != nz:
+                raise ValueError("`angle_list` vector has wrong length. It must equal the number of frames in the cube")
+            ifs = _adi_pca_channels_batched(cube_t, angles, int(ncomps[0]), _s(algo_params.scaling),
+                                            algo_params.mask_center_px, _s(algo_params.collapse), algo_params.weights,
+                                            mv_nan)
+            frame = B.collapse(ifs, _s(algo_params.collapse_ifs))
+            return host(frame, np.float64)
         outs = []
         # the channels are independent: issue them round-robin on two streams in asynchronous mode, so that the
         # latency-bound eigensolver of one channel runs beside the derotation of the previous one (unless the
