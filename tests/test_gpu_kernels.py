@@ -447,6 +447,19 @@ def test_derotate_fft_golden_128(B):
     assert np.abs(got0 - g["derot_128"]).max() < 5e-5      # no exact zeros in this cube
 
 
+def test_derotate_fft_1024_vs_oracle(B):
+    """Le = 4096 (two waves per line, blocked intermediates): the oracle on three frames in different rot90 quadrants."""
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(1024)
+    angles = np.array([17.3, 100.0, 250.5])
+    cube = rng.standard_normal((3, 1024, 1024)).astype(np.float32)
+    cube[1, 7:9, 11] = np.nan
+    got = cube_derotate(cube, angles, method="fft")
+    ref = O.cube_derotate(cube, angles)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.nanmax(np.abs(got - ref)) < 3e-5
+
+
 def test_derotate_fft_1024_delta(B):
     """Le = 4096 plan: delta-function known answers and a round trip."""
     from vip_amd.preproc import cube_derotate
