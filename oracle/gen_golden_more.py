@@ -60,3 +60,21 @@ for tag, kw in (("a", dict(ncomp=[1, 3, 6], asize=8, fwhm=4, delta_rot=(0.1, 1))
     g[tag + "_out"], g[tag + "_der"], g[tag + "_frames"] = co.astype(np.float32), cd.astype(np.float32), np.stack(fr_)
     g[tag + "_dtypes"] = np.array([str(co.dtype), str(cd.dtype), str(fr_[0].dtype)])
 save("g12_annular_list", **g)
+
+# ---- G13: pca_annular with a reference cube (RDI), an estimated-signal cube, and both (pca_local.py:716-724,862-891) ---
+cube, _ = O.synth_adi(14, 40, seed=80)
+ang = np.linspace(0, 80, 14)
+cref = O.synth_adi(8, 40, seed=81)[0]
+yy, xx = np.mgrid[:40, :40]
+sig = np.stack([0.7 * np.exp(-((yy - 20 - 9 * np.sin(a)) ** 2 + (xx - 20 - 9 * np.cos(a)) ** 2) / (2 * 1.7 ** 2))
+                for a in np.deg2rad(ang)]).astype(np.float32)
+cube = (cube + sig).astype(np.float32)
+sig = (0.9 * sig).astype(np.float32)
+g = {"cube": cube, "angles": ang, "cube_ref": cref, "cube_sig": sig}
+for tag, kw in (("ref", dict(cube_ref=cref, ncomp=3, asize=8, fwhm=4, delta_rot=(0.1, 1))),
+                ("sig", dict(cube_sig=sig, ncomp=2, asize=8, fwhm=4, delta_rot=0.5, scaling="temp-mean")),
+                ("both", dict(cube_ref=cref, cube_sig=sig, ncomp=[2, 5], asize=10, fwhm=4, delta_rot=1, n_segments=2))):
+    co, cd, fr_ = ref.pca_annular(cube, ang, full_output=True, verbose=False, nproc=1, **kw)
+    g[tag + "_out"], g[tag + "_der"] = np.asarray(co, dtype=np.float32), np.asarray(cd, dtype=np.float32)
+    g[tag + "_frame"] = np.stack(fr_) if isinstance(fr_, list) else fr_
+save("g13_annular_ref_sig", **g)

@@ -824,11 +824,14 @@ def pca_4d(cube, angle_list, ncomp=1, collapse_ifs="mean", full_output=False, **
 def pca_annular(cube, angle_list, radius_int=0, fwhm=4, asize=4, n_segments=1,
                 delta_rot=(0.1, 1), ncomp=1, svd_mode="lapack", min_frames_lib=2,
                 max_frames_lib=200, scaling=None, collapse="median", theta_init=0,
-                weights=None, full_output=False, rot_options=None):
+                weights=None, full_output=False, rot_options=None, cube_ref=None, cube_sig=None):
     """3-D ADI annular PCA (int / per-annulus tuple ncomp / LIST of ncomp: one decomposition with max(ncomp) per
     frame and segment, residuals for every V[:k] -> 4-D float64 cube_out / cube_der and a list of frames).
     Ref: psfsub/pca_local.py:228-278,594-827 (list: :665-668,744-749,799-807) and do_pca_patch :830-909
-    (list: :892-902); get_eigenvectors svd.py:694-700."""
+    (list: :892-902); get_eigenvectors svd.py:694-700.
+    ``cube_ref`` (RDI, :716-720,879-885): the reference frames of the segment (scaled on their own) are stacked on top
+    of every frame's PA-selected library.  ``cube_sig`` (:721-724,862-866,887-891): libraries and the projected frame
+    are taken from ``matrix - cube_sig`` (cube_sig unscaled), the model is subtracted from ``matrix``."""
     if cube.ndim != 3:
         raise TypeError("Input array is not a cube or 3d array")
     if cube.shape[0] != np.asarray(angle_list).shape[0]:
@@ -870,23 +873,27 @@ def pca_annular(cube, angle_list, radius_int=0, fwhm=4, asize=4, n_segments=1,
         segs = get_annulus_segments((y, x), inner_radius, asize, n_segments[ann], theta_init)
         for yy, xx in segs:
             m = matrix_scaling(cube[:, yy, xx], scaling)
+            mref = matrix_scaling(cube_ref[:, yy, xx], scaling) if cube_ref is not None else None
+            memp = m - cube_sig[:, yy, xx] if cube_sig is not None else m
             for fr in range(n):
                 if pa_thr != 0:
                     idx = find_indices_adi(angle_list, fr, pa_thr, truncate=True,
                                            max_frames=max_frames_lib)
-                    lib = m[idx]
-                    if lib.shape[0] < min_frames_lib:
+                    lib = memp[idx]
+                    if lib.shape[0] < min_frames_lib and mref is None:
                         raise RuntimeError("Too few frames left in the PCA library.")
                 else:
-                    lib = m
+                    lib = memp
+                if mref is not None:
+                    lib = np.vstack((mref, lib))
                 k = min(k_ann, min(lib.shape))
                 V = svd_wrapper(lib, svd_mode, k)
-                cur = m[fr]
+                cur, cur_emp = m[fr], memp[fr]
                 if is_list:
                     for nn, kk in enumerate(ncomp):
-                        cube_out[nn, fr][yy, xx] = cur - (cur @ V[:kk].T) @ V[:kk]
+                        cube_out[nn, fr][yy, xx] = cur - (cur_emp @ V[:kk].T) @ V[:kk]
                 else:
-                    cube_out[fr][yy, xx] = cur - (cur @ V.T) @ V
+                    cube_out[fr][yy, xx] = cur - (cur_emp @ V.T) @ V
     if is_list:
         cube_der = np.zeros_like(cube_out)
         frame = []

@@ -182,6 +182,29 @@ def test_pca_annular_list_ncomp_golden(tag, kw):
     assert np.abs(single - frames[1]).max() < 2e-5
 
 
+@pytest.mark.parametrize("tag,kw", [("ref", dict(ref=True, ncomp=3, asize=8, fwhm=4, delta_rot=(0.1, 1))),
+                                    ("sig", dict(sig=True, ncomp=2, asize=8, fwhm=4, delta_rot=0.5, scaling="temp-mean")),
+                                    ("both", dict(ref=True, sig=True, ncomp=[2, 5], asize=10, fwhm=4, delta_rot=1,
+                                                  n_segments=2))])
+def test_pca_annular_ref_sig_golden(tag, kw):
+    """pca_annular with cube_ref (RDI) / cube_sig against the reference's outputs (pca_local.py:716-724,862-891)."""
+    from vip_amd.psfsub import pca_annular
+    g = load_golden("g13_annular_ref_sig")
+    kw = dict(kw)
+    if kw.pop("ref", False):
+        kw["cube_ref"] = g["cube_ref"]
+    if kw.pop("sig", False):
+        kw["cube_sig"] = g["cube_sig"]
+    co, cd, fr = pca_annular(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    fr = np.stack(fr) if isinstance(fr, list) else fr
+    assert co.shape == g[tag + "_out"].shape
+    assert np.abs(co - g[tag + "_out"]).max() < TOL
+    assert np.nanmax(np.abs(cd - g[tag + "_der"])) < TOL
+    assert np.abs(fr - g[tag + "_frame"]).max() < TOL
+    with pytest.raises(TypeError):
+        pca_annular(g["cube"], g["angles"], cube_sig=g["cube_sig"][:-1], ncomp=2, asize=8, verbose=False)
+
+
 def test_pca_annular_scaling_and_errors():
     from vip_amd.psfsub import pca_annular
     cube, ang = O.synth_adi(20, 48, seed=4)

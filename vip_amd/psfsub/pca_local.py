@@ -9,8 +9,8 @@ the matrix cores, and every frame's library PCA is obtained from the correspondi
 
 ``ncomp``: int, per-annulus tuple, or a list (several truncations of one decomposition -> 4-D ``cube_out`` /
 ``cube_der`` and a list of frames).  4-D cubes without ``scale_list`` run the same path per spectral channel.
-Not accelerated (NotImplementedError): ``scale_list`` (mSDI), ``cube_ref``, ``cube_sig``, ``left_eigv``,
-``ncomp='auto'``.
+``cube_ref`` (RDI: reference frames stacked on every library) and ``cube_sig`` are supported.  Not accelerated
+(NotImplementedError): ``scale_list`` (mSDI), ``left_eigv``, ``ncomp='auto'``.
 """
 import ctypes
 from collections import OrderedDict
@@ -173,8 +173,13 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         raise TypeError("Input array is not a cube or 3d array")
     if cube.shape[0] != np.asarray(angle_list).shape[0]:
         raise TypeError("Input vector or parallactic angles has wrong length")
-    if cube_ref is not None or cube_sig is not None or left_eigv:
-        raise NotImplementedError("cube_ref / cube_sig / left_eigv are outside the accelerated annular path")
+    if left_eigv:
+        raise NotImplementedError("left_eigv is outside the accelerated annular path")
+    if cube_ref is not None and (cube_ref.ndim != 3 or tuple(cube_ref.shape[1:]) != tuple(cube.shape[1:])):
+        raise TypeError("`cube_ref` must be a cube with the frame size of `cube`")
+    if cube_sig is not None and tuple(cube_sig.shape) != tuple(cube.shape):
+        raise TypeError("`cube_sig` must have the shape of `cube`")
+    nref = 0 if cube_ref is None else int(cube_ref.shape[0])
     if isinstance(ncomp, str):
         raise NotImplementedError("ncomp='auto' is outside the accelerated annular path")
     ks = None
@@ -187,8 +192,9 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     n, y, x = cube.shape
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
     plan, plan_dev = cached_annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot,
-                                         ncomp if ks is None else int(ks.max()), min_frames_lib, max_frames_lib,
-                                         theta_init)
+                                         ncomp if ks is None else int(ks.max()),
+                                         min_frames_lib if nref == 0 else 0,      # with a reference cube any library size
+                                         max_frames_lib, theta_init)             # is accepted (pca_local.py:868-870)
     if verbose:
         print("N annuli = {}, FWHM = {:.3f}".format(int((y / 2 - radius_int) / asize), fwhm))
     ctx = B.get_context(cube.device.index)
@@ -214,22 +220,49 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         ctx.call("vipmi_gather_f32", B.ptr(cube), n, P, B.ptr(pix), npx, B.ptr(A))
         if scaling is not None:
             A = B.scale(A, scaling)
-        key = id(seg["libs"])
+        # cube_sig (pca_local.py:721-724,862-866,887-891): libraries and projections from A - S (S unscaled), model
+        # subtracted from A:  A - proj(A - S) = (A_emp - proj(A_emp)) + S
+        S = None
+        if cube_sig is not None:
+            S = B.empty((n, npx), device=dev)
+            ctx.call("vipmi_gather_f32", B.ptr(cube_sig), n, P, B.ptr(pix), npx, B.ptr(S))
+            A = B.lincomb(A, S, 1.0, -1.0)
+        # cube_ref (pca_local.py:716-720,879-885): the reference frames of the segment, scaled on their own, are stacked
+        # on top of every frame's library -> one matrix of nref + n rows whose first nref rows only serve as library
+        nrow = n + nref
+        if nref:
+            Aref = B.empty((nref, npx), device=dev)
+            ctx.call("vipmi_gather_f32", B.ptr(cube_ref), nref, P, B.ptr(pix), npx, B.ptr(Aref))
+            if scaling is not None:
+                Aref = B.scale(Aref, scaling)
+            A = torch.cat((Aref, A))
+        key = (id(seg["libs"]), nref)
         if key not in lib_cache:
-            idx, ln, max_lib = _pack_libs(seg["libs"])
+            libs = seg["libs"]
+            if nref:
+                head = np.arange(nref, dtype=np.int64)
+                libs = [np.array([r]) for r in range(nref)] + [np.concatenate((head, np.asarray(li, dtype=np.int64) + nref))
+                                                               for li in libs]
+            idx, ln, max_lib = _pack_libs(libs)
             lib_cache[key] = (torch.from_numpy(idx).to(cube.device), torch.from_numpy(ln).to(cube.device), max_lib)
         idx_t, ln_t, max_lib = lib_cache[key]
         if ks is None:
-            R = B.empty((n, npx), device=dev)
-            ctx.call("vipmi_annular_residuals_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
+            R = B.empty((nrow, npx), device=dev)
+            ctx.call("vipmi_annular_residuals_f32", B.ptr(A), nrow, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
                      int(seg["ncomp"]), B.ptr(R))
-            ctx.call("vipmi_scatter_f32", B.ptr(R), n, P, B.ptr(pix), npx, B.ptr(cube_out))
+            R = R[nref:]
+            if S is not None:
+                R = B.lincomb(R, S, 1.0, 1.0)
+            ctx.call("vipmi_scatter_f32", B.ptr(R.contiguous()), n, P, B.ptr(pix), npx, B.ptr(cube_out))
         else:
-            R = B.empty((len(ks), n, npx), device=dev)
-            ctx.call("vipmi_annular_residuals_multi_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
+            R = B.empty((len(ks), nrow, npx), device=dev)
+            ctx.call("vipmi_annular_residuals_multi_f32", B.ptr(A), nrow, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
                      ks.ctypes.data_as(ctypes.c_void_p), len(ks), B.ptr(R))
             for nn in range(len(ks)):
-                ctx.call("vipmi_scatter_f32", B.ptr(R[nn]), n, P, B.ptr(pix), npx, B.ptr(cube_out[nn]))
+                Rn = R[nn, nref:]
+                if S is not None:
+                    Rn = B.lincomb(Rn, S, 1.0, 1.0)
+                ctx.call("vipmi_scatter_f32", B.ptr(Rn.contiguous()), n, P, B.ptr(pix), npx, B.ptr(cube_out[nn]))
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
     if not mv_nan and mask_val != 0:
@@ -296,8 +329,13 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
         fwhm = algo_params.fwhm
         if np.isscalar(fwhm):
             fwhm = [fwhm] * nch
+        if algo_params.cube_sig is not None:
+            raise NotImplementedError("cube_sig with a 4-D cube is outside the accelerated annular path")
+        ref_t = None
         if algo_params.cube_ref is not None:
-            raise NotImplementedError("cube_ref is outside the accelerated annular path")
+            ref_t = B.to_device_f32(algo_params.cube_ref)
+            if ref_t.ndim != 4 or ref_t.shape[0] != nch:
+                raise TypeError("Ref cube has wrong format for 4d input cube")
         outs = []
         # independent channels: two streams in asynchronous mode (see the 4-D loop of psfsub/pca_fullfr.py)
         pipelined = nch > 1 and not B.is_async()
@@ -314,7 +352,7 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
                     st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t[ch], fwhm=fwhm[ch], ncomp=ncomp[ch],
-                                          full_output=True)
+                                          full_output=True, cube_ref=None if ref_t is None else ref_t[ch])
                     outs.append(_pca_adi_rdi(**fp, **rot_options))
             if pipelined:
                 for st in streams:
@@ -329,7 +367,12 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
             return (host(torch.stack([o[0] for o in outs])), host(torch.stack([o[1] for o in outs])),
                     host4(frame))
         return host4(frame)
-    fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t, full_output=True)
+    extra = {}
+    if algo_params.cube_ref is not None:
+        extra["cube_ref"] = B.to_device_f32(algo_params.cube_ref)
+    if algo_params.cube_sig is not None:
+        extra["cube_sig"] = B.to_device_f32(algo_params.cube_sig)
+    fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t, full_output=True, **extra)
     cube_out, cube_der, frame = _pca_adi_rdi(**fp, **rot_options)
     if isinstance(frame, list):
         # list ncomp: the reference allocates cube_out / cube_der with np.zeros (float64, pca_local.py:666-668,800)
