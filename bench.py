@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ncomp", type=int, default=20)
+    ap.add_argument("--scaling", default=None,
+                    help="matrix_scaling of the reference (None = its default; 'temp-mean' subtracts the per-pixel mean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
     ap.add_argument("--no-stage-timing", action="store_true",
@@ -124,7 +126,7 @@ def main():
     ctx = B.get_context()
 
     def step():
-        frame = pca(cube_t, angles, ncomp=k, verbose=False, check_memory=False)
+        frame = pca(cube_t, angles, ncomp=k, scaling=args.scaling, verbose=False, check_memory=False)
         return frame.cpu()                      # D2H of the final frame is part of the metric
 
     def barrier():
@@ -153,7 +155,7 @@ def main():
             return
         for i in range(nsteps):
             with torch.cuda.stream(streams[i % depth]):
-                frame = pca(cube_t, angles, ncomp=k, verbose=False, check_memory=False)
+                frame = pca(cube_t, angles, ncomp=k, scaling=args.scaling, verbose=False, check_memory=False)
                 pinned[i].copy_(frame, non_blocking=True)
 
     STAGES = ("scale", "gram", "eigh", "project", "derotate", "collapse", "k_rot_s1", "k_rot_s2", "k_rot_s3",
@@ -251,7 +253,8 @@ def main():
             "ms_per_step": ms_per_step, "latency_ms_per_call": latency_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: %dx%dx%d ADI cube, full-frame PCA ncomp=%d, float32, "
-                                   "vip-fft derotation, median collapse" % (n, N, N, k),
+                                   "vip-fft derotation, median collapse" % (n, N, N, k) +
+                                   (", scaling=%s" % args.scaling if args.scaling else ""),
                        "cubes_per_step": world, "parallelism": "one cube per GPU (no data-path collective)",
                        "pipeline_depth": depth},
             "ms_per_svd": ms_svd,
