@@ -438,6 +438,27 @@ def test_derotate_batching_is_bit_identical(B, N):
         ctx.set_option("rot_batch", 0)
 
 
+def test_derotate_fft_edge_cases(B):
+    """Few frames (fewer tasks than workgroups in the dynamic queues), a single frame, an all-NaN frame, a constant
+    frame and angles that are exact multiples of 90 / 360 degrees."""
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3):
+        cube = rng.standard_normal((n, 128, 128)).astype(np.float32)
+        ang = np.array([33.3, -120.0, 361.0])[:n]
+        got = cube_derotate(cube, ang, method="fft")
+        assert np.nanmax(np.abs(got - O.cube_derotate(cube, ang))) < 2e-5, n
+    cube = rng.standard_normal((4, 128, 128)).astype(np.float32)
+    cube[1] = np.nan
+    cube[2] = 3.5
+    ang = np.array([0.0, 77.0, 180.0, -360.0])
+    got = cube_derotate(cube, ang, method="fft")
+    ref = O.cube_derotate(cube, ang)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[1]).all()
+    assert np.nanmax(np.abs(got - ref)) < 2e-5
+    assert np.abs(got[0] - cube[0]).max() < 5e-6                          # angle 0: identity up to FFT round-off
+
+
 def test_derotate_fft_golden_128(B):
     from vip_amd.preproc import cube_derotate
     g = load_golden("g3_rotate")
