@@ -110,10 +110,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # (test hooks: VIPMI_BENCH_DEVICE pins every rank to one device and VIPMI_BENCH_BACKEND=gloo replaces RCCL, so that the
+    # multi-rank code path can be exercised on a single-GPU box; the driver's runs use neither)
+    torch.cuda.set_device(int(os.environ.get("VIPMI_BENCH_DEVICE", local_rank)))
+    backend = os.environ.get("VIPMI_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from vip_amd import backend as B
     from vip_amd.psfsub import pca
@@ -187,7 +190,7 @@ def main():
         B.check_deferred()
     out = pinned[args.steps - 1] if depth > 1 else last[0]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(out).all())
