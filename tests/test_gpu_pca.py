@@ -370,6 +370,30 @@ def test_pca_many_matches_serial():
     assert backend._async["on"] is False
 
 
+@pytest.mark.parametrize("n,N,k", [(50, 128, 5), (120, 256, 8)])
+def test_pipelined_calls_are_bit_identical(n, N, k):
+    """Many pca() calls in flight on two streams (asynchronous mode: dynamic task queues, the barrier-free task ring of
+    shear 1, the gate between calls): every frame must be bit-identical to a serial call's."""
+    import torch
+    from vip_amd import backend as B
+    from vip_amd.psfsub import pca
+    cube, ang = O.synth_adi(n, N, seed=9)
+    ct = torch.from_numpy(cube).cuda()
+    ref = pca(ct, ang, ncomp=k, verbose=False).clone()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    B.set_async(True)
+    try:
+        outs = []
+        for i in range(60):
+            with torch.cuda.stream(streams[i % 2]):
+                outs.append(pca(ct, ang, ncomp=k, verbose=False))
+        torch.cuda.synchronize()
+        B.check_deferred()
+    finally:
+        B.set_async(False)
+    assert all(torch.equal(o, ref) for o in outs)
+
+
 def test_pca_annular_4d_golden():
     """4-D cube without scale_list: per-channel annular PCA, then the spectral collapse (pca_local.py:279-325)."""
     from vip_amd.psfsub import pca_annular
