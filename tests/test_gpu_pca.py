@@ -95,6 +95,39 @@ def test_pca_4d_golden():
         assert fast.dtype == np.float64 and np.abs(fast - loop).max() < 2e-5, kw
 
 
+def test_raw_c_abi_binding_as_in_integration_md():
+    """The ctypes stub of INTEGRATION.md section 3, verbatim in spirit: dlopen, vipmi_create on the current stream, one
+    vipmi_pca_fullframe_f32 call with plain pointers and sizes, vipmi_last_error on failure -- no vip_amd front end."""
+    import ctypes
+    import os
+    import torch
+    from conftest import ROOT
+    g = load_golden("g6_pca_small")
+    cube_np, angle_list, ncomp = g["cube"], g["angles"], 3
+    n, N = cube_np.shape[0], cube_np.shape[1]
+    lib = ctypes.CDLL(os.path.join(ROOT, "vip_amd", "libvipmi.so"))
+    lib.vipmi_last_error.restype = ctypes.c_char_p
+    ctx = ctypes.c_void_p()
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.vipmi_create(0, ctypes.c_void_p(stream), ctypes.byref(ctx)) == 0
+    cube = torch.from_numpy(cube_np).cuda()
+    frame = torch.empty((N, N), dtype=torch.float32, device="cuda")
+    angles = np.ascontiguousarray(O.check_pa_vector(angle_list), dtype=np.float64)
+    lib.vipmi_pca_fullframe_f32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + \
+        [ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+    st = lib.vipmi_pca_fullframe_f32(ctx, cube.data_ptr(), angles.ctypes.data, n, N, ncomp, 0, None, 0,
+                                     frame.data_ptr(), None, None, None, None)
+    assert st == 0, lib.vipmi_last_error().decode()
+    torch.cuda.synchronize()
+    assert np.abs(frame.cpu().numpy() - g["k3_frame"]).max() < TOL
+    # error convention: negative status + message, no exception / abort
+    st = lib.vipmi_pca_fullframe_f32(ctx, cube.data_ptr(), angles.ctypes.data, n, N, 0, 0, None, 0,
+                                     frame.data_ptr(), None, None, None, None)
+    assert st < 0 and b"PCs" in lib.vipmi_last_error()
+    lib.vipmi_destroy.argtypes = [ctypes.c_void_p]
+    assert lib.vipmi_destroy(ctx) == 0
+
+
 def test_device_tensor_api_and_algo_params():
     import torch
     from vip_amd.psfsub import pca, PCA_Params
