@@ -147,6 +147,12 @@ int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_hos
 int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode,
                        const float* w, int64_t trim_n, float* out);
 
+/* ---- median_sub(mode='annular') core: psfsub/medsub.py:602-641 ----
+ * out[j,p] = A[j,p] - nanmedian over the frames lib_idx[j, 0 .. lib_len[j]) of A[.,p]  (A: n x npx annulus matrix,
+ * lib_idx: [n][max_lib] device int32, max_lib <= 32: the `nframes` closest frames beyond the PA threshold). */
+int vipmi_subset_median_sub_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                                const int32_t* lib_len, int64_t max_lib, float* out);
+
 /* ---- pca_annular core: psfsub/pca_local.py:710-787,830-909 ----
  * For one annulus segment matrix A[n,npx] (already gathered + scaled) and per-frame library index
  * lists (lib_idx[n*max_lib], lib_len[n], device int32), computes residuals[n,npx] =

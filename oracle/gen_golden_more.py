@@ -78,3 +78,14 @@ for tag, kw in (("ref", dict(cube_ref=cref, ncomp=3, asize=8, fwhm=4, delta_rot=
     g[tag + "_out"], g[tag + "_der"] = np.asarray(co, dtype=np.float32), np.asarray(cd, dtype=np.float32)
     g[tag + "_frame"] = np.stack(fr_) if isinstance(fr_, list) else fr_
 save("g13_annular_ref_sig", **g)
+
+# ---- G14: median_sub(mode='annular'): ADI with nframes (default 4 and 2), radius_int, and RDI (medsub.py:316-371,602-676) --
+cube, _ = O.synth_adi(18, 44, seed=90)
+ang = np.linspace(0, 75, 18)
+cref = O.synth_adi(7, 44, seed=91)[0]
+g = {"cube": cube, "angles": ang, "cube_ref": cref}
+for tag, kw in (("a", dict(asize=4, fwhm=4, delta_rot=1)), ("b", dict(asize=6, fwhm=3, delta_rot=0.5, nframes=2, collapse="mean")),
+                ("c", dict(asize=5, fwhm=4, radius_int=4, nframes=6)), ("d", dict(asize=4, cube_ref=cref, collapse_ref="mean"))):
+    co, cd, fr_ = ref.median_sub(cube, ang, mode="annular", full_output=True, verbose=False, nproc=1, **kw)
+    g["ms_%s_out" % tag], g["ms_%s_der" % tag], g["ms_%s_frame" % tag] = co, cd, fr_
+save("g14_medsub_annular", **g)

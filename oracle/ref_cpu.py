@@ -347,9 +347,9 @@ def cube_collapse(cube, mode="median", n=50, w=None):
 # --------------------------------------------------------------------------------------
 
 
-def find_indices_adi(angle_list, frame, thr, truncate=False, max_frames=200):
-    """Library indices for ``frame``.  Ref: preproc/derotation.py:410-496 (nframes=None,
-    out_closest=False branch)."""
+def find_indices_adi(angle_list, frame, thr, truncate=False, max_frames=200, nframes=None):
+    """Library indices for ``frame``.  Ref: preproc/derotation.py:410-496 (out_closest=False; ``nframes``: the
+    nframes/2 frames on either side of the excluded window, :458-474)."""
     n = angle_list.shape[0]
     index_prev = 0
     for i in range(frame):
@@ -361,6 +361,10 @@ def find_indices_adi(angle_list, frame, thr, truncate=False, max_frames=200):
         if abs(angle_list[k] - angle_list[frame]) > thr:
             break
         index_foll += 1
+    if nframes is not None:
+        window = nframes // 2
+        ind1, ind4 = max(index_prev - window, 0), min(index_foll + window, n)
+        return np.array(list(range(ind1, index_prev)) + list(range(index_foll, ind4)), dtype="int32")
     idx = np.array(list(range(0, index_prev)) + list(range(index_foll, n)), dtype="int32")
     if truncate:
         lim = min(n - 1, max_frames)
@@ -553,6 +557,50 @@ def median_sub_fullfr(cube, angle_list, radius_int=0, collapse="median", cube_re
     else:
         arr -= np.median(arr, axis=0)
     cube_out = arr
+    cube_der = cube_derotate(cube_out, angle_list, mask_val=mask_val)
+    if radius_int:
+        cube_out = mask_circle(cube_out, radius_int)
+        cube_der = mask_circle(cube_der, radius_int)
+    frame = cube_collapse(cube_der, mode=collapse)
+    if full_output:
+        return cube_out, cube_der, frame
+    return frame
+
+
+def median_sub_annular(cube, angle_list, fwhm=4, radius_int=0, asize=4, delta_rot=1, nframes=4, collapse="median",
+                       cube_ref=None, collapse_ref="median", full_output=False):
+    """``median_sub(cube, angles, mode='annular')`` for a 3-D cube.  Ref: psfsub/medsub.py:279-281 (global median
+    model, ADI only), :316-371 (annuli loop, nframes must be even), :602-641 (_median_subt_ann_adi: per frame the median
+    of the ``nframes`` frames closest in time beyond the PA threshold; _define_annuli with strict=False),
+    :644-676 (_median_subt_ann_rdi: the collapsed reference frame, last-annulus rule NOT applied), :376-387."""
+    arr = cube.copy()
+    n, y, x = arr.shape
+    mask_val = 0 if radius_int else np.nan
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    if cube_ref is not None:
+        ref_frame = np.median(cube_ref, axis=0) if "median" in collapse_ref else np.mean(cube_ref, axis=0)
+    else:
+        arr -= np.median(arr, axis=0)
+        if nframes is not None and nframes % 2 != 0:
+            raise TypeError("`nframes` argument must be even value")
+    cube_out = np.zeros_like(arr)
+    n_annuli = int((y / 2 - radius_int) / asize)
+    for ann in range(n_annuli):
+        if cube_ref is not None:
+            inner_radius = radius_int + ann * asize
+            yy, xx = get_annulus_segments((y, x), inner_radius, asize)[0]
+            cube_out[:, yy, xx] = arr[:, yy, xx] - ref_frame[yy, xx]
+            continue
+        pa_thr, inner_radius, _ = define_annuli(angle_list, ann, n_annuli, fwhm, radius_int, asize, delta_rot,
+                                                strict=False)
+        yy, xx = get_annulus_segments((y, x), inner_radius, asize)[0]
+        matrix = arr[:, yy, xx]
+        res = np.zeros_like(matrix)
+        for fr in range(n):
+            disc = matrix[find_indices_adi(angle_list, fr, pa_thr, nframes=nframes)] if pa_thr != 0 else matrix
+            with np.errstate(all="ignore"):
+                res[fr] = matrix[fr] - np.nanmedian(disc, axis=0)
+        cube_out[:, yy, xx] = res
     cube_der = cube_derotate(cube_out, angle_list, mask_val=mask_val)
     if radius_int:
         cube_out = mask_circle(cube_out, radius_int)

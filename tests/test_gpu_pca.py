@@ -371,7 +371,29 @@ def test_median_sub_golden(tag, kw):
         assert np.abs(a - b).max() < TOL, (tag, nm, np.abs(a - b).max())
     assert np.abs(median_sub(g["cube"], g["angles"], verbose=False, **kw) - g["ms_%s_frame" % tag]).max() < TOL
     with pytest.raises(NotImplementedError):
-        median_sub(g["cube"], g["angles"], mode="annular", verbose=False)
+        median_sub(g["cube"], g["angles"], mode="annular", nframes=None, verbose=False)
+
+
+@pytest.mark.parametrize("tag,kw", [("a", dict(asize=4, fwhm=4, delta_rot=1)),
+                                    ("b", dict(asize=6, fwhm=3, delta_rot=0.5, nframes=2, collapse="mean")),
+                                    ("c", dict(asize=5, fwhm=4, radius_int=4, nframes=6)),
+                                    ("d", dict(asize=4, rdi=True, collapse_ref="mean"))])
+def test_median_sub_annular_golden(tag, kw):
+    """median_sub(mode='annular') (reference medsub.py:316-371,602-676) against the reference's outputs."""
+    from vip_amd.psfsub import median_sub
+    g = load_golden("g14_medsub_annular")
+    kw = dict(kw)
+    if kw.pop("rdi", False):
+        kw["cube_ref"] = g["cube_ref"]
+    co, cd, fr = median_sub(g["cube"], g["angles"], mode="annular", full_output=True, verbose=False, **kw)
+    for got, nm in ((co, "out"), (cd, "der"), (fr, "frame")):
+        exp = g["ms_%s_%s" % (tag, nm)]
+        assert got.shape == exp.shape and got.dtype == exp.dtype, nm
+        assert np.nanmax(np.abs(got - exp)) < (2e-6 if nm == "out" else 2e-5), (tag, nm)
+    with pytest.raises(TypeError):
+        median_sub(g["cube"], g["angles"], mode="annular", nframes=3, verbose=False)
+    with pytest.raises(RuntimeError):
+        median_sub(g["cube"], g["angles"], mode="nope", verbose=False)
 
 
 def test_stim_maps_golden():

@@ -419,6 +419,12 @@ int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, 
   return collapse_f32(ctx, cube, n, P, mode, w, trim_n, out);
 }
 
+int vipmi_subset_median_sub_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                                const int32_t* lib_len, int64_t max_lib, float* out) {
+  CTX_GUARD();
+  return subset_median_sub_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, out);
+}
+
 int vipmi_gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
                      int64_t npx, float* A) {
   CTX_GUARD();

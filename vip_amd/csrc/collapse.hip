@@ -191,6 +191,52 @@ __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ c
   }
 }
 
+// out[j][p] = A[j][p] - nanmedian_{i in lib_j} A[i][p]: the "optimised reference" of annular median subtraction
+// (psfsub/medsub.py:629-639: for every frame the median of the `nframes` frames closest in time beyond the PA
+// threshold).  Libraries are small (nframes, default 4): one thread per (frame, pixel) holds the samples in
+// registers and selects by rank counting (NaN-aware, even counts -> mean of the two middle values in float32).
+template <int W>
+__global__ __launch_bounds__(256) void subset_median_sub_kernel(const float* __restrict__ A, int n, int64_t npx,
+                                                                const int32_t* __restrict__ idx,
+                                                                const int32_t* __restrict__ len, int wmax,
+                                                                float* __restrict__ out) {
+  const int j = blockIdx.y;
+  const int lj = len[j] < wmax ? len[j] : wmax;
+  const int32_t* ij = idx + (size_t)j * wmax;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+    unsigned key[W];
+    int m = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      unsigned kk = 0xffffffffu;
+      if (w < lj) {
+        const float v = A[(size_t)ij[w] * npx + p];
+        if (v == v) {
+          kk = f2key(v);
+          ++m;
+        }
+      }
+      key[w] = kk;
+    }
+    float med = __uint_as_float(0x7fc00000u);
+    if (m > 0) {
+      const int klo = (m - 1) >> 1, khi = m >> 1;
+      unsigned vlo = 0, vhi = 0;
+#pragma unroll
+      for (int a = 0; a < W; ++a) {
+        int rank = 0;
+#pragma unroll
+        for (int b = 0; b < W; ++b) rank += (key[b] < key[a] || (key[b] == key[a] && b < a)) ? 1 : 0;
+        if (rank == klo) vlo = key[a];
+        if (rank == khi) vhi = key[a];
+      }
+      const float lo = key2f(vlo), hi = key2f(vhi);
+      med = (m & 1) ? lo : (lo + hi) * 0.5f;
+    }
+    out[(size_t)j * npx + p] = A[(size_t)j * npx + p] - med;
+  }
+}
+
 __global__ void colreduce_kernel(const float* __restrict__ cube, int n, int64_t P, int mode,
                                  const float* __restrict__ w, float* __restrict__ out) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
@@ -319,6 +365,27 @@ int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mo
       set_error("mode not recognized");
       return VIPMI_ERR_ARG;
   }
+}
+
+int subset_median_sub_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* idx,
+                          const int32_t* len, int64_t wmax, float* out) {
+  VIPMI_REQUIRE(A && idx && len && out, "subset_median_sub: null pointer");
+  VIPMI_REQUIRE(n > 0 && npx > 0 && wmax > 0, "subset_median_sub: bad sizes");
+  VIPMI_REQUIRE(wmax <= 32, "subset_median_sub: libraries of more than 32 frames are not supported (nframes=%ld)",
+                (long)wmax);
+  StageScope sc(ctx, "collapse");
+  unsigned gx = (unsigned)cdiv(npx, 256);
+  if (gx > 1024) gx = 1024;
+  const dim3 grid(gx, (unsigned)n), block(256);
+#define VIPMI_SMS(W_)                                                                                          \
+  hipLaunchKernelGGL(subset_median_sub_kernel<W_>, grid, block, 0, ctx->stream, A, (int)n, npx, idx, len, (int)wmax, out)
+  if (wmax <= 4) VIPMI_SMS(4);
+  else if (wmax <= 8) VIPMI_SMS(8);
+  else if (wmax <= 16) VIPMI_SMS(16);
+  else VIPMI_SMS(32);
+#undef VIPMI_SMS
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
 }
 
 }  // namespace vipmi

@@ -152,6 +152,8 @@ int gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const in
 int scatter_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t P, const int32_t* pix, int64_t npx,
                 float* cube);
 int gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, int64_t P, double* G);
+int subset_median_sub_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* idx, const int32_t* len,
+                          int64_t wmax, float* out);
 int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                                 const int32_t* lib_len, int64_t max_lib, const int32_t* ncomps, int64_t nk,
                                 float* residuals);

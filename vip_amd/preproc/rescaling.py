@@ -157,7 +157,8 @@ def zoom_frames(X, E, chan):
     work = B.empty((2 * nb * dout * ldk,), device=X.device.index)
     out = B.empty((nb, dout, dout), device=X.device.index)
     ctx = B.get_context(X.device.index)
-    ctx.call("vipmi_zoom_frames_f32", B.ptr(X.contiguous()), nb, din, B.ptr(er), B.ptr(ei), B.ptr(chan_t), dout, ldk,
+    X = X.contiguous()
+    ctx.call("vipmi_zoom_frames_f32", B.ptr(X), nb, din, B.ptr(er), B.ptr(ei), B.ptr(chan_t), dout, ldk,
              B.ptr(work), B.ptr(out))
     return out
 

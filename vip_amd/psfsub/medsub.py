@@ -1,10 +1,11 @@
-"""Median-ADI / median-RDI, full-frame mode: drop-in for ``vip_hci.psfsub.median_sub`` (reference
-psfsub/medsub.py:60-88 MEDIAN_SUB_Params, :91-519 median_sub; full-frame branch :279-319, :376-387, :516-519;
-SURVEY 8(f) #3).  Composed from the device kernels of the PCA path: NaN-aware median over the frames, subtraction
-(the project/subtract kernel with a single all-ones coefficient), FFT derotation, collapse.
+"""Median-ADI / median-RDI: drop-in for ``vip_hci.psfsub.median_sub`` (reference psfsub/medsub.py:60-88
+MEDIAN_SUB_Params, :91-519 median_sub; full-frame branch :279-319, annular branch :316-371 with
+_median_subt_ann_adi / _median_subt_ann_rdi :602-676, :376-387, :516-519).  Composed from the device
+kernels of the PCA path: NaN-aware median over the frames, subtraction (the project/subtract kernel with a single
+all-ones coefficient), annulus gather / scatter, a small per-frame subset median, FFT derotation, collapse.
 
-Not accelerated (NotImplementedError): ``mode='annular'``, 4-D (SDI) cubes, flux-scaled reference subtraction
-(``collapse_ref`` starting with ``sc``).
+Not accelerated (NotImplementedError): 4-D (SDI) cubes, flux-scaled reference subtraction (``collapse_ref`` starting
+with ``sc``), ``mode='annular'`` with ``nframes=None`` or more than 32 frames per optimised reference.
 """
 from dataclasses import dataclass
 from enum import Enum
@@ -15,8 +16,9 @@ import numpy as np
 from .. import backend as B
 from ..config.paramenum import ALGO_KEY, Collapse, Imlib, Interpolation
 from ..config.utils_param import separate_kwargs_dict
+from ..preproc.derotation import _define_annuli, _find_indices_adi
 from ..preproc.parangles import check_pa_vector
-from ..var.shapes import center_mask_u8
+from ..var.shapes import center_mask_u8, get_annulus_segments
 
 
 @dataclass
@@ -49,6 +51,62 @@ def _s(x):
     return str(getattr(x, "value", x)) if x is not None else None
 
 
+def _annular_pass(cube_t, sub_t, angle_list, algo_params, rdi):
+    """mode='annular' (reference medsub.py:316-371).  ``sub_t`` = cube minus the global model (median of the cube for
+    ADI, collapsed reference for RDI).  ADI: in every annulus each frame additionally loses the median of the
+    ``nframes`` frames closest in time beyond the annulus' PA threshold (:602-641); RDI: the annuli keep ``sub_t``
+    (:644-676).  Pixels outside the annuli are zero."""
+    torch = B._torch()
+    n, y, x = sub_t.shape
+    P = y * x
+    dev = sub_t.device.index
+    ctx = B.get_context(dev)
+    radius_int, asize = algo_params.radius_int, algo_params.asize
+    n_annuli = int((y / 2 - radius_int) / asize)
+    if algo_params.verbose:
+        print("N annuli = {}, FWHM = {}".format(n_annuli, algo_params.fwhm))
+    nframes = algo_params.nframes
+    if not rdi and nframes is not None and nframes % 2 != 0:
+        raise TypeError("`nframes` argument must be even value")
+    cube_out = torch.zeros_like(sub_t)
+    for ann in range(n_annuli):
+        if rdi:
+            inner_radius = radius_int + ann * asize            # (no last-annulus rule in the RDI branch, :650)
+            pa_thr = 0
+        else:
+            pa_thr, inner_radius, _ = _define_annuli(angle_list, ann, n_annuli, algo_params.fwhm, radius_int, asize,
+                                                     algo_params.delta_rot, 1, False)
+        yy, xx = get_annulus_segments((y, x), inner_radius, asize, 1)[0]
+        pix = torch.from_numpy((yy.astype(np.int64) * x + xx).astype(np.int32)).to(sub_t.device)
+        npx = int(pix.numel())
+        if npx == 0:
+            continue
+        A = B.empty((n, npx), device=dev)
+        ctx.call("vipmi_gather_f32", B.ptr(sub_t), n, P, B.ptr(pix), npx, B.ptr(A))
+        if not rdi:
+            if pa_thr != 0:
+                if nframes is None:
+                    raise NotImplementedError("median_sub(mode='annular', nframes=None) is not accelerated")
+                libs = [_find_indices_adi(angle_list, fr, pa_thr, nframes=nframes) for fr in range(n)]
+            else:
+                libs = [np.arange(n, dtype=np.int32) for _ in range(n)]
+            wmax = max(1, max(len(li) for li in libs))
+            if wmax > 32:
+                raise NotImplementedError("median_sub(mode='annular'): libraries of more than 32 frames "
+                                          "(nframes={}) are not accelerated".format(nframes))
+            idx = np.zeros((n, wmax), dtype=np.int32)
+            ln = np.zeros(n, dtype=np.int32)
+            for fr, li in enumerate(libs):
+                idx[fr, :len(li)] = li
+                ln[fr] = len(li)
+            R = B.empty((n, npx), device=dev)
+            idx_t, ln_t = torch.from_numpy(idx).to(sub_t.device), torch.from_numpy(ln).to(sub_t.device)   # (kept alive)
+            ctx.call("vipmi_subset_median_sub_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), wmax, B.ptr(R))
+            A = R
+        ctx.call("vipmi_scatter_f32", B.ptr(A), n, P, B.ptr(pix), npx, B.ptr(cube_out))
+    return cube_out
+
+
 def median_sub(*all_args: List, **all_kwargs: dict):
     """Median PSF subtraction of a 3-D ADI cube on the MI355X.  Returns ``frame`` or
     ``(cube_out, cube_der, frame)``."""
@@ -71,10 +129,9 @@ def median_sub(*all_args: List, **all_kwargs: dict):
         raise NotImplementedError("4-D (SDI) median subtraction is not accelerated")
     if _s(algo_params.imlib) != "vip-fft":
         raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
-    if algo_params.mode == "annular":
-        raise NotImplementedError("median_sub(mode='annular') is not accelerated")
-    if algo_params.mode != "fullfr":
+    if algo_params.mode not in ("fullfr", "annular"):
         raise RuntimeError("Mode not recognized")
+    annular = algo_params.mode == "annular"
     torch = B._torch()
     angle_list = check_pa_vector(np.asarray(algo_params.angle_list, dtype=np.float64))
     dev_in = B.is_device_tensor(cube)
@@ -103,11 +160,14 @@ def median_sub(*all_args: List, **all_kwargs: dict):
     ctx = B.get_context(t.device.index)
     ones = torch.ones((n, 1), dtype=torch.float32, device=t.device)
     cube_out = B.empty((n, P), device=t.device.index)
-    ctx.call("vipmi_subtract_gemm_f32", B.ptr(t.reshape(n, P)), B.ptr(ones), B.ptr(model.reshape(1, P).contiguous()),
+    model_row = model.reshape(1, P).contiguous()          # (named: a temporary must outlive the enqueued kernel's launch)
+    ctx.call("vipmi_subtract_gemm_f32", B.ptr(t.reshape(n, P)), B.ptr(ones), B.ptr(model_row),
              n, 1, P, B.ptr(cube_out), None)
     cube_out = cube_out.reshape(n, y, x)
+    if annular:
+        cube_out = _annular_pass(t, cube_out, angle_list, algo_params, rdi=algo_params.cube_ref is not None)
     if algo_params.verbose:
-        print("Median psf reference subtracted")
+        print("Optimized median psf reference subtracted" if annular else "Median psf reference subtracted")
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
     if not mv_nan and mask_val != 0:

@@ -253,7 +253,8 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             R = R[nref:]
             if S is not None:
                 R = B.lincomb(R, S, 1.0, 1.0)
-            ctx.call("vipmi_scatter_f32", B.ptr(R.contiguous()), n, P, B.ptr(pix), npx, B.ptr(cube_out))
+            R = R.contiguous()
+            ctx.call("vipmi_scatter_f32", B.ptr(R), n, P, B.ptr(pix), npx, B.ptr(cube_out))
         else:
             R = B.empty((len(ks), nrow, npx), device=dev)
             ctx.call("vipmi_annular_residuals_multi_f32", B.ptr(A), nrow, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
@@ -262,7 +263,8 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                 Rn = R[nn, nref:]
                 if S is not None:
                     Rn = B.lincomb(Rn, S, 1.0, 1.0)
-                ctx.call("vipmi_scatter_f32", B.ptr(Rn.contiguous()), n, P, B.ptr(pix), npx, B.ptr(cube_out[nn]))
+                Rn = Rn.contiguous()
+                ctx.call("vipmi_scatter_f32", B.ptr(Rn), n, P, B.ptr(pix), npx, B.ptr(cube_out[nn]))
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
     if not mv_nan and mask_val != 0:

@@ -38,7 +38,8 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
         ctx = B.get_context(mat_t.device.index)
         V = B.empty((ncomp, P), device=mat_t.device.index)
         W = E.to(torch.float32).contiguous()
-        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(W), B.ptr(mat_t), ncomp, n, P, B.ptr(inv.contiguous()), B.ptr(V))
+        inv = inv.contiguous()
+        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(W), B.ptr(mat_t), ncomp, n, P, B.ptr(inv), B.ptr(V))
     return sig_all, E, V
 
 
