@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency > $OUT/bench_under_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_prof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python $REPO/tools/prof_stage.py pca 400 512 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python $REPO/tools/prof_stage.py pca 400 512 1 > $OUT/pmc_write.log 2>&1
 cd $REPO
