@@ -238,6 +238,21 @@ def test_pca_annular_ref_sig_golden(tag, kw):
         pca_annular(g["cube"], g["angles"], cube_sig=g["cube_sig"][:-1], ncomp=2, asize=8, verbose=False)
 
 
+def test_pca_annular_4d_with_reference_cube():
+    """4-D cube + 4-D reference cube (pca_local.py:279-325): every channel equals the 3-D RDI call on that channel."""
+    from vip_amd.psfsub import pca_annular
+    c4 = np.stack([O.synth_adi(12, 40, seed=40 + i)[0] for i in range(3)])
+    r4 = np.stack([O.synth_adi(6, 40, seed=60 + i)[0] for i in range(3)])
+    ang = np.linspace(0, 80, 12)
+    kw = dict(asize=8, ncomp=2, fwhm=4, delta_rot=(0.1, 1), verbose=False)
+    co, cd, fr = pca_annular(c4, ang, cube_ref=r4, full_output=True, **kw)
+    per = [pca_annular(c4[ch], ang, cube_ref=r4[ch], full_output=True, **kw) for ch in range(3)]
+    assert np.abs(co - np.stack([p[0] for p in per])).max() < 1e-6
+    assert np.abs(fr - np.mean(np.stack([p[2] for p in per]).astype(np.float64), axis=0)).max() < 1e-6
+    ref0 = O.pca_annular(c4[0], ang, cube_ref=r4[0], asize=8, ncomp=2, fwhm=4, delta_rot=(0.1, 1), full_output=True)
+    assert np.abs(per[0][0] - ref0[0]).max() < TOL
+
+
 def test_pca_annular_scaling_and_errors():
     from vip_amd.psfsub import pca_annular
     cube, ang = O.synth_adi(20, 48, seed=4)
