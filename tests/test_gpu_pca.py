@@ -357,6 +357,20 @@ def test_pca_pa_rejection_errors():
         pca(g["cube"], g["angles"], ncomp=(1, 3), source_xy=(34, 24), fwhm=4, verbose=False)
 
 
+def test_sharded_modes_world1_use_the_device_path():
+    """vip_amd.dist with its DEFAULT compute (the device pca) on one rank: survey mode and the 4-D channel split."""
+    from vip_amd import dist as D
+    from vip_amd.psfsub import pca
+    cubes = [O.synth_adi(10, 32, seed=s)[0] for s in (1, 2, 3)]
+    angs = [np.linspace(0, 60, 10)] * 3
+    frames = D.pca_cubes(cubes, angs, ncomp=2, verbose=False).cpu().numpy()
+    for i in range(3):
+        assert np.abs(frames[i] - pca(cubes[i], angs[i], ncomp=2, verbose=False)).max() < 1e-6
+    g = load_golden("g6_pca_4d")
+    frame, ifs = D.pca_4d(g["cube"], g["angles"], ncomp=2, verbose=False)
+    assert np.abs(frame - g["frame"]).max() < TOL and np.abs(ifs - g["ifs"]).max() < TOL
+
+
 def test_single_cube_sharded_path_world1():
     """vip_amd.dist.pca_single_cube with the device kernels (one rank: the slab / exchange code paths degenerate to
     local copies) reproduces pca()."""
