@@ -15,8 +15,7 @@ N_FR, N_PX, K = 400, 512, 20
 def c2():
     import torch
     from vip_amd.psfsub import pca
-    from vip_amd.synth import synth_adi
-    cube, ang = synth_adi(N_FR, N_PX, seed=0)
+    cube, ang = O.synth_adi(N_FR, N_PX, seed=0)        # the generator (and seed) of tests/golden/g15_pca_c2.npz
     cube_t = torch.from_numpy(cube).cuda()
     out = pca(cube_t, ang, ncomp=K, full_output=True, verbose=False, check_memory=False)
     return cube, ang, cube_t, out
@@ -74,3 +73,17 @@ def test_c2_derotation_linearity_and_quarter_turns():
         emb[:N_PX, :N_PX] = src
         exp = np.rot90(emb, k)[:N_PX, :N_PX]
         assert np.abs(got - exp).max() < 2e-5, ang
+
+
+def test_c2_against_the_real_reference(c2):
+    """BASELINE.json configs[1] pinned directly: tests/golden/g15_pca_c2.npz holds outputs of the real reference's
+    pca(cube, angles, ncomp=20, svd_mode='lapack') on this very cube (oracle/gen_golden_c2.py, ~15 min of CPU)."""
+    from conftest import load_golden
+    g = load_golden("g15_pca_c2")
+    cube, ang, cube_t, (frame, pcs, recon, res, res_der) = c2
+    assert np.abs(frame.cpu().numpy() - g["frame"]).max() < 1e-4
+    keep = [int(i) for i in g["keep"]]
+    assert np.abs(res[keep].cpu().numpy() - g["res_keep"]).max() < 1e-4
+    assert np.nanmax(np.abs(res_der[keep].cpu().numpy() - g["resd_keep"])) < 1e-4
+    rows = res.reshape(N_FR, -1).double().sum(dim=1).cpu().numpy()
+    assert np.abs(rows - g["res_rowsum"]).max() < 1e-4 * np.sqrt(N_PX * N_PX) * 4
