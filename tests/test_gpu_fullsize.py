@@ -87,3 +87,38 @@ def test_c2_against_the_real_reference(c2):
     assert np.nanmax(np.abs(res_der[keep].cpu().numpy() - g["resd_keep"])) < 1e-4
     rows = res.reshape(N_FR, -1).double().sum(dim=1).cpu().numpy()
     assert np.abs(rows - g["res_rowsum"]).max() < 1e-4 * np.sqrt(N_PX * N_PX) * 4
+
+
+def test_c3_annular_against_the_real_reference():
+    """BASELINE.json configs[2]: pca_annular(400 x 512 x 512, 8 annuli, ncomp=10) against the real reference's run
+    (oracle/gen_golden_c3c4.py c3 -> tests/golden/g16_annular_c3.npz)."""
+    import torch
+    from conftest import load_golden
+    from vip_amd.psfsub import pca_annular
+    g = load_golden("g16_annular_c3")
+    cube, ang = O.synth_adi(N_FR, N_PX, seed=0)
+    co, cd, fr = pca_annular(torch.from_numpy(cube).cuda(), ang, ncomp=10, asize=32, fwhm=4, delta_rot=(0.1, 1),
+                             n_segments=1, full_output=True, verbose=False)
+    assert np.abs(fr.cpu().numpy() - g["frame"]).max() < 1e-4
+    keep = [int(i) for i in g["keep"]]
+    assert np.abs(co[keep].cpu().numpy() - g["out_keep"]).max() < 1e-4
+    rows = co.reshape(N_FR, -1).double().sum(dim=1).cpu().numpy()
+    assert np.abs(rows - g["out_rowsum"]).max() < 1e-4 * N_PX * 4
+
+
+def test_c4_per_channel_pca_against_the_real_reference():
+    """BASELINE.json configs[3]: pca(39 x 200 x 256 x 256, ncomp=20) per channel + spectral mean against the real
+    reference's run (oracle/gen_golden_c3c4.py c4 -> tests/golden/g17_pca4d_c4.npz); both the batched frame-only path
+    and the per-channel loop of full_output."""
+    import torch
+    from conftest import load_golden
+    from vip_amd.psfsub import pca
+    g = load_golden("g17_pca4d_c4")
+    c4 = torch.stack([torch.from_numpy(O.synth_adi(200, 256, seed=s)[0]) for s in range(39)]).cuda()
+    ang = np.linspace(0, 90, 200)
+    frame = pca(c4, ang, ncomp=20, verbose=False, check_memory=False)
+    assert np.abs(frame.cpu().numpy() - g["frame"]).max() < 1e-4
+    out = pca(c4, ang, ncomp=20, full_output=True, verbose=False, check_memory=False)
+    chs = [int(c) for c in g["ifs_channels"]]
+    assert np.abs(out[-1][chs].cpu().numpy() - g["ifs"]).max() < 1e-4
+    assert np.abs(out[0].cpu().numpy() - g["frame"]).max() < 1e-4
