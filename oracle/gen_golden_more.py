@@ -89,3 +89,18 @@ for tag, kw in (("a", dict(asize=4, fwhm=4, delta_rot=1)), ("b", dict(asize=6, f
     co, cd, fr_ = ref.median_sub(cube, ang, mode="annular", full_output=True, verbose=False, nproc=1, **kw)
     g["ms_%s_out" % tag], g["ms_%s_der" % tag], g["ms_%s_frame" % tag] = co, cd, fr_
 save("g14_medsub_annular", **g)
+
+# ---- G18: ADI+mSDI at a larger / odd frame size (zoom operators for odd and even sizes, more channels) ---------------
+for N_ in (64, 65):
+    z_, n_ = 7, 12
+    c4 = np.stack([O.synth_adi(n_, N_, seed=100 + i)[0] for i in range(z_)]).astype(np.float32)
+    a4 = np.linspace(0, 70, n_)
+    sc = np.linspace(1.0, 1.4, z_)[::-1].copy()
+    g = {"cube": c4, "angles": a4, "scale_list": sc}
+    fo = ref.pca(c4, a4, scale_list=sc, adimsdi="double", ncomp=(2, 3), full_output=True, verbose=False, nproc=1)
+    for nm, a in zip(("frame", "rcc", "rcc_der"), fo):
+        g["d_%s" % nm] = np.asarray(a)
+    fo = ref.pca(c4, a4, scale_list=sc, adimsdi="single", ncomp=4, full_output=True, verbose=False, nproc=1)
+    g["s_frame"] = np.asarray(fo[0])
+    g["s_adi"] = np.asarray(fo[3])
+    save("g18_msdi_%d" % N_, **g)

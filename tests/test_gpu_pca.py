@@ -541,6 +541,23 @@ def test_msdi_single_golden(tag, kw):
         assert np.abs(a - b).max() < TOL, (tag, nm, np.abs(a - b).max())
 
 
+@pytest.mark.parametrize("N", [64, 65])
+def test_msdi_larger_sizes_golden(N):
+    """ADI+mSDI with 7 channels at an even and an odd frame size against the reference's outputs."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g18_msdi_%d" % N)
+    fo = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", ncomp=(2, 3), full_output=True,
+             verbose=False)
+    for nm, a in zip(("frame", "rcc", "rcc_der"), fo):
+        b = g["d_%s" % nm]
+        assert a.shape == b.shape and a.dtype == b.dtype, nm
+        assert np.nanmax(np.abs(a - b)) < TOL, (nm, np.nanmax(np.abs(a - b)))
+    fs = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="single", ncomp=4, full_output=True,
+             verbose=False)
+    assert np.abs(fs[0] - g["s_frame"]).max() < TOL
+    assert np.nanmax(np.abs(fs[3] - g["s_adi"])) < TOL
+
+
 def test_msdi_errors():
     from vip_amd.psfsub import pca
     g = load_golden("g10_msdi")
