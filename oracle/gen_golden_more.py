@@ -104,3 +104,15 @@ for N_ in (64, 65):
     g["s_frame"] = np.asarray(fo[0])
     g["s_adi"] = np.asarray(fo[3])
     save("g18_msdi_%d" % N_, **g)
+
+# ---- G19: rarely used switches: pca_annular(n_segments='auto', theta_init, radius_int, max_frames_lib), pca(collapse='wmean') --
+cube, _ = O.synth_adi(20, 48, seed=110)
+ang = np.linspace(0, 85, 20)
+w = np.linspace(0.5, 1.5, 20)
+g = {"cube": cube, "angles": ang, "weights": w}
+co, cd, fr_ = ref.pca_annular(cube, ang, ncomp=2, asize=6, fwhm=4, delta_rot=(0.1, 0.8), n_segments="auto", theta_init=30,
+                              radius_int=6, max_frames_lib=9, full_output=True, verbose=False, nproc=1)
+g["ann_out"], g["ann_der"], g["ann_frame"] = co, cd, fr_
+g["pca_wmean"] = ref.pca(cube, ang, ncomp=3, collapse="wmean", weights=w, verbose=False, nproc=1)
+g["ann_wmean"] = ref.pca_annular(cube, ang, ncomp=2, asize=8, fwhm=4, collapse="wmean", weights=w, verbose=False, nproc=1)
+save("g19_switches", **g)

@@ -253,6 +253,22 @@ def test_pca_annular_4d_with_reference_cube():
     assert np.abs(per[0][0] - ref0[0]).max() < TOL
 
 
+def test_rare_switches_golden():
+    """n_segments='auto' (radian quirk kept), theta_init, radius_int, max_frames_lib; weighted-mean collapse -- against
+    the reference's outputs."""
+    from vip_amd.psfsub import pca, pca_annular
+    g = load_golden("g19_switches")
+    cube, ang, w = g["cube"], g["angles"], g["weights"]
+    co, cd, fr = pca_annular(cube, ang, ncomp=2, asize=6, fwhm=4, delta_rot=(0.1, 0.8), n_segments="auto", theta_init=30,
+                             radius_int=6, max_frames_lib=9, full_output=True, verbose=False)
+    assert np.abs(co - g["ann_out"]).max() < TOL
+    assert np.nanmax(np.abs(cd - g["ann_der"])) < TOL
+    assert np.abs(fr - g["ann_frame"]).max() < TOL
+    assert np.abs(pca(cube, ang, ncomp=3, collapse="wmean", weights=w, verbose=False) - g["pca_wmean"]).max() < TOL
+    assert np.abs(pca_annular(cube, ang, ncomp=2, asize=8, fwhm=4, collapse="wmean", weights=w, verbose=False)
+                  - g["ann_wmean"]).max() < TOL
+
+
 def test_pca_annular_scaling_and_errors():
     from vip_amd.psfsub import pca_annular
     cube, ang = O.synth_adi(20, 48, seed=4)
