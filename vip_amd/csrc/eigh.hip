@@ -345,7 +345,8 @@ int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals,
   // larger problems: 8 waves per workgroup (256-VGPR budget, 8 columns x n doubles of LDS)
   if (rpl <= 16) return launch_jacobi<8, 16>(ctx, G, batch, (int)n, evals, evecs);
   if (rpl <= 32) return launch_jacobi<8, 32>(ctx, G, batch, (int)n, evals, evecs);
-  set_error("eigh: n=%ld too large for the LDS-resident block Jacobi (max 2048)", (long)n);
+  set_error("eigh: matrices of more than 2048 x 2048 (cubes / libraries of more than 2048 frames) are not supported by "
+            "the device eigensolvers yet (n=%ld)", (long)n);
   return VIPMI_ERR_UNSUPPORTED;
 }
 
