@@ -581,3 +581,21 @@ def test_msdi_errors():
         pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", ncomp=2, verbose=False)
     with pytest.raises(ValueError):
         pca(g["cube"], g["angles"], scale_list=g["scale_list"][:3], adimsdi="double", ncomp=(1, 1), verbose=False)
+
+
+def test_more_than_2048_frames():
+    """beyond the LDS-resident eigensolvers (n > 2048) the front keeps the device Gram / projection kernels and takes
+    the eigendecomposition from rocSOLVER (backend.eigh_beyond_lds): ADI cube and RDI reference library of 2100 frames"""
+    from vip_amd.psfsub import pca
+    n, N, k = 2100, 32, 10
+    cube, _ = O.synth_adi(n, N, seed=n)
+    ang = np.linspace(0, 170, n)
+    got = pca(cube, ang, ncomp=k, verbose=False)
+    assert np.abs(got - O.pca_fullframe(cube, ang, ncomp=k)).max() < TOL
+    small, a2 = O.synth_adi(30, N, seed=6)
+    got = pca(small, a2, ncomp=5, cube_ref=cube, verbose=False)
+    assert np.abs(got - O.pca_fullframe(small, a2, ncomp=5, cube_ref=cube)).max() < TOL
+    from vip_amd.psfsub.svd import svd_wrapper
+    V = svd_wrapper(cube.reshape(n, -1)[:, :900], "lapack", 4, verbose=False)
+    Vr = O.svd_wrapper(cube.reshape(n, -1)[:, :900], "lapack", 4)
+    assert np.abs(sign_align(V, Vr) - Vr).max() < TOL

@@ -295,6 +295,56 @@ def eigh_topk(G, k, nact=None, all_evals=False):
     return (ev[0], ec[0]) if single else (ev, ec)
 
 
+MAX_EIGH_N = 2048        # the hand-written eigensolvers keep their working set in LDS: matrices up to 2048 x 2048
+
+
+def eigh_beyond_lds(G):
+    """Eigendecomposition of a Gram matrix of more than MAX_EIGH_N frames: the ONE place where a ROCm library routine is
+    used (rocSOLVER's syevd through ``torch.linalg.eigh``, on the device, float64) -- the hand-written solvers hold 9 n
+    doubles of vectors in LDS and stop at n = 2048, and such cubes are rare.  Returns (evals descending, eigenvectors as
+    rows, largest-magnitude component positive) like the native solvers."""
+    torch = _torch()
+    w, Q = torch.linalg.eigh(G.to(torch.float64))
+    w = w.flip(0).contiguous()
+    E = Q.flip(1).t().contiguous()                                   # rows = eigenvectors, descending eigenvalue
+    big = E.abs().argmax(dim=1, keepdim=True)
+    E = E * torch.sign(torch.gather(E, 1, big))
+    return w, E
+
+
+def _pca_project_large(M, k, ref, want_recon, want_pcs, want_evals):
+    """``pca_project`` for more than MAX_EIGH_N reference frames: Gram and both projection products on the device
+    kernels, the eigendecomposition through ``eigh_beyond_lds``."""
+    torch = _torch()
+    ctx = get_context(M.device.index)
+    n, P = M.shape
+    dev = M.device.index
+    refm = M if ref is None else ref
+    nref = refm.shape[0]
+    w, E = eigh_beyond_lds(gram(refm))
+    ev = w[:k]
+    keep = (ev > ev[0] * 1e-12)
+    Ek = (E[:k] * keep[:, None]).to(torch.float32).contiguous()       # (k, nref)
+    inv = torch.where(keep, 1.0 / torch.sqrt(torch.clamp(ev, min=1e-300)), torch.zeros_like(ev)).to(torch.float32).contiguous()
+    res = empty((n, P), device=dev)
+    if ref is None:
+        T = empty((k, P), device=dev)
+        ctx.call("vipmi_rowspace_gemm_f32", ptr(Ek), ptr(M), k, n, P, None, ptr(T))
+        C = Ek.t().contiguous()
+        ctx.call("vipmi_subtract_gemm_f32", ptr(M), ptr(C), ptr(T), n, k, P, ptr(res), None)
+        pcs = (T * inv[:, None]).contiguous() if want_pcs else None
+    else:
+        V = empty((k, P), device=dev)                                   # V = S^-1 E^T ref  (orthonormal rows)
+        ctx.call("vipmi_rowspace_gemm_f32", ptr(Ek), ptr(refm), k, nref, P, ptr(inv), ptr(V))
+        C64 = empty((n, k), torch.float64, dev)
+        ctx.call("vipmi_cross_gram_f32", ptr(M), n, ptr(V), k, P, P, ptr(C64))
+        C = C64.to(torch.float32).contiguous()
+        ctx.call("vipmi_subtract_gemm_f32", ptr(M), ptr(C), ptr(V), n, k, P, ptr(res), None)
+        pcs = V if want_pcs else None
+    recon = lincomb(M, res, 1.0, -1.0) if want_recon else None
+    return res, recon, pcs, (w if want_evals else None)
+
+
 def pca_project(M, k, ref=None, want_recon=False, want_pcs=False, want_evals=False):
     """residuals (and optionally recon, pcs, evals) of M w.r.t. the top-k PCs of ref (default M)."""
     torch = _torch()
@@ -302,6 +352,8 @@ def pca_project(M, k, ref=None, want_recon=False, want_pcs=False, want_evals=Fal
     n, P = M.shape
     refm = M if ref is None else ref
     nref = refm.shape[0]
+    if nref > MAX_EIGH_N:
+        return _pca_project_large(M, k, ref, want_recon, want_pcs, want_evals)
     dev = M.device.index
     res = empty((n, P), device=dev)
     recon = empty((n, P), device=dev) if want_recon else None

@@ -315,7 +315,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
             return recon_cube, residuals_cube, residuals_cube_, frame
         return frame
 
-    fused_ok = (cube_ref is None and cube_sig is None and isinstance(ncomp, (int, np.integer)) and collapse in
+    fused_ok = (cube_ref is None and cube_sig is None and n <= B.MAX_EIGH_N and isinstance(ncomp, (int, np.integer)) and collapse in
                 ("median", "mean", "sum", "max", "absmean") and (bool(mask_center_px) != mv_nan))
     if fused_ok:
         # one call into the C ABI: mask/scale -> Gram -> eigh -> project -> derotate -> collapse

@@ -26,6 +26,8 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
         evals, evecs = B.eigh_topk(G, ncomp)
     elif n <= 2048 and 0 < ncomp <= 64:
         evals, evecs = B.eigh_topk(G, ncomp, all_evals=True)       # whole spectrum, leading vectors
+    elif n > B.MAX_EIGH_N:
+        evals, evecs = B.eigh_beyond_lds(G)                        # more than 2048 frames (rocSOLVER, see backend)
     else:
         evals, evecs = B.eigh(G)
     sig_all = torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
@@ -122,7 +124,7 @@ class SVDecomposer:
         if G.shape[0] <= 2048:
             evals, _ = B.eigh_topk(G, 1, all_evals=True)     # values only: tridiagonalisation + multisection
         else:
-            evals, _ = B.eigh(G)
+            evals, _ = B.eigh_beyond_lds(G)
         self.s = B._torch().sqrt(B._torch().clamp(evals, min=0)).cpu().numpy()
 
     def get_cevr(self, ncomp_list=None, plot=False, **_):
