@@ -286,6 +286,81 @@ def frame_rotate_fft(frame, angle, mask_val=np.nan):
     return out
 
 
+def _warp_weights(taps):
+    """Separable float32 weights of OpenCV's 32 sub-pixel phases (imgwarp.cpp interpolateLinear / Cubic / Lanczos4)."""
+    tab = np.zeros((32, taps), dtype=np.float32)
+    for i in range(32):
+        x = np.float32(i / 32.0)
+        one = np.float32(1)
+        if taps == 2:
+            tab[i] = (one - x, x)
+        elif taps == 4:
+            A = np.float32(-0.75)
+            c0 = ((A * (x + one) - 5 * A) * (x + one) + 8 * A) * (x + one) - 4 * A
+            c1 = ((A + 2) * x - (A + 3)) * x * x + one
+            c2 = ((A + 2) * (one - x) - (A + 3)) * (one - x) * (one - x) + one
+            tab[i] = (c0, c1, c2, one - np.float32(c0) - np.float32(c1) - np.float32(c2))
+        else:
+            if x < np.finfo(np.float32).eps:
+                tab[i, 3] = 1
+                continue
+            s45 = 0.70710678118654752440084436210485
+            cs = [(1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1), (-s45, s45)]
+            y0 = -(float(x) + 3) * np.pi * 0.25
+            s0, c0 = np.sin(y0), np.cos(y0)
+            c = np.array([(cs[k][0] * s0 + cs[k][1] * c0) / (-(float(x) + 3 - k) * np.pi * 0.25) ** 2 for k in range(8)],
+                         dtype=np.float32)
+            tot = np.float32(0)
+            for k in range(8):
+                tot = np.float32(tot + c[k])
+            tab[i] = c * np.float32(one / tot)
+    return tab
+
+
+def warp_rotate(frame, angle, interpolation="lanczos4", cxy=None):
+    """``frame_rotate(frame, angle, imlib='opencv', interpolation=..., border_mode='constant')``.
+    Ref: preproc/derotation.py:218 (NaN -> 0), :223-226 (centre = frame_center), :279-305 (cv2.getRotationMatrix2D +
+    cv2.warpAffine on float32).  PARITY UNPINNED: opencv-python (pyproject.toml:56, no version pin) is not installed
+    here, so this restates OpenCV 4.x's published algorithm (modules/imgproc/src/imgwarp.cpp: inverted affine map in
+    double, source coordinates in 1/1024-pixel fixed point truncated to 1/32 pixel, separable float tables, border
+    constant 0) and could not be compared with cv2 itself."""
+    taps = {"nearneig": 1, "bilinear": 2, "bicubic": 4, "lanczos4": 8}[interpolation]
+    a = np.where(np.isnan(np.asarray(frame, dtype=np.float32)), np.float32(0), np.asarray(frame, dtype=np.float32))
+    ny, nx = a.shape
+    cy, cx = frame_center(a) if cxy is None else (cxy[1], cxy[0])
+    al, be = np.cos(np.deg2rad(angle)), np.sin(np.deg2rad(angle))
+    M = np.array([al, be, (1 - al) * cx - be * cy, -be, al, be * cx + (1 - al) * cy], dtype=np.float64)
+    D = M[0] * M[4] - M[1] * M[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[4] * D, M[0] * D
+    M[0], M[1], M[3], M[4] = A11, M[1] * -D, M[3] * -D, A22
+    b1 = -M[0] * M[2] - M[1] * M[5]
+    b2 = -M[3] * M[2] - M[4] * M[5]
+    M[2], M[5] = b1, b2
+    xs = np.arange(nx, dtype=np.float64)
+    ys = np.arange(ny, dtype=np.float64)
+    rd = 512 if taps == 1 else 16
+    X0 = (np.rint((M[1] * ys + M[2]) * 1024).astype(np.int64) + rd)[:, None] + np.rint(M[0] * xs * 1024).astype(np.int64)[None]
+    Y0 = (np.rint((M[4] * ys + M[5]) * 1024).astype(np.int64) + rd)[:, None] + np.rint(M[3] * xs * 1024).astype(np.int64)[None]
+    pad = np.zeros((ny + 2, nx + 2), dtype=np.float32)          # a zero frame around the image = the constant border
+    pad[1:-1, 1:-1] = a
+
+    def tap(sy, sx):
+        return pad[np.clip(sy + 1, 0, ny + 1), np.clip(sx + 1, 0, nx + 1)]
+
+    if taps == 1:
+        return tap(Y0 >> 10, X0 >> 10)
+    X, Y = X0 >> 5, Y0 >> 5
+    tab = _warp_weights(taps)
+    wx, wy = tab[X & 31], tab[Y & 31]                           # (ny, nx, taps)
+    sx, sy = (X >> 5) - (taps // 2 - 1), (Y >> 5) - (taps // 2 - 1)
+    out = np.zeros((ny, nx), dtype=np.float32)
+    for r in range(taps):
+        for c in range(taps):
+            out += tap(sy + r, sx + c) * (wy[..., r] * wx[..., c])
+    return out
+
+
 def cube_derotate(cube, angle_list, mask_val=np.nan, out_dtype=None):
     """nproc=1 semantics: output dtype = input dtype.  Ref: derotation.py:383-391."""
     if cube.ndim != 3:

@@ -576,3 +576,46 @@ def test_eigh_spectrum(B, n, k):
     assert ev.shape == (n,) and ec.shape == (k, n)
     np.testing.assert_allclose(ev, w, atol=1e-12 * w[0])
     _topk_check(G, ev[:k], ec, k)
+
+
+@pytest.mark.parametrize("N", [64, 65, 101])
+@pytest.mark.parametrize("interp", ["nearneig", "bilinear", "bicubic", "lanczos4"])
+def test_rotate_opencv_style(N, interp):
+    """imlib='opencv' (derotation.py:279-305): the warp kernel against the oracle's restatement of OpenCV's warpAffine
+    (fixed-point coordinates, 1/32-pixel weight tables, zero border; cv2 itself is absent => parity unpinned), plus
+    the exact cases (0 / 90 degrees) and closeness to the 'vip-fft' rotation on a smooth frame."""
+    from vip_amd.preproc import cube_derotate, frame_rotate
+    rng = np.random.default_rng(N)
+    yy, xx = np.mgrid[:N, :N]
+    smooth = np.exp(-((yy - 0.6 * N) ** 2 + (xx - 0.4 * N) ** 2) / (0.02 * N * N)).astype(np.float32)
+    cube = np.stack([smooth, rng.standard_normal((N, N)).astype(np.float32), smooth, smooth, smooth])
+    cube[1, 3, 5] = np.nan
+    ang = np.array([33.0, -147.3, 0.0, -90.0, 211.7])
+    got = cube_derotate(cube, ang, imlib="opencv", interpolation=interp)
+    assert got.dtype == np.float32 and got.shape == cube.shape
+    for i in range(len(ang)):
+        ref = O.warp_rotate(cube[i], -ang[i], interp)
+        assert np.abs(got[i] - ref).max() < 2e-6 * max(1.0, np.abs(ref).max()), (i, interp)
+    assert np.array_equal(got[2], smooth)
+    assert np.array_equal(got[3], np.rot90(smooth, 1)[:N, :N]) or N % 2 == 0
+    fft = cube_derotate(cube[:1], ang[:1])
+    b = N // 6
+    assert np.abs(got[0] - fft[0])[b:-b, b:-b].max() < {"nearneig": 0.2, "bilinear": 0.05, "bicubic": 0.03, "lanczos4": 0.02}[interp]
+    one = frame_rotate(cube[0], 12.5, imlib="opencv", interpolation=interp, cxy=(N / 2 - 0.5, N / 2 - 0.5))
+    assert one.dtype == np.float32
+    assert np.abs(one - O.warp_rotate(cube[0], 12.5, interp, cxy=(N / 2 - 0.5, N / 2 - 0.5))).max() < 2e-6
+
+
+def test_rotate_opencv_style_errors():
+    from vip_amd.preproc import cube_derotate
+    cube = np.zeros((2, 16, 16), dtype=np.float32)
+    with pytest.raises(ValueError):
+        cube_derotate(cube, [0, 1], imlib="opencv", interpolation="spline")
+    with pytest.raises(NotImplementedError):
+        cube_derotate(cube, [0, 1], imlib="opencv", border_mode="reflect")
+    with pytest.raises(ValueError):
+        cube_derotate(cube, [0, 1], imlib="opencv", border_mode="nope")
+    with pytest.raises(NotImplementedError):
+        cube_derotate(cube, [0, 1], imlib="skimage")
+    with pytest.raises(ValueError):
+        cube_derotate(cube, [0, 1], imlib="nope")

@@ -599,3 +599,24 @@ def test_more_than_2048_frames():
     V = svd_wrapper(cube.reshape(n, -1)[:, :900], "lapack", 4, verbose=False)
     Vr = O.svd_wrapper(cube.reshape(n, -1)[:, :900], "lapack", 4)
     assert np.abs(sign_align(V, Vr) - Vr).max() < TOL
+
+
+def test_pca_with_opencv_style_rotation():
+    """pca(..., imlib='opencv'): same residuals as the parity path, derotated with the interpolating warp (oracle:
+    project_subtract + warp_rotate + median); full-frame and annular."""
+    from vip_amd.psfsub import pca, pca_annular
+    n, N, k = 24, 49, 4
+    cube, ang = O.synth_adi(n, N, seed=77)
+    out = pca(cube, ang, ncomp=k, imlib="opencv", interpolation="bicubic", full_output=True, verbose=False)
+    frame, res, resd = out[0], out[3], out[4]
+    ref_res = O.pca_fullframe(cube, ang, ncomp=k, full_output=True)[3]
+    assert np.abs(res - ref_res).max() < TOL
+    ref_der = np.stack([O.warp_rotate(ref_res[i], -ang[i], "bicubic") for i in range(n)])
+    assert np.abs(resd - ref_der).max() < TOL
+    assert np.abs(frame - np.median(ref_der, axis=0)).max() < TOL
+    co, cd, fa = pca_annular(cube, ang, ncomp=3, asize=6, fwhm=4, imlib="opencv", interpolation="lanczos4",
+                             full_output=True, verbose=False)
+    co_fft = pca_annular(cube, ang, ncomp=3, asize=6, fwhm=4, full_output=True, verbose=False)[0]
+    assert np.array_equal(co, co_fft)                       # the residuals do not depend on the rotation
+    ref_der = np.stack([O.warp_rotate(co[i], -ang[i], "lanczos4") for i in range(n)])
+    assert np.abs(cd - ref_der).max() < 1e-5 and np.abs(fa - np.median(ref_der, axis=0)).max() < 1e-5

@@ -363,7 +363,73 @@ def pca_project(M, k, ref=None, want_recon=False, want_pcs=False, want_evals=Fal
     return res, recon, pcs, evals
 
 
+INTERP_MODES = {"nearneig": 0, "bilinear": 1, "bicubic": 2, "lanczos4": 3}
+_ROTATION = ["vip-fft", "lanczos4"]          # rotation used by derotate(): set by rotation_mode() / with_rotation
+
+
+def check_imlib(imlib, interpolation="lanczos4"):
+    """Validate the reference's (imlib, interpolation) switches: 'vip-fft' (parity path) or 'opencv' (interpolating
+    rotation, derotation.py:279-305); the others are not implemented on the device."""
+    imlib = str(getattr(imlib, "value", imlib))
+    interpolation = str(getattr(interpolation, "value", interpolation))
+    if imlib == "vip-fft":
+        return imlib, interpolation
+    if imlib == "opencv":
+        if interpolation not in INTERP_MODES:
+            raise ValueError("Opencv interpolation method `%s` is not recognized" % interpolation)
+        return imlib, interpolation
+    if imlib in ("skimage", "torch-fft", "ndimage"):
+        raise NotImplementedError("vip_amd implements imlib='vip-fft' and imlib='opencv' only (got %r)" % imlib)
+    raise ValueError("Image transformation library not recognized")
+
+
+class rotation_mode:
+    """``with rotation_mode(imlib, interpolation):`` -- every ``derotate`` inside uses that rotation."""
+
+    def __init__(self, imlib, interpolation="lanczos4"):
+        self.mode = list(check_imlib(imlib, interpolation))
+
+    def __enter__(self):
+        self.saved = list(_ROTATION)
+        _ROTATION[:] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _ROTATION[:] = self.saved
+        return False
+
+
+def with_rotation(fn):
+    """Decorator: run ``fn`` under the rotation named by its ``imlib`` / ``interpolation`` arguments."""
+    import functools
+    import inspect
+    sig = inspect.signature(fn)
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        b = sig.bind(*a, **k)
+        b.apply_defaults()
+        with rotation_mode(b.arguments.get("imlib", "vip-fft"), b.arguments.get("interpolation", "lanczos4")):
+            return fn(*a, **k)
+    return wrapper
+
+
+def rotate_interp(cube, angles, interpolation="lanczos4", cxy=None, out=None):
+    """frames rotated by -angles with OpenCV's warpAffine arithmetic (imlib='opencv'); centre = frame_center."""
+    ctx = get_context(cube.device.index)
+    n, Ny, Nx = cube.shape
+    if Ny != Nx:
+        raise ValueError("derotation on the device requires square frames")
+    out = empty(cube.shape, device=cube.device.index) if out is None else out
+    cx, cy = (float(Nx // 2), float(Ny // 2)) if cxy is None else (float(cxy[0]), float(cxy[1]))   # coords.py:61-100
+    ah, ap = host_f64(angles)
+    ctx.call("vipmi_rotate_interp_f32", ptr(cube), ap, n, Ny, cx, cy, INTERP_MODES[interpolation], ptr(out))
+    return out
+
+
 def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=None):
+    if _ROTATION[0] == "opencv":
+        return rotate_interp(cube, angles, _ROTATION[1], out=out)
     ctx = get_context(cube.device.index)
     n, Ny, Nx = cube.shape
     if Ny != Nx:

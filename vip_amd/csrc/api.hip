@@ -219,7 +219,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_variant", "reserve_cus", "rot_wpb", "eigh_method", "eigh_multi", "eigh_nt", "bgemm_tb", "bgemm_lds", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_variant", "reserve_cus", "rot_wpb", "eigh_method", "eigh_multi", "eigh_nt", "bgemm_tb", "bgemm_lds", "warp_direct", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
@@ -411,6 +411,12 @@ int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_hos
                        float* out, int mask_nan, int mask_zero, int method) {
   CTX_GUARD();
   return derotate_f32(ctx, in, angles_host, n, N, out, mask_nan, mask_zero, method);
+}
+
+int vipmi_rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
+                            double cx, double cy, int interp, float* out) {
+  CTX_GUARD();
+  return rotate_interp_f32(ctx, in, angles_host, n, N, cx, cy, interp, out);
 }
 
 int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,

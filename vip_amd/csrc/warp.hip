@@ -1,0 +1,224 @@
+// Interpolating rotation: cube_derotate / frame_rotate(imlib='opencv') of the reference (preproc/derotation.py:279-305),
+// i.e. cv2.getRotationMatrix2D + cv2.warpAffine(float32, INTER_NEAREST | LINEAR | CUBIC | LANCZOS4, BORDER_CONSTANT 0).
+// opencv-python (pyproject.toml:56, unpinned) is absent from this image, so the kernel follows OpenCV's published
+// algorithm (modules/imgproc/src/imgwarp.cpp, 4.x float path) and its parity against cv2 itself is NOT pinned:
+//   * the affine map is inverted in double; source coordinates are evaluated in 1/1024-pixel fixed point
+//     (round-to-nearest-even of M*x*1024 per column and of (M*y + b)*1024 per row, plus a rounding offset) and
+//     truncated to 1/32 pixel; the 32 x 32 sub-pixel phases index separable float weight tables;
+//   * taps outside the frame contribute the border value 0; NaN pixels are zeros (derotation.py:218).
+// One thread per output pixel, 64 x 4 pixel tiles: 4 B written and ~4 B fetched from HBM per pixel (the taps of a
+// tile overlap in L1/L2), i.e. an HBM-streaming kernel ~30x cheaper than the 3-shear FFT rotation.  It is the fast,
+// lower-fidelity option the reference documents (README.rst:183); the default remains 'vip-fft'.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include "common.h"
+
+namespace vipmi {
+
+struct WarpFrame {
+  double m[6];                   // dst (x, y) -> src: X = m0 x + m1 y + m2, Y = m3 x + m4 y + m5
+};
+
+constexpr int WARP_AB_BITS = 10, WARP_INTER_BITS = 5, WARP_TAB = 1 << WARP_INTER_BITS;
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ in, const WarpFrame* __restrict__ frames,
+                                                          const float* __restrict__ tab, int N, float* __restrict__ out) {
+  __shared__ float w1[WARP_TAB * (TAPS > 1 ? TAPS : 1)];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if (TAPS > 1)
+    for (int i = tid; i < WARP_TAB * TAPS; i += 256) w1[i] = tab[i];
+  __syncthreads();
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= N || y >= N) return;
+  const WarpFrame f = frames[blockIdx.z];
+  const float* src = in + (size_t)blockIdx.z * N * N;
+  const int round_delta = TAPS == 1 ? (1 << WARP_AB_BITS) / 2 : (1 << WARP_AB_BITS) / WARP_TAB / 2;
+  const double sc = (double)(1 << WARP_AB_BITS);
+  const int X0 = __double2int_rn((f.m[1] * y + f.m[2]) * sc) + round_delta + __double2int_rn(f.m[0] * x * sc);
+  const int Y0 = __double2int_rn((f.m[4] * y + f.m[5]) * sc) + round_delta + __double2int_rn(f.m[3] * x * sc);
+  float v = 0.f;
+  if (TAPS == 1) {
+    const int sx = X0 >> WARP_AB_BITS, sy = Y0 >> WARP_AB_BITS;
+    if ((unsigned)sx < (unsigned)N && (unsigned)sy < (unsigned)N) {
+      v = src[(size_t)sy * N + sx];
+      v = v == v ? v : 0.f;
+    }
+  } else {
+    const int X = X0 >> (WARP_AB_BITS - WARP_INTER_BITS), Y = Y0 >> (WARP_AB_BITS - WARP_INTER_BITS);
+    const int sx = (X >> WARP_INTER_BITS) - (TAPS / 2 - 1), sy = (Y >> WARP_INTER_BITS) - (TAPS / 2 - 1);
+    const float* wx = w1 + (X & (WARP_TAB - 1)) * TAPS;
+    const float* wy = w1 + (Y & (WARP_TAB - 1)) * TAPS;
+    if (sx + TAPS > 0 && sx < N && sy + TAPS > 0 && sy < N) {
+#pragma unroll
+      for (int r = 0; r < TAPS; ++r) {
+        const int yy = sy + r;
+        if ((unsigned)yy >= (unsigned)N) continue;
+        const float* row = src + (size_t)yy * N;
+        const float wr = wy[r];
+#pragma unroll
+        for (int c = 0; c < TAPS; ++c) {
+          const int xx = sx + c;
+          float s = (unsigned)xx < (unsigned)N ? row[xx] : 0.f;
+          s = s == s ? s : 0.f;
+          v += s * (wr * wx[c]);
+        }
+      }
+    }
+  }
+  out[(size_t)blockIdx.z * N * N + (size_t)y * N + x] = v;
+}
+
+// 16 x 16 output tile per workgroup with its source footprint staged in LDS: the footprint of a rotated tile is at
+// most 16 (|cos| + |sin|) + TAPS - 1 <= 22 + TAPS pixels wide, so a (24 + TAPS)^2 box is loaded once (coalesced rows,
+// border and NaN pixels already replaced by 0) and the TAPS^2 taps of every pixel are LDS reads without bounds
+// checks.  (Reading the taps from global memory makes every wave load touch ~20 cache lines of a slanted source line:
+// 7 ms for 400 x 512^2 lanczos4 frames against ~1 ms from LDS.)  The fixed-point coordinates are sums of a
+// monotone function of x and one of y, so their extremes over the tile are at its four corners.
+template <int TAPS>
+__global__ __launch_bounds__(256) void warp_tile_kernel(const float* __restrict__ in, const WarpFrame* __restrict__ frames,
+                                                        const float* __restrict__ tab, int N, float* __restrict__ out) {
+  constexpr int TS = 16, BOX = 24 + TAPS, LS = BOX + 1, H = TAPS / 2 - 1;
+  __shared__ float w1[WARP_TAB * TAPS];
+  __shared__ float tile[BOX * LS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < WARP_TAB * TAPS; i += 256) w1[i] = tab[i];
+  const WarpFrame f = frames[blockIdx.z];
+  const float* src = in + (size_t)blockIdx.z * N * N;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  const int round_delta = (1 << WARP_AB_BITS) / WARP_TAB / 2;
+  const double sc = (double)(1 << WARP_AB_BITS);
+  auto fx = [&](int x, int y) { return __double2int_rn((f.m[1] * y + f.m[2]) * sc) + round_delta + __double2int_rn(f.m[0] * x * sc); };
+  auto fy = [&](int x, int y) { return __double2int_rn((f.m[4] * y + f.m[5]) * sc) + round_delta + __double2int_rn(f.m[3] * x * sc); };
+  const int xa = fx(x0, y0), xb = fx(x0 + TS - 1, y0), xc = fx(x0, y0 + TS - 1), xd = fx(x0 + TS - 1, y0 + TS - 1);
+  const int ya = fy(x0, y0), yb = fy(x0 + TS - 1, y0), yc = fy(x0, y0 + TS - 1), yd = fy(x0 + TS - 1, y0 + TS - 1);
+  const int bx = (min(min(xa, xb), min(xc, xd)) >> WARP_AB_BITS) - H;      // first source column / row of the box
+  const int by = (min(min(ya, yb), min(yc, yd)) >> WARP_AB_BITS) - H;
+  for (int i = tid; i < BOX * BOX; i += 256) {
+    const int r = i / BOX, c = i - r * BOX;
+    const int gy = by + r, gx = bx + c;
+    float v = 0.f;
+    if ((unsigned)gx < (unsigned)N && (unsigned)gy < (unsigned)N) v = src[(size_t)gy * N + gx];
+    tile[r * LS + c] = v == v ? v : 0.f;
+  }
+  __syncthreads();
+  const int x = x0 + (tid & (TS - 1)), y = y0 + (tid >> 4);
+  if (x >= N || y >= N) return;
+  const int X = fx(x, y) >> (WARP_AB_BITS - WARP_INTER_BITS), Y = fy(x, y) >> (WARP_AB_BITS - WARP_INTER_BITS);
+  const int sx = min(max((X >> WARP_INTER_BITS) - H - bx, 0), BOX - TAPS);
+  const int sy = min(max((Y >> WARP_INTER_BITS) - H - by, 0), BOX - TAPS);
+  float wx[TAPS], wy[TAPS];
+#pragma unroll
+  for (int c = 0; c < TAPS; ++c) {
+    wx[c] = w1[(X & (WARP_TAB - 1)) * TAPS + c];
+    wy[c] = w1[(Y & (WARP_TAB - 1)) * TAPS + c];
+  }
+  const float* t = tile + sy * LS + sx;
+  float v = 0.f;
+#pragma unroll
+  for (int r = 0; r < TAPS; ++r)
+#pragma unroll
+    for (int c = 0; c < TAPS; ++c) v += t[r * LS + c] * (wy[r] * wx[c]);
+  out[(size_t)blockIdx.z * N * N + (size_t)y * N + x] = v;
+}
+
+// separable weights of the 32 sub-pixel phases (imgwarp.cpp: interpolateLinear / interpolateCubic / interpolateLanczos4)
+static void warp_weights(int taps, std::vector<float>& tab) {
+  tab.assign((size_t)WARP_TAB * taps, 0.f);
+  for (int i = 0; i < WARP_TAB; ++i) {
+    const float x = (float)i / WARP_TAB;
+    float* c = tab.data() + (size_t)i * taps;
+    if (taps == 2) {
+      c[0] = 1.f - x;
+      c[1] = x;
+    } else if (taps == 4) {
+      const float A = -0.75f;
+      c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+      c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+      c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+      c[3] = 1.f - c[0] - c[1] - c[2];
+    } else {
+      if (x < 1.1920929e-7f) {
+        c[3] = 1.f;
+        continue;
+      }
+      const double s45 = 0.70710678118654752440084436210485, pi = 3.1415926535897932384626433832795;
+      const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+      const double y0 = -(x + 3) * pi * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+      float sum = 0.f;
+      for (int k = 0; k < 8; ++k) {
+        const double yk = -(x + 3 - k) * pi * 0.25;
+        c[k] = (float)((cs[k][0] * s0 + cs[k][1] * c0) / (yk * yk));
+        sum += c[k];
+      }
+      sum = 1.f / sum;
+      for (int k = 0; k < 8; ++k) c[k] *= sum;
+    }
+  }
+}
+
+int rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N, double cx,
+                      double cy, int interp, float* out) {
+  VIPMI_REQUIRE(in && out && angles_host, "rotate_interp: null pointer");
+  VIPMI_REQUIRE(n >= 1 && n <= 65535 && N >= 1 && N <= 16384, "rotate_interp: bad sizes (n=%lld, N=%lld)", (long long)n,
+                (long long)N);
+  VIPMI_REQUIRE(in != out, "rotate_interp: in-place rotation is not supported");
+  const int taps = interp == VIPMI_INTERP_NEAREST ? 1 : interp == VIPMI_INTERP_BILINEAR ? 2 : interp == VIPMI_INTERP_BICUBIC ? 4
+                   : interp == VIPMI_INTERP_LANCZOS4 ? 8 : 0;
+  VIPMI_REQUIRE(taps != 0, "rotate_interp: unknown interpolation %d", interp);
+  StageScope scope(ctx, "warp");
+  std::vector<WarpFrame> h((size_t)n);
+  const double pi = 3.14159265358979323846;
+  for (int64_t i = 0; i < n; ++i) {
+    // forward matrix of cv2.getRotationMatrix2D((cx, cy), -angle, 1), inverted as warpAffine does
+    const double ang = -angles_host[i] * pi / 180.0;
+    const double a = std::cos(ang), b = std::sin(ang);
+    double M[6] = {a, b, (1 - a) * cx - b * cy, -b, a, b * cx + (1 - a) * cy};
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11;
+    M[1] *= -D;
+    M[3] *= -D;
+    M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1;
+    M[5] = b2;
+    std::memcpy(h[i].m, M, sizeof(M));
+  }
+  WarpFrame* d_frames = nullptr;
+  VIPMI_TRY(ws(ctx, "warp_frames", (size_t)n, &d_frames));
+  VIPMI_TRY(ctx->upload_async("warp_frames", h.data(), sizeof(WarpFrame) * n, d_frames));
+  float* d_tab = nullptr;
+  if (taps > 1) {
+    std::vector<float> tab;
+    warp_weights(taps, tab);
+    void* p = nullptr;
+    const std::string nm = "warp_tab" + std::to_string(taps);
+    VIPMI_TRY(ctx->upload_cached(nm.c_str(), nm, tab.data(), tab.size() * sizeof(float), &p));
+    d_tab = (float*)p;
+  }
+  dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(N, 4), (unsigned)n), block(64, 4);
+  dim3 tgrid((unsigned)cdiv(N, 16), (unsigned)cdiv(N, 16), (unsigned)n);
+  const bool direct = ctx->opt("warp_direct", 0) != 0;         // A/B switch: taps from global memory
+  switch (taps) {
+    case 1: warp_affine_kernel<1><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out); break;
+    case 2:
+      if (direct) warp_affine_kernel<2><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      else warp_tile_kernel<2><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      break;
+    case 4:
+      if (direct) warp_affine_kernel<4><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      else warp_tile_kernel<4><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      break;
+    default:
+      if (direct) warp_affine_kernel<8><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      else warp_tile_kernel<8><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      break;
+  }
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+}  // namespace vipmi

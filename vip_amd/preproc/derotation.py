@@ -8,15 +8,16 @@ import numpy as np
 from .. import backend as B
 
 
-def _check_rot_options(imlib, cxy, edge_blend, mask_val, shape):
-    imlib = str(getattr(imlib, "value", imlib))
-    if imlib != "vip-fft":
-        if imlib in ("opencv", "skimage", "torch-fft", "ndimage"):
-            raise NotImplementedError("vip_amd implements the reference's default imlib='vip-fft' rotation "
-                                      "only (got %r)" % imlib)
-        raise ValueError("Image transformation library not recognized")
+def _check_rot_options(imlib, cxy, edge_blend, mask_val, shape, interpolation="lanczos4", border_mode="constant"):
+    imlib, interpolation = B.check_imlib(imlib, interpolation)
     if edge_blend not in (None, ""):
         raise NotImplementedError("edge_blend is outside the accelerated path")
+    if imlib == "opencv":
+        if border_mode != "constant":
+            if border_mode in ("edge", "symmetric", "reflect", "wrap"):
+                raise NotImplementedError("imlib='opencv' on the device implements border_mode='constant' only")
+            raise ValueError("Opencv `border_mode` not recognized.")
+        return None
     if cxy is not None:
         cx, cy = cxy
         if (cy, cx) != (shape[0] // 2, shape[1] // 2):
@@ -30,20 +31,25 @@ def _check_rot_options(imlib, cxy, edge_blend, mask_val, shape):
 def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", cxy=None, nproc=1,
                   border_mode="constant", mask_val=np.nan, edge_blend=None, interp_zeros=False, ker=1,
                   method="auto"):
-    """Rotate frame i by -angle_list[i] degrees with the reference's 3-shear FFT rotation.
+    """Rotate frame i by -angle_list[i] degrees: the reference's 3-shear FFT rotation (``imlib='vip-fft'``, the
+    parity path) or OpenCV's interpolating warpAffine (``imlib='opencv'``, ``interpolation`` = 'nearneig' | 'bilinear'
+    | 'bicubic' | 'lanczos4', ``border_mode='constant'``, optional centre ``cxy``; derotation.py:279-305).
 
     Output dtype follows the reference's ``nproc=1`` branch (same dtype as the input);
     ``nproc`` is accepted and ignored (all frames are rotated concurrently on the GPU).
-    ``method``: 'auto' | 'fft' | 'direct' (device algorithm, identical results up to float32 rounding)."""
+    ``method``: 'auto' | 'fft' | 'direct' (device algorithm of 'vip-fft', identical results up to float32 rounding)."""
     if array.ndim != 3:
         raise TypeError("Input array is not a cube or 3d array.")
-    mv_nan = _check_rot_options(imlib, cxy, edge_blend, mask_val, array.shape[1:])
+    mv_nan = _check_rot_options(imlib, cxy, edge_blend, mask_val, array.shape[1:], interpolation, border_mode)
     angle_list = np.asarray(angle_list, dtype=np.float64)
     if angle_list.shape[0] != array.shape[0]:
         raise ValueError("`angle_list` must have one angle per frame")
     dev_in = B.is_device_tensor(array)
     t = B.to_device_f32(array)
-    out = B.derotate(t, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan, method=method)
+    if mv_nan is None:
+        out = B.rotate_interp(t, angle_list, str(getattr(interpolation, "value", interpolation)), cxy=cxy)
+    else:
+        out = B.derotate(t, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan, method=method)
     if dev_in:
         return out
     return out.cpu().numpy().astype(array.dtype if array.dtype.kind == "f" else np.float64, copy=False)
@@ -52,15 +58,16 @@ def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", 
 def frame_rotate(array, angle, imlib="vip-fft", interpolation="lanczos4", cxy=None,
                  border_mode="constant", mask_val=np.nan, edge_blend=None, interp_zeros=False, ker=1,
                  method="auto"):
-    """Rotate one frame by ``angle`` degrees (reference returns float64; so do we for numpy input)."""
+    """Rotate one frame by ``angle`` degrees (the reference returns float64 for 'vip-fft' and cv2's float32 for
+    'opencv'; so do we for numpy input)."""
     if array.ndim != 2:
         raise TypeError("Input array is not a frame or 2d array")
     dev_in = B.is_device_tensor(array)
-    res = cube_derotate(array[None], np.array([-float(angle)]), imlib=imlib, cxy=cxy, mask_val=mask_val,
-                        edge_blend=edge_blend, method=method)[0]
+    res = cube_derotate(array[None], np.array([-float(angle)]), imlib=imlib, interpolation=interpolation, cxy=cxy,
+                        border_mode=border_mode, mask_val=mask_val, edge_blend=edge_blend, method=method)[0]
     if dev_in:
         return res
-    return res.astype(np.float64)
+    return res.astype(np.float32 if str(getattr(imlib, "value", imlib)) == "opencv" else np.float64)
 
 
 def _find_indices_adi(angle_list, frame, thr, nframes=None, out_closest=False, truncate=False,

@@ -9,7 +9,7 @@ libvipmi.so; numpy in -> numpy out, cuda tensor in -> cuda tensors out (no host 
 Tuple/list ``ncomp`` (the ``pca_grid`` of final frames), ``source_xy`` (PA-threshold frame rejection), ``cube_ref``
 (RDI / ARDI), ``cube_sig`` and 4-D cubes with ``scale_list`` (ADI+mSDI, psfsub/pca_msdi.py) are accelerated.  Not
 accelerated (raise NotImplementedError): ``pca_grid`` scored by S/N (tuple ``ncomp`` + ``source_xy``), ``batch``
-(incremental PCA), ``left_eigv``, ``mask_rdi``, ``smooth``, ``imlib != 'vip-fft'``.
+(incremental PCA), ``left_eigv``, ``mask_rdi``, ``smooth``, ``imlib`` other than 'vip-fft' (parity path) and 'opencv' (interpolating rotation, 3-D cubes).
 """
 from dataclasses import dataclass
 from enum import Enum
@@ -244,6 +244,7 @@ def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scali
     return R, M, ln
 
 
+@B.with_rotation
 def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot, fwhm, scaling,
                  mask_center_px, svd_mode, imlib, interpolation, collapse, verbose, start_time, nproc,
                  full_output, weights=None, mask_rdi=None, cube_sig=None, left_eigv=False,
@@ -255,8 +256,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         raise NotImplementedError("mask_rdi / left_eigv / smooth are outside the accelerated path")
     if cube_sig is not None and tuple(cube_sig.shape) != tuple(cube.shape):
         raise TypeError("`cube_sig` must have the shape of `cube`")
-    if _s(imlib) != "vip-fft":
-        raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
+    B.check_imlib(imlib, interpolation)         # 'vip-fft' or 'opencv'; the decorator selects the rotation
     n, y, x = cube.shape
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
     if not n == angle_list.shape[0]:
@@ -315,7 +315,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
             return recon_cube, residuals_cube, residuals_cube_, frame
         return frame
 
-    fused_ok = (cube_ref is None and cube_sig is None and n <= B.MAX_EIGH_N and isinstance(ncomp, (int, np.integer)) and collapse in
+    fused_ok = (cube_ref is None and cube_sig is None and n <= B.MAX_EIGH_N and _s(imlib) == "vip-fft" and isinstance(ncomp, (int, np.integer)) and collapse in
                 ("median", "mean", "sum", "max", "absmean") and (bool(mask_center_px) != mv_nan))
     if fused_ok:
         # one call into the C ABI: mask/scale -> Gram -> eigh -> project -> derotate -> collapse

@@ -162,6 +162,7 @@ def _pack_libs(libs):
     return idx, ln, max_lib
 
 
+@B.with_rotation
 def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, delta_rot=1, ncomp=1,
                  svd_mode="lapack", nproc=None, min_frames_lib=2, max_frames_lib=200, tol=1e-1,
                  scaling=None, imlib="vip-fft", interpolation="lanczos4", collapse="median",
@@ -187,8 +188,7 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         ks = np.asarray([int(k) for k in ncomp], dtype=np.int32)
         if ks.size == 0 or ks.min() <= 0:
             raise ValueError("every ncomp of the list must be a positive integer")
-    if _s(imlib) != "vip-fft":
-        raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
+    B.check_imlib(imlib, interpolation)         # 'vip-fft' or 'opencv'; the decorator selects the rotation
     n, y, x = cube.shape
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
     plan, plan_dev = cached_annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot,
