@@ -578,7 +578,7 @@ def test_eigh_spectrum(B, n, k):
     _topk_check(G, ev[:k], ec, k)
 
 
-@pytest.mark.parametrize("N", [64, 65, 101])
+@pytest.mark.parametrize("N", [7, 64, 65, 101])
 @pytest.mark.parametrize("interp", ["nearneig", "bilinear", "bicubic", "lanczos4"])
 def test_rotate_opencv_style(N, interp):
     """imlib='opencv' (derotation.py:279-305): the warp kernel against the oracle's restatement of OpenCV's warpAffine
@@ -600,7 +600,7 @@ def test_rotate_opencv_style(N, interp):
     assert np.array_equal(got[3], np.rot90(smooth, 1)[:N, :N]) or N % 2 == 0
     fft = cube_derotate(cube[:1], ang[:1])
     b = N // 6
-    assert np.abs(got[0] - fft[0])[b:-b, b:-b].max() < {"nearneig": 0.2, "bilinear": 0.05, "bicubic": 0.03, "lanczos4": 0.02}[interp]
+    assert N < 32 or np.abs(got[0] - fft[0])[b:-b, b:-b].max() < {"nearneig": 0.2, "bilinear": 0.05, "bicubic": 0.03, "lanczos4": 0.02}[interp]
     one = frame_rotate(cube[0], 12.5, imlib="opencv", interpolation=interp, cxy=(N / 2 - 0.5, N / 2 - 0.5))
     assert one.dtype == np.float32
     assert np.abs(one - O.warp_rotate(cube[0], 12.5, interp, cxy=(N / 2 - 0.5, N / 2 - 0.5))).max() < 2e-6

@@ -6,9 +6,9 @@
 //     (round-to-nearest-even of M*x*1024 per column and of (M*y + b)*1024 per row, plus a rounding offset) and
 //     truncated to 1/32 pixel; the 32 x 32 sub-pixel phases index separable float weight tables;
 //   * taps outside the frame contribute the border value 0; NaN pixels are zeros (derotation.py:218).
-// One thread per output pixel, 64 x 4 pixel tiles: 4 B written and ~4 B fetched from HBM per pixel (the taps of a
-// tile overlap in L1/L2), i.e. an HBM-streaming kernel ~30x cheaper than the 3-shear FFT rotation.  It is the fast,
-// lower-fidelity option the reference documents (README.rst:183); the default remains 'vip-fft'.
+// warp_affine_kernel: one thread per output pixel, taps from global memory (used for nearest; A/B option "warp_direct");
+// warp_tile_kernel: source tiles staged in LDS.  4 B read + 4 B written per pixel, 4-10x cheaper than the 3-shear FFT
+// rotation: the fast, lower-fidelity option the reference documents (README.rst:183); the default remains vip-fft.
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -70,57 +70,86 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
   out[(size_t)blockIdx.z * N * N + (size_t)y * N + x] = v;
 }
 
-// 16 x 16 output tile per workgroup with its source footprint staged in LDS: the footprint of a rotated tile is at
-// most 16 (|cos| + |sin|) + TAPS - 1 <= 22 + TAPS pixels wide, so a (24 + TAPS)^2 box is loaded once (coalesced rows,
-// border and NaN pixels already replaced by 0) and the TAPS^2 taps of every pixel are LDS reads without bounds
-// checks.  (Reading the taps from global memory makes every wave load touch ~20 cache lines of a slanted source line:
-// 7 ms for 400 x 512^2 lanczos4 frames against ~1 ms from LDS.)  The fixed-point coordinates are sums of a
-// monotone function of x and one of y, so their extremes over the tile are at its four corners.
+// 32 x 32 output tile per workgroup (4 pixels per thread) with its source footprint staged in LDS: the footprint of a
+// rotated tile is at most 31 (|cos| + |sin|) + TAPS <= 44 + TAPS pixels wide, so a box of (46 + TAPS)^2 at most is
+// loaded once (coalesced rows, border and NaN pixels already replaced by 0, ~10 independent loads in flight per thread
+// to cover the HBM latency) and the TAPS^2 taps of every pixel are LDS reads without bounds checks, evaluated
+// separably (row sums with the x weights, then the y weights: TAPS (TAPS + 1) FMAs instead of 2 TAPS^2 operations
+// with OpenCV's product table; the difference is float rounding).  Reading the taps from global memory makes every
+// wave load touch ~20 cache lines of a slanted source line: 7 ms for 400 x 512^2 lanczos4 frames.  The fixed-point
+// coordinates are sums of a monotone function of x and one of y, so their extremes over the tile are at its corners.
 template <int TAPS>
 __global__ __launch_bounds__(256) void warp_tile_kernel(const float* __restrict__ in, const WarpFrame* __restrict__ frames,
                                                         const float* __restrict__ tab, int N, float* __restrict__ out) {
-  constexpr int TS = 16, BOX = 24 + TAPS, LS = BOX + 1, H = TAPS / 2 - 1;
+  constexpr int TS = 32, PPT = 4, BOX = 46 + TAPS, LS = BOX + 1, H = TAPS / 2 - 1;
   __shared__ float w1[WARP_TAB * TAPS];
   __shared__ float tile[BOX * LS];
-  const int tid = threadIdx.x;
+  __shared__ int colx[TS], coly[TS], rowx[TS], rowy[TS];
+  const int tid = threadIdx.x, tx = tid & (TS - 1), ty = tid >> 5;
   for (int i = tid; i < WARP_TAB * TAPS; i += 256) w1[i] = tab[i];
   const WarpFrame f = frames[blockIdx.z];
   const float* src = in + (size_t)blockIdx.z * N * N;
   const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  const int x = x0 + tx;
   const int round_delta = (1 << WARP_AB_BITS) / WARP_TAB / 2;
   const double sc = (double)(1 << WARP_AB_BITS);
-  auto fx = [&](int x, int y) { return __double2int_rn((f.m[1] * y + f.m[2]) * sc) + round_delta + __double2int_rn(f.m[0] * x * sc); };
-  auto fy = [&](int x, int y) { return __double2int_rn((f.m[4] * y + f.m[5]) * sc) + round_delta + __double2int_rn(f.m[3] * x * sc); };
-  const int xa = fx(x0, y0), xb = fx(x0 + TS - 1, y0), xc = fx(x0, y0 + TS - 1), xd = fx(x0 + TS - 1, y0 + TS - 1);
-  const int ya = fy(x0, y0), yb = fy(x0 + TS - 1, y0), yc = fy(x0, y0 + TS - 1), yd = fy(x0 + TS - 1, y0 + TS - 1);
-  const int bx = (min(min(xa, xb), min(xc, xd)) >> WARP_AB_BITS) - H;      // first source column / row of the box
-  const int by = (min(min(ya, yb), min(yc, yd)) >> WARP_AB_BITS) - H;
-  for (int i = tid; i < BOX * BOX; i += 256) {
-    const int r = i / BOX, c = i - r * BOX;
-    const int gy = by + r, gx = bx + c;
-    float v = 0.f;
-    if ((unsigned)gx < (unsigned)N && (unsigned)gy < (unsigned)N) v = src[(size_t)gy * N + gx];
-    tile[r * LS + c] = v == v ? v : 0.f;
+  // fixed-point coordinate = (row term of y) + (column term of x); the tile's terms are exchanged through LDS
+  const int bxx = __double2int_rn(f.m[0] * x * sc), byy = __double2int_rn(f.m[3] * x * sc);
+  int ax[PPT], ay[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int y = y0 + ty + 8 * p;
+    ax[p] = __double2int_rn((f.m[1] * y + f.m[2]) * sc) + round_delta;
+    ay[p] = __double2int_rn((f.m[4] * y + f.m[5]) * sc) + round_delta;
+    if (tx == 0) {
+      rowx[ty + 8 * p] = ax[p];
+      rowy[ty + 8 * p] = ay[p];
+    }
+  }
+  if (ty == 0) {
+    colx[tx] = bxx;
+    coly[tx] = byy;
   }
   __syncthreads();
-  const int x = x0 + (tid & (TS - 1)), y = y0 + (tid >> 4);
-  if (x >= N || y >= N) return;
-  const int X = fx(x, y) >> (WARP_AB_BITS - WARP_INTER_BITS), Y = fy(x, y) >> (WARP_AB_BITS - WARP_INTER_BITS);
-  const int sx = min(max((X >> WARP_INTER_BITS) - H - bx, 0), BOX - TAPS);
-  const int sy = min(max((Y >> WARP_INTER_BITS) - H - by, 0), BOX - TAPS);
-  float wx[TAPS], wy[TAPS];
-#pragma unroll
-  for (int c = 0; c < TAPS; ++c) {
-    wx[c] = w1[(X & (WARP_TAB - 1)) * TAPS + c];
-    wy[c] = w1[(Y & (WARP_TAB - 1)) * TAPS + c];
+  const int bx = ((min(rowx[0], rowx[TS - 1]) + min(colx[0], colx[TS - 1])) >> WARP_AB_BITS) - H;   // first column / row
+  const int by = ((min(rowy[0], rowy[TS - 1]) + min(coly[0], coly[TS - 1])) >> WARP_AB_BITS) - H;
+  const int bw = ((max(rowx[0], rowx[TS - 1]) + max(colx[0], colx[TS - 1])) >> WARP_AB_BITS) + TAPS - H - bx;  // <= 45 + TAPS
+  const int bh = min(((max(rowy[0], rowy[TS - 1]) + max(coly[0], coly[TS - 1])) >> WARP_AB_BITS) + TAPS - H - by, BOX);
+  {
+    const int c = tid & 63, gx = bx + c;
+    const bool okx = c < bw && (unsigned)gx < (unsigned)N;
+    for (int r = tid >> 6; r < bh; r += 4) {
+      const int gy = by + r;
+      float v = 0.f;
+      if (okx && (unsigned)gy < (unsigned)N) v = src[(size_t)gy * N + gx];
+      if (c < BOX) tile[r * LS + c] = v == v ? v : 0.f;
+    }
   }
-  const float* t = tile + sy * LS + sx;
-  float v = 0.f;
+  __syncthreads();
+  if (x >= N) return;
 #pragma unroll
-  for (int r = 0; r < TAPS; ++r)
+  for (int p = 0; p < PPT; ++p) {
+    const int y = y0 + ty + 8 * p;
+    if (y >= N) break;
+    const int X = (ax[p] + bxx) >> (WARP_AB_BITS - WARP_INTER_BITS), Y = (ay[p] + byy) >> (WARP_AB_BITS - WARP_INTER_BITS);
+    const int sx = min(max((X >> WARP_INTER_BITS) - H - bx, 0), BOX - TAPS);
+    const int sy = min(max((Y >> WARP_INTER_BITS) - H - by, 0), BOX - TAPS);
+    const float* wx = w1 + (X & (WARP_TAB - 1)) * TAPS;
+    const float* wy = w1 + (Y & (WARP_TAB - 1)) * TAPS;
+    float wxr[TAPS];
 #pragma unroll
-    for (int c = 0; c < TAPS; ++c) v += t[r * LS + c] * (wy[r] * wx[c]);
-  out[(size_t)blockIdx.z * N * N + (size_t)y * N + x] = v;
+    for (int c = 0; c < TAPS; ++c) wxr[c] = wx[c];
+    const float* t = tile + sy * LS + sx;
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < TAPS; ++r) {
+      float srow = 0.f;
+#pragma unroll
+      for (int c = 0; c < TAPS; ++c) srow = fmaf(t[r * LS + c], wxr[c], srow);
+      v = fmaf(srow, wy[r], v);
+    }
+    out[(size_t)blockIdx.z * N * N + (size_t)y * N + x] = v;
+  }
 }
 
 // separable weights of the 32 sub-pixel phases (imgwarp.cpp: interpolateLinear / interpolateCubic / interpolateLanczos4)
@@ -200,7 +229,7 @@ int rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host
     d_tab = (float*)p;
   }
   dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(N, 4), (unsigned)n), block(64, 4);
-  dim3 tgrid((unsigned)cdiv(N, 16), (unsigned)cdiv(N, 16), (unsigned)n);
+  dim3 tgrid((unsigned)cdiv(N, 32), (unsigned)cdiv(N, 32), (unsigned)n);
   const bool direct = ctx->opt("warp_direct", 0) != 0;         // A/B switch: taps from global memory
   switch (taps) {
     case 1: warp_affine_kernel<1><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out); break;
