@@ -620,3 +620,21 @@ def test_pca_with_opencv_style_rotation():
     assert np.array_equal(co, co_fft)                       # the residuals do not depend on the rotation
     ref_der = np.stack([O.warp_rotate(co[i], -ang[i], "lanczos4") for i in range(n)])
     assert np.abs(cd - ref_der).max() < 1e-5 and np.abs(fa - np.median(ref_der, axis=0)).max() < 1e-5
+
+
+def test_median_sub_and_stim_with_opencv_style_rotation():
+    """median_sub / STIM maps with imlib='opencv': model subtraction as on the parity path, derotation by the warp
+    (oracle: warp_rotate), then the reference's collapse / STIM formula (metrics/stim.py:20-58)."""
+    from vip_amd.psfsub import median_sub
+    from vip_amd.metrics import inverse_stim_map
+    n, N = 18, 41
+    cube, ang = O.synth_adi(n, N, seed=91)
+    co, cd, fr = median_sub(cube, ang, imlib="opencv", interpolation="bilinear", full_output=True, verbose=False)
+    ref_out = cube - np.median(cube, axis=0)
+    assert np.abs(co - ref_out).max() < 1e-5
+    ref_der = np.stack([O.warp_rotate(ref_out[i], -ang[i], "bilinear") for i in range(n)])
+    assert np.abs(cd - ref_der).max() < 1e-5 and np.abs(fr - np.median(ref_der, axis=0)).max() < 1e-5
+    inv = inverse_stim_map(ref_out, ang, imlib="opencv", interpolation="bicubic")
+    d = np.stack([O.warp_rotate(ref_out[i], ang[i], "bicubic") for i in range(n)]).astype(np.float64)
+    exp = O.stim_map(d)
+    assert np.abs(inv - exp).max() < 2e-3 * max(1.0, np.abs(exp).max())

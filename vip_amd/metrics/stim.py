@@ -44,11 +44,10 @@ def stim_map(cube_der):
 
 def inverse_stim_map(cube, angle_list, **rot_options):
     """STIM map of the cube de-rotated with the opposite angles."""
-    if rot_options.get("imlib", "vip-fft") != "vip-fft":
-        raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
     dev_in = B.is_device_tensor(cube)
     t = B.to_device_f32(cube)
-    der = B.derotate(t, -np.asarray(angle_list, dtype=np.float64))
+    with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4")):
+        der = B.derotate(t, -np.asarray(angle_list, dtype=np.float64))
     return _wrap(_stim_dev(der), dev_in, cube)
 
 
@@ -69,5 +68,6 @@ def normalized_stim_map(cube, angle_list, mask=None, **rot_options):
     max_inv = float(B.collapse(inv_map.reshape(-1, 1, 1), "max").item())
     if max_inv <= 0:
         raise ValueError("The normalization value is found to be {}".format(max_inv))
-    der = B.derotate(t, np.asarray(angle_list, dtype=np.float64))
+    with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4")):
+        der = B.derotate(t, np.asarray(angle_list, dtype=np.float64))
     return _wrap(B.lincomb(_stim_dev(der), None, 1.0 / max_inv), dev_in, cube)

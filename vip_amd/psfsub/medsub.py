@@ -127,8 +127,7 @@ def median_sub(*all_args: List, **all_kwargs: dict):
         raise TypeError("Input array is not a 3d or 4d array")
     if cube.ndim == 4:
         raise NotImplementedError("4-D (SDI) median subtraction is not accelerated")
-    if _s(algo_params.imlib) != "vip-fft":
-        raise NotImplementedError("vip_amd implements imlib='vip-fft' only")
+    rot_mode = B.rotation_mode(algo_params.imlib, algo_params.interpolation)    # 'vip-fft' or 'opencv' (medsub.py:376-387)
     if algo_params.mode not in ("fullfr", "annular"):
         raise RuntimeError("Mode not recognized")
     annular = algo_params.mode == "annular"
@@ -172,7 +171,8 @@ def median_sub(*all_args: List, **all_kwargs: dict):
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
     if not mv_nan and mask_val != 0:
         raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
-    cube_der = B.derotate(cube_out, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
+    with rot_mode:
+        cube_der = B.derotate(cube_out, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
     if algo_params.radius_int:
         mask = B.to_device_f32(center_mask_u8((y, x), algo_params.radius_int).astype(np.float32)).to(torch.uint8)
         cube_out = B.apply_mask(cube_out.reshape(n, -1), mask.reshape(-1), 0.0).reshape(n, y, x)
