@@ -638,3 +638,18 @@ def test_median_sub_and_stim_with_opencv_style_rotation():
     d = np.stack([O.warp_rotate(ref_out[i], ang[i], "bicubic") for i in range(n)]).astype(np.float64)
     exp = O.stim_map(d)
     assert np.abs(inv - exp).max() < 2e-3 * max(1.0, np.abs(exp).max())
+
+
+def test_pca_4d_with_opencv_style_rotation():
+    """4-D cube without scale_list (per-channel ADI, pca_fullfr.py:544-658) under imlib='opencv': every channel is the
+    3-D result; ADI+mSDI keeps requiring 'vip-fft'."""
+    from vip_amd.psfsub import pca
+    nch, n, N = 3, 14, 33
+    cubes = np.stack([O.synth_adi(n, N, seed=200 + c)[0] for c in range(nch)])
+    ang = O.synth_adi(n, N, seed=200)[1]
+    kw = dict(ncomp=2, imlib="opencv", interpolation="bilinear", verbose=False)
+    got = pca(cubes, ang, **kw)
+    per_channel = np.stack([pca(cubes[c], ang, **kw) for c in range(nch)])
+    assert got.shape == (N, N) and np.abs(got - per_channel.mean(axis=0)).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        pca(cubes, ang, scale_list=np.linspace(1.0, 1.2, nch), adimsdi="single", ncomp=1, imlib="opencv", verbose=False)
