@@ -156,6 +156,10 @@ int vipmi_rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angle
  * w (device, n floats) only for WMEAN; trim_n only for TRIMMEAN. */
 int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode,
                        const float* w, int64_t trim_n, float* out);
+/* the same for `batch` contiguous cubes [batch][n][P] -> out[batch][P] in one launch: the per-channel collapses of a
+ * 4-D cube (pca_fullfr.py:544-658) and the per-frame channel collapses of ADI+mSDI (pca_fullfr.py:1339-1344,1519) */
+int vipmi_collapse_batched_f32(vipmi_ctx* ctx, const float* cubes, int64_t batch, int64_t n, int64_t P, int mode,
+                               const float* w, int64_t trim_n, float* out);
 
 /* ---- median_sub(mode='annular') core: psfsub/medsub.py:602-641 ----
  * out[j,p] = A[j,p] - nanmedian over the frames lib_idx[j, 0 .. lib_len[j]) of A[.,p]  (A: n x npx annulus matrix,

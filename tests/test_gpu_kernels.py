@@ -619,3 +619,26 @@ def test_rotate_opencv_style_errors():
         cube_derotate(cube, [0, 1], imlib="skimage")
     with pytest.raises(ValueError):
         cube_derotate(cube, [0, 1], imlib="nope")
+
+
+@pytest.mark.parametrize("mode", ["median", "mean", "sum", "max", "absmean", "wmean", "trimmean"])
+def test_collapse_batched_equals_per_cube(mode):
+    """one launch over a stack of cubes (blockIdx.y = cube) gives exactly the per-cube collapses, NaNs included"""
+    import torch
+    from vip_amd import backend as B
+    rng = np.random.default_rng(5)
+    stack = rng.standard_normal((5, 39, 23, 23)).astype(np.float32)
+    stack[1, 3, 4, 5] = np.nan
+    stack[2, :, 0, 0] = np.nan
+    t = torch.from_numpy(stack).cuda()
+    w = rng.random(39).astype(np.float32) if mode == "wmean" else None
+    kw = dict(trim_n=11) if mode == "trimmean" else {}
+    got = B.collapse_batched(t, mode, w=w, **kw).cpu().numpy()
+    exp = np.stack([B.collapse(t[b], mode, w=w, **kw).cpu().numpy() for b in range(5)])
+    assert got.shape == (5, 23, 23) and np.array_equal(got, exp, equal_nan=True)
+    if mode == "median":
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                assert np.array_equal(got, np.nanmedian(stack, axis=1), equal_nan=True)

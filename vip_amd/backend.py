@@ -451,6 +451,19 @@ def collapse(cube, mode="median", w=None, trim_n=0):
     return out
 
 
+def collapse_batched(cubes, mode="median", w=None, trim_n=0):
+    """collapse of every cube of a contiguous stack (batch, n, ...) -> (batch, ...) in one launch."""
+    ctx = get_context(cubes.device.index)
+    if not cubes.is_contiguous():
+        cubes = cubes.contiguous()
+    nb, n = cubes.shape[0], cubes.shape[1]
+    P = cubes[0, 0].numel()
+    out = empty((nb,) + tuple(cubes.shape[2:]), device=cubes.device.index)
+    wt = to_device_f32(w, cubes.device.index) if w is not None else None
+    ctx.call("vipmi_collapse_batched_f32", ptr(cubes), nb, n, P, COLLAPSE_MODES[mode], ptr(wt), int(trim_n), ptr(out))
+    return out
+
+
 def pca_fullframe(cube, angles, ncomp, scaling=None, mask_u8=None, collapse_mode="median",
                   full_output=False):
     """Fused 3-D ADI path.  Returns frame or (frame, pcs, recon, residuals, residuals_der)."""

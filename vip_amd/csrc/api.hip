@@ -425,6 +425,12 @@ int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, 
   return collapse_f32(ctx, cube, n, P, mode, w, trim_n, out);
 }
 
+int vipmi_collapse_batched_f32(vipmi_ctx* ctx, const float* cubes, int64_t batch, int64_t n, int64_t P, int mode,
+                               const float* w, int64_t trim_n, float* out) {
+  CTX_GUARD();
+  return collapse_batched_f32(ctx, cubes, batch, n, P, mode, w, trim_n, out);
+}
+
 int vipmi_subset_median_sub_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                                 const int32_t* lib_len, int64_t max_lib, float* out) {
   CTX_GUARD();

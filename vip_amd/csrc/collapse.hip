@@ -74,9 +74,11 @@ __device__ __forceinline__ unsigned select_rank(const unsigned (&key)[RPL], int 
 // TRIM = false: nanmedian.  TRIM = true: mean of sorted[t0 : t0+tn] (np.sort order, NaN last, then nanmean):
 // the reference's 'trimmean' (subsampling.py:87-96).
 template <int RPL, bool TRIM>
-__global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ cube, int n, int64_t P,
-                                                     int TP, float* __restrict__ out, int t0, int tn) {
+__global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ cube0, int n, int64_t P,
+                                                     int TP, float* __restrict__ out0, int t0, int tn) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // n x (TP+1)
+  const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;       // blockIdx.y = cube of the batch
+  float* __restrict__ out = out0 + (size_t)blockIdx.y * P;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
   const int ldt = TP + 1;
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(256) void subset_median_sub_kernel(const float* __r
   }
 }
 
-__global__ void colreduce_kernel(const float* __restrict__ cube, int n, int64_t P, int mode,
-                                 const float* __restrict__ w, float* __restrict__ out) {
+__global__ void colreduce_kernel(const float* __restrict__ cube0, int n, int64_t P, int mode,
+                                 const float* __restrict__ w, float* __restrict__ out0) {
+  const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;       // blockIdx.y = cube of the batch
+  float* __restrict__ out = out0 + (size_t)blockIdx.y * P;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
        p += (int64_t)gridDim.x * blockDim.x) {
     double s = 0, s2 = 0;
@@ -292,14 +296,15 @@ __global__ void colreduce_kernel(const float* __restrict__ cube, int n, int64_t 
 }
 
 template <int RPL, bool TRIM>
-int launch_median(vipmi_ctx* ctx, const float* cube, int n, int64_t P, float* out, int t0, int tn) {
+int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64_t P, float* out, int t0, int tn) {
   int TP = 32;
   while (TP > 1 && (size_t)n * (TP + 1) * 4 > 150 * 1024) TP >>= 1;
   const size_t lds = (size_t)n * (TP + 1) * 4;
   auto kern = median_kernel<RPL, TRIM>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP)), dim3(512), lds, ctx->stream, cube, n, P, TP, out, t0, tn);
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(P, TP), (unsigned)batch), dim3(512), lds, ctx->stream, cube, n, P, TP, out,
+                     t0, tn);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -308,8 +313,14 @@ int launch_median(vipmi_ctx* ctx, const float* cube, int n, int64_t P, float* ou
 
 int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,
                  int64_t trim_n, float* out) {
+  return collapse_batched_f32(ctx, cube, 1, n, P, mode, w, trim_n, out);
+}
+
+// `batch` contiguous cubes [batch][n][P] -> out[batch][P] in one launch (blockIdx.y = cube)
+int collapse_batched_f32(vipmi_ctx* ctx, const float* cube, int64_t batch, int64_t n, int64_t P, int mode, const float* w,
+                         int64_t trim_n, float* out) {
   VIPMI_REQUIRE(cube && out, "collapse: null pointer");
-  VIPMI_REQUIRE(n > 0 && P > 0, "collapse: bad sizes");
+  VIPMI_REQUIRE(n > 0 && P > 0 && batch > 0 && batch <= 65535, "collapse: bad sizes");
   StageScope sc(ctx, "collapse");
   switch (mode) {
     case VIPMI_COLLAPSE_MEDIAN:
@@ -333,8 +344,8 @@ int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mo
       }
       const int rpl = (int)cdiv(n, 64);
 #define VIPMI_MED(R)                                                                              \
-  return trim ? launch_median<R, true>(ctx, cube, (int)n, P, out, t0, tn)                        \
-              : launch_median<R, false>(ctx, cube, (int)n, P, out, 0, 0)
+  return trim ? launch_median<R, true>(ctx, cube, batch, (int)n, P, out, t0, tn)                 \
+              : launch_median<R, false>(ctx, cube, batch, (int)n, P, out, 0, 0)
       if (rpl <= 1) { VIPMI_MED(1); }
       if (rpl <= 2) { VIPMI_MED(2); }
       if (rpl <= 4) { VIPMI_MED(4); }
@@ -356,7 +367,7 @@ int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mo
     case VIPMI_COLLAPSE_STIM:
     case VIPMI_COLLAPSE_ABSMEAN: {
       int64_t b = cdiv(P, 256);
-      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)(b > 8192 ? 8192 : b), (unsigned)batch), dim3(256), 0, ctx->stream,
                          cube, (int)n, P, mode, w, out);
       VIPMI_CHECK_HIP(hipGetLastError());
       return VIPMI_OK;

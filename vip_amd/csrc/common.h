@@ -149,6 +149,8 @@ int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int
                  float* out, int mask_nan, int mask_zero, int method);
 int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,
                  int64_t trim_n, float* out);
+int collapse_batched_f32(vipmi_ctx* ctx, const float* cube, int64_t batch, int64_t n, int64_t P, int mode, const float* w,
+                         int64_t trim_n, float* out);
 int gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
                int64_t npx, float* A);
 int scatter_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t P, const int32_t* pix, int64_t npx,

@@ -392,7 +392,7 @@ def _adi_pca_channels_batched(cube4, angle_list, ncomp, scaling, mask_center_px,
         ctx.call("vipmi_subtract_gemm_f32", B.ptr(M[c]), B.ptr(Ct[c]), B.ptr(T), n, k, P, B.ptr(R[c]), None)
     der = B.derotate(R.reshape(nch * n, y, x), np.tile(angle_list, nch), mask_nan=mv_nan, mask_zero=not mv_nan)
     der = der.reshape(nch, n, y, x)
-    frames = torch.stack([B.collapse(der[c], collapse, w=weights) for c in range(nch)])
+    frames = B.collapse_batched(der, collapse, w=weights)                 # every channel in one launch
     if mask is not None:
         frames = B.apply_mask(frames.reshape(nch, -1), mask.reshape(-1), 0.0).reshape(nch, y, x)
     return frames

@@ -272,7 +272,7 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     if ks is not None:
         cube_der = torch.stack([B.derotate(cube_out[nn], angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
                                 for nn in range(len(ks))])
-        frames = [B.collapse(cube_der[nn], _s(collapse), w=weights) for nn in range(len(ks))]
+        frames = list(B.collapse_batched(cube_der, _s(collapse), w=weights))
         if verbose:
             print("Done derotating and combining.")
         if full_output:

@@ -117,7 +117,7 @@ def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
     if ncomp_ifs is None:
         # first stage skipped: median of the channels of every multispectral frame (pca_fullfr.py:1479-1480)
         per = cube[i0:i1].permute(1, 0, 2, 3).contiguous()               # (n, zc, y, x)
-        res_cube_channels = torch.stack([B.collapse(per[f], "median") for f in range(n)])
+        res_cube_channels = B.collapse_batched(per, "median")
     else:
         # 1. rescale every channel of every frame (reflect padded to the largest scale), frame-major order
         E = channel_operators(y_in, scale_list)
@@ -132,7 +132,7 @@ def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
         desc = zoom_frames(res_all.reshape(n * zc, big, big), Einv, np.tile(np.arange(zc), n))
         ys = desc.shape[1]
         desc = desc.reshape(n, zc, ys, ys)
-        res_cube_channels = torch.stack([B.collapse(desc[f], _s(collapse_ifs)) for f in range(n)])
+        res_cube_channels = B.collapse_batched(desc, _s(collapse_ifs))
         if mask_center_px:
             mask = B.to_device_f32(center_mask_u8((ys, ys), mask_center_px).astype(np.float32)).to(torch.uint8)
             res_cube_channels = B.apply_mask(res_cube_channels.reshape(n, -1), mask.reshape(-1), 0.0).reshape(n, ys, ys)
@@ -181,7 +181,7 @@ def adimsdi_single(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
     desc = zoom_frames(sel, Einv, np.tile(np.arange(zc), n))
     ys = desc.shape[1]
     desc = desc.reshape(n, zc, ys, ys)
-    resadi = torch.stack([B.collapse(desc[f], _s(collapse_ifs)) for f in range(n)])
+    resadi = B.collapse_batched(desc, _s(collapse_ifs))
     cube_desc = desc.permute(1, 0, 2, 3).contiguous()
     der = B.derotate(resadi, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
     if mask_center_px:
