@@ -193,6 +193,13 @@ int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float
                           int64_t P, int64_t k, float* residuals, float* recon, float* pcs,
                           double* evals_out);
 
+/* R[b] = M[b] - E[b]^T (E[b] M[b]) for a contiguous batch of equally shaped problems: M, R [nb][n][P] and
+ * E [nb][k][n] (rows = leading eigenvectors of M[b] M[b]^T from vipmi_eigh_topk_f64, in float32).  The projection of
+ * pca_fullfr.py:1727-1731 for every multispectral frame of ADI+mSDI (:1482-1520) / every channel of a 4-D cube
+ * (:544-658) in two launches. */
+int vipmi_project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t nb, int64_t n, int64_t k,
+                              int64_t P, float* R);
+
 /* ---- fused full-frame ADI path: psfsub/pca_fullfr.py:801-1007 (3-D, int ncomp, no cube_ref) ----
  * cube[n,N,N] float32 -> frame[N,N].  Optional outputs may be NULL: pcs[k,N,N], recon[n,N,N],
  * residuals[n,N,N], residuals_der[n,N,N].  scaling: 0 or VIPMI_SCALE_*.  mask: N*N bytes or NULL. */

@@ -642,3 +642,27 @@ def test_collapse_batched_equals_per_cube(mode):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 assert np.array_equal(got, np.nanmedian(stack, axis=1), equal_nan=True)
+
+
+@pytest.mark.parametrize("shape", [(7, 39, 3, 33 * 33), (3, 20, 5, 64 * 64), (2, 70, 40, 1000)])
+def test_project_batched_equals_per_problem(shape):
+    """vipmi_project_batched_f32 = the rowspace + subtract products of every problem (same kernels, blockIdx = problem)"""
+    import torch
+    from vip_amd import backend as B
+    nb, n, k, P = shape
+    rng = np.random.default_rng(nb * n)
+    M = torch.from_numpy(rng.standard_normal((nb, n, P)).astype(np.float32)).cuda()
+    Q = np.stack([np.linalg.qr(rng.standard_normal((n, k)))[0].T for _ in range(nb)]).astype(np.float32)
+    E = torch.from_numpy(Q).cuda().contiguous()
+    got = B.project_batched(M, E).cpu().numpy()
+    ctx = B.get_context(0)
+    for b in range(nb):
+        T = B.empty((k, P), device=0)
+        R = B.empty((n, P), device=0)
+        Cb = E[b].t().contiguous()
+        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(E[b]), B.ptr(M[b]), k, n, P, None, B.ptr(T))
+        ctx.call("vipmi_subtract_gemm_f32", B.ptr(M[b]), B.ptr(Cb), B.ptr(T), n, k, P, B.ptr(R), None)
+        assert np.array_equal(got[b], R.cpu().numpy()), b
+    Mn = M.cpu().numpy().astype(np.float64)
+    ref = Mn - np.einsum("bkn,bkp->bnp", Q.astype(np.float64), np.einsum("bkn,bnp->bkp", Q.astype(np.float64), Mn))
+    assert np.abs(got - ref).max() < 2e-5

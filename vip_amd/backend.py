@@ -451,6 +451,16 @@ def collapse(cube, mode="median", w=None, trim_n=0):
     return out
 
 
+def project_batched(M, E):
+    """R[b] = M[b] - E[b]^T (E[b] M[b]):  M (nb, n, P) float32, E (nb, k, n) float32 rows = eigenvectors."""
+    ctx = get_context(M.device.index)
+    nb, n, P = M.shape
+    k = E.shape[1]
+    R = empty((nb, n, P), device=M.device.index)
+    ctx.call("vipmi_project_batched_f32", ptr(M), ptr(E), nb, n, k, P, ptr(R))
+    return R
+
+
 def collapse_batched(cubes, mode="median", w=None, trim_n=0):
     """collapse of every cube of a contiguous stack (batch, n, ...) -> (batch, ...) in one launch."""
     ctx = get_context(cubes.device.index)

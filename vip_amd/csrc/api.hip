@@ -425,6 +425,12 @@ int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, 
   return collapse_f32(ctx, cube, n, P, mode, w, trim_n, out);
 }
 
+int vipmi_project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t nb, int64_t n, int64_t k,
+                              int64_t P, float* R) {
+  CTX_GUARD();
+  return project_batched_f32(ctx, M, E, nb, n, k, P, R);
+}
+
 int vipmi_collapse_batched_f32(vipmi_ctx* ctx, const float* cubes, int64_t batch, int64_t n, int64_t P, int mode,
                                const float* w, int64_t trim_n, float* out) {
   CTX_GUARD();

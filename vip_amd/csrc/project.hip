@@ -11,6 +11,7 @@
 // kh = lane>>5) loads M[f0+kh][px0 + 4j .. 4j+3]; component c feeds MFMA number c whose output
 // column j is pixel px0 + 4j + c, so four 32x32 accumulators cover 128 contiguous pixels with
 // fully coalesced 512-byte row segments and no LDS transpose.
+#include <algorithm>
 #include "common.h"
 
 namespace vipmi {
@@ -55,7 +56,10 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void rowspace_kernel(const float* __restrict__ Wt, int kld,
                                                        const float* __restrict__ M, int k, int n,
                                                        int64_t P, const float* __restrict__ rowscale,
-                                                       float* __restrict__ T) {
+                                                       float* __restrict__ T, int64_t sWt, int64_t sM, int64_t sT) {
+  Wt += blockIdx.z * sWt;                    // blockIdx.z = problem of the batch (strides 0 for a single one)
+  M += blockIdx.z * sM;
+  T += blockIdx.z * sT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   const int64_t px0 = tile * 128;
@@ -102,7 +106,11 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
                                                        const float* __restrict__ Ct, int nld,
                                                        const float* __restrict__ T, int n, int k,
                                                        int64_t P, float* __restrict__ R,
-                                                       float* __restrict__ recon) {
+                                                       float* __restrict__ recon, int64_t sM, int64_t sCt, int64_t sT) {
+  M += blockIdx.y * sM;                      // blockIdx.y = problem of the batch (strides 0 for a single one)
+  R += blockIdx.y * sM;
+  Ct += blockIdx.y * sCt;
+  T += blockIdx.y * sT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   const int64_t px0 = tile * 128;
@@ -151,14 +159,27 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
   }
 }
 
-// dst[cols, ldd] = src[rows, cols]^T, zero padded to ldd
+// dst[cols, ldd] = src[rows, cols]^T, zero padded to ldd (blockIdx.y = matrix of a contiguous batch)
 __global__ void transpose_pad_kernel(const float* __restrict__ src, int rows, int cols,
                                      float* __restrict__ dst, int ldd) {
+  src += (int64_t)blockIdx.y * rows * cols;
+  dst += (int64_t)blockIdx.y * cols * ldd;
   int64_t total = (int64_t)cols * ldd;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(e / ldd), r = (int)(e % ldd);
     dst[e] = (r < rows) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+}
+
+// dst[rows, ldd] = src[rows, cols], zero padded to ldd (blockIdx.y = matrix of a contiguous batch)
+__global__ void pad_cols_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int ldd) {
+  src += (int64_t)blockIdx.y * rows * cols;
+  dst += (int64_t)blockIdx.y * rows * ldd;
+  const int64_t total = (int64_t)rows * ldd;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / ldd), c = (int)(e % ldd);
+    dst[e] = (c < cols) ? src[(int64_t)r * cols + c] : 0.f;
   }
 }
 
@@ -173,10 +194,10 @@ int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, in
   dim3 grid((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(k, 32)), block(256);
   if (vec)
     hipLaunchKernelGGL(rowspace_kernel<true>, grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P,
-                       rowscale, T);
+                       rowscale, T, (int64_t)0, (int64_t)0, (int64_t)0);
   else
     hipLaunchKernelGGL(rowspace_kernel<false>, grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P,
-                       rowscale, T);
+                       rowscale, T, (int64_t)0, (int64_t)0, (int64_t)0);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -188,7 +209,7 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
   dim3 grid((unsigned)cdiv(cdiv(P, 128), 4)), block(256);
 #define LAUNCH(V, RC)                                                                             \
   hipLaunchKernelGGL((subtract_kernel<V, RC>), grid, block, 0, ctx->stream, M, Ct, nld, T, (int)n, \
-                     (int)k, P, R, recon)
+                     (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0)
   if (vec) {
     if (recon) LAUNCH(true, true); else LAUNCH(true, false);
   } else {
@@ -223,6 +244,48 @@ int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const floa
   hipLaunchKernelGGL(transpose_pad_kernel, dim3(64), dim3(256), 0, ctx->stream, C, (int)n, (int)k, Ct, nld);
   VIPMI_CHECK_HIP(hipGetLastError());
   return subtract_gemm_t(ctx, M, Ct, nld, B, n, k, P, R, recon);
+}
+
+// R[b] = M[b] - E[b]^T (E[b] M[b]) for a contiguous batch: M, R [nb][n][P], E [nb][k][n] (rows = the leading
+// eigenvectors of M[b] M[b]^T, already zeroed where rejected).  Two launches per chunk of problems instead of four
+// per problem: the spectral PCAs of ADI+mSDI (one per multispectral frame, pca_fullfr.py:1482-1520) and the channels
+// of a 4-D cube (pca_fullfr.py:544-658) are launch-bound otherwise.
+int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t nb, int64_t n, int64_t k, int64_t P,
+                        float* R) {
+  VIPMI_REQUIRE(M && E && R, "project_batched: null pointer");
+  VIPMI_REQUIRE(nb > 0 && k > 0 && n > 0 && P > 0 && k <= n, "project_batched: bad sizes");
+  StageScope sc(ctx, "project");
+  const int kld = (int)cdiv(k, 32) * 32, nld = (int)cdiv(n, 32) * 32;
+  // chunk of problems per launch: T of at most ~256 MB, grid dimensions within 65535
+  int64_t chunk = std::max<int64_t>(1, (int64_t)(256u << 20) / (int64_t)(k * P * sizeof(float)));
+  chunk = std::min<int64_t>(std::min<int64_t>(chunk, nb), 65535);
+  float *Wt = nullptr, *Ct = nullptr, *T = nullptr;
+  VIPMI_TRY(ws(ctx, "projb_wt", (size_t)chunk * n * kld, &Wt));
+  VIPMI_TRY(ws(ctx, "projb_ct", (size_t)chunk * k * nld, &Ct));
+  VIPMI_TRY(ws(ctx, "projb_t", (size_t)chunk * k * P, &T));
+  const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(R) && aligned16(T);
+  for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
+    const int64_t cb = std::min(chunk, nb - b0);
+    const float* Mb = M + b0 * n * P;
+    const float* Eb = E + b0 * k * n;
+    float* Rb = R + b0 * n * P;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(8, (unsigned)cb), dim3(256), 0, ctx->stream, Eb, (int)k, (int)n, Wt, kld);
+    hipLaunchKernelGGL(pad_cols_kernel, dim3(8, (unsigned)cb), dim3(256), 0, ctx->stream, Eb, (int)k, (int)n, Ct, nld);
+    dim3 g1((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(k, 32), (unsigned)cb), g2((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cb);
+    if (vec) {
+      hipLaunchKernelGGL(rowspace_kernel<true>, g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
+                         (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
+      hipLaunchKernelGGL((subtract_kernel<true, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
+                         (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+    } else {
+      hipLaunchKernelGGL(rowspace_kernel<false>, g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
+                         (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
+      hipLaunchKernelGGL((subtract_kernel<false, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
+                         (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+    }
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  return VIPMI_OK;
 }
 
 }  // namespace vipmi

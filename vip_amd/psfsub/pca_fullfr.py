@@ -382,14 +382,7 @@ def _adi_pca_channels_batched(cube4, angle_list, ncomp, scaling, mask_center_px,
     ev, ec = B.eigh_topk(G, k)                                            # (nch, k), (nch, k, n)
     keep = (ev > ev[:, :1] * 1e-12).to(torch.float32)
     E = (ec.to(torch.float32) * keep[:, :, None]).contiguous()
-    Ct = E.transpose(1, 2).contiguous()
-    dev = cube4.device.index
-    ctx = B.get_context(dev)
-    T = B.empty((k, P), device=dev)
-    R = B.empty((nch, n, P), device=dev)
-    for c in range(nch):
-        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(E[c]), B.ptr(M[c]), k, n, P, None, B.ptr(T))
-        ctx.call("vipmi_subtract_gemm_f32", B.ptr(M[c]), B.ptr(Ct[c]), B.ptr(T), n, k, P, B.ptr(R[c]), None)
+    R = B.project_batched(M.contiguous(), E)                              # every channel's projection in two launches
     der = B.derotate(R.reshape(nch * n, y, x), np.tile(angle_list, nch), mask_nan=mv_nan, mask_zero=not mv_nan)
     der = der.reshape(nch, n, y, x)
     frames = B.collapse_batched(der, collapse, w=weights)                 # every channel in one launch

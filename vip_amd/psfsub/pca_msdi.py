@@ -61,15 +61,7 @@ def _residuals_batched(M4, ncomp, scaling, mask_center_px):
     ev, ec = B.eigh_topk(G, int(ncomp))                                   # (nb, k), (nb, k, nf)
     keep = (ev > ev[:, :1] * 1e-12).to(torch.float32)
     E = (ec.to(torch.float32) * keep[:, :, None]).contiguous()            # rows = leading eigenvectors
-    Ct = E.transpose(1, 2).contiguous()                                   # (nb, nf, k)
-    k = E.shape[1]
-    dev = M.device.index
-    ctx = B.get_context(dev)
-    T = B.empty((k, P), device=dev)
-    R = B.empty((nb, nf, P), device=dev)
-    for b in range(nb):
-        ctx.call("vipmi_rowspace_gemm_f32", B.ptr(E[b]), B.ptr(M[b]), k, nf, P, None, B.ptr(T))
-        ctx.call("vipmi_subtract_gemm_f32", B.ptr(M[b]), B.ptr(Ct[b]), B.ptr(T), nf, k, P, B.ptr(R[b]), None)
+    R = B.project_batched(M.contiguous(), E)                              # every frame's projection in two launches
     return R.reshape(nb, nf, y, x)
 
 
