@@ -143,13 +143,17 @@ int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_hos
 
 /* ---- cube_derotate / frame_rotate(imlib='opencv'): preproc/derotation.py:279-305 ----
  * out[n,N,N] = frames of in[n,N,N] rotated by -angles_host[i] degrees about (cx, cy) with OpenCV's
- * getRotationMatrix2D + warpAffine arithmetic (float32, 1/32-pixel phases, border constant 0; NaN -> 0).
+ * getRotationMatrix2D + warpAffine arithmetic (float32, 1/32-pixel phases, border = VIPMI_BORDER_*; NaN -> 0).
  * interp = VIPMI_INTERP_* ('nearneig' | 'bilinear' | 'bicubic' | 'lanczos4').  The fast, lower-fidelity
  * alternative to vipmi_derotate_f32 (README.rst:183); cv2 is absent from the build image, so parity with
  * cv2 itself is unpinned (see oracle/ref_cpu.py warp_rotate). */
 enum { VIPMI_INTERP_NEAREST = 0, VIPMI_INTERP_BILINEAR = 1, VIPMI_INTERP_BICUBIC = 2, VIPMI_INTERP_LANCZOS4 = 3 };
+/* border_mode 'constant' | 'edge' | 'symmetric' | 'reflect' | 'wrap' = cv2.BORDER_CONSTANT (0) | REPLICATE | REFLECT |
+ * REFLECT_101 | WRAP (derotation.py:294-305) */
+enum { VIPMI_BORDER_CONSTANT = 0, VIPMI_BORDER_REPLICATE = 1, VIPMI_BORDER_REFLECT = 2, VIPMI_BORDER_REFLECT101 = 3,
+       VIPMI_BORDER_WRAP = 4 };
 int vipmi_rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
-                            double cx, double cy, int interp, float* out);
+                            double cx, double cy, int interp, int border, float* out);
 
 /* ---- cube_collapse: preproc/subsampling.py:30-116 ---- */
 /* out[P] = collapse over the n frames of cube[n,P]; NaN-aware (nanmedian/nanmean/...).

@@ -317,7 +317,23 @@ def _warp_weights(taps):
     return tab
 
 
-def warp_rotate(frame, angle, interpolation="lanczos4", cxy=None):
+def _border_index(p, length, mode):
+    """cv::borderInterpolate for the reference's border_mode names (derotation.py:294-305); -1 = constant border."""
+    p = np.asarray(p, dtype=np.int64)
+    if mode == "constant":
+        return np.where((p >= 0) & (p < length), p, -1)
+    if mode == "edge":
+        return np.clip(p, 0, length - 1)
+    if mode == "wrap":
+        return np.mod(p, length)
+    if length == 1:
+        return np.zeros_like(p)
+    period = 2 * length if mode == "symmetric" else 2 * length - 2      # fedcba|abcdefgh|hgfedcb  /  gfedcb|abcdefgh|gfedcba
+    q = np.mod(p, period)
+    return np.where(q < length, q, period - q - (1 if mode == "symmetric" else 0))
+
+
+def warp_rotate(frame, angle, interpolation="lanczos4", cxy=None, border_mode="constant"):
     """``frame_rotate(frame, angle, imlib='opencv', interpolation=..., border_mode='constant')``.
     Ref: preproc/derotation.py:218 (NaN -> 0), :223-226 (centre = frame_center), :279-305 (cv2.getRotationMatrix2D +
     cv2.warpAffine on float32).  PARITY UNPINNED: opencv-python (pyproject.toml:56, no version pin) is not installed
@@ -342,11 +358,9 @@ def warp_rotate(frame, angle, interpolation="lanczos4", cxy=None):
     rd = 512 if taps == 1 else 16
     X0 = (np.rint((M[1] * ys + M[2]) * 1024).astype(np.int64) + rd)[:, None] + np.rint(M[0] * xs * 1024).astype(np.int64)[None]
     Y0 = (np.rint((M[4] * ys + M[5]) * 1024).astype(np.int64) + rd)[:, None] + np.rint(M[3] * xs * 1024).astype(np.int64)[None]
-    pad = np.zeros((ny + 2, nx + 2), dtype=np.float32)          # a zero frame around the image = the constant border
-    pad[1:-1, 1:-1] = a
-
     def tap(sy, sx):
-        return pad[np.clip(sy + 1, 0, ny + 1), np.clip(sx + 1, 0, nx + 1)]
+        iy, ix = _border_index(sy, ny, border_mode), _border_index(sx, nx, border_mode)
+        return np.where((iy >= 0) & (ix >= 0), a[np.maximum(iy, 0), np.maximum(ix, 0)], np.float32(0))
 
     if taps == 1:
         return tap(Y0 >> 10, X0 >> 10)

@@ -611,8 +611,6 @@ def test_rotate_opencv_style_errors():
     cube = np.zeros((2, 16, 16), dtype=np.float32)
     with pytest.raises(ValueError):
         cube_derotate(cube, [0, 1], imlib="opencv", interpolation="spline")
-    with pytest.raises(NotImplementedError):
-        cube_derotate(cube, [0, 1], imlib="opencv", border_mode="reflect")
     with pytest.raises(ValueError):
         cube_derotate(cube, [0, 1], imlib="opencv", border_mode="nope")
     with pytest.raises(NotImplementedError):
@@ -666,3 +664,21 @@ def test_project_batched_equals_per_problem(shape):
     Mn = M.cpu().numpy().astype(np.float64)
     ref = Mn - np.einsum("bkn,bkp->bnp", Q.astype(np.float64), np.einsum("bkn,bnp->bkp", Q.astype(np.float64), Mn))
     assert np.abs(got - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("border", ["edge", "symmetric", "reflect", "wrap"])
+@pytest.mark.parametrize("interp", ["nearneig", "bilinear", "lanczos4"])
+def test_rotate_opencv_style_borders(border, interp):
+    """the reference's border_mode switch of imlib='opencv' (derotation.py:294-305 -> cv2.BORDER_REPLICATE / REFLECT /
+    REFLECT_101 / WRAP): kernel against the oracle (cv::borderInterpolate restated; np.pad pins the index maps)"""
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(3)
+    for N in (9, 50):
+        cube = rng.standard_normal((3, N, N)).astype(np.float32)
+        ang = np.array([17.0, -63.0, 200.5])
+        got = cube_derotate(cube, ang, imlib="opencv", interpolation=interp, border_mode=border)
+        for i in range(3):
+            ref = O.warp_rotate(cube[i], -ang[i], interp, border_mode=border)
+            assert np.abs(got[i] - ref).max() < 5e-6 * max(1.0, np.abs(ref).max()), (N, i)
+        const = cube_derotate(cube, ang, imlib="opencv", interpolation=interp)
+        assert not np.array_equal(got, const)

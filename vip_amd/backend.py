@@ -364,7 +364,14 @@ def pca_project(M, k, ref=None, want_recon=False, want_pcs=False, want_evals=Fal
 
 
 INTERP_MODES = {"nearneig": 0, "bilinear": 1, "bicubic": 2, "lanczos4": 3}
-_ROTATION = ["vip-fft", "lanczos4"]          # rotation used by derotate(): set by rotation_mode() / with_rotation
+BORDER_MODES = {"constant": 0, "edge": 1, "symmetric": 2, "reflect": 3, "wrap": 4}     # derotation.py:294-305
+_ROTATION = ["vip-fft", "lanczos4", "constant"]   # rotation used by derotate(): set by rotation_mode() / with_rotation
+
+
+def check_border(border_mode):
+    if border_mode not in BORDER_MODES:
+        raise ValueError("Opencv `border_mode` not recognized.")
+    return border_mode
 
 
 def check_imlib(imlib, interpolation="lanczos4"):
@@ -386,8 +393,9 @@ def check_imlib(imlib, interpolation="lanczos4"):
 class rotation_mode:
     """``with rotation_mode(imlib, interpolation):`` -- every ``derotate`` inside uses that rotation."""
 
-    def __init__(self, imlib, interpolation="lanczos4"):
+    def __init__(self, imlib, interpolation="lanczos4", border_mode="constant"):
         self.mode = list(check_imlib(imlib, interpolation))
+        self.mode.append(check_border(border_mode) if self.mode[0] == "opencv" else "constant")
 
     def __enter__(self):
         self.saved = list(_ROTATION)
@@ -409,12 +417,14 @@ def with_rotation(fn):
     def wrapper(*a, **k):
         b = sig.bind(*a, **k)
         b.apply_defaults()
-        with rotation_mode(b.arguments.get("imlib", "vip-fft"), b.arguments.get("interpolation", "lanczos4")):
+        extra = b.arguments.get("rot_options", None) or {}
+        with rotation_mode(b.arguments.get("imlib", "vip-fft"), b.arguments.get("interpolation", "lanczos4"),
+                           extra.get("border_mode", "constant")):
             return fn(*a, **k)
     return wrapper
 
 
-def rotate_interp(cube, angles, interpolation="lanczos4", cxy=None, out=None):
+def rotate_interp(cube, angles, interpolation="lanczos4", cxy=None, out=None, border_mode="constant"):
     """frames rotated by -angles with OpenCV's warpAffine arithmetic (imlib='opencv'); centre = frame_center."""
     ctx = get_context(cube.device.index)
     n, Ny, Nx = cube.shape
@@ -423,13 +433,14 @@ def rotate_interp(cube, angles, interpolation="lanczos4", cxy=None, out=None):
     out = empty(cube.shape, device=cube.device.index) if out is None else out
     cx, cy = (float(Nx // 2), float(Ny // 2)) if cxy is None else (float(cxy[0]), float(cxy[1]))   # coords.py:61-100
     ah, ap = host_f64(angles)
-    ctx.call("vipmi_rotate_interp_f32", ptr(cube), ap, n, Ny, cx, cy, INTERP_MODES[interpolation], ptr(out))
+    ctx.call("vipmi_rotate_interp_f32", ptr(cube), ap, n, Ny, cx, cy, INTERP_MODES[interpolation],
+             BORDER_MODES[check_border(border_mode)], ptr(out))
     return out
 
 
 def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=None):
     if _ROTATION[0] == "opencv":
-        return rotate_interp(cube, angles, _ROTATION[1], out=out)
+        return rotate_interp(cube, angles, _ROTATION[1], out=out, border_mode=_ROTATION[2])
     ctx = get_context(cube.device.index)
     n, Ny, Nx = cube.shape
     if Ny != Nx:

@@ -414,9 +414,9 @@ int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_hos
 }
 
 int vipmi_rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
-                            double cx, double cy, int interp, float* out) {
+                            double cx, double cy, int interp, int border, float* out) {
   CTX_GUARD();
-  return rotate_interp_f32(ctx, in, angles_host, n, N, cx, cy, interp, out);
+  return rotate_interp_f32(ctx, in, angles_host, n, N, cx, cy, interp, border, out);
 }
 
 int vipmi_collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,

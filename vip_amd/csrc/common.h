@@ -126,7 +126,7 @@ bool eigh_topk_supported(int64_t n, int64_t k);
 int eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                   double* evals, double* evecs, bool all_evals = false);
 int rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N, double cx,
-                      double cy, int interp, float* out);
+                      double cy, int interp, int border, float* out);
 int lincomb_f32(vipmi_ctx* ctx, const float* x, const float* y, float a, float b, int64_t total, float* out);
 // batched C[b] = A0[ia[b]] B0[ib[b]]^T - A1[ia[b]] B1[ib[b]]^T (bgemm.hip)
 int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float* A1, const float* B1,

@@ -1,11 +1,12 @@
 // Interpolating rotation: cube_derotate / frame_rotate(imlib='opencv') of the reference (preproc/derotation.py:279-305),
-// i.e. cv2.getRotationMatrix2D + cv2.warpAffine(float32, INTER_NEAREST | LINEAR | CUBIC | LANCZOS4, BORDER_CONSTANT 0).
+// i.e. cv2.getRotationMatrix2D + cv2.warpAffine(float32, INTER_NEAREST | LINEAR | CUBIC | LANCZOS4, any border mode).
 // opencv-python (pyproject.toml:56, unpinned) is absent from this image, so the kernel follows OpenCV's published
 // algorithm (modules/imgproc/src/imgwarp.cpp, 4.x float path) and its parity against cv2 itself is NOT pinned:
 //   * the affine map is inverted in double; source coordinates are evaluated in 1/1024-pixel fixed point
 //     (round-to-nearest-even of M*x*1024 per column and of (M*y + b)*1024 per row, plus a rounding offset) and
 //     truncated to 1/32 pixel; the 32 x 32 sub-pixel phases index separable float weight tables;
-//   * taps outside the frame contribute the border value 0; NaN pixels are zeros (derotation.py:218).
+//   * taps outside the frame follow cv::borderInterpolate (constant 0 / replicate / reflect / reflect-101 / wrap);
+//     NaN pixels are zeros (derotation.py:218).
 // warp_affine_kernel: one thread per output pixel, taps from global memory (used for nearest; A/B option "warp_direct");
 // warp_tile_kernel: source tiles staged in LDS.  4 B read + 4 B written per pixel, 4-10x cheaper than the 3-shear FFT
 // rotation: the fast, lower-fidelity option the reference documents (README.rst:183); the default remains vip-fft.
@@ -22,9 +23,39 @@ struct WarpFrame {
 
 constexpr int WARP_AB_BITS = 10, WARP_INTER_BITS = 5, WARP_TAB = 1 << WARP_INTER_BITS;
 
+// cv::borderInterpolate: source index of an out-of-range coordinate, -1 = the constant border (value 0)
+__device__ __forceinline__ int warp_border(int p, int len, int mode) {
+  if ((unsigned)p < (unsigned)len) return p;
+  switch (mode) {
+    case VIPMI_BORDER_REPLICATE: return p < 0 ? 0 : len - 1;
+    case VIPMI_BORDER_REFLECT:
+    case VIPMI_BORDER_REFLECT101: {
+      const int delta = mode == VIPMI_BORDER_REFLECT101;
+      if (len == 1) return 0;
+      do {
+        p = p < 0 ? -p - 1 + delta : len - 1 - (p - len) - delta;
+      } while ((unsigned)p >= (unsigned)len);
+      return p;
+    }
+    case VIPMI_BORDER_WRAP:
+      p %= len;
+      return p < 0 ? p + len : p;
+    default: return -1;
+  }
+}
+
+__device__ __forceinline__ float warp_fetch(const float* __restrict__ src, int N, int gx, int gy, int border) {
+  gx = warp_border(gx, N, border);
+  gy = warp_border(gy, N, border);
+  if (gx < 0 || gy < 0) return 0.f;
+  const float v = src[(size_t)gy * N + gx];
+  return v == v ? v : 0.f;
+}
+
 template <int TAPS>
 __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restrict__ in, const WarpFrame* __restrict__ frames,
-                                                          const float* __restrict__ tab, int N, float* __restrict__ out) {
+                                                          const float* __restrict__ tab, int N, float* __restrict__ out,
+                                                          int border) {
   __shared__ float w1[WARP_TAB * (TAPS > 1 ? TAPS : 1)];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   if (TAPS > 1)
@@ -40,30 +71,18 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
   const int Y0 = __double2int_rn((f.m[4] * y + f.m[5]) * sc) + round_delta + __double2int_rn(f.m[3] * x * sc);
   float v = 0.f;
   if (TAPS == 1) {
-    const int sx = X0 >> WARP_AB_BITS, sy = Y0 >> WARP_AB_BITS;
-    if ((unsigned)sx < (unsigned)N && (unsigned)sy < (unsigned)N) {
-      v = src[(size_t)sy * N + sx];
-      v = v == v ? v : 0.f;
-    }
+    v = warp_fetch(src, N, X0 >> WARP_AB_BITS, Y0 >> WARP_AB_BITS, border);
   } else {
     const int X = X0 >> (WARP_AB_BITS - WARP_INTER_BITS), Y = Y0 >> (WARP_AB_BITS - WARP_INTER_BITS);
     const int sx = (X >> WARP_INTER_BITS) - (TAPS / 2 - 1), sy = (Y >> WARP_INTER_BITS) - (TAPS / 2 - 1);
     const float* wx = w1 + (X & (WARP_TAB - 1)) * TAPS;
     const float* wy = w1 + (Y & (WARP_TAB - 1)) * TAPS;
-    if (sx + TAPS > 0 && sx < N && sy + TAPS > 0 && sy < N) {
+    if (border != VIPMI_BORDER_CONSTANT || (sx + TAPS > 0 && sx < N && sy + TAPS > 0 && sy < N)) {
 #pragma unroll
       for (int r = 0; r < TAPS; ++r) {
-        const int yy = sy + r;
-        if ((unsigned)yy >= (unsigned)N) continue;
-        const float* row = src + (size_t)yy * N;
         const float wr = wy[r];
 #pragma unroll
-        for (int c = 0; c < TAPS; ++c) {
-          const int xx = sx + c;
-          float s = (unsigned)xx < (unsigned)N ? row[xx] : 0.f;
-          s = s == s ? s : 0.f;
-          v += s * (wr * wx[c]);
-        }
+        for (int c = 0; c < TAPS; ++c) v += warp_fetch(src, N, sx + c, sy + r, border) * (wr * wx[c]);
       }
     }
   }
@@ -80,7 +99,8 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const float* __restric
 // coordinates are sums of a monotone function of x and one of y, so their extremes over the tile are at its corners.
 template <int TAPS>
 __global__ __launch_bounds__(256) void warp_tile_kernel(const float* __restrict__ in, const WarpFrame* __restrict__ frames,
-                                                        const float* __restrict__ tab, int N, float* __restrict__ out) {
+                                                        const float* __restrict__ tab, int N, float* __restrict__ out,
+                                                        int border) {
   constexpr int TS = 32, PPT = 4, BOX = 46 + TAPS, LS = BOX + 1, H = TAPS / 2 - 1;
   __shared__ float w1[WARP_TAB * TAPS];
   __shared__ float tile[BOX * LS];
@@ -116,12 +136,12 @@ __global__ __launch_bounds__(256) void warp_tile_kernel(const float* __restrict_
   const int bw = ((max(rowx[0], rowx[TS - 1]) + max(colx[0], colx[TS - 1])) >> WARP_AB_BITS) + TAPS - H - bx;  // <= 45 + TAPS
   const int bh = min(((max(rowy[0], rowy[TS - 1]) + max(coly[0], coly[TS - 1])) >> WARP_AB_BITS) + TAPS - H - by, BOX);
   {
-    const int c = tid & 63, gx = bx + c;
-    const bool okx = c < bw && (unsigned)gx < (unsigned)N;
+    const int c = tid & 63, gx = warp_border(bx + c, N, border);
+    const bool okx = c < bw && gx >= 0;
     for (int r = tid >> 6; r < bh; r += 4) {
-      const int gy = by + r;
+      const int gy = warp_border(by + r, N, border);
       float v = 0.f;
-      if (okx && (unsigned)gy < (unsigned)N) v = src[(size_t)gy * N + gx];
+      if (okx && gy >= 0) v = src[(size_t)gy * N + gx];
       if (c < BOX) tile[r * LS + c] = v == v ? v : 0.f;
     }
   }
@@ -188,7 +208,7 @@ static void warp_weights(int taps, std::vector<float>& tab) {
 }
 
 int rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N, double cx,
-                      double cy, int interp, float* out) {
+                      double cy, int interp, int border, float* out) {
   VIPMI_REQUIRE(in && out && angles_host, "rotate_interp: null pointer");
   VIPMI_REQUIRE(n >= 1 && n <= 65535 && N >= 1 && N <= 16384, "rotate_interp: bad sizes (n=%lld, N=%lld)", (long long)n,
                 (long long)N);
@@ -196,6 +216,7 @@ int rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host
   const int taps = interp == VIPMI_INTERP_NEAREST ? 1 : interp == VIPMI_INTERP_BILINEAR ? 2 : interp == VIPMI_INTERP_BICUBIC ? 4
                    : interp == VIPMI_INTERP_LANCZOS4 ? 8 : 0;
   VIPMI_REQUIRE(taps != 0, "rotate_interp: unknown interpolation %d", interp);
+  VIPMI_REQUIRE(border >= VIPMI_BORDER_CONSTANT && border <= VIPMI_BORDER_WRAP, "rotate_interp: unknown border mode %d", border);
   StageScope scope(ctx, "warp");
   std::vector<WarpFrame> h((size_t)n);
   const double pi = 3.14159265358979323846;
@@ -232,18 +253,18 @@ int rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host
   dim3 tgrid((unsigned)cdiv(N, 32), (unsigned)cdiv(N, 32), (unsigned)n);
   const bool direct = ctx->opt("warp_direct", 0) != 0;         // A/B switch: taps from global memory
   switch (taps) {
-    case 1: warp_affine_kernel<1><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out); break;
+    case 1: warp_affine_kernel<1><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out, border); break;
     case 2:
-      if (direct) warp_affine_kernel<2><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
-      else warp_tile_kernel<2><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      if (direct) warp_affine_kernel<2><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out, border);
+      else warp_tile_kernel<2><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out, border);
       break;
     case 4:
-      if (direct) warp_affine_kernel<4><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
-      else warp_tile_kernel<4><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      if (direct) warp_affine_kernel<4><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out, border);
+      else warp_tile_kernel<4><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out, border);
       break;
     default:
-      if (direct) warp_affine_kernel<8><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
-      else warp_tile_kernel<8><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out);
+      if (direct) warp_affine_kernel<8><<<grid, block, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out, border);
+      else warp_tile_kernel<8><<<tgrid, 256, 0, ctx->stream>>>(in, d_frames, d_tab, (int)N, out, border);
       break;
   }
   VIPMI_CHECK_HIP(hipGetLastError());

@@ -46,7 +46,8 @@ def inverse_stim_map(cube, angle_list, **rot_options):
     """STIM map of the cube de-rotated with the opposite angles."""
     dev_in = B.is_device_tensor(cube)
     t = B.to_device_f32(cube)
-    with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4")):
+    with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4"),
+                         rot_options.get("border_mode", "constant")):
         der = B.derotate(t, -np.asarray(angle_list, dtype=np.float64))
     return _wrap(_stim_dev(der), dev_in, cube)
 
@@ -68,6 +69,7 @@ def normalized_stim_map(cube, angle_list, mask=None, **rot_options):
     max_inv = float(B.collapse(inv_map.reshape(-1, 1, 1), "max").item())
     if max_inv <= 0:
         raise ValueError("The normalization value is found to be {}".format(max_inv))
-    with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4")):
+    with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4"),
+                         rot_options.get("border_mode", "constant")):
         der = B.derotate(t, np.asarray(angle_list, dtype=np.float64))
     return _wrap(B.lincomb(_stim_dev(der), None, 1.0 / max_inv), dev_in, cube)

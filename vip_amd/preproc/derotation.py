@@ -13,10 +13,7 @@ def _check_rot_options(imlib, cxy, edge_blend, mask_val, shape, interpolation="l
     if edge_blend not in (None, ""):
         raise NotImplementedError("edge_blend is outside the accelerated path")
     if imlib == "opencv":
-        if border_mode != "constant":
-            if border_mode in ("edge", "symmetric", "reflect", "wrap"):
-                raise NotImplementedError("imlib='opencv' on the device implements border_mode='constant' only")
-            raise ValueError("Opencv `border_mode` not recognized.")
+        B.check_border(border_mode)
         return None
     if cxy is not None:
         cx, cy = cxy
@@ -33,7 +30,7 @@ def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", 
                   method="auto"):
     """Rotate frame i by -angle_list[i] degrees: the reference's 3-shear FFT rotation (``imlib='vip-fft'``, the
     parity path) or OpenCV's interpolating warpAffine (``imlib='opencv'``, ``interpolation`` = 'nearneig' | 'bilinear'
-    | 'bicubic' | 'lanczos4', ``border_mode='constant'``, optional centre ``cxy``; derotation.py:279-305).
+    | 'bicubic' | 'lanczos4', ``border_mode`` = 'constant' | 'edge' | 'symmetric' | 'reflect' | 'wrap', optional centre ``cxy``; derotation.py:279-305).
 
     Output dtype follows the reference's ``nproc=1`` branch (same dtype as the input);
     ``nproc`` is accepted and ignored (all frames are rotated concurrently on the GPU).
@@ -47,7 +44,8 @@ def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", 
     dev_in = B.is_device_tensor(array)
     t = B.to_device_f32(array)
     if mv_nan is None:
-        out = B.rotate_interp(t, angle_list, str(getattr(interpolation, "value", interpolation)), cxy=cxy)
+        out = B.rotate_interp(t, angle_list, str(getattr(interpolation, "value", interpolation)), cxy=cxy,
+                              border_mode=border_mode)
     else:
         out = B.derotate(t, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan, method=method)
     if dev_in:

@@ -127,7 +127,7 @@ def median_sub(*all_args: List, **all_kwargs: dict):
         raise TypeError("Input array is not a 3d or 4d array")
     if cube.ndim == 4:
         raise NotImplementedError("4-D (SDI) median subtraction is not accelerated")
-    rot_mode = B.rotation_mode(algo_params.imlib, algo_params.interpolation)    # 'vip-fft' or 'opencv' (medsub.py:376-387)
+    rot_mode = B.rotation_mode(algo_params.imlib, algo_params.interpolation, rot_options.get("border_mode", "constant"))    # 'vip-fft' or 'opencv' (medsub.py:376-387)
     if algo_params.mode not in ("fullfr", "annular"):
         raise RuntimeError("Mode not recognized")
     annular = algo_params.mode == "annular"
