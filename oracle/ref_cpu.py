@@ -1052,24 +1052,4 @@ def pca_annular(cube, angle_list, radius_int=0, fwhm=4, asize=4, n_segments=1,
 # --------------------------------------------------------------------------------------
 
 
-def synth_adi(n, N, seed=0, planet=True, dtype=np.float32):
-    """Halo + 30 geometric-spectrum speckle modes + unit noise, max|cube| ~ 10."""
-    rng = np.random.default_rng(seed)
-    c = N // 2
-    yy, xx = np.mgrid[:N, :N]
-    r = np.sqrt((yy - c) ** 2 + (xx - c) ** 2)
-    env = np.exp(-r / (N / 8))
-    nmodes = 30
-    modes = rng.standard_normal((nmodes, N, N)) * env
-    coef = rng.standard_normal((n, nmodes)) * 2.0 ** (-np.arange(nmodes) / 3)
-    cube = np.tensordot(coef, modes, axes=1) + env[None] * 3.0
-    angles = np.linspace(0, 90, n)
-    if planet:
-        sig = 4 / 2.3548200450309493
-        for i, th in enumerate(np.deg2rad(angles)):
-            py, px = c + (N / 4) * np.sin(th), c + (N / 4) * np.cos(th)
-            cube[i] += 0.5 * np.exp(-((yy - py) ** 2 + (xx - px) ** 2) / (2 * sig ** 2))
-    cube *= 9.0 / np.max(np.abs(cube))
-    cube += rng.standard_normal((n, N, N))
-    cube *= 10.0 / np.max(np.abs(cube))
-    return cube.astype(dtype), angles
+from vip_amd.synth import synth_adi  # noqa: E402,F401  (one generator for the goldens, the tests and bench.py)

@@ -653,3 +653,55 @@ def test_pca_4d_with_opencv_style_rotation():
     assert got.shape == (N, N) and np.abs(got - per_channel.mean(axis=0)).max() < 1e-5
     with pytest.raises(NotImplementedError):
         pca(cubes, ang, scale_list=np.linspace(1.0, 1.2, nch), adimsdi="single", ncomp=1, imlib="opencv", verbose=False)
+
+
+def test_trimmean_collapse_through_the_pipelines():
+    """collapse='trimmean' through pca / pca_annular / median_sub: the reference calls cube_collapse(mode=collapse) with its
+    default n=50 (subsampling.py:30,88-96) -- on short cubes the python-slice semantics of sorted[k:k+n] apply."""
+    from vip_amd.psfsub import pca, pca_annular, median_sub
+    for n in (24, 70):                                    # n < 50 (slice clipped) and n > 50
+        cube, ang = O.synth_adi(n, 64, seed=4)
+        fr = pca(cube, ang, ncomp=3, collapse="trimmean", verbose=False)
+        ref = O.pca_fullframe(cube, ang, ncomp=3, collapse="trimmean")
+        assert np.abs(fr - ref).max() < TOL
+        fo = pca(cube, ang, ncomp=3, collapse="trimmean", verbose=False, full_output=True)
+        assert np.abs(fo[0] - ref).max() < TOL
+        fa = pca_annular(cube, ang, ncomp=2, asize=8, fwhm=4, collapse="trimmean", verbose=False)
+        ra = O.pca_annular(cube, ang, ncomp=2, asize=8, fwhm=4, collapse="trimmean")
+        assert np.abs(fa - ra).max() < TOL
+        fm = median_sub(cube, ang, collapse="trimmean", verbose=False)
+        assert np.abs(fm - O.median_sub_fullfr(cube, ang, collapse="trimmean")).max() < TOL
+
+
+def test_stim_is_not_a_public_collapse_mode():
+    from vip_amd.psfsub import pca, pca_annular
+    cube, ang = O.synth_adi(12, 40, seed=2)
+    with pytest.raises(TypeError):
+        pca(cube, ang, ncomp=2, collapse="stim", verbose=False)
+    with pytest.raises(TypeError):
+        pca_annular(cube, ang, ncomp=2, asize=8, collapse="stim", verbose=False)
+
+
+def test_pca_4d_frame_rejection_and_grid_return_packing():
+    """4-D cube with source_xy (per-channel frame rejection) and with a list ncomp applied as a grid to every channel
+    (reference pca_fullfr.py:603-658,772-788): tuple layouts and values against the per-channel oracle."""
+    from vip_amd.psfsub import pca
+    chans = [O.synth_adi(20, 48, seed=s)[0] for s in (1, 2, 3)]
+    cube4 = np.stack(chans)
+    ang = np.linspace(0, 90, 20)
+    kw = dict(ncomp=2, source_xy=(34, 24), fwhm=4, delta_rot=0.5, min_frames_pca=3)
+    out = pca(cube4, ang, full_output=True, verbose=False, **kw)
+    assert len(out) == 5                                   # frame, recon_cube, residuals, residuals_, ifs_adi_frames
+    per = [O.pca_pa_rejection(c, ang, 2, (34, 24), 4, 0.5, min_frames_pca=3, full_output=True) for c in chans]
+    ifs = np.stack([p[0] for p in per])
+    assert out[4].shape == (3, 48, 48) and np.abs(out[4] - ifs).max() < TOL
+    assert np.abs(out[0] - ifs.mean(axis=0)).max() < TOL
+    assert out[1].shape == (3, 20, 48, 48)
+    fr = pca(cube4, ang, verbose=False, **kw)
+    assert np.abs(fr - ifs.mean(axis=0)).max() < TOL
+    # grid: list of 2 PCs on 3 channels -> (n_grid, y, x) collapsed over channels
+    grid = pca(cube4, ang, ncomp=[1, 3], verbose=False)
+    exp = np.stack([np.mean([O.pca_fullframe(c, ang, ncomp=k) for c in chans], axis=0) for k in (1, 3)])
+    assert grid.shape == (2, 48, 48) and np.abs(grid - exp).max() < TOL
+    g3 = pca(cube4, ang, ncomp=[1, 3], verbose=False, full_output=True)
+    assert len(g3) == 3 and g3[1] == [[1, 3]] * 3 and g3[2].shape == (3, 2, 48, 48)

@@ -1,17 +1,29 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): kernel-trace stats of bench.py + separate PMC passes of one pca() call.
-# usage: tools/profile_round.sh rNN
+# usage: tools/profile_round.sh rNN        (every rocprofv3 run under its own timeout; counters never mixed with traces
+#                                           other than --kernel-trace)
 set -u
-R=${1:-r01}
+R=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_prof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python $REPO/tools/prof_stage.py pca 400 512 1 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python $REPO/tools/prof_stage.py pca 400 512 1 > $OUT/pmc_write.log 2>&1
+timeout 120 rocprofv3 -L > $OUT/counters_available.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_prof.log 2>&1
+CMD="python $REPO/tools/prof_stage.py pca 400 512 2"
+pass() {   # pass NAME "COUNTERS"
+  timeout 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT/pmc_$1 -o p -- $CMD > $OUT/pmc_$1.log 2>&1 || echo "pass $1 failed rc=$?" >> $OUT/failed_passes.txt
+}
+pass fetch "FETCH_SIZE"
+pass write "WRITE_SIZE"
+pass sq1 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"
+pass sq2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+pass sq3 "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES"
+pass grbm "GRBM_GUI_ACTIVE GRBM_COUNT"
+pass tcc "TCC_HIT_sum TCC_MISS_sum"
 cd $REPO
 python tools/pmc_summary.py $OUT/pmc_hbm.json $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.log 2>&1
+python tools/pmc_sq_summary.py $OUT/pmc_sq.json $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_grbm $OUT/pmc_tcc > $OUT/pmc_sq_summary.log 2>&1
 find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -size +20M -delete
 ls -la $OUT

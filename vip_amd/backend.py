@@ -11,8 +11,11 @@ import numpy as np
 
 from . import _lib
 
-_ctx_cache = {}
+import collections
+
+_ctx_cache = collections.OrderedDict()      # (device, stream handle) -> Context, least recently used first
 _ctx_lock = threading.Lock()
+MAX_CONTEXTS = int(os.environ.get("VIPMI_MAX_CONTEXTS", "8"))   # every context owns hipMalloc'ed workspaces (GBs at C2 scale)
 
 SCALE_MODES = {None: 0, "temp-mean": 1, "temp-standard": 2, "spat-mean": 3, "spat-standard": 4}
 COLLAPSE_MODES = {"median": 0, "mean": 1, "sum": 2, "max": 3, "absmean": 4, "wmean": 5, "trimmean": 6, "stim": 7}
@@ -71,10 +74,15 @@ class Context:
         st = getattr(self.lib, name)(self.handle, *args)
         _lib.raise_for_status(st, name)
 
+    def destroy(self):
+        """Synchronise the context's stream and free every workspace it owns (hipFree); the object is dead afterwards."""
+        h, self.handle = self.handle, None
+        if h:
+            self.lib.vipmi_destroy(h)
+
     def __del__(self):
         try:
-            if self.handle:
-                self.lib.vipmi_destroy(self.handle)
+            self.destroy()
         except Exception:
             pass
 
@@ -151,13 +159,25 @@ def get_context(device=None):
     with _ctx_lock:
         c = _ctx_cache.get(key)
         if c is None:
+            while len(_ctx_cache) >= max(1, MAX_CONTEXTS):       # least recently used context: synchronised and freed
+                _ctx_cache.popitem(last=False)[1].destroy()
             c = Context(dev)
             if _async["on"]:
                 c.set_option("eigh_check", 0)
                 c.set_option("reserve_cus", _async["reserve_cus"])
                 c.lib.vipmi_set_gate(c.handle, _gate())
             _ctx_cache[key] = c
+        else:
+            _ctx_cache.move_to_end(key)
         return c
+
+
+def release_workspaces():
+    """Destroy every cached context (stream synchronised, all of its hipMalloc'ed workspaces freed).  The next call
+    on a stream builds a fresh context; use between phases of a long-running process that worked on large cubes."""
+    with _ctx_lock:
+        while _ctx_cache:
+            _ctx_cache.popitem(last=False)[1].destroy()
 
 
 # ---- array plumbing ------------------------------------------------------------------------------
@@ -365,7 +385,11 @@ def pca_project(M, k, ref=None, want_recon=False, want_pcs=False, want_evals=Fal
 
 INTERP_MODES = {"nearneig": 0, "bilinear": 1, "bicubic": 2, "lanczos4": 3}
 BORDER_MODES = {"constant": 0, "edge": 1, "symmetric": 2, "reflect": 3, "wrap": 4}     # derotation.py:294-305
-_ROTATION = ["vip-fft", "lanczos4", "constant"]   # rotation used by derotate(): set by rotation_mode() / with_rotation
+import contextvars
+
+# rotation used by derotate(): set by rotation_mode() / with_rotation; a ContextVar, so concurrent calls from different
+# threads (or asyncio tasks) with different `imlib` values never see each other's choice
+_ROTATION = contextvars.ContextVar("vipmi_rotation", default=("vip-fft", "lanczos4", "constant"))
 
 
 def check_border(border_mode):
@@ -398,12 +422,11 @@ class rotation_mode:
         self.mode.append(check_border(border_mode) if self.mode[0] == "opencv" else "constant")
 
     def __enter__(self):
-        self.saved = list(_ROTATION)
-        _ROTATION[:] = self.mode
+        self.token = _ROTATION.set(tuple(self.mode))
         return self
 
     def __exit__(self, *exc):
-        _ROTATION[:] = self.saved
+        _ROTATION.reset(self.token)
         return False
 
 
@@ -439,8 +462,9 @@ def rotate_interp(cube, angles, interpolation="lanczos4", cxy=None, out=None, bo
 
 
 def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=None):
-    if _ROTATION[0] == "opencv":
-        return rotate_interp(cube, angles, _ROTATION[1], out=out, border_mode=_ROTATION[2])
+    rot = _ROTATION.get()
+    if rot[0] == "opencv":
+        return rotate_interp(cube, angles, rot[1], out=out, border_mode=rot[2])
     ctx = get_context(cube.device.index)
     n, Ny, Nx = cube.shape
     if Ny != Nx:
@@ -452,7 +476,7 @@ def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=No
     return out
 
 
-def collapse(cube, mode="median", w=None, trim_n=0):
+def collapse(cube, mode="median", w=None, trim_n=50):     # n=50: subsampling.py:30 default of cube_collapse
     ctx = get_context(cube.device.index)
     n = cube.shape[0]
     P = cube[0].numel()
@@ -472,7 +496,7 @@ def project_batched(M, E):
     return R
 
 
-def collapse_batched(cubes, mode="median", w=None, trim_n=0):
+def collapse_batched(cubes, mode="median", w=None, trim_n=50):
     """collapse of every cube of a contiguous stack (batch, n, ...) -> (batch, ...) in one launch."""
     ctx = get_context(cubes.device.index)
     if not cubes.is_contiguous():

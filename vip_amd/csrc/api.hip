@@ -549,7 +549,7 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
   if (!der) VIPMI_TRY(ws(ctx, "pca_der", (size_t)n * P, &der));
   // pca(): mask_center_px without rot_options -> mask_val=0 (pca_fullfr.py:412-415)
   VIPMI_TRY(derotate_f32(ctx, res, angles_host, n, N, der, mask ? 0 : 1, mask ? 1 : 0, VIPMI_ROT_AUTO));
-  VIPMI_TRY(collapse_f32(ctx, der, n, P, collapse_mode, nullptr, 0, frame));
+  VIPMI_TRY(collapse_f32(ctx, der, n, P, collapse_mode, nullptr, 50, frame));   // cube_collapse(..., n=50) default (subsampling.py:30)
   VIPMI_TRY(ctx->gate_leave());
   if (mask) {
     // pca_fullfr.py:985-987: residuals_cube_ and frame are masked again

@@ -277,13 +277,13 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         raise ValueError("Number of PCs too low. It should be > 0.")
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
-    if not mv_nan and mask_val != 0:
+    if not mv_nan and mask_val != 0 and _s(imlib) != "opencv":       # (mask_val is unused by the opencv rotation)
         raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
     if rot_options.get("edge_blend") not in (None, ""):
         raise NotImplementedError("edge_blend is outside the accelerated path")
     scaling = _s(scaling)
     collapse = _s(collapse)
-    if collapse not in B.COLLAPSE_MODES:
+    if collapse not in B.COLLAPSE_MODES or collapse == "stim":        # ('stim' is an internal mode, subsampling.py:79-114)
         raise TypeError("mode not recognized")
     if collapse == "wmean" and weights is None:
         raise ValueError("Weights have to be provided for weighted mean mode")
@@ -519,7 +519,7 @@ def pca(*all_args: List, **all_kwargs: dict):
         if not isinstance(ncomp, list):
             ncomps = [ncomp] * nch
         elif len(ncomp) != nch:
-            raise NotImplementedError("list ncomp of length != n_channels (pca_grid) is not accelerated yet")
+            ncomps = [ncomp] * nch            # the list is a PCA grid applied to every channel (pca_fullfr.py:548-551)
         else:
             ncomps = ncomp
         fwhm = algo_params.fwhm
@@ -532,7 +532,7 @@ def pca(*all_args: List, **all_kwargs: dict):
                 and algo_params.mask_rdi is None and algo_params.smooth is None and not algo_params.left_eigv
                 and _s(algo_params.imlib) == "vip-fft" and (mv_nan or mask_val == 0)
                 and rot_options.get("edge_blend") in (None, "") and 0 < int(ncomps[0]) <= min(64, nz) and nz <= 512
-                and _s(algo_params.collapse) in B.COLLAPSE_MODES
+                and _s(algo_params.collapse) in B.COLLAPSE_MODES and _s(algo_params.collapse) != "stim"
                 and not (_s(algo_params.collapse) == "wmean" and algo_params.weights is None)):
             angles = check_pa_vector(np.asarray(algo_params.angle_list, dtype=np.float64))
             if angles.shape[0] != nz:
@@ -577,8 +577,29 @@ def pca(*all_args: List, **all_kwargs: dict):
         finally:
             if pipelined:
                 B.set_async(False)
-        ifs = torch.stack([o[4] if fo else o for o in outs])
+        grid_ch = [isinstance(kc, (tuple, list)) for kc in ncomps]
+        if any(grid_ch):
+            # per-channel PCA grid (pca_fullfr.py:614-617,626-629,639-646): one collapsed frame per grid entry
+            if algo_params.source_xy is not None:
+                raise NotImplementedError("the S/N-scored pca_grid on 4-D cubes is outside the accelerated path")
+            if not all(grid_ch):
+                raise TypeError("`ncomp` must be a grid for every channel or for none")
+            cubes_ch = torch.stack([o[0] if fo else o for o in outs])          # (nch, n_grid, y, x)
+            final = torch.stack([B.collapse(cubes_ch[:, i].contiguous(), _s(algo_params.collapse_ifs))
+                                 for i in range(cubes_ch.shape[1])])
+            if algo_params.med_of_npcs:
+                final = B.collapse(final, "median")
+            if fo:
+                return host(final, np.float64), [o[1] for o in outs], host(cubes_ch, np.float64)
+            return host(final, np.float64)
+        ifs = torch.stack([o[-1] if fo else o for o in outs])
         frame = B.collapse(ifs, _s(algo_params.collapse_ifs))
+        if fo and algo_params.source_xy is not None:
+            # frame rejection per channel (pca_fullfr.py:619-623,783-788): (frame, recon_cube, residuals, residuals_, ifs)
+            recon = torch.stack([o[0] for o in outs])
+            res = torch.stack([o[1] for o in outs])
+            resd = torch.stack([o[2] for o in outs])
+            return host(frame, np.float64), host(recon), host(res), host(resd), host(ifs, np.float64)
         if fo:
             pcs = torch.stack([o[0] for o in outs])
             recon = torch.stack([o[1] for o in outs])
@@ -630,7 +651,7 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
     if n_items != len(angle_lists):
         raise ValueError("cubes and angle_lists must have the same length")
     depth = max(1, min(int(depth), n_items)) if n_items else 1
-    streams = [torch.cuda.Stream() for _ in range(depth)]
+    streams = B.side_streams(depth)       # cached: every stream owns a context with its own workspaces (backend._ctx_cache)
     dev_in = [B.is_device_tensor(c) for c in cubes]
     outs = [None] * n_items
     B.set_async(True)

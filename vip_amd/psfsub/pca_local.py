@@ -189,6 +189,8 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         if ks.size == 0 or ks.min() <= 0:
             raise ValueError("every ncomp of the list must be a positive integer")
     B.check_imlib(imlib, interpolation)         # 'vip-fft' or 'opencv'; the decorator selects the rotation
+    if _s(collapse) is not None and (_s(collapse) not in B.COLLAPSE_MODES or _s(collapse) == "stim"):
+        raise TypeError("mode not recognized")                      # cube_collapse, subsampling.py:113-114
     n, y, x = cube.shape
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
     plan, plan_dev = cached_annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot,
