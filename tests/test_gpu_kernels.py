@@ -310,6 +310,37 @@ def test_median_sizes_bitexact(B, n, P):
     assert np.array_equal(got, exp, equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [5, 64, 100, 399, 400, 448, 1000, 2000, 4096])
+def test_median_bucket_selection_hard_cases(B, n):
+    """The median kernel bins the samples of a pixel between their minimum and maximum and finishes exactly on the bin
+    that holds the wanted rank: columns built to defeat the binning (outliers that squeeze everything else into one bin,
+    heavy ties, two clusters with the median at the gap, +-0, infinities, a range that overflows float32, denormals)."""
+    rng = np.random.default_rng(n)
+    P = 64
+    cube = rng.standard_normal((n, P)).astype(np.float32)
+    cube[0, 0] = 1e30                                   # one outlier: every other sample lands in bin 0 -> second level
+    cube[0, 1], cube[1 % n, 1] = -3e38, 3e38            # fhi - flo overflows -> bisection
+    cube[:, 2] = np.round(cube[:, 2] * 2) / 2           # heavy ties (9 distinct values)
+    cube[:, 3] = np.where(np.arange(n) % 2 == 0, -5.0, 5.0) + 1e-3 * cube[:, 3]    # two clusters, median at the gap
+    cube[:, 4] = np.where(np.arange(n) % 3 == 0, -0.0, 0.0)
+    cube[0, 5], cube[n - 1, 5] = -np.inf, np.inf
+    cube[:, 6] = (cube[:, 6] * 1e-42).astype(np.float32)                           # denormals
+    cube[:, 7] = 7.0
+    cube[0, 7] = 1e20                                   # all ties but one outlier
+    cube[:, 8] = np.float32(1.0) + np.arange(n, dtype=np.float32) * np.float32(1.1920929e-07)   # consecutive floats
+    cube[1:, 9] = np.nan                                # one valid sample
+    cube[:, 10] = np.exp(8 * cube[:, 10])               # log-normal: long tail, crowded first bins
+    cube[:, 11] = np.where(rng.random(n) < 0.7, 0.0, cube[:, 11])                  # 70 % exact zeros (masked frames)
+    cube[rng.random((n, P)) < 0.05] = np.nan
+    cube[:, 12] = np.nan
+    got = B.collapse(dev(B, cube).reshape(n, P, 1), "median").cpu().numpy().reshape(P)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = np.nanmedian(cube, axis=0)
+    assert np.array_equal(got, exp, equal_nan=True), np.nonzero(~((got == exp) | (np.isnan(got) & np.isnan(exp))))
+
+
 @pytest.mark.parametrize("n,P,tn", [(7, 50, 3), (8, 50, 3), (8, 64, 4), (7, 33, 9), (7, 33, 50), (65, 333, 20),
                                     (400, 1024, 100), (129, 100, 129), (10, 40, 1)])
 def test_trimmean_sizes(B, n, P, tn):

@@ -71,17 +71,199 @@ __device__ __forceinline__ unsigned select_rank(const unsigned (&key)[RPL], int 
   return ans;
 }
 
+// ---- median by bucket selection -------------------------------------------------------------------------------------
+// The 32-step bisection above costs ~830 VALU instructions per pixel (98 % VALU busy, rocprofv3 SQ counters of round 2).
+// For the median itself: ONE pass that bins the wave's keys linearly in VALUE between their minimum and maximum (256
+// bins, LDS histogram private to the wave; the binning is a weakly monotone function of the key, so the bin in which the
+// cumulative count crosses the wanted rank holds the wanted element), a DPP prefix sum over the bins, and an exact finish
+// on the <= 64 keys of that bin: one key per lane, rank by counting against every candidate (readlane broadcasts).  A
+// bin with more than 64 keys (outliers stretching the range, ties) is binned again over its own range, at most 3
+// levels; then the bisection takes over.  Every comparison that decides a rank is made on the order-preserving keys.
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = umax_(v, dpp_u32<0xB1>(v));
+  v = umax_(v, dpp_u32<0x4E>(v));
+  v = umax_(v, dpp_u32<0x141>(v));
+  v = umax_(v, dpp_u32<0x140>(v));
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return umax_(umax_(a, b), umax_(c, d));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_rows(unsigned v) {      // lanes of rows outside ROWMASK (and invalid sources) read 0
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
+  v += dpp_rows<0x111, 0xf>(v);      // row_shr:1
+  v += dpp_rows<0x112, 0xf>(v);      // row_shr:2
+  v += dpp_rows<0x114, 0xf>(v);      // row_shr:4
+  v += dpp_rows<0x118, 0xf>(v);      // row_shr:8   -> inclusive sums inside every row of 16 lanes
+  v += dpp_rows<0x142, 0xa>(v);      // row_bcast:15 -> rows 1 and 3 add the total of the row before
+  v += dpp_rows<0x143, 0xc>(v);      // row_bcast:31 -> rows 2 and 3 add the total of rows 0..1
+  return v;
+}
+// Lanes of one wave exchanging data through LDS: the hardware executes a wave's LDS instructions in order, but the
+// COMPILER needs the fences -- without them it forwards a lane's own earlier store to its later load across the other
+// lanes' atomics / stores (it sank the histogram read into the divergent branch of the lanes that had added to it).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int lane_rank_in(unsigned long long mask) {   // set bits of `mask` below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Lower median key (rank k = (m-1)/2 of the m valid keys) and, for even m, the upper one (rank k+1); invalid entries
+// carry the key 0xffffffff.  hist: 256 words of LDS private to the wave.
+template <int RPL>
+__device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, unsigned* __restrict__ hist, int lane,
+                                            unsigned& klow, unsigned& khigh) {
+  const int k = (m - 1) >> 1;
+  const bool even = (m & 1) == 0;
+  unsigned lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    lo = umin_(lo, key[r]);
+    hi = umax_(hi, key[r] == 0xffffffffu ? 0u : key[r]);
+  }
+  lo = wave_min_u32(lo);
+  hi = wave_max_u32(hi);
+  int rank = k;                                  // rank of the wanted key among the keys in [lo, hi]
+  bool done = false;
+  for (int level = 0; level < 3 && !done; ++level) {
+    if (lo == hi) {                              // every remaining key is the same value
+      klow = lo;
+      khigh = lo;                                // (rank + 1 may lie above the range: fixed below)
+      done = true;
+      // upper median outside a range of identical keys: the smallest key above it
+      if (even) {
+        int cle = 0;
+        unsigned nxt = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          cle += (key[r] <= lo) ? 1 : 0;
+          if (key[r] > lo && key[r] < nxt) nxt = key[r];
+        }
+        if (wave_count<RPL>(cle) < k + 2) khigh = wave_min_u32(nxt);
+      }
+      break;
+    }
+    const float flo = key2f(lo), fhi = key2f(hi);
+    const float scale = 256.0f / (fhi - flo);
+    if (!(scale > 0.f && scale < 3.0e38f)) break;          // range overflows / underflows: bisection
+    reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      if (key[r] >= lo && key[r] <= hi) {
+        int b = (int)((key2f(key[r]) - flo) * scale);
+        b = b > 255 ? 255 : b;
+        atomicAdd(&hist[b], 1u);
+      }
+    }
+    wave_lds_sync();
+    const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];
+    const unsigned s4 = h.x + h.y + h.z + h.w;
+    const unsigned incl = wave_inclusive_sum(s4);
+    const unsigned long long above = __ballot(incl > (unsigned)rank);
+    const int L = __builtin_ctzll(above);        // (never empty: the range holds more than `rank` keys)
+    const unsigned hx = (unsigned)__builtin_amdgcn_readlane((int)h.x, L), hy = (unsigned)__builtin_amdgcn_readlane((int)h.y, L);
+    const unsigned hz = (unsigned)__builtin_amdgcn_readlane((int)h.z, L), hw = (unsigned)__builtin_amdgcn_readlane((int)h.w, L);
+    unsigned rem = (unsigned)rank - ((unsigned)__builtin_amdgcn_readlane((int)incl, L) - (hx + hy + hz + hw));
+    int j = 0;
+    unsigned c = hx;
+    if (rem >= c) { rem -= c; j = 1; c = hy; }
+    if (j == 1 && rem >= c) { rem -= c; j = 2; c = hz; }
+    if (j == 2 && rem >= c) { rem -= c; j = 3; c = hw; }
+    const int bstar = 4 * L + j;
+    rank = (int)rem;
+    wave_lds_sync();
+    if (c <= 64u) {
+      // compact the bin's keys into LDS (the histogram is dead), one per lane, rank by counting
+      unsigned base = 0;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        bool pred = false;
+        if (key[r] >= lo && key[r] <= hi) {
+          int b = (int)((key2f(key[r]) - flo) * scale);
+          b = b > 255 ? 255 : b;
+          pred = b == bstar;
+        }
+        const unsigned long long pm = __ballot(pred);
+        if (pred) hist[base + lane_rank_in(pm)] = key[r];
+        base += (unsigned)__popcll(pm);
+      }
+      wave_lds_sync();
+      const unsigned cand = (unsigned)lane < c ? hist[lane] : 0xffffffffu;
+      int less = 0;
+      for (unsigned q = 0; q < c; ++q) {
+        const unsigned kq = (unsigned)__builtin_amdgcn_readlane((int)cand, (int)q);
+        less += (kq < cand) ? 1 : 0;
+      }
+      const bool mine = (unsigned)lane < c;
+      klow = wave_max_u32(mine && less <= rank ? cand : 0u);     // largest key with at most `rank` keys below it
+      khigh = klow;
+      if (even) {
+        if ((unsigned)rank + 1u < c) {
+          khigh = wave_max_u32(mine && less <= rank + 1 ? cand : 0u);
+        } else {                                 // the next key lives in a later bin: the smallest key above klow
+          unsigned nxt = 0xffffffffu;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r)
+            if (key[r] > klow && key[r] < nxt) nxt = key[r];
+          khigh = wave_min_u32(nxt);
+        }
+      }
+      wave_lds_sync();
+      done = true;
+    } else {
+      // crowded bin: its own key range becomes the next level's range
+      unsigned nlo = 0xffffffffu, nhi = 0u;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        if (key[r] >= lo && key[r] <= hi) {
+          int b = (int)((key2f(key[r]) - flo) * scale);
+          b = b > 255 ? 255 : b;
+          if (b == bstar) {
+            nlo = umin_(nlo, key[r]);
+            nhi = umax_(nhi, key[r]);
+          }
+        }
+      }
+      lo = wave_min_u32(nlo);
+      hi = wave_max_u32(nhi);
+    }
+  }
+  if (!done) {                                   // bisection on all keys (global rank k)
+    klow = select_rank<RPL>(key, k);
+    khigh = klow;
+    if (even) {
+      int cle = 0;
+      unsigned nxt = 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        cle += (key[r] <= klow) ? 1 : 0;
+        if (key[r] > klow && key[r] < nxt) nxt = key[r];
+      }
+      if (wave_count<RPL>(cle) < k + 2) khigh = wave_min_u32(nxt);
+    }
+  }
+}
+
 // TRIM = false: nanmedian.  TRIM = true: mean of sorted[t0 : t0+tn] (np.sort order, NaN last, then nanmean):
 // the reference's 'trimmean' (subsampling.py:87-96).
 template <int RPL, bool TRIM>
 __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ cube0, int n, int64_t P,
                                                      int TP, float* __restrict__ out0, int t0, int tn) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // n x (TP+1)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 256 histogram words per wave, then the n x (TP+1) tile
   const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;       // blockIdx.y = cube of the batch
   float* __restrict__ out = out0 + (size_t)blockIdx.y * P;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
   const int ldt = TP + 1;
+  unsigned* hist = reinterpret_cast<unsigned*>(smem) + 256 * wave;
+  float* tile = smem + 256 * nw;
   const int64_t p0 = (int64_t)blockIdx.x * TP;
   // stage: TP consecutive pixels of every frame.  The kernel is bound by this load (400 row segments of 128 bytes,
   // 1 MB apart), so each thread issues a batch of 16-byte loads (8 threads per segment, 32 frames per pass) before
@@ -171,23 +353,9 @@ __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ c
     } else if (m == 0) {
       res = __uint_as_float(0x7fc00000u);
     } else {
-      const int k = (m - 1) >> 1;              // lower median rank (0-based)
-      const unsigned ans = select_rank<RPL>(key, k);
-      const float lo = key2f(ans);
-      if (m & 1) {
-        res = lo;
-      } else {
-        int cle = 0;
-        unsigned nxt = 0xffffffffu;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          cle += __popcll(__ballot(key[r] <= ans));
-          if (key[r] > ans && key[r] < nxt) nxt = key[r];
-        }
-        nxt = wave_min_u32(nxt);
-        const float hi = (cle >= k + 2) ? lo : key2f(nxt);
-        res = (lo + hi) * 0.5f;
-      }
+      unsigned klow, khigh;
+      median_keys<RPL>(key, m, hist, lane, klow, khigh);
+      res = (m & 1) ? key2f(klow) : (key2f(klow) + key2f(khigh)) * 0.5f;    // even: (a+b)*0.5 in float32, as numpy
     }
     if (lane == 0) out[p] = res;
   }
@@ -298,8 +466,9 @@ __global__ void colreduce_kernel(const float* __restrict__ cube0, int n, int64_t
 template <int RPL, bool TRIM>
 int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64_t P, float* out, int t0, int tn) {
   int TP = 32;
-  while (TP > 1 && (size_t)n * (TP + 1) * 4 > 150 * 1024) TP >>= 1;
-  const size_t lds = (size_t)n * (TP + 1) * 4;
+  const size_t hist_bytes = 8 * 256 * 4;                    // 8 waves per workgroup
+  while (TP > 1 && (size_t)n * (TP + 1) * 4 + hist_bytes > 150 * 1024) TP >>= 1;
+  const size_t lds = (size_t)n * (TP + 1) * 4 + hist_bytes;
   auto kern = median_kernel<RPL, TRIM>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

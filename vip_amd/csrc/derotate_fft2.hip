@@ -32,13 +32,15 @@ __device__ __forceinline__ void sincos_pi(double s, float& sn, float& cs) {
   sincospif((float)r, &sn, &cs);
 }
 
-// v = x1 + i x2 (D1) -> y1 + i y2 (D1), real shifts by s1 / s2; alt1/alt2 = alternating sums of x1 / x2
-template <class P>
+// v = x1 + i x2 (D1) -> y1 + i y2 (D1), real shifts by s1 / s2; alt1/alt2 = alternating sums of x1 / x2.
+// LIVE4: only the inputs at the frame's canvas positions [3L/8, 5L/8) are set (pruned first butterflies);
+// KEEP4: only those output positions are produced (pruned last butterflies).
+template <class P, bool LIVE4 = false, bool KEEP4 = false>
 __device__ __forceinline__ void pair_shift(cf (&v)[P::VL], const Twiddles<P>& tw, cf* __restrict__ lds, double s1,
                                            double s2, int lane, int sub, float& alt1, float& alt2,
                                            float& sin1, float& sin2) {   // sinX = sin(pi sX)/L
   constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3;
-  fft_forward<P>(v, tw, lds, lane, sub);
+  fft_forward<P, LIVE4>(v, tw, lds, lane, sub);
   const int u0 = sub * P::U3L;
 #pragma unroll
   for (int ul = 0; ul < P::U3L; ++ul) {
@@ -55,10 +57,12 @@ __device__ __forceinline__ void pair_shift(cf (&v)[P::VL], const Twiddles<P>& tw
   ShearPhase<P> p1, p2;
   p1.init(s1, lane, sub);
   p2.init(s2, lane, sub);
+  p1.pa = mkcf(0.5f * p1.pa.x, 0.5f * p1.pa.y);        // W = q1 (Z + conj Z~)/2 + q2 (Z - conj Z~)/2: halves folded in
+  p2.pa = mkcf(0.5f * p2.pa.x, 0.5f * p2.pa.y);
   float sn1, cn1, sn2, cn2;
   sincos_pi(s1, sn1, cn1);
   sincos_pi(s2, sn2, cn2);
-  const float c1n = cn1 * (1.0f / (float)P::L), c2n = cn2 * (1.0f / (float)P::L);
+  const float c1n = cn1 * (0.5f / (float)P::L), c2n = cn2 * (0.5f / (float)P::L);
   sin1 = sn1 * (1.0f / (float)P::L);
   sin2 = sn2 * (1.0f / (float)P::L);
 #pragma unroll
@@ -88,17 +92,16 @@ __device__ __forceinline__ void pair_shift(cf (&v)[P::VL], const Twiddles<P>& tw
         q1 = mkcf(c1n, 0.f);
         q2 = mkcf(c2n, 0.f);
       }
-      const cf A = mkcf(0.5f * (q1.x + q2.x), 0.5f * (q1.y + q2.y));
-      const cf B = mkcf(0.5f * (q1.x - q2.x), 0.5f * (q1.y - q2.y));
+      // spectra of the two real lines: E = Z + conj(Z~) = 2 X1, O = Z - conj(Z~) = 2i X2;  W = q1 E + q2 O
       const cf z = v[ul * R3 + kb];
-      v[ul * R3 + kb] = mkcf(z.x * A.x - z.y * A.y + zm.x * B.x + zm.y * B.y,
-                                    z.x * A.y + z.y * A.x + zm.x * B.y - zm.y * B.x);
+      const cf E = cadd_conj(z, zm), O = csub_conj(z, zm);
+      v[ul * R3 + kb] = cmla(q2, O, cmul(q1, E));
     }
     p1.next_u();
     p2.next_u();
   }
   xbar<P>(tw);                               // every mirror read done before the inverse reuses the region
-  fft_inverse<P>(v, tw, lds, lane, sub);
+  fft_inverse<P, KEEP4>(v, tw, lds, lane, sub);
 }
 
 struct Aux {          // per-batch auxiliary arrays (device)
@@ -213,16 +216,20 @@ struct RingTasks {
 // every such request moves a whole line between L2 and L1 (measured: 1.3 ms for the loads and 1.2 ms for the stores of
 // shear 2 at C2, the transforms hidden behind them).  Any two lines may share a transform, so the pairs are chosen
 // 64 apart -- rows (Y, Y+64), columns (X, X+64) -- and the intermediates are stored as 2x2 blocks
-//     blk[t][u] = (Y1@X1, Y2@X1, Y1@X2, Y2@X2),  Y1 = off + 128 (t/64) + t%64,  X1 = 128 (u/64) + u%64:
+//     blk[t][u] = (Y1@X1, Y2@X1, Y1@X2, Y2@X2),  Y1 = row0 + 128 (t/64) + t%64,  X1 = 128 (u/64) + u%64
+// (row0 = first data row r0 in A1r, = off in A2r):
 // element j of a line lives in lane j%64, so both rows of a block are registers of the SAME lane of the column
 // kernel and both columns registers of the same lane of the row kernels -- every access is one float4 with no
 // shuffle: 16 bytes per scattered request in shear 2 (half the requests), 1 KB contiguous per instruction in shears
-// 1 and 3.  Block rows per frame: N/2 + 1 (the last one only holds canvas row off + N, live when the rot90
-// pre-step moves the data down by one row).
+// 1 and 3.  A1r is indexed by DATA row (canvas row - r0; r0 = off or off + 1 after the rot90 pre-step): the kernels always
+// place a frame's N live samples at the canonical line positions [off, off + N) and add the integer displacement
+// (r0 - off, c0 - off) to the shift instead -- R_s x = R_{s+d} x' for x'[j] = x[j + d], exactly (the kernel is a function
+// of position - shift), and sin(pi(s+d)) alt(x') = sin(pi s) alt(x).  So exactly R1/4 of the R1 inputs of every first
+// butterfly are live and the pruned butterflies of fft_wave.h apply (Plan::CAN_PRUNE).
 template <class P>
 struct Blk {
   static constexpr int N = P::L / 4, OFF = 3 * P::L / 8;
-  static constexpr int NB = N / 2 + 1;          // block rows per frame
+  static constexpr int NB = N / 2;              // block rows per frame
   static constexpr int NBC = P::L / 2;          // block columns
   static constexpr int NG = N / 128;            // groups of 64 block rows
   // register of line element jb + lane (jb a multiple of 64)
@@ -279,35 +286,33 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
     const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
     const int c0 = (p.q == 2 || p.q == 3) ? g.alt0 : g.off;
     const int tb = pr % half;                                       // block row (BLK)
-    const int Y1 = BLK ? g.off + 128 * (tb / 64) + (tb % 64) : r0 + 2 * tb;
-    const int Y2 = BLK ? Y1 + 64 : Y1 + 1;
-    const int yrel = Y1 - r0;
-    const bool lv1 = Y1 >= r0 && Y1 < r0 + g.N, lv2 = Y2 >= r0 && Y2 < r0 + g.N;   // always true unless BLK
-    if (BLK && !(live && (lv1 || lv2))) continue;                   // (one wave per line: no barrier inside)
     const float* frame = in + (int64_t)f * g.N * g.N;
-    int b1, st1, b2, st2;
-    src_map(p.q, Y1, g, b1, st1);
-    src_map(p.q, Y2, g, b2, st2);
     cf v[P::VL];
-#pragma unroll
-    for (int ul = 0; ul < P::U1L; ++ul)
-#pragma unroll
-      for (int n1 = 0; n1 < P::R1; ++n1) {
-        float x1 = 0.f, x2 = 0.f;
-        if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {       // compile-time window
-          const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
-          if (X >= c0 && X < c0 + g.N) {
-            const float t1 = lv1 ? frame[b1 + X * st1] : 0.f, t2 = lv2 ? frame[b2 + X * st2] : 0.f;
-            x1 = (t1 == t1) ? t1 : 0.f;
-            x2 = (t2 == t2) ? t2 : 0.f;
-          }
-        }
-        v[ul * P::R1 + n1] = mkcf(x1, x2);
-      }
-    const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
-    float alt1, alt2, sn1, sn2;
-    pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
     if constexpr (BLK) {
+      // data rows yrel, yrel + 64 (canvas rows r0 + yrel); the N live columns [c0, c0 + N) are placed at the canonical
+      // positions [off, off + N) and the displacement c0 - off goes into the shift (see Blk)
+      constexpr bool PR = P::CAN_PRUNE;
+      if (!live) continue;                                          // (one wave per line: no barrier inside)
+      const int yrel = 128 * (tb / 64) + (tb % 64);
+      const int Y1 = r0 + yrel, Y2 = Y1 + 64, dc = c0 - g.off;
+      int b1, st1, b2, st2;
+      src_map(p.q, Y1, g, b1, st1);
+      src_map(p.q, Y2, g, b2, st2);
+      if constexpr (!PR) {
+#pragma unroll
+        for (int i = 0; i < P::VL; ++i) v[i] = mkcf(0.f, 0.f);
+      }
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
+          const int X = P::M1 * n1 + lane + 64 * ul + dc;           // canvas column of canonical position M1 n1 + ...
+          const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
+          v[ul * P::R1 + n1] = mkcf((t1 == t1) ? t1 : 0.f, (t2 == t2) ? t2 : 0.f);
+        }
+      const double s1 = p.a * (double)(Y1 - g.c) + (double)dc, s2 = p.a * (double)(Y2 - g.c) + (double)dc;
+      float alt1, alt2, sn1, sn2;
+      pair_shift<P, PR, false>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
       using B = Blk<P>;
       float4* o = reinterpret_cast<float4*>(A1r) + ((int64_t)fl * B::NB + tb) * B::NBC + lane;
 #pragma unroll
@@ -315,24 +320,49 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
         const cf a = v[B::reg(128 * gq)], b = v[B::reg(128 * gq + 64)];
         o[64 * gq] = make_float4(a.x, a.y, b.x, b.y);
       }
-      if (lane == 0) {
-        if (lv1) aux.beta[fl * g.N + yrel] = sn1 * alt1;
-        if (lv2) aux.beta[fl * g.N + yrel + 64] = sn2 * alt2;
+      if (lane == 0) {                          // sin(pi(s+dc)) alt(x') = sin(pi s) alt(x): no sign to restore
+        aux.beta[fl * g.N + yrel] = sn1 * alt1;
+        aux.beta[fl * g.N + yrel + 64] = sn2 * alt2;
       }
-    } else if (live) {
-      float* o1 = A1r + ((int64_t)fl * g.N + yrel) * P::L;
-      float* o2 = o1 + P::L;
+    } else {
+      const int Y1 = r0 + 2 * tb, Y2 = Y1 + 1;
+      const int yrel = Y1 - r0;
+      int b1, st1, b2, st2;
+      src_map(p.q, Y1, g, b1, st1);
+      src_map(p.q, Y2, g, b2, st2);
 #pragma unroll
       for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
         for (int n1 = 0; n1 < P::R1; ++n1) {
-          const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
-          o1[X] = v[ul * P::R1 + n1].x;
-          o2[X] = v[ul * P::R1 + n1].y;
+          float x1 = 0.f, x2 = 0.f;
+          if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {       // compile-time window
+            const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
+            if (X >= c0 && X < c0 + g.N) {
+              const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
+              x1 = (t1 == t1) ? t1 : 0.f;
+              x2 = (t2 == t2) ? t2 : 0.f;
+            }
+          }
+          v[ul * P::R1 + n1] = mkcf(x1, x2);
         }
-      if (sub == 0 && lane == 0) {
-        aux.beta[fl * g.N + yrel] = sn1 * alt1;
-        aux.beta[fl * g.N + yrel + 1] = sn2 * alt2;
+      const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
+      float alt1, alt2, sn1, sn2;
+      pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+      if (live) {
+        float* o1 = A1r + ((int64_t)fl * g.N + yrel) * P::L;
+        float* o2 = o1 + P::L;
+#pragma unroll
+        for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+          for (int n1 = 0; n1 < P::R1; ++n1) {
+            const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
+            o1[X] = v[ul * P::R1 + n1].x;
+            o2[X] = v[ul * P::R1 + n1].y;
+          }
+        if (sub == 0 && lane == 0) {
+          aux.beta[fl * g.N + yrel] = sn1 * alt1;
+          aux.beta[fl * g.N + yrel + 1] = sn2 * alt2;
+        }
       }
     }
    }
@@ -520,24 +550,25 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
     const int X1 = 128 * (u / 64) + (u % 64), X2 = X1 + 64;
     const RotFrame p = fr[f];
     const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+    const int dr = r0 - g.off;                     // the data rows sit at the canonical positions: displacement -> shift
     const float4* src = reinterpret_cast<const float4*>(A1r) + (int64_t)fl * B::NB * B::NBC + u;
+    constexpr bool PR = P::CAN_PRUNE;
     cf v[P::VL];
+    if constexpr (!PR) {
 #pragma unroll
-    for (int i = 0; i < P::VL; ++i) v[i] = mkcf(0.f, 0.f);
-#pragma unroll
-    for (int G = 0; G <= B::NG; ++G) {
-      const int Y1 = B::OFF + 128 * G + lane, Y2 = Y1 + 64;
-      const bool lv1 = Y1 >= r0 && Y1 < r0 + B::N, lv2 = (G < B::NG) && Y2 >= r0 && Y2 < r0 + B::N;
-      float4 blk = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lv1 || lv2) blk = src[(int64_t)(64 * G + lane) * B::NBC];
-      v[B::reg(B::OFF + 128 * G)] = lv1 ? mkcf(blk.x, blk.z) : mkcf(0.f, 0.f);
-      if (G < B::NG) v[B::reg(B::OFF + 128 * G + 64)] = lv2 ? mkcf(blk.y, blk.w) : mkcf(0.f, 0.f);
+      for (int i = 0; i < P::VL; ++i) v[i] = mkcf(0.f, 0.f);
     }
-    const double s1 = p.b * (double)(X1 - g.c), s2 = p.b * (double)(X2 - g.c);
+#pragma unroll
+    for (int G = 0; G < B::NG; ++G) {
+      const float4 blk = src[(int64_t)(64 * G + lane) * B::NBC];
+      v[B::reg(B::OFF + 128 * G)] = mkcf(blk.x, blk.z);
+      v[B::reg(B::OFF + 128 * G + 64)] = mkcf(blk.y, blk.w);
+    }
+    const double s1 = p.b * (double)(X1 - g.c) + (double)dr, s2 = p.b * (double)(X2 - g.c) + (double)dr;
     float alt1, alt2, sn1, sn2;
-    pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
-    // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m
-    const float bfl = aux.bf[fl];
+    pair_shift<P, PR, PR>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+    // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m;  sn = sin(pi(s+dr))/L
+    const float bfl = (dr & 1) ? -aux.bf[fl] : aux.bf[fl];
     const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
     const float k2c = sn2 * ((X2 & 1) ? -bfl : bfl);
     float4* dst = reinterpret_cast<float4*>(A2r) + (int64_t)fl * B::NB * B::NBC + u;
@@ -619,7 +650,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
     }
     const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
     float alt1, alt2, sn1, sn2;
-    pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+    pair_shift<P, false, BLK && P::CAN_PRUNE>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
     if (live) {
       const float gs = aux.gsum[fl];
       const float c1 = sn1 * (aux.kv[fl * g.N + m] + ((Y1 & 1) ? -gs : gs));
@@ -699,7 +730,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   const dim3 blk(64 * P::WPB);
   for (int64_t f0 = 0; f0 < n; f0 += chunk) {
     const int nf = (int)((n - f0) < chunk ? (n - f0) : chunk);
-    const int64_t npairs = (int64_t)nf * (g.N / 2 + (BLK ? 1 : 0));
+    const int64_t npairs = (int64_t)nf * (g.N / 2);
     int gr = (int)cdiv(npairs, P::LPB);
     if (gr > maxwg) gr = maxwg;
     if (gr < 8) gr = 8;

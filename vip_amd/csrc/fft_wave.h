@@ -36,6 +36,25 @@ __device__ __forceinline__ cf cmulc(cf a, cf b) {
       : "=&v"(d) : "v"(a), "v"(b));
   return d;
 }
+// a*b + c in two instructions
+__device__ __forceinline__ cf cmla(cf a, cf b, cf c) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// a + conj(b) and a - conj(b)
+__device__ __forceinline__ cf cadd_conj(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ cf csub_conj(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 // a + (-i) b = (a.x + b.y, a.y - b.x)   and   a - (-i) b = a + i b = (a.x - b.y, a.y + b.x)
@@ -141,6 +160,55 @@ struct Dft<16, INV> {
   }
 };
 
+// v * w16^E (forward) or v * conj(w16^E) (inverse), E a compile-time exponent
+template <bool INV, int E>
+__device__ __forceinline__ cf mulw16(cf v) {
+  constexpr int e = E & 15;
+  if constexpr (e == 0) return v;
+  else if constexpr (e == 8) return mkcf(-v.x, -v.y);
+  else if constexpr (e == 4) return mul_mi<INV>(v);              // w16^4 = -i
+  else if constexpr (e == 12) return mul_mi<!INV>(v);            // w16^12 = +i
+  else if constexpr (e < 8) return twc<INV>(v, e);
+  else {
+    const cf t = twc<INV>(v, e - 8);
+    return mkcf(-t.x, -t.y);
+  }
+}
+
+// Pruned radix-16 butterflies.  A frame of N = L/4 pixels sits at canvas offset 3L/8, so of the 16 inputs of a first-stage
+// (decimation-in-frequency) butterfly only n1 = 6..9 are non-zero, and of the 16 outputs of a last-stage inverse
+// butterfly only n1 = 6..9 survive the crop.  With k = l + 4h:
+//   X[l + 4h] = sum_m a_m w16^((6+m)(l+4h)) = (-1)^h sum_m [a_m w16^((6+m) l)] w4^(hm)
+// i.e. four 4-point DFTs of twiddled inputs; the factor (-1)^h = w4^(2h) is a circular shift of the DFT4 input by two.
+// 4 DFT4 + 8 non-trivial twiddles instead of 8 DFT4 + 8 twiddles (forward), + 12 adds (inverse).
+__device__ __forceinline__ void dft16_fwd_live4(cf* __restrict__ v) {      // in: v[6..9]; out: v[0..15] natural order
+  const cf a0 = v[6], a1 = v[7], a2 = v[8], a3 = v[9];
+#define VIPMI_P16_FWD(l)                                                                             \
+  {                                                                                                  \
+    cf y0 = mulw16<false, 6 * l>(a0), y1 = mulw16<false, 7 * l>(a1), y2 = mulw16<false, 8 * l>(a2),  \
+       y3 = mulw16<false, 9 * l>(a3);                                                                \
+    dft4<false>(y2, y3, y0, y1);                                                                     \
+    v[l] = y2; v[l + 4] = y3; v[l + 8] = y0; v[l + 12] = y1;                                         \
+  }
+  VIPMI_P16_FWD(0) VIPMI_P16_FWD(1) VIPMI_P16_FWD(2) VIPMI_P16_FWD(3)
+#undef VIPMI_P16_FWD
+}
+__device__ __forceinline__ void dft16_inv_keep4(cf* __restrict__ v) {      // in: v[0..15]; out: v[6..9] only
+  cf x0, x1, x2, x3;
+#define VIPMI_P16_INV(l)                                                                             \
+  {                                                                                                  \
+    cf z0 = v[l], z1 = v[l + 4], z2 = v[l + 8], z3 = v[l + 12];                                      \
+    dft4<true>(z0, z1, z2, z3);                                                                      \
+    const cf t0 = mulw16<true, 6 * l>(z2), t1 = mulw16<true, 7 * l>(z3), t2 = mulw16<true, 8 * l>(z0), \
+             t3 = mulw16<true, 9 * l>(z1);                                                           \
+    if (l == 0) { x0 = t0; x1 = t1; x2 = t2; x3 = t3; }                                              \
+    else { x0 = cadd(x0, t0); x1 = cadd(x1, t1); x2 = cadd(x2, t2); x3 = cadd(x3, t3); }             \
+  }
+  VIPMI_P16_INV(0) VIPMI_P16_INV(1) VIPMI_P16_INV(2) VIPMI_P16_INV(3)
+#undef VIPMI_P16_INV
+  v[6] = x0; v[7] = x1; v[8] = x2; v[9] = x3;
+}
+
 template <int R1_, int R2_, int R3_, int S1_, int T1_, int T2_, int WPB_, int WPL_>
 struct Plan {
   static constexpr int R1 = R1_, R2 = R2_, R3 = R3_;
@@ -159,6 +227,7 @@ struct Plan {
   // n1 in [NLO, NLO + NCNT) are exactly the N output positions; inputs may be shifted by one
   // (rot90 pre-step), which adds n1 = NLO + NCNT.
   static constexpr int NLO = 3 * R1_ / 8, NCNT = R1_ / 4;
+  static constexpr bool CAN_PRUNE = (R1_ == 16);         // pruned first / last radix-16 stage (dft16_fwd_live4 / dft16_inv_keep4)
   static_assert(U1 * R1 == VPT && U2 * R2 == VPT && U3 * R3 == VPT, "bad radix plan");
 };
 // WPL > 1: the line is split over WPL waves (VL = 16 complex registers per lane instead of 32/64), which
@@ -265,15 +334,18 @@ __device__ __forceinline__ void xbar(const Twiddles<P>& tw) {
 }
 
 // forward transform: D1 in, D3 (spectrum) out
-template <class P>
+// LIVE4: only the inputs n1 = 6..9 of every first-stage butterfly are set (and non-zero); the others are not read
+template <class P, bool LIVE4 = false>
 __device__ __forceinline__ void fft_forward(cf (&v)[P::VL], const Twiddles<P>& tw, cf* __restrict__ lds, int lane,
                                             int sub) {
+  static_assert(!LIVE4 || P::CAN_PRUNE, "pruned first stage needs R1 = 16");
   constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3, M2 = P::M2;
   // ---------------- forward (DIF) ----------------
 #pragma unroll
   for (int ul = 0; ul < P::U1L; ++ul) {
     const int u = sub * P::U1L + ul;
-    Dft<R1, false>::run(&v[ul * R1]);
+    if constexpr (LIVE4) dft16_fwd_live4(&v[ul * R1]);
+    else Dft<R1, false>::run(&v[ul * R1]);
 #pragma unroll
     for (int k1 = 1; k1 < R1; ++k1) v[ul * R1 + k1] = tw.template apply1<false>(v[ul * R1 + k1], u, k1);
 #pragma unroll
@@ -309,9 +381,11 @@ __device__ __forceinline__ void fft_forward(cf (&v)[P::VL], const Twiddles<P>& t
 }
 
 // inverse transform: spectrum in D3 (v[ul*R3 + kb]) -> D1 natural order; unnormalised (fold 1/L into the multiplier)
-template <class P>
+// KEEP4: only the outputs n1 = 6..9 of every last-stage butterfly are produced (the crop window)
+template <class P, bool KEEP4 = false>
 __device__ __forceinline__ void fft_inverse(cf (&v)[P::VL], const Twiddles<P>& tw, cf* __restrict__ lds, int lane,
                                             int sub) {
+  static_assert(!KEEP4 || P::CAN_PRUNE, "pruned last stage needs R1 = 16");
   constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3, M2 = P::M2;
 #pragma unroll
   for (int ul = 0; ul < P::U3L; ++ul) {
@@ -350,7 +424,8 @@ __device__ __forceinline__ void fft_inverse(cf (&v)[P::VL], const Twiddles<P>& t
     const int u = sub * P::U1L + ul;
 #pragma unroll
     for (int k1 = 1; k1 < R1; ++k1) v[ul * R1 + k1] = tw.template apply1<true>(v[ul * R1 + k1], u, k1);
-    Dft<R1, true>::run(&v[ul * R1]);
+    if constexpr (KEEP4) dft16_inv_keep4(&v[ul * R1]);
+    else Dft<R1, true>::run(&v[ul * R1]);
   }
 }
 
