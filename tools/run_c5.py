@@ -7,15 +7,8 @@ from vip_amd.psfsub import pca
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-g = torch.Generator(device="cuda").manual_seed(0)
-yy, xx = torch.meshgrid(torch.arange(N, device="cuda"), torch.arange(N, device="cuda"), indexing="ij")
-env = torch.exp(-torch.sqrt((yy - N // 2) ** 2.0 + (xx - N // 2) ** 2.0) / (N / 8)).float()
-modes = torch.randn((30, N, N), device="cuda", generator=g) * env
-coef = torch.randn((n, 30), device="cuda", generator=g) * (2.0 ** (-torch.arange(30, device="cuda") / 3))
-cube = torch.empty((n, N, N), device="cuda")
-for i in range(0, n, 100):
-    cube[i:i + 100] = torch.tensordot(coef[i:i + 100], modes, dims=1) + 3 * env + 0.2 * torch.randn((min(100, n - i), N, N), device="cuda", generator=g)
-ang = np.linspace(0, 90, n)
+from vip_amd.synth import synth_adi_device
+cube, ang = synth_adi_device(n, N, seed=0)
 ctx = B.get_context(); ctx.set_option("timing", 1)
 for rep in range(2):
     ctx.reset_timers(); torch.cuda.synchronize(); t = time.perf_counter()

@@ -115,10 +115,12 @@ __device__ __forceinline__ int lane_rank_in(unsigned long long mask) {   // set 
 }
 
 // Lower median key (rank k = (m-1)/2 of the m valid keys) and, for even m, the upper one (rank k+1); invalid entries
-// carry the key 0xffffffff.  hist: 256 words of LDS private to the wave.
+// carry the key 0xffffffff.
 template <int RPL>
 __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, unsigned* __restrict__ hist, int lane,
                                             unsigned& klow, unsigned& khigh) {
+  // hist: HIST_WORDS words of LDS private to the wave: 256 bins, one dump bin for the keys outside the current range
+  // (keeps the loops free of divergent branches), then 64 dump slots for the lanes that have no candidate to store
   const int k = (m - 1) >> 1;
   const bool even = (m & 1) == 0;
   unsigned lo = 0xffffffffu, hi = 0u;
@@ -134,10 +136,9 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
   for (int level = 0; level < 3 && !done; ++level) {
     if (lo == hi) {                              // every remaining key is the same value
       klow = lo;
-      khigh = lo;                                // (rank + 1 may lie above the range: fixed below)
+      khigh = lo;
       done = true;
-      // upper median outside a range of identical keys: the smallest key above it
-      if (even) {
+      if (even) {                                // upper median: the same value again, or the smallest key above it
         int cle = 0;
         unsigned nxt = 0xffffffffu;
 #pragma unroll
@@ -153,15 +154,19 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
     const float scale = 256.0f / (fhi - flo);
     if (!(scale > 0.f && scale < 3.0e38f)) break;          // range overflows / underflows: bisection
     reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane == 0) hist[256] = 0u;
     wave_lds_sync();
+    // bin of every key (256 = outside the range) and, from the returning atomic, its ordinal inside the bin
+    int bin[RPL];
+    unsigned ord[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
-      if (key[r] >= lo && key[r] <= hi) {
-        int b = (int)((key2f(key[r]) - flo) * scale);
-        b = b > 255 ? 255 : b;
-        atomicAdd(&hist[b], 1u);
-      }
+      int b = (int)((key2f(key[r]) - flo) * scale);
+      b = b > 255 ? 255 : b;
+      bin[r] = (key[r] >= lo && key[r] <= hi) ? b : 256;
     }
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) ord[r] = atomicAdd(&hist[bin[r]], 1u);
     wave_lds_sync();
     const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];
     const unsigned s4 = h.x + h.y + h.z + h.w;
@@ -180,20 +185,9 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
     rank = (int)rem;
     wave_lds_sync();
     if (c <= 64u) {
-      // compact the bin's keys into LDS (the histogram is dead), one per lane, rank by counting
-      unsigned base = 0;
+      // the bin's keys go to slots 0..c-1 of the (dead) histogram by their ordinals, everything else to the dump slots
 #pragma unroll
-      for (int r = 0; r < RPL; ++r) {
-        bool pred = false;
-        if (key[r] >= lo && key[r] <= hi) {
-          int b = (int)((key2f(key[r]) - flo) * scale);
-          b = b > 255 ? 255 : b;
-          pred = b == bstar;
-        }
-        const unsigned long long pm = __ballot(pred);
-        if (pred) hist[base + lane_rank_in(pm)] = key[r];
-        base += (unsigned)__popcll(pm);
-      }
+      for (int r = 0; r < RPL; ++r) hist[bin[r] == bstar ? ord[r] : 257u + (unsigned)lane] = key[r];
       wave_lds_sync();
       const unsigned cand = (unsigned)lane < c ? hist[lane] : 0xffffffffu;
       int less = 0;
@@ -222,13 +216,9 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
       unsigned nlo = 0xffffffffu, nhi = 0u;
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
-        if (key[r] >= lo && key[r] <= hi) {
-          int b = (int)((key2f(key[r]) - flo) * scale);
-          b = b > 255 ? 255 : b;
-          if (b == bstar) {
-            nlo = umin_(nlo, key[r]);
-            nhi = umax_(nhi, key[r]);
-          }
+        if (bin[r] == bstar) {
+          nlo = umin_(nlo, key[r]);
+          nhi = umax_(nhi, key[r]);
         }
       }
       lo = wave_min_u32(nlo);
@@ -251,6 +241,8 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
   }
 }
 
+constexpr int HIST_WORDS = 384;                  // 256 bins + dump bin + 64 dump slots, padded to a multiple of 64 words
+
 // TRIM = false: nanmedian.  TRIM = true: mean of sorted[t0 : t0+tn] (np.sort order, NaN last, then nanmean):
 // the reference's 'trimmean' (subsampling.py:87-96).
 template <int RPL, bool TRIM>
@@ -262,8 +254,8 @@ __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
   const int ldt = TP + 1;
-  unsigned* hist = reinterpret_cast<unsigned*>(smem) + 256 * wave;
-  float* tile = smem + 256 * nw;
+  unsigned* hist = reinterpret_cast<unsigned*>(smem) + HIST_WORDS * wave;
+  float* tile = smem + HIST_WORDS * nw;
   const int64_t p0 = (int64_t)blockIdx.x * TP;
   // stage: TP consecutive pixels of every frame.  The kernel is bound by this load (400 row segments of 128 bytes,
   // 1 MB apart), so each thread issues a batch of 16-byte loads (8 threads per segment, 32 frames per pass) before
@@ -466,7 +458,7 @@ __global__ void colreduce_kernel(const float* __restrict__ cube0, int n, int64_t
 template <int RPL, bool TRIM>
 int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64_t P, float* out, int t0, int tn) {
   int TP = 32;
-  const size_t hist_bytes = 8 * 256 * 4;                    // 8 waves per workgroup
+  const size_t hist_bytes = 8 * HIST_WORDS * 4;             // 8 waves per workgroup
   while (TP > 1 && (size_t)n * (TP + 1) * 4 + hist_bytes > 150 * 1024) TP >>= 1;
   const size_t lds = (size_t)n * (TP + 1) * 4 + hist_bytes;
   auto kern = median_kernel<RPL, TRIM>;

@@ -35,10 +35,20 @@ __device__ __forceinline__ void sincos_pi(double s, float& sn, float& cs) {
 // v = x1 + i x2 (D1) -> y1 + i y2 (D1), real shifts by s1 / s2; alt1/alt2 = alternating sums of x1 / x2.
 // LIVE4: only the inputs at the frame's canvas positions [3L/8, 5L/8) are set (pruned first butterflies);
 // KEEP4: only those output positions are produced (pruned last butterflies).
-template <class P, bool LIVE4 = false, bool KEEP4 = false>
+// dph (optional): the per-frame table of rs_phase_delta for s2 - s1 -- the phases of the second line then follow from
+// those of the first by three complex multiplies instead of four more sincos evaluations.
+template <class P, bool LIVE4 = false, bool KEEP4 = false, bool DELTA = false>
 __device__ __forceinline__ void pair_shift(cf (&v)[P::VL], const Twiddles<P>& tw, cf* __restrict__ lds, double s1,
                                            double s2, int lane, int sub, float& alt1, float& alt2,
-                                           float& sin1, float& sin2) {   // sinX = sin(pi sX)/L
+                                           float& sin1, float& sin2,      // sinX = sin(pi sX)/L
+                                           const cf* __restrict__ dph = nullptr) {
+  cf d_lane = mkcf(1.f, 0.f), d_z = d_lane, d_w = d_lane, d_pi = d_lane;
+  if constexpr (DELTA) {                                 // issued before the transform: the loads are back long before they are used
+    d_lane = dph[lane];
+    d_z = dph[64];
+    d_w = dph[65];
+    d_pi = dph[66];
+  }
   constexpr int R1 = P::R1, R2 = P::R2, R3 = P::R3;
   fft_forward<P, LIVE4>(v, tw, lds, lane, sub);
   const int u0 = sub * P::U3L;
@@ -56,12 +66,18 @@ __device__ __forceinline__ void pair_shift(cf (&v)[P::VL], const Twiddles<P>& tw
   }
   ShearPhase<P> p1, p2;
   p1.init(s1, lane, sub);
-  p2.init(s2, lane, sub);
   p1.pa = mkcf(0.5f * p1.pa.x, 0.5f * p1.pa.y);        // W = q1 (Z + conj Z~)/2 + q2 (Z - conj Z~)/2: halves folded in
-  p2.pa = mkcf(0.5f * p2.pa.x, 0.5f * p2.pa.y);
   float sn1, cn1, sn2, cn2;
   sincos_pi(s1, sn1, cn1);
-  sincos_pi(s2, sn2, cn2);
+  if constexpr (DELTA) {
+    p2.init_from(p1, d_lane, d_z, d_w);
+    sn2 = sn1 * d_pi.x + cn1 * d_pi.y;                 // sin / cos of pi (s1 + delta)
+    cn2 = cn1 * d_pi.x - sn1 * d_pi.y;
+  } else {
+    p2.init(s2, lane, sub);
+    p2.pa = mkcf(0.5f * p2.pa.x, 0.5f * p2.pa.y);
+    sincos_pi(s2, sn2, cn2);
+  }
   const float c1n = cn1 * (0.5f / (float)P::L), c2n = cn2 * (0.5f / (float)P::L);
   sin1 = sn1 * (1.0f / (float)P::L);
   sin2 = sn2 * (1.0f / (float)P::L);
@@ -110,6 +126,7 @@ struct Aux {          // per-batch auxiliary arrays (device)
   float* kv;          // [nf][N]   K[off + m]
   float* gam;         // [nf][L]   (-1)^X gamma_X
   float* gsum;        // [nf]      Gam
+  cf* dph;            // [nf][2][DPH_STRIDE] phase factors of the 64-line increments (rs_phase_delta), blocked plans only
 };
 
 #define VIPMI_SLOT_PROLOGUE()                                                     \
@@ -247,6 +264,27 @@ __device__ __forceinline__ void src_map(int q, int Y, const RotGeom& g, int& bas
   }
 }
 
+// Phase factors of a shift increment delta (= 64 a for the row shears, 64 b for the column shear: the two lines of a
+// pair are 64 apart): out[fl][dir][0..63] = exp(-2 pi i m_lane delta/L) (m_lane as in ShearPhase::init), [64] the factor
+// of z, [65] the factor of w, [66] = (cos(pi delta), sin(pi delta)).  float64 evaluation, one tiny launch per batch.
+constexpr int DPH_STRIDE = 68;
+template <class P>
+__global__ __launch_bounds__(128) void rs_phase_delta(const RotFrame* __restrict__ fr, int f0, cf* __restrict__ out) {
+  const int fl = blockIdx.x, dir = blockIdx.y, t = threadIdx.x;
+  if (t >= 67) return;
+  const RotFrame p = fr[f0 + fl];
+  const double delta = 64.0 * (dir == 0 ? p.a : p.b);
+  double turns;
+  if (t < 64) turns = (double)(t / P::R2 + P::R1 * (t % P::R2)) * delta / (double)P::L;
+  else if (t == 64) turns = (double)(64 / P::R2) * delta / (double)P::L;
+  else if (t == 65) turns = (double)(P::R1 * P::R2) * delta / (double)P::L;
+  else turns = -0.5 * delta;                      // exp(+i pi delta) = (cos, sin)(pi delta)
+  turns -= rint(turns);
+  double sn, cs;
+  sincospi(-2.0 * turns, &sn, &cs);
+  out[((int64_t)fl * 2 + dir) * DPH_STRIDE + t] = mkcf((float)cs, (float)sn);
+}
+
 // ---- shear 1: row pairs (2p, 2p+1) ----
 template <class P>
 __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict__ in,
@@ -312,7 +350,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
         }
       const double s1 = p.a * (double)(Y1 - g.c) + (double)dc, s2 = p.a * (double)(Y2 - g.c) + (double)dc;
       float alt1, alt2, sn1, sn2;
-      pair_shift<P, PR, false>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+      pair_shift<P, PR, false, true>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2,
+                               aux.dph + ((int64_t)fl * 2 + 0) * DPH_STRIDE);
       using B = Blk<P>;
       float4* o = reinterpret_cast<float4*>(A1r) + ((int64_t)fl * B::NB + tb) * B::NBC + lane;
 #pragma unroll
@@ -325,29 +364,27 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
         aux.beta[fl * g.N + yrel + 64] = sn2 * alt2;
       }
     } else {
-      const int Y1 = r0 + 2 * tb, Y2 = Y1 + 1;
+      constexpr bool PR = P::CAN_PRUNE;
+      const int Y1 = r0 + 2 * tb, Y2 = Y1 + 1, dc = c0 - g.off;
       const int yrel = Y1 - r0;
       int b1, st1, b2, st2;
       src_map(p.q, Y1, g, b1, st1);
       src_map(p.q, Y2, g, b2, st2);
+      if constexpr (!PR) {
+#pragma unroll
+        for (int i = 0; i < P::VL; ++i) v[i] = mkcf(0.f, 0.f);
+      }
 #pragma unroll
       for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
-        for (int n1 = 0; n1 < P::R1; ++n1) {
-          float x1 = 0.f, x2 = 0.f;
-          if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {       // compile-time window
-            const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
-            if (X >= c0 && X < c0 + g.N) {
-              const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
-              x1 = (t1 == t1) ? t1 : 0.f;
-              x2 = (t2 == t2) ? t2 : 0.f;
-            }
-          }
-          v[ul * P::R1 + n1] = mkcf(x1, x2);
+        for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {      // the N live columns at the canonical positions (see Blk)
+          const int X = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul) + dc;
+          const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
+          v[ul * P::R1 + n1] = mkcf((t1 == t1) ? t1 : 0.f, (t2 == t2) ? t2 : 0.f);
         }
-      const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
+      const double s1 = p.a * (double)(Y1 - g.c) + (double)dc, s2 = p.a * (double)(Y2 - g.c) + (double)dc;
       float alt1, alt2, sn1, sn2;
-      pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+      pair_shift<P, PR, false>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
       if (live) {
         float* o1 = A1r + ((int64_t)fl * g.N + yrel) * P::L;
         float* o2 = o1 + P::L;
@@ -475,26 +512,28 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2(const float* __restrict
         tile[row * LDT + c] = (c < wcols) ? src[(int64_t)row * P::L + c] : 0.f;
       }
       __syncthreads();
+      constexpr bool PR = P::CAN_PRUNE;
+      const int dr = r0 - g.off;                   // data rows at the canonical positions, displacement -> shift (see Blk)
       cf v[P::VL];
+      if constexpr (!PR) {
+#pragma unroll
+        for (int i = 0; i < P::VL; ++i) v[i] = mkcf(0.f, 0.f);
+      }
 #pragma unroll
       for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
-        for (int n1 = 0; n1 < P::R1; ++n1) {
-          cf val = mkcf(0.f, 0.f);
-          if (n1 >= P::NLO && n1 <= P::NLO + P::NCNT) {     // compile-time window
-            const int yrel = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul) - r0;
-            if (yrel >= 0 && yrel < g.N) val = mkcf(tile[yrel * LDT + 2 * slot], tile[yrel * LDT + 2 * slot + 1]);
-          }
-          v[ul * P::R1 + n1] = val;
+        for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
+          const int yrel = P::M1 * (n1 - P::NLO) + lane + 64 * (sub * P::U1L + ul);      // off == M1*NLO
+          v[ul * P::R1 + n1] = mkcf(tile[yrel * LDT + 2 * slot], tile[yrel * LDT + 2 * slot + 1]);
         }
       __syncthreads();
       const int X1 = X0 + 2 * slot, X2 = X1 + 1;
-      const double s1 = p.b * (double)(X1 - g.c), s2 = p.b * (double)(X2 - g.c);
+      const double s1 = p.b * (double)(X1 - g.c) + (double)dr, s2 = p.b * (double)(X2 - g.c) + (double)dr;
       float alt1, alt2, sn1, sn2;
-      pair_shift<P>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+      pair_shift<P, PR, PR>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
       __syncthreads();
-      // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m
-      const float bfl = aux.bf[fl];
+      // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m;  sn = sin(pi(s+dr))/L
+      const float bfl = (dr & 1) ? -aux.bf[fl] : aux.bf[fl];
       const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
       const float k2c = sn2 * ((X2 & 1) ? -bfl : bfl);
 #pragma unroll
@@ -566,7 +605,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
     }
     const double s1 = p.b * (double)(X1 - g.c) + (double)dr, s2 = p.b * (double)(X2 - g.c) + (double)dr;
     float alt1, alt2, sn1, sn2;
-    pair_shift<P, PR, PR>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+    pair_shift<P, PR, PR, true>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2,
+                          aux.dph + ((int64_t)fl * 2 + 1) * DPH_STRIDE);
     // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m;  sn = sin(pi(s+dr))/L
     const float bfl = (dr & 1) ? -aux.bf[fl] : aux.bf[fl];
     const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
@@ -650,7 +690,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
     }
     const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
     float alt1, alt2, sn1, sn2;
-    pair_shift<P, false, BLK && P::CAN_PRUNE>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2);
+    pair_shift<P, false, P::CAN_PRUNE, BLK>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2,
+                                                   aux.dph + ((int64_t)fl * 2 + 0) * DPH_STRIDE);
     if (live) {
       const float gs = aux.gsum[fl];
       const float c1 = sn1 * (aux.kv[fl * g.N + m] + ((Y1 & 1) ? -gs : gs));
@@ -699,6 +740,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   VIPMI_TRY(ws(ctx, "rot_kv", (size_t)(chunk * g.N), &aux.kv));
   VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * P::L), &aux.gam));
   VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
+  VIPMI_TRY(ws(ctx, "rot_dph", (size_t)chunk * 2 * DPH_STRIDE, &aux.dph));
   int* counters = nullptr;                       // 3 kernels x 8 task queues, one 128-byte line each
   VIPMI_TRY(ws(ctx, "rot_counters", (size_t)3 * 256, &counters));
   size_t lds = (size_t)P::LPB * P::LDS_ELEMS * sizeof(cf);
@@ -744,6 +786,8 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     int ga = (int)cdiv(nf, P::LPB);
     if (ga > maxwg) ga = maxwg;
     VIPMI_CHECK_HIP(hipMemsetAsync(counters, 0, 3 * 256 * sizeof(int), ctx->stream));
+    if constexpr (BLK)
+      hipLaunchKernelGGL(rs_phase_delta<P>, dim3(nf, 2), dim3(128), 0, ctx->stream, d_frames, (int)f0, aux.dph);
     ctx->tic("k_rot_s1");
     hipLaunchKernelGGL(k1, dim3(gr), blk, lds, ctx->stream, in, d_frames, g, A1r, aux, (int)f0, nf, twtab, counters);
     ctx->toc("k_rot_s1");

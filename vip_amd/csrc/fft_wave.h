@@ -209,8 +209,9 @@ __device__ __forceinline__ void dft16_inv_keep4(cf* __restrict__ v) {      // in
   v[6] = x0; v[7] = x1; v[8] = x2; v[9] = x3;
 }
 
-template <int R1_, int R2_, int R3_, int S1_, int T1_, int T2_, int WPB_, int WPL_>
+template <int R1_, int R2_, int R3_, int S1_, int T1_, int T2_, int WPB_, int WPL_, bool TW2R_ = false>
 struct Plan {
+  static constexpr bool TW2R = TW2R_;                   // composed stage-2 twiddles live in registers (R2 - 1 complex)
   static constexpr int R1 = R1_, R2 = R2_, R3 = R3_;
   static constexpr int L = R1 * R2 * R3, M1 = L / R1, M2 = R3;
   static constexpr int U1 = M1 / 64, U2 = R1 * M2 / 64, U3 = R1 * R2 / 64;
@@ -233,11 +234,11 @@ struct Plan {
 // WPL > 1: the line is split over WPL waves (VL = 16 complex registers per lane instead of 32/64), which
 // keeps the kernels under 128 VGPRs (4 waves/SIMD, no spills); the exchanges then need a workgroup barrier.
 using Plan512 = Plan<8, 8, 8, 72, 72, 9, 8, 1>;
-using Plan1024 = Plan<16, 8, 8, 72, 72, 9, 8, 1>;
+using Plan1024 = Plan<16, 8, 8, 72, 72, 9, 8, 1, true>;
 using Plan1024w4 = Plan<16, 8, 8, 72, 72, 9, 4, 1>;        // 4-wave workgroups: 3 of them per CU (<= 168 VGPRs)
 using Plan2048 = Plan<16, 16, 8, 136, 152, 9, 16, 2>;
 using Plan2048w12 = Plan<16, 16, 8, 136, 152, 9, 12, 2>;   // 3 waves/SIMD, 170-VGPR budget
-using Plan2048w1 = Plan<16, 16, 8, 136, 152, 9, 8, 1>;     // one wave per line: no workgroup barriers, 2 waves/SIMD
+using Plan2048w1 = Plan<16, 16, 8, 136, 152, 9, 8, 1, true>;   // one wave per line: no workgroup barriers, 2 waves/SIMD
 using Plan4096 = Plan<16, 16, 16, 272, 272, 17, 16, 4>;
 using Plan4096w2 = Plan<16, 16, 16, 272, 272, 17, 8, 2>;    // two waves per line, 2 waves/SIMD, 256-VGPR budget
 
@@ -260,6 +261,7 @@ struct Twiddles {
   static constexpr int PER_LANE = 6 + N1H + N2H;          // table entries per lane
   static constexpr int LDS_ELEMS = PER_LANE * 64 + 8;      // table + 16 barrier counters (64 B)
   const cf* tab;                                          // LDS, already offset by lane
+  cf w2[P::TW2R ? P::R2 - 1 : 1];                         // TW2R: w_M1^(b ka), ka = 1 .. R2-1, composed once per kernel
   unsigned* bar;                                          // LDS arrival counter of this line slot (WPL > 1)
   mutable unsigned bar_target;
   static constexpr int BAR_ELEMS = 8;                     // LDS reserved for the counters, in cf units (64 B)
@@ -275,6 +277,13 @@ struct Twiddles {
     tab = ltab + lane;
     bar = counters + (threadIdx.x >> 6) / P::WPL;
     bar_target = 0;
+    if constexpr (P::TW2R) {
+#pragma unroll
+      for (int ka = 1; ka < P::R2; ++ka) {
+        const int h = ka >> 2, l = ka & 3;
+        w2[ka - 1] = (h && l) ? cmul(t2h(h), t2l(l)) : (h ? t2h(h) : t2l(l));
+      }
+    }
   }
   static void fill_table(std::vector<cf>& tabv) {
     tabv.resize(64 * PER_LANE);
@@ -307,6 +316,7 @@ struct Twiddles {
   }
   template <bool CONJ>
   __device__ __forceinline__ cf apply2(cf v, int ka) const {
+    if constexpr (P::TW2R) return CONJ ? cmulc(v, w2[ka - 1]) : cmul(v, w2[ka - 1]);
     const int h = ka >> 2, l = ka & 3;
     cf w;
     if (h && l) w = cmul(t2h(h), t2l(l));
@@ -450,6 +460,15 @@ struct ShearPhase {
     const int u0 = sub * P::U3L;
     pa = expi_turns((double)(lane / P::R2 + (64 / P::R2) * u0 + P::R1 * (lane % P::R2)) * sl);
     pa = mkcf(pa.x * (1.0f / (float)P::L), pa.y * (1.0f / (float)P::L));
+    wp[0] = mkcf(1.f, 0.f);
+#pragma unroll
+    for (int i = 1; i <= P::R3 / 2; ++i) wp[i] = cmul(wp[i - 1], w);
+  }
+  // phases of the shift s + delta from those of s: d_lane = exp(-2 pi i m_lane delta/L) etc. (pa keeps its scale)
+  __device__ __forceinline__ void init_from(const ShearPhase& o, cf d_lane, cf d_z, cf d_w) {
+    pa = cmul(o.pa, d_lane);
+    z = cmul(o.z, d_z);
+    const cf w = cmul(o.wp[1], d_w);
     wp[0] = mkcf(1.f, 0.f);
 #pragma unroll
     for (int i = 1; i <= P::R3 / 2; ++i) wp[i] = cmul(wp[i - 1], w);
