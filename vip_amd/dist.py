@@ -59,21 +59,50 @@ def _comm_device():
     return torch.device("cpu")
 
 
-def gather_units(local, n_units, unit_shape, owners, dtype=None):
-    """All ranks contribute their units {index: array}; every rank returns the full (n_units, *unit_shape)
-    array (all_gather of a zero-filled stack + ownership mask: units are disjoint, so a sum is exact)."""
+def _all_gather_ragged(mine, counts, dev):
+    """all_gather of per-rank stacks whose leading sizes ``counts[r]`` differ (known on every rank): RCCL takes ragged
+    lists as they are; gloo needs equal shapes, so the stacks are padded to the largest."""
     import torch
     dist = _dist()
     rank, world = world_info()
+    tail = tuple(mine.shape[1:])
+    if world == 1:
+        return [mine]
+    if dist.get_backend() == "nccl":
+        out = [torch.empty((c,) + tail, dtype=mine.dtype, device=dev) for c in counts]
+        dist.all_gather(out, mine.contiguous())
+        return out
+    cmax = max(counts)
+    pad = torch.zeros((cmax,) + tail, dtype=mine.dtype, device=dev)
+    pad[:mine.shape[0]] = mine
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return [bufs[r][:counts[r]] for r in range(world)]
+
+
+def gather_units(local, n_units, unit_shape, owners, dtype=None):
+    """All ranks contribute their units {index: array}; every rank returns the full (n_units, *unit_shape) array.
+    ``owners[r]`` = sorted unit indices of rank r (None: round-robin).  One all_gather of the per-rank stacks -- every
+    unit crosses the links once (no reduction over zero-filled copies of the whole stack)."""
+    import torch
+    rank, world = world_info()
     dev = _comm_device()
     dtype = dtype or torch.float32
-    buf = torch.zeros((n_units,) + tuple(unit_shape), dtype=dtype, device=dev)
-    for i, a in local.items():
+    if owners is None:
+        owners = [shard_round_robin(n_units, r, world) for r in range(world)]
+    mine_idx = owners[rank]
+    if sorted(local.keys()) != list(mine_idx):
+        raise ValueError("gather_units: this rank computed units %r but owns %r" % (sorted(local.keys()), list(mine_idx)))
+    mine = torch.zeros((len(mine_idx),) + tuple(unit_shape), dtype=dtype, device=dev)
+    for j, i in enumerate(mine_idx):
+        a = local[i]
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
-        buf[i] = t.to(device=dev, dtype=dtype)
-    if world > 1:
-        # disjoint ownership: a sum over ranks reassembles the stack exactly (x + 0 == x)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        mine[j] = t.to(device=dev, dtype=dtype)
+    parts = _all_gather_ragged(mine, [len(o) for o in owners], dev)
+    buf = torch.zeros((n_units,) + tuple(unit_shape), dtype=dtype, device=dev)
+    for r in range(world):
+        if len(owners[r]):
+            buf[torch.as_tensor(list(owners[r]), dtype=torch.long, device=dev)] = parts[r]
     return buf
 
 
@@ -109,32 +138,47 @@ def pca_4d(cube4d, angle_list, ncomp=1, collapse_ifs="mean", compute=None, colla
     return frame, ifs_np
 
 
+def _segment_owners(plan):
+    """owner rank of every segment of an annulus plan (balanced by pixel count, identical on every rank)."""
+    rank, world = world_info()
+    weights = [len(s["pix"]) for s in plan]
+    owner = [0] * len(plan)
+    for r in range(world):
+        for si in shard_balanced(weights, r, world):
+            owner[si] = r
+    return owner
+
+
 def pca_annular_residuals(cube, angle_list, plan, residual_fn):
     """Annuli of an annular PCA dealt over ranks by pixel count.  ``plan`` = list of segment dicts
     (vip_amd.psfsub.pca_local.annulus_plan); ``residual_fn(seg) -> (n, npx) residuals`` computes one
-    segment.  Returns cube_out (n, y, x) on every rank; segments are applied in plan order so the
-    1-pixel overlap of the last annulus is resolved exactly as in the reference (pca_local.py:786-787)."""
+    segment.  Returns cube_out (n, y, x) on every rank (what ``full_output`` needs); segments are applied in plan order
+    so the 1-pixel overlap of the last annulus is resolved exactly as in the reference (pca_local.py:786-787).
+    One all_gather of every rank's residual columns.  For the final frame alone use ``pca_annular_frame``, which never
+    assembles the whole residual cube on any rank."""
     import torch
-    dist = _dist()
     rank, world = world_info()
-    weights = [len(s["pix"]) for s in plan]
-    mine = set(shard_balanced(weights))
+    owner = _segment_owners(plan)
     n = cube.shape[0]
     y, x = cube.shape[-2:]
     dev = _comm_device()
-    out = torch.zeros((n, y * x), dtype=torch.float32, device=dev)
+    cols = []
     for si, seg in enumerate(plan):
-        owner_has = si in mine
-        npx = len(seg["pix"])
-        buf = torch.zeros((n, npx), dtype=torch.float32, device=dev)
-        if owner_has:
+        if owner[si] == rank:
             r = residual_fn(seg)
             r = r if isinstance(r, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r))
-            buf.copy_(r.to(device=dev, dtype=torch.float32)[:, :npx])
-        if world > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            cols.append(r.to(device=dev, dtype=torch.float32)[:, :len(seg["pix"])].t())       # (npx, n): pixel-major
+    mine = torch.cat(cols, dim=0).contiguous() if cols else torch.zeros((0, n), dtype=torch.float32, device=dev)
+    counts = [sum(len(seg["pix"]) for si, seg in enumerate(plan) if owner[si] == r) for r in range(world)]
+    parts = _all_gather_ragged(mine, counts, dev)
+    out = torch.zeros((n, y * x), dtype=torch.float32, device=dev)
+    offs = [0] * world
+    for si, seg in enumerate(plan):
+        r = owner[si]
+        npx = len(seg["pix"])
         pix = torch.from_numpy(np.asarray(seg["pix"], dtype=np.int64)).to(dev)
-        out[:, pix] = buf
+        out[:, pix] = parts[r][offs[r]:offs[r] + npx].t()
+        offs[r] += npx
     return out.reshape(n, y, x)
 
 
@@ -206,9 +250,34 @@ class DeviceOps:
         ctx.call("vipmi_subtract_gemm_f32", B.ptr(M), B.ptr(C), B.ptr(T), n, k, P, B.ptr(R), None)
         return R
 
-    def derotate(self, frames, angles):
+    def derotate(self, frames, angles, mask_zero=False):
         from . import backend as B
-        return B.derotate(frames, angles)
+        return B.derotate(frames.contiguous(), angles, mask_nan=not mask_zero, mask_zero=mask_zero)
+
+    def segment_residuals(self, cube_t, seg):
+        """(n, npx) residuals of one annulus segment (plain ADI annular PCA: gather the segment's pixel columns, one
+        batched launch for the n per-frame library decompositions; reference psfsub/pca_local.py:708-757,830-909)."""
+        from . import backend as B
+        from .psfsub.pca_local import _pack_libs
+        torch = B._torch()
+        n = cube_t.shape[0]
+        P = cube_t[0].numel()
+        dev = cube_t.device
+        pix_h = np.asarray(seg["pix"], dtype=np.int32)
+        npx0 = pix_h.size
+        if npx0 % 4:                                 # zero columns: 16-byte aligned rows, Gram unchanged
+            pix_h = np.concatenate([pix_h, np.full(4 - npx0 % 4, -1, dtype=np.int32)])
+        pix = torch.from_numpy(pix_h).to(dev)
+        npx = int(pix.numel())
+        ctx = B.get_context(dev.index)
+        A = B.empty((n, npx), device=dev.index)
+        ctx.call("vipmi_gather_f32", B.ptr(cube_t), n, P, B.ptr(pix), npx, B.ptr(A))
+        idx, ln, max_lib = _pack_libs(seg["libs"])
+        idx_t, ln_t = torch.from_numpy(idx).to(dev), torch.from_numpy(ln).to(dev)
+        R = B.empty((n, npx), device=dev.index)
+        ctx.call("vipmi_annular_residuals_f32", B.ptr(A), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib, int(seg["ncomp"]),
+                 B.ptr(R))
+        return R[:, :npx0]
 
     def collapse(self, cube, mode):
         """cube: (n, P_g, 1)-shaped view -> (P_g,)"""
@@ -256,8 +325,22 @@ def pca_single_cube(cube, angle_list, ncomp, collapse="median", ops=None):
     recv_shapes = [(f1 - f0, r1 - r0, x) for (r0, r1) in rows]
     parts = _all_to_all(send, recv_shapes, R.dtype, dev)
     frames = torch.cat(parts, dim=1)                                           # (f1-f0, y, x)
+    return _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, dev)
+
+
+def _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, dev, **rot):
+    """Tail shared by the sharded single-cube and annular paths: this rank holds the whole residual frames of its
+    frame shard -> local derotation -> all_to_all (whole frames -> pixel-row slabs of ALL frames) -> local collapse of
+    the slab -> all_gather of the final frame's row slabs."""
+    import torch
+    dist = _dist()
+    rank, world = world_info()
+    n = frs[-1][1]
+    x = frames.shape[-1]
+    y0, y1 = rows[rank]
+    f0, f1 = frs[rank]
     # 4. derotate own frames
-    der = ops.derotate(frames, angle_list[f0:f1]) if f1 > f0 else frames
+    der = ops.derotate(frames, angle_list[f0:f1], **rot) if f1 > f0 else frames
     # 5. whole frames -> slabs of all frames
     send = [der[:, r0:r1, :] for (r0, r1) in rows]
     recv_shapes = [(b - a, y1 - y0, x) for (a, b) in frs]
@@ -267,14 +350,68 @@ def pca_single_cube(cube, angle_list, ncomp, collapse="median", ops=None):
     mine = ops.collapse(slab, collapse).reshape(y1 - y0, x)
     if world == 1:
         return mine
-    pieces = [torch.empty((r1 - r0, x), dtype=mine.dtype, device=dev) for (r0, r1) in rows]
-    if dist.get_backend() == "nccl" or all(p.shape == pieces[0].shape for p in pieces):
-        dist.all_gather(pieces, mine.contiguous())
-    else:                                   # gloo all_gather needs equal shapes: pad to the largest slab
-        hmax = max(r1 - r0 for (r0, r1) in rows)
-        pad = torch.zeros((hmax, x), dtype=mine.dtype, device=dev)
-        pad[:y1 - y0] = mine
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)
-        pieces = [bufs[r][:rows[r][1] - rows[r][0]] for r in range(world)]
+    pieces = _all_gather_ragged(mine.contiguous(), [r1 - r0 for (r0, r1) in rows], dev)
     return torch.cat(pieces, dim=0)
+
+
+def pca_annular_frame(cube, angle_list, plan, residual_fn, collapse="median", ops=None, mask_zero=False):
+    """Final frame of an annular ADI PCA with the partition of SURVEY 8(e), row "C3 annular":
+
+      annuli (segments) dealt to the ranks by pixel count -> each rank computes the residual COLUMNS (n frames x its
+      pixels) of its segments -> all_to_all (pixel columns -> whole frames, frames sharded; every residual crosses the
+      links once) -> sharded derotation -> all_to_all back (whole frames -> pixel-row slabs of all frames) -> sharded
+      collapse -> all_gather of the frame's row slabs.
+
+    No rank ever holds the whole residual cube, no reduction over zero-padded copies, and derotation + collapse -- a
+    seventh of the single-GPU time at C3 -- scale with the number of ranks too.  ``plan`` / ``residual_fn`` as in
+    ``pca_annular_residuals``; segments are applied in plan order (1-pixel overlap of the last annulus)."""
+    import torch
+    rank, world = world_info()
+    ops = ops or DeviceOps()
+    n = cube.shape[0]
+    y, x = cube.shape[-2:]
+    angle_list = np.asarray(angle_list, dtype=np.float64)
+    owner = _segment_owners(plan)
+    dev = _comm_device()
+    frs = _split(n, world)
+    rows = _split(y, world)
+    f0, f1 = frs[rank]
+    cols = []
+    for si, seg in enumerate(plan):
+        if owner[si] == rank:
+            r = residual_fn(seg)
+            r = r if isinstance(r, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r))
+            cols.append(r.to(device=dev, dtype=torch.float32)[:, :len(seg["pix"])])
+    mine = torch.cat(cols, dim=1) if cols else torch.zeros((n, 0), dtype=torch.float32, device=dev)   # (n, npx_mine)
+    counts = [sum(len(seg["pix"]) for si, seg in enumerate(plan) if owner[si] == r) for r in range(world)]
+    # pixel columns -> whole frames of the own frame shard
+    send = [mine[a:b] for (a, b) in frs]
+    recv_shapes = [(f1 - f0, counts[r]) for r in range(world)]
+    parts = _all_to_all(send, recv_shapes, torch.float32, dev)
+    frames = torch.zeros((f1 - f0, y * x), dtype=torch.float32, device=dev)
+    offs = [0] * world
+    for si, seg in enumerate(plan):
+        r = owner[si]
+        npx = len(seg["pix"])
+        pix = torch.from_numpy(np.asarray(seg["pix"], dtype=np.int64)).to(dev)
+        frames[:, pix] = parts[r][:, offs[r]:offs[r] + npx]
+        offs[r] += npx
+    rot = {"mask_zero": True} if mask_zero else {}
+    return _derotate_exchange_collapse(frames.reshape(f1 - f0, y, x), angle_list, frs, rows, collapse, ops, dev, **rot)
+
+
+def pca_annular(cube, angle_list, ncomp=1, asize=4, fwhm=4, radius_int=0, n_segments=1, delta_rot=(0.1, 1),
+                min_frames_lib=2, max_frames_lib=200, collapse="median", theta_init=0, ops=None):
+    """``vip_amd.psfsub.pca_annular(cube, angle_list, ...)`` (plain ADI: no reference cube, no scaling) with the annuli
+    sharded over the ranks -- BASELINE.json configs[2].  Every rank passes the same cube; returns the final frame on
+    every rank."""
+    from .psfsub.pca_local import cached_annulus_plan
+    from .preproc.parangles import check_pa_vector
+    ops = ops or DeviceOps()
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
+    n, y, x = cube.shape
+    plan, _ = cached_annulus_plan((y, x), angle_list, radius_int, fwhm, asize, n_segments, delta_rot, ncomp,
+                                  min_frames_lib, max_frames_lib, theta_init)
+    cube_dev = ops.to_dev(cube)
+    return pca_annular_frame(cube_dev, angle_list, plan, lambda seg: ops.segment_residuals(cube_dev, seg), collapse=collapse,
+                             ops=ops, mask_zero=bool(radius_int))
