@@ -1,6 +1,8 @@
 """GPU parity tests, end to end: vip_amd.psfsub.pca / cube_derotate / cube_collapse through the C ABI
 against fixtures frozen from the reference (tests/golden) and the CPU oracle; tolerances: residual
 cubes and frames max|d| < 1e-4 on max|cube| ~ 10 data (BASELINE.json), index sets bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -705,3 +707,35 @@ def test_pca_4d_frame_rejection_and_grid_return_packing():
     assert grid.shape == (2, 48, 48) and np.abs(grid - exp).max() < TOL
     g3 = pca(cube4, ang, ncomp=[1, 3], verbose=False, full_output=True)
     assert len(g3) == 3 and g3[1] == [[1, 3]] * 3 and g3[2].shape == (3, 2, 48, 48)
+
+
+def test_sharded_annular_world1_matches_pca_annular():
+    """vip_amd.dist.pca_annular (annuli -> residual columns -> frame shards -> derotation -> row slabs -> collapse) on one
+    rank with the device kernels against pca_annular itself."""
+    from vip_amd import dist as D
+    from vip_amd.psfsub import pca_annular
+    cube, ang = O.synth_adi(24, 64, seed=6)
+    for kw in (dict(ncomp=3, asize=8, fwhm=4), dict(ncomp=2, asize=8, fwhm=4, radius_int=6, n_segments=2)):
+        ref = pca_annular(cube, ang, verbose=False, **kw)
+        got = D.pca_annular(cube, ang, **kw).cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.nanmax(np.abs(got - ref)) < 1e-5
+
+
+def test_bench_sharded_modes_two_ranks_on_one_gpu():
+    """bench.py --mode single-cube / annular under torchrun with 2 ranks sharing this GPU (gloo for the collectives): the
+    multi-rank code paths that RCCL will run on an 8-GPU node -- ragged all_gather / all_to_all lists included."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, VIPMI_BENCH_BACKEND="gloo", VIPMI_BENCH_DEVICE="0")
+    for mode, extra in (("single-cube", ["--frames", "30", "--size", "128", "--ncomp", "4"]),
+                        ("annular", ["--frames", "30", "--size", "128"])):
+        cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                             "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                             "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode] + extra,
+                            capture_output=True, text=True, env=env, timeout=600)
+        assert cp.returncode == 0, cp.stderr[-3000:]
+        rec = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+        assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0

@@ -51,6 +51,16 @@ def shard_balanced(weights, rank=None, world=None):
     return sorted(i for i in range(len(weights)) if owner[i] == rank)
 
 
+def _work_device(*arrays):
+    """Device on which a sharded routine assembles its buffers: that of the first cuda tensor among ``arrays``, else
+    the communication device (cpu under gloo)."""
+    import torch
+    for a in arrays:
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.device
+    return _comm_device()
+
+
 def _comm_device():
     import torch
     dist = _dist()
@@ -68,6 +78,9 @@ def _all_gather_ragged(mine, counts, dev):
     tail = tuple(mine.shape[1:])
     if world == 1:
         return [mine]
+    cdev = _comm_device()
+    if mine.device != cdev:                       # gloo with device tensors (single-GPU test rig): stage through the host
+        return [p.to(mine.device) for p in _all_gather_ragged(mine.to(cdev), counts, cdev)]
     if dist.get_backend() == "nccl":
         out = [torch.empty((c,) + tail, dtype=mine.dtype, device=dev) for c in counts]
         dist.all_gather(out, mine.contiguous())
@@ -86,7 +99,7 @@ def gather_units(local, n_units, unit_shape, owners, dtype=None):
     unit crosses the links once (no reduction over zero-filled copies of the whole stack)."""
     import torch
     rank, world = world_info()
-    dev = _comm_device()
+    dev = _work_device(*local.values())
     dtype = dtype or torch.float32
     if owners is None:
         owners = [shard_round_robin(n_units, r, world) for r in range(world)]
@@ -161,7 +174,7 @@ def pca_annular_residuals(cube, angle_list, plan, residual_fn):
     owner = _segment_owners(plan)
     n = cube.shape[0]
     y, x = cube.shape[-2:]
-    dev = _comm_device()
+    dev = _work_device(cube)
     cols = []
     for si, seg in enumerate(plan):
         if owner[si] == rank:
@@ -199,6 +212,10 @@ def _all_to_all(send_chunks, recv_shapes, dtype, dev):
     import torch
     dist = _dist()
     rank, world = world_info()
+    cdev = _comm_device() if world > 1 else dev
+    if torch.device(dev) != cdev:                 # gloo with device tensors: stage through the host
+        got = _all_to_all([c.to(cdev) for c in send_chunks], recv_shapes, dtype, cdev)
+        return [g.to(dev) for g in got]
     recv = [torch.empty(s, dtype=dtype, device=dev) for s in recv_shapes]
     send = [c.contiguous() for c in send_chunks]
     if world == 1:
@@ -315,7 +332,12 @@ def pca_single_cube(cube, angle_list, ncomp, collapse="median", ops=None):
     G = ops.gram(M)
     dev = G.device
     if world > 1:
-        dist.all_reduce(G, op=dist.ReduceOp.SUM)
+        if G.device != _comm_device():            # gloo with device tensors: stage through the host
+            Gh = G.to(_comm_device())
+            dist.all_reduce(Gh, op=dist.ReduceOp.SUM)
+            G = Gh.to(dev)
+        else:
+            dist.all_reduce(G, op=dist.ReduceOp.SUM)
     # 2. identical decomposition everywhere, local residual slab
     ev, ec = ops.leading(G, k)
     R = ops.residuals(M, ev, ec)                                               # (n, (y1-y0)*x)
@@ -372,7 +394,7 @@ def pca_annular_frame(cube, angle_list, plan, residual_fn, collapse="median", op
     y, x = cube.shape[-2:]
     angle_list = np.asarray(angle_list, dtype=np.float64)
     owner = _segment_owners(plan)
-    dev = _comm_device()
+    dev = _work_device(cube)
     frs = _split(n, world)
     rows = _split(y, world)
     f0, f1 = frs[rank]
