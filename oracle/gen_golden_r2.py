@@ -1,0 +1,48 @@
+"""Fixtures added in round 2 (G20 ...): outputs of the REAL reference (imported read-only through oracle/_shim.py) frozen
+as data under tests/golden/; runs only in the build container:
+
+    python oracle/gen_golden_r2.py
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _shim, ref_cpu as O  # noqa: E402
+
+warnings.simplefilter("ignore")
+ref = _shim.load()
+OUT = os.path.join(ROOT, "tests", "golden")
+from vip_hci.psfsub.utils_pca import pca_annulus  # noqa: E402
+from vip_hci.metrics.snr_source import indep_ap_centers  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# ---- G20: pca_annulus (psfsub/utils_pca.py:617-755): ADI, RDI, scaling, residual cube, 4-D; and the aperture centres of
+# the S/N statistic (metrics/snr_source.py:226-318; the aperture sums themselves need photutils, absent here) ----------
+n, N = 16, 48
+cube, ang = O.synth_adi(n, N, seed=70)
+cref = O.synth_adi(11, N, seed=71)[0]
+g = {"cube": cube, "angles": ang, "cube_ref": cref}
+g["adi"] = pca_annulus(cube, ang, ncomp=3, annulus_width=8, r_guess=14)
+g["adi_mean_tm"] = pca_annulus(cube, ang, ncomp=2, annulus_width=6, r_guess=10, scaling="temp-mean", collapse="mean")
+g["rdi"] = pca_annulus(cube, ang, ncomp=4, annulus_width=8, r_guess=13.5, cube_ref=cref)
+g["cube_res_der"] = pca_annulus(cube, ang, ncomp=3, annulus_width=8, r_guess=14, collapse=None)
+g["cube_res"] = pca_annulus(cube, None, ncomp=3, annulus_width=8, r_guess=14, collapse=None)
+c4 = np.stack([O.synth_adi(n, N, seed=72 + i)[0] for i in range(3)])
+g["cube4"] = c4
+g["ifs"] = pca_annulus(c4, ang, ncomp=[2, 3, 2], annulus_width=8, r_guess=14, collapse="median", collapse_ifs="mean")
+fr = np.zeros((N, N))
+for i, (xy, fw, ex) in enumerate((((33.2, 29.7), 4.0, False), ((10.0, 12.5), 5.3, True), ((24.0, 40.0), 3.0, False))):
+    yy, xx = indep_ap_centers(fr, xy, fw, exclude_negative_lobes=ex)
+    g["apc_in_%d" % i] = np.array([xy[0], xy[1], fw, float(ex)])
+    g["apc_yy_%d" % i], g["apc_xx_%d" % i] = yy, xx
+save("g20_pca_annulus", **g)

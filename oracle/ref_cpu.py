@@ -43,7 +43,11 @@ def disk_indices(center, radius, shape):
     row-major order.  Third-party dependency of the reference (scikit-image 0.25.2,
     not vendored); used at var/shapes.py:88."""
     cy, cx = center
-    rr, cc = np.mgrid[:shape[0], :shape[1]]
+    if shape is None:                     # unbounded (metrics use disk((y, x), fwhm/2) without a shape)
+        rr, cc = np.mgrid[int(np.ceil(cy - radius)):int(np.floor(cy + radius)) + 1,
+                          int(np.ceil(cx - radius)):int(np.floor(cx + radius)) + 1]
+    else:
+        rr, cc = np.mgrid[:shape[0], :shape[1]]
     m = ((rr - cy) / radius) ** 2 + ((cc - cx) / radius) ** 2 < 1
     return rr[m], cc[m]
 
@@ -587,6 +591,131 @@ def pca_grid_frames(cube, angle_list, range_pcs, scaling=None, mask_center_px=No
     if full_output:
         return cubeout, pclist
     return cubeout
+
+
+# --------------------------------------------------------------------------------------
+# S/N of a test aperture (metrics/snr_source.py) -- PARITY UNPINNED for the aperture sums: the reference takes them from
+# photutils.aperture_photometry(method='exact') (photutils 2.3.0 in its uv.lock; absent from this image), i.e. every
+# pixel weighted by the exact area of its unit square inside the circle.  Restated here by 1-D quadrature of that area
+# (independent of the product's closed form); everything around it (aperture centres, Student-t statistic, grid
+# scoring) follows the reference's lines.
+# --------------------------------------------------------------------------------------
+
+_GL_X, _GL_W = np.polynomial.legendre.leggauss(48)
+
+
+def _pixel_circle_area(x0, y0, r):
+    """Area of the pixel [x0, x0+1] x [y0, y0+1] (relative to the circle centre) inside the circle of radius r:
+    integral over u of the length of [y0, y0+1] n [-h(u), h(u)], h = sqrt(r^2 - u^2), with u = r sin(t) (removes the
+    square-root end-point singularity) and Gauss-Legendre on every smooth piece."""
+    a, b = max(x0, -r), min(x0 + 1.0, r)
+    if b <= a:
+        return 0.0
+    cuts = {a, b}
+    for yv in (y0, y0 + 1.0):
+        if abs(yv) < r:
+            for u in (np.sqrt(r * r - yv * yv), -np.sqrt(r * r - yv * yv)):
+                if a < u < b:
+                    cuts.add(float(u))
+    cuts = sorted(cuts)
+    total = 0.0
+    for ca, cb in zip(cuts[:-1], cuts[1:]):
+        ta, tb = np.arcsin(np.clip(ca / r, -1, 1)), np.arcsin(np.clip(cb / r, -1, 1))
+        t = 0.5 * (tb - ta) * _GL_X + 0.5 * (tb + ta)
+        h = r * np.cos(t)
+        seg = np.maximum(0.0, np.minimum(y0 + 1.0, h) - np.maximum(y0, -h))
+        total += 0.5 * (tb - ta) * np.sum(_GL_W * seg * r * np.cos(t))
+    return float(total)
+
+
+def aperture_sum_exact(array, xc, yc, r):
+    """photutils CircularAperture((xc, yc), r) summed with method='exact' (pixel centres at integer coordinates)."""
+    ny, nx = array.shape
+    tot = 0.0
+    for j in range(max(int(np.floor(yc - r + 0.5)), 0), min(int(np.ceil(yc + r - 0.5)), ny - 1) + 1):
+        for i in range(max(int(np.floor(xc - r + 0.5)), 0), min(int(np.ceil(xc + r - 0.5)), nx - 1) + 1):
+            tot += _pixel_circle_area(i - 0.5 - xc, j - 0.5 - yc, r) * float(array[j, i])
+    return tot
+
+
+def indep_ap_centers(shape, source_xy, fwhm, exclude_negative_lobes=False):
+    """metrics/snr_source.py:226-318 (no exclude_theta_range / no_gap): (yy, xx), the test aperture first."""
+    sourcex, sourcey = source_xy
+    centery, centerx = frame_center(shape)
+    sep = np.sqrt((centery - float(sourcey)) ** 2 + (centerx - float(sourcex)) ** 2)
+    if not sep > (fwhm / 2):
+        raise RuntimeError("`source_xy` is too close to the frame center")
+    angle = np.arcsin(fwhm / 2.0 / sep) * 2
+    nap = int(np.floor(2 * np.pi / angle))
+    ca, sa = np.cos(angle), np.sin(angle)
+    xs, ys = [sourcex - centerx], [sourcey - centery]
+    xa, ya = np.zeros(nap), np.zeros(nap)
+    xa[0], ya[0] = xs[0], ys[0]
+    for i in range(nap - 1):                          # clockwise: sign = -1
+        xa[i + 1] = ca * xa[i] + sa * ya[i]
+        ya[i + 1] = ca * ya[i] - sa * xa[i]
+        if exclude_negative_lobes and (i == 0 or i == nap - 2):
+            continue
+        xs.append(xa[i + 1])
+        ys.append(ya[i + 1])
+    return np.array(ys) + centery, np.array(xs) + centerx
+
+
+def snr(array, source_xy, fwhm, full_output=False, exclude_negative_lobes=False):
+    """metrics/snr_source.py:321-456 (one array)."""
+    yy, xx = indep_ap_centers(array.shape, source_xy, fwhm, exclude_negative_lobes)
+    fluxes = np.array([aperture_sum_exact(array, x_, y_, fwhm / 2.0) for y_, x_ in zip(yy, xx)])
+    f_source = fluxes[0]
+    rest = fluxes[1:]
+    n2 = rest.shape[0]
+    val = (f_source - rest.mean()) / (rest.std(ddof=1) * np.sqrt(1 + (1 / n2)))
+    if full_output:
+        return source_xy[1], source_xy[0], f_source, rest, val
+    return val
+
+
+def pca_grid_snr(cube, angle_list, range_pcs, source_xy, fwhm, fmerit="mean", **kw):
+    """``pca(cube, angles, ncomp=<tuple/list>, source_xy=..., fwhm=...)``: grid of frames scored by S/N at ``source_xy``.
+    Ref: psfsub/utils_pca.py:239-277 (get_snr), :364-402 (loop, argmax, table).  Returns (cubeout, finalfr, pclist,
+    snrlist, fluxlist, opt_npc)."""
+    cubeout, pclist = pca_grid_frames(cube, angle_list, range_pcs, full_output=True, **kw)
+    x, y = source_xy
+    snrlist, fluxlist = [], []
+    for fr in cubeout:
+        fr = np.asarray(fr, dtype=np.float64)
+        if fmerit == "px":
+            r = snr(fr, (x, y), fwhm, full_output=True)
+            sv, fl = r[-1], r[2]
+        else:
+            yy, xx = disk_indices((y, x), fwhm / 2.0, None)
+            res = [snr(fr, (x_, y_), fwhm, full_output=True) for y_, x_ in zip(yy, xx)]
+            sn = np.array([r[-1] for r in res])
+            fx = np.array([r[2] for r in res])
+            sv, fl = (np.max(sn), fx[int(np.argmax(sn))]) if fmerit == "max" else (np.mean(sn), np.mean(fx))
+        snrlist.append(0 if np.isnan(sv) else sv)
+        fluxlist.append(fl)
+    argmax = int(np.argmax(snrlist))
+    return cubeout, cubeout[argmax], pclist, snrlist, fluxlist, pclist[argmax]
+
+
+def pca_annulus(cube, angs, ncomp, annulus_width, r_guess, cube_ref=None, svd_mode="lapack", scaling=None,
+                collapse="median", weights=None, mask_val=np.nan):
+    """3-D branch of psfsub/utils_pca.py:678-709: PCA on the one-segment annulus [r_guess -+ width/2], residuals scattered
+    into a zero cube, derotated, collapsed."""
+    inrad = int(r_guess - annulus_width / 2.0)
+    outrad = int(r_guess + annulus_width / 2.0)
+    yy, xx = get_annulus_segments(cube.shape[1:], inrad, int(np.round(outrad - inrad)), 1)[0]
+    data = matrix_scaling(cube[:, yy, xx], scaling)
+    data_svd = data if cube_ref is None else matrix_scaling(cube_ref[:, yy, xx], scaling)
+    V = svd_wrapper(data_svd, svd_mode, ncomp)
+    residuals = data - np.dot(np.dot(data, V.T), V)
+    cube_zeros = np.zeros_like(cube)
+    cube_zeros[:, yy, xx] = residuals
+    out = cube_zeros if angs is None else cube_derotate(cube_zeros, check_pa_vector(np.asarray(angs, dtype=float)),
+                                                        mask_val=mask_val)
+    if collapse is not None:
+        return cube_collapse(out, mode=collapse, w=weights)
+    return out
 
 
 def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scaling=None, mask_center_px=None,

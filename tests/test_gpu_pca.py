@@ -739,3 +739,161 @@ def test_bench_sharded_modes_two_ranks_on_one_gpu():
         assert cp.returncode == 0, cp.stderr[-3000:]
         rec = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
         assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+
+
+# ---- SURVEY 8(f) #1 / #4 remainders: pca_annulus, the S/N-scored PCA grid, a PPPCA-shaped caller ---------------------
+
+def test_pca_annulus_golden():
+    """reference psfsub/utils_pca.py:617-755 (G20: ADI, scaling, RDI, residual cubes, 4-D)."""
+    from vip_amd.psfsub import pca_annulus
+    g = load_golden("g20_pca_annulus")
+    cube, ang, cref = g["cube"], g["angles"], g["cube_ref"]
+    fr = pca_annulus(cube, ang, ncomp=3, annulus_width=8, r_guess=14)
+    assert fr.dtype == np.float32 and np.nanmax(np.abs(fr - g["adi"])) < TOL
+    assert np.array_equal(np.isnan(fr), np.isnan(g["adi"]))
+    fr = pca_annulus(cube, ang, ncomp=2, annulus_width=6, r_guess=10, scaling="temp-mean", collapse="mean")
+    assert np.nanmax(np.abs(fr - g["adi_mean_tm"])) < TOL
+    fr = pca_annulus(cube, ang, ncomp=4, annulus_width=8, r_guess=13.5, cube_ref=cref)
+    assert np.nanmax(np.abs(fr - g["rdi"])) < TOL
+    cd = pca_annulus(cube, ang, ncomp=3, annulus_width=8, r_guess=14, collapse=None)
+    assert cd.shape == cube.shape and np.nanmax(np.abs(cd - g["cube_res_der"])) < TOL
+    cr = pca_annulus(cube, None, ncomp=3, annulus_width=8, r_guess=14, collapse=None)
+    assert np.nanmax(np.abs(cr - g["cube_res"])) < TOL
+    ifs = pca_annulus(g["cube4"], ang, ncomp=[2, 3, 2], annulus_width=8, r_guess=14, collapse="median", collapse_ifs="mean")
+    assert ifs.dtype == np.float64 and np.nanmax(np.abs(ifs - g["ifs"])) < TOL
+    with pytest.raises(ValueError):
+        pca_annulus(g["cube4"], ang, ncomp=2, annulus_width=8, r_guess=14, collapse=None)
+    with pytest.raises(TypeError):
+        pca_annulus(g["cube4"], ang, ncomp=[2, 3], annulus_width=8, r_guess=14)
+
+
+def _cube_with_companion(n=20, N=48, seed=9, r=11.0, flux=3.0):
+    cube, ang = O.synth_adi(n, N, seed=seed, planet=False)
+    ang = np.linspace(0, 80, n)
+    yy, xx = np.mgrid[:N, :N]
+    c = N // 2
+    for i, th in enumerate(np.deg2rad(ang)):                    # rotates with the field: fixed position after derotation
+        py, px = c + r * np.sin(th + 0.3), c + r * np.cos(th + 0.3)
+        cube[i] += (flux * np.exp(-((yy - py) ** 2 + (xx - px) ** 2) / (2 * 1.7 ** 2))).astype(np.float32)
+    return cube, ang, (c + r * np.cos(0.3), c + r * np.sin(0.3))
+
+
+def test_pca_grid_scored_by_snr():
+    """pca(ncomp=<tuple>, source_xy=..., fwhm=...): grid of frames on the device + S/N scoring on the host
+    (reference psfsub/utils_pca.py:239-277,364-402, pca_fullfr.py:706-713,779-790), against the oracle."""
+    from vip_amd.psfsub import pca, pca_grid
+    cube, ang, (sx, sy) = _cube_with_companion()
+    xy = (float(round(sx)), float(round(sy)))
+    ref = O.pca_grid_snr(cube, ang, (1, 6, 1), xy, 4.0)
+    out = pca(cube, ang, ncomp=(1, 6, 1), source_xy=xy, fwhm=4.0, full_output=True, verbose=False)
+    assert len(out) == 3
+    cubeout, frame, table = out
+    assert cubeout.shape == (6, 48, 48) and np.nanmax(np.abs(cubeout - ref[0])) < TOL
+    assert list(table["PCs"]) == ref[2]
+    assert np.abs(np.array(table["S/Ns"], dtype=float) - np.array(ref[3], dtype=float)).max() < 2e-3 * max(1.0, np.max(np.abs(ref[3])))
+    assert np.abs(np.array(table["fluxes"], dtype=float) - np.array(ref[4], dtype=float)).max() < 1e-3
+    assert np.nanmax(np.abs(frame - ref[1])) < TOL                                 # the frame of the best S/N
+    only = pca(cube, ang, ncomp=(1, 6, 1), source_xy=xy, fwhm=4.0, verbose=False)
+    assert np.array_equal(only, frame, equal_nan=True)
+    # the public pca_grid, every figure of merit + the annular mode
+    for fm in ("px", "max", "mean"):
+        co, fin, df, opt = pca_grid(cube, ang, fwhm=4.0, range_pcs=[2, 4], source_xy=xy, fmerit=fm, verbose=False)
+        r2 = O.pca_grid_snr(cube, ang, [2, 4], xy, 4.0, fmerit=fm)
+        assert opt == r2[5] and np.abs(np.array(df["S/Ns"], dtype=float) - np.array(r2[3], dtype=float)).max() < 2e-3 * max(1.0, np.max(np.abs(r2[3])))
+    co, fin, df, opt = pca_grid(cube, ang, fwhm=4.0, range_pcs=(1, 3), source_xy=xy, mode="annular", annulus_width=8,
+                                verbose=False)
+    for i, k in enumerate((1, 2, 3)):
+        exp = O.pca_annulus(cube, ang, k, 8, np.hypot(xy[0] - 24, xy[1] - 24))
+        assert np.nanmax(np.abs(co[i] - exp)) < TOL
+    with pytest.raises(ValueError):
+        pca_grid(cube, ang, range_pcs=(1, 3), source_xy=xy, verbose=False)          # fwhm missing
+
+
+def test_pppca_shaped_caller():
+    """A caller shaped like the reference's PPPCA object (objects/pppca.py:131-417): a dataclass carrying the PCA_Params
+    fields plus its own, calling ``pca(**{"algo_params": self, **rot_options})`` and unpacking the result by the tuple
+    layouts of ``_find_pca_mode`` (:285-413) -- every layout the accelerated path serves."""
+    from dataclasses import dataclass, field
+    from vip_amd.psfsub import pca, PCA_Params
+
+    @dataclass
+    class PostProc(PCA_Params):
+        dataset: object = None
+        results: object = None
+        extras: dict = field(default_factory=dict)
+
+        def run(self, **rot_options):
+            res = pca(**{"algo_params": self, **rot_options})
+            self._find_pca_mode(res)
+            return res
+
+        def _find_pca_mode(self, res):
+            it = isinstance(self.ncomp, (tuple, list))
+            if self.scale_list is not None and self.adimsdi == "double":
+                self.frame_final, self.cube_residuals, self.cube_residuals_der = res
+            elif self.scale_list is not None and not it:
+                self.frame_final, self.cube_residuals, _, _ = res                  # (:759-761 returns four elements)
+            elif (self.cube_ref is not None or self.source_xy is None) and it:
+                if self.cube.ndim == 4:
+                    self.frames_final, self.pc_list, _ = res
+                else:
+                    self.frames_final, self.pc_list = res
+            elif (self.cube_ref is not None or self.source_xy is None) and not it:
+                if self.cube.ndim == 4:
+                    (self.frame_final, self.pcs, self.cube_reconstructed, self.cube_residuals, self.cube_residuals_der,
+                     _) = res
+                else:
+                    (self.frame_final, self.pcs, self.cube_reconstructed, self.cube_residuals,
+                     self.cube_residuals_der) = res
+            elif self.source_xy is not None and it:
+                self.final_residuals_cube, self.frame_final, _ = res
+            else:
+                if self.cube.ndim == 4:
+                    self.frame_final, self.cube_reconstructed, self.cube_residuals, self.cube_residuals_der, _ = res
+                else:
+                    self.frame_final, self.cube_reconstructed, self.cube_residuals, self.cube_residuals_der = res
+
+    g = load_golden("g6_pca_small")
+    cube, ang = g["cube"], g["angles"]
+    common = dict(cube=cube, angle_list=ang, full_output=True, verbose=False)
+    # ADI_FULLFRAME_STANDARD, 3-D
+    pp = PostProc(ncomp=3, **common)
+    pp.run()
+    assert np.abs(pp.frame_final - O.pca_fullframe(cube, ang, ncomp=3)).max() < TOL
+    assert pp.pcs.shape == (3,) + cube.shape[1:] and pp.cube_residuals_der.shape == cube.shape
+    # ... with rot_options passed beside algo_params (mask_val = 0 -> zeros restored after the rotation)
+    pp = PostProc(ncomp=3, mask_center_px=3, **common)
+    pp.run(mask_val=0, interp_zeros=True, ker=1)
+    assert np.abs(pp.frame_final - O.pca_fullframe(cube, ang, ncomp=3, mask_center_px=3)).max() < TOL
+    # ADI_FULLFRAME_GRID, 3-D
+    pp = PostProc(ncomp=(1, 3), **common)
+    pp.run()
+    assert pp.pc_list == [1, 2, 3] and np.abs(pp.frames_final - O.pca_grid_frames(cube, ang, (1, 3))).max() < TOL
+    # PCA_ROT_THRESH, 3-D
+    pp = PostProc(ncomp=2, source_xy=(31, 20), fwhm=4, delta_rot=0.3, min_frames_pca=2, **common)
+    pp.run()
+    exp = O.pca_pa_rejection(cube, ang, 2, (31, 20), 4, 0.3, min_frames_pca=2)
+    assert np.nanmax(np.abs(pp.frame_final - exp)) < TOL and pp.cube_reconstructed.shape == cube.shape
+    # PCA_GRID_SN, 3-D
+    c2, a2, (sx, sy) = _cube_with_companion()
+    pp = PostProc(cube=c2, angle_list=a2, ncomp=(1, 4), source_xy=(float(round(sx)), float(round(sy))), fwhm=4.0,
+                  full_output=True, verbose=False)
+    pp.run()
+    assert pp.final_residuals_cube.shape == (4, 48, 48) and pp.frame_final.shape == (48, 48)
+    # 4-D standard and rotation-threshold layouts
+    g4 = load_golden("g6_pca_4d")
+    pp = PostProc(cube=g4["cube"], angle_list=g4["angles"], ncomp=2, full_output=True, verbose=False)
+    pp.run()
+    assert np.abs(pp.frame_final - g4["frame"]).max() < TOL and pp.pcs.shape[0] == g4["cube"].shape[0]
+    pp = PostProc(cube=g4["cube"], angle_list=g4["angles"], ncomp=2, source_xy=(25, 16), fwhm=4, delta_rot=0.3,
+                  min_frames_pca=2, full_output=True, verbose=False)
+    pp.run()
+    assert pp.cube_residuals.shape == g4["cube"].shape
+    # ADI+mSDI double pass
+    gm = load_golden("g10_msdi")
+    pp = PostProc(cube=gm["cube"], angle_list=gm["angles"], scale_list=gm["scale_list"], ncomp=(2, 2), adimsdi="double",
+                  full_output=True, verbose=False)
+    pp.run()
+    assert pp.frame_final.ndim == 2 and pp.cube_residuals.ndim == 3
+    # frame only: every mode returns the bare frame (pppca.py uses full_output=True, contrast curves do not)
+    assert pca(algo_params=PostProc(ncomp=3, cube=cube, angle_list=ang, verbose=False)).shape == cube.shape[1:]

@@ -146,55 +146,6 @@ def _prepared_matrices(cube_t, cube_ref_t, scaling, mask_center_px):
     return prep(cube_t), (prep(cube_ref_t) if cube_ref_t is not None else None)
 
 
-def _pca_grid(cube, angle_list, range_pcs, cube_ref, scaling, mask_center_px, svd_mode, collapse, weights,
-              full_output, verbose, mv_nan):
-    """Device version of ``pca_grid(mode='fullfr', source_xy=None)`` (reference psfsub/utils_pca.py:25-428,
-    called from pca_fullfr.py:1010-1035): ONE decomposition with the largest number of PCs, then for every entry of
-    the grid truncate -> subtract -> derotate -> collapse.  Returns ``cubeout`` (n_grid, y, x)[, pclist]."""
-    torch = B._torch()
-    n, y, x = cube.shape
-    if isinstance(range_pcs, list):
-        pclist = list(range_pcs)
-        pcmax = max(pclist)
-    else:
-        if len(range_pcs) == 2:
-            pcmin, pcmax = range_pcs
-            pcmax = min(pcmax, n)
-            step = 1
-        elif len(range_pcs) == 3:
-            pcmin, pcmax, step = range_pcs
-            pcmax = min(pcmax, n)
-        else:
-            raise TypeError("`range_pcs` must be None or a tuple, corresponding to (PC_INI, PC_MAX) or "
-                            "(PC_INI, PC_MAX, STEP)")
-        pclist = list(range(pcmin, pcmax + 1, step))
-    M, ref = _prepared_matrices(cube, cube_ref, scaling, mask_center_px)
-    ref_lib = M if ref is None else ref
-    if pcmax > min(ref_lib.shape):
-        msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
-        msg += " Increase the size of the patches or request less PCs"
-        raise RuntimeError(msg.format(pcmax, ref_lib.shape[0], ref_lib.shape[1]))
-    from .svd import _decompose
-    _sig, _E, V = _decompose(ref_lib, int(pcmax), want_pcs=True, leading_only=True)      # V: (pcmax, P)
-    coeff = B.cross_gram(M, V).to(torch.float32)                                        # M V^T: (n, pcmax)
-    ctx = B.get_context(cube.device.index)
-    P = y * x
-    frames = []
-    for pc in pclist:
-        C = coeff[:, :pc].contiguous()
-        R = B.empty((n, P), device=cube.device.index)
-        ctx.call("vipmi_subtract_gemm_f32", B.ptr(M), B.ptr(C), B.ptr(V), n, int(pc), P, B.ptr(R), None)
-        der = B.derotate(R.reshape(n, y, x), angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
-        frames.append(B.collapse(der, collapse, w=weights))
-    cubeout = torch.stack(frames)
-    if verbose:
-        print("Computed residual frames for PCs interval: {}".format(range_pcs))
-        print("Number of steps", len(pclist))
-    if full_output:
-        return cubeout, pclist
-    return cubeout
-
-
 def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scaling, mask_center_px, min_frames_pca,
                       max_frames_pca, verbose, cube_sig=None):
     """Device version of the ``source_xy`` branch (reference pca_fullfr.py:911-965 + the per-frame mode of
@@ -264,9 +215,6 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
     if not np.isscalar(ncomp) and not isinstance(ncomp, (tuple, list)):
         raise TypeError("`ncomp` must be an int, float, tuple or list in the ADI case")
     grid = not np.isscalar(ncomp)
-    if grid and source_xy is not None:
-        raise NotImplementedError("pca_grid with source_xy needs the S/N metrics of vip_hci.metrics (CPU, outside "
-                                  "the accelerated path); run the grid without source_xy and score the frames there")
     nref = cube_ref.shape[0] if cube_ref is not None else n
     if grid:
         pass
@@ -289,10 +237,15 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         raise ValueError("Weights have to be provided for weighted mean mode")
 
     if grid:
+        # pca_fullfr.py:1010-1035: one decomposition, every truncation derotated + collapsed on the device; with
+        # source_xy the frames are scored by the mean S/N in a FWHM aperture (host) -> (cubeout, finalfr, df, opt_npc)
         if cube_sig is not None:
             raise NotImplementedError("cube_sig with a grid of ncomp is outside the accelerated path")
-        return _pca_grid(cube, angle_list, ncomp, cube_ref, scaling, mask_center_px, svd_mode, collapse, weights,
-                         full_output, verbose, mv_nan)
+        from .utils_pca import pca_grid
+        return pca_grid(cube, angle_list, fwhm, range_pcs=ncomp, source_xy=source_xy, cube_ref=cube_ref, mode="fullfr",
+                        svd_mode=svd_mode, scaling=scaling, mask_center_px=mask_center_px, fmerit="mean",
+                        collapse=collapse, verbose=verbose, full_output=full_output, debug=False, plot=False,
+                        weights=weights, imlib=imlib, interpolation=interpolation, **rot_options)
     if source_xy is not None:
         if cube_ref is not None:
             raise NotImplementedError("source_xy together with cube_ref is outside the accelerated path")
@@ -621,6 +574,12 @@ def pca(*all_args: List, **all_kwargs: dict):
     fp = setup_parameters(algo_params, _adi_rdi_pca, cube=cube_t, cube_ref=cube_ref_t, **add)
     out = _adi_rdi_pca(**fp, **rot_options)
     if isinstance(algo_params.ncomp, (tuple, list)):
+        if algo_params.source_xy is not None:
+            # S/N-scored grid (pca_fullfr.py:706-713,779-783,789-790): (final_residuals_cube, frame, table) or the frame
+            cubeout, finalfr, table, _opt = out
+            if algo_params.med_of_npcs:
+                cubeout = B.collapse(cubeout, "median")
+            return (host(cubeout), host(finalfr), table) if fo else host(finalfr)
         # PCA grid (pca_fullfr.py:716-717,776-777,792-793): cube of final frames [, list of PCs]
         cubeout, pclist = out if fo else (out, None)
         if algo_params.med_of_npcs:
