@@ -242,7 +242,26 @@ static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, in
   const int ntiles = (int)tiles.size();
   // slices: ~2 workgroups per CU in total, slice length a multiple of 16, >= 64 pixels
   int64_t target = ctx->opt("gram_slices", 0);
-  if (target <= 0) target = cdiv((int64_t)2 * ctx->num_cu, ngroups);
+  if (target <= 0) {
+    // two workgroups fit a CU: slices so that the launch fills whole rounds of 2 * num_cu workgroups.  With many tile
+    // groups (n = 2000: 66 groups) the plain ceiling gave 8 slices = 528 workgroups = one full round + a round of 16
+    // workgroups, i.e. half of the MFMA time idle; search the neighbourhood for the best-filled last round.
+    const int64_t slots = (int64_t)2 * ctx->num_cu;
+    target = cdiv(slots, ngroups);
+    if (batch == 1 && ngroups > 8) {
+      double best = 0.0;
+      int64_t pick = target;
+      for (int64_t ns = target > 2 ? target / 2 : 1; ns <= 4 * target; ++ns) {
+        const int64_t wgs = ns * ngroups;
+        const double eff = (double)wgs / (double)(cdiv(wgs, slots) * slots);
+        if (eff > best + 0.02) {           // prefer fewer slices (less partial traffic) unless clearly better filled
+          best = eff;
+          pick = ns;
+        }
+      }
+      target = pick;
+    }
+  }
   if (batch > 1 && ctx->opt("gram_slices", 0) <= 0) {
     // many small problems: ~6 workgroups per CU in total, so that the hardware dispatcher evens out workgroups of
     // different weight (the tile groups of one problem are not alike)
@@ -252,7 +271,7 @@ static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, in
   int64_t klen = cdiv(cdiv(P, target), 16) * 16;
   if (klen < 64) klen = 64;
   int nslices = (int)cdiv(P, klen);
-  if (nslices > 8) {                       // keep same-slice workgroups on one XCD (b % 8)
+  if (nslices > 8 && !(batch == 1 && ngroups > 8 && ctx->opt("gram_slices", 0) <= 0)) {   // keep same-slice workgroups on one XCD (b % 8)
     nslices = (nslices / 8) * 8;
     klen = cdiv(cdiv(P, nslices), 16) * 16;
     nslices = (int)cdiv(P, klen);
