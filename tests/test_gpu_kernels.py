@@ -397,10 +397,11 @@ def test_rotate_masks_and_cube_direct(B):
     assert np.abs(got - g["derot_128"]).max() < 5e-5
 
 
-@pytest.mark.parametrize("N", [21, 101, 200, 301])
+@pytest.mark.parametrize("N", [21, 101, 129, 200, 255, 256, 301, 400, 511, 512])
 def test_derotate_generic_sizes_vs_oracle(B, N):
-    """Non-power-of-two padded lengths take the real-split direct path (rot_variant 0) -- every rot90 quadrant, angles
-    whose shears land next to integer shifts, NaN mask -- and the complex-field correlation (rot_variant 1) agrees."""
+    """Non-power-of-two padded lengths take the real-split direct path (rot_variant 0; from 129 px its passes run as
+    power-of-two circular convolutions, derotate_conv.inc) -- every rot90 quadrant, angles whose shears land next to
+    integer shifts, NaN mask -- and the complex-field correlation (rot_variant 1) agrees."""
     from vip_amd.preproc import cube_derotate
     rng = np.random.default_rng(N)
     angles = np.array([10.0, 50.0, 100.0, 200.0, 300.0, 359.0, -44.9, 45.1, 180.0, 0.0])
@@ -415,8 +416,13 @@ def test_derotate_generic_sizes_vs_oracle(B, N):
             got = cube_derotate(cube, angles[:n], method="direct")
             assert np.array_equal(np.isnan(got), np.isnan(ref))
             assert np.nanmax(np.abs(got - ref)) < (2e-5 if variant == 0 else 5e-5), variant
+        if 128 < N <= 512:                      # the convolution passes against the direct correlations they replace
+            ctx.set_option("rot_conv", 0)
+            slow = cube_derotate(cube, angles[:n], method="direct")
+            assert np.nanmax(np.abs(slow - ref)) < 2e-5
     finally:
         ctx.set_option("rot_variant", 0)
+        ctx.set_option("rot_conv", 1)
 
 
 @pytest.mark.parametrize("N", [80, 81])

@@ -371,8 +371,8 @@ def test_pca_pa_rejection_errors():
         pca(g["cube"], g["angles"], ncomp=2, source_xy=(34, 24), verbose=False)            # fwhm / delta_rot missing
     with pytest.raises(RuntimeError):
         pca(g["cube"], g["angles"], ncomp=2, source_xy=(26, 24), fwhm=4, delta_rot=20, verbose=False)   # empty libraries
-    with pytest.raises(NotImplementedError):
-        pca(g["cube"], g["angles"], ncomp=(1, 3), source_xy=(34, 24), fwhm=4, verbose=False)
+    fr = pca(g["cube"], g["angles"], ncomp=(1, 3), source_xy=(34, 24), fwhm=4, verbose=False)   # S/N-scored grid: a frame
+    assert fr.shape == g["cube"].shape[1:]
 
 
 def test_sharded_modes_world1_use_the_device_path():

@@ -18,6 +18,7 @@
 // DFT sums over an LDS table of the Le-th roots of unity (8 N^2 complex multiply-adds per frame).
 #include "common.h"
 #include "rot_common.h"
+#include "fft_wave.h"
 
 namespace vipmi {
 
@@ -431,6 +432,8 @@ __global__ __launch_bounds__(1024) void ds_shear3(const float* __restrict__ A2r,
   }
 }
 
+#include "derotate_conv.inc"
+
 }  // namespace
 
 int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n, float* out,
@@ -491,8 +494,18 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
   int t2 = (int)cdiv((int64_t)CT * (Npad / TNA), 64) * 64;
   if (t2 > 1024) t2 = 1024;
   if (t2 < 256) t2 = 256;
+  // 129 .. 512 px: the three passes as power-of-two circular convolutions (derotate_conv.inc); option rot_conv = 0 keeps
+  // the direct correlations
+  const bool conv = ctx->opt("rot_conv", 1) != 0 && g.N > 128 && g.N <= 512;
   for (int64_t f0 = 0; f0 < n; f0 += chunk) {
     const unsigned nf = (unsigned)((n - f0) < chunk ? (n - f0) : chunk);
+    if (conv) {
+      if (2 * g.N - 1 <= 512)
+        VIPMI_TRY((conv_passes<fftw::Plan512>(ctx, in, d_frames, g, A1r, A2r, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
+      else
+        VIPMI_TRY((conv_passes<fftw::Plan1024>(ctx, in, d_frames, g, A1r, A2r, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
+      continue;
+    }
     ctx->tic("k_rot_s1");
     hipLaunchKernelGGL(ds_shear1, dim3(g.N, nf), dim3(t1), lds1, ctx->stream, in, d_frames, g, A1r, aux, (int)f0, Npad,
                        Lpad);
