@@ -102,6 +102,8 @@ def pmc_traffic(frames_per_launch, N, kernel="rs_shear2"):
         for name, e in doc["kernels"].items():
             if name.startswith(kernel):
                 per_launch = 1024.0 * (e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"])
+                if "frames_per_launch" in doc:          # (round 2 on) every profiled launch covers the whole cube
+                    return per_launch * frames_per_launch / float(doc["frames_per_launch"])
                 return per_launch * frames_per_launch / (400.0 / e["launches"])
     except Exception:
         return None

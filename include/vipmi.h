@@ -212,6 +212,16 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
                             int collapse_mode, float* frame, float* pcs, float* recon,
                             float* residuals, float* residuals_der);
 
+/* ---- 4-D (IFS) cube without scale_list: psfsub/pca_fullfr.py:544-658 ----
+ * cube4[nch,n,N,N] float32: one full-frame ADI PCA per spectral channel (same integer ncomp, no reference cube), then
+ * the spectral collapse (collapse_ifs) of the nch per-channel frames -> frame[N,N].  ifs_frames[nch,N,N] (the
+ * reference's ifs_adi_frames) is optional (NULL).  The per-channel stages are batched: one Gram, one eigensolver, two
+ * projection, one derotation and one collapse launch for all channels.  n <= 512 frames and <= 64 PCs per channel
+ * (else VIPMI_ERR_ARG: loop vipmi_pca_fullframe_f32 over the channels). */
+int vipmi_pca_4d_f32(vipmi_ctx* ctx, const float* cube4, const double* angles_host, int64_t nch, int64_t n, int64_t N,
+                     int64_t ncomp, int scaling, const uint8_t* mask, int collapse_mode, int collapse_ifs_mode,
+                     float* frame, float* ifs_frames);
+
 #ifdef __cplusplus
 }
 #endif

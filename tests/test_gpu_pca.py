@@ -897,3 +897,45 @@ def test_pppca_shaped_caller():
     assert pp.frame_final.ndim == 2 and pp.cube_residuals.ndim == 3
     # frame only: every mode returns the bare frame (pppca.py uses full_output=True, contrast curves do not)
     assert pca(algo_params=PostProc(ncomp=3, cube=cube, angle_list=ang, verbose=False)).shape == cube.shape[1:]
+
+
+def test_raw_c_abi_pca_4d():
+    """vipmi_pca_4d_f32 by raw ctypes (SURVEY 8(b) minimum surface): the 4-D per-channel PCA + spectral collapse of
+    reference pca_fullfr.py:544-658 in one C call, against the reference golden; mask + scaling + median against the
+    Python front end's per-channel loop."""
+    import ctypes
+    import torch
+    from conftest import ROOT
+    from vip_amd.psfsub import pca
+    from vip_amd.var.shapes import center_mask_u8
+    g = load_golden("g6_pca_4d")
+    cube_np, angle_list = g["cube"], g["angles"]
+    nch, n, N = cube_np.shape[0], cube_np.shape[1], cube_np.shape[2]
+    lib = ctypes.CDLL(os.path.join(ROOT, "vip_amd", "libvipmi.so"))
+    lib.vipmi_last_error.restype = ctypes.c_char_p
+    ctx = ctypes.c_void_p()
+    assert lib.vipmi_create(0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(ctx)) == 0
+    cube = torch.from_numpy(cube_np).cuda()
+    frame = torch.empty((N, N), dtype=torch.float32, device="cuda")
+    ifs = torch.empty((nch, N, N), dtype=torch.float32, device="cuda")
+    angles = np.ascontiguousarray(O.check_pa_vector(angle_list), dtype=np.float64)
+    lib.vipmi_pca_4d_f32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 4 + [ctypes.c_int, ctypes.c_void_p,
+                                                                                     ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 2
+    st = lib.vipmi_pca_4d_f32(ctx, cube.data_ptr(), angles.ctypes.data, nch, n, N, 2, 0, None, 0, 1, frame.data_ptr(),
+                              ifs.data_ptr())
+    assert st == 0, lib.vipmi_last_error().decode()
+    torch.cuda.synchronize()
+    assert np.abs(frame.cpu().numpy() - g["frame"]).max() < TOL
+    assert np.abs(ifs.cpu().numpy() - g["ifs"]).max() < TOL
+    mask = torch.from_numpy(center_mask_u8((N, N), 3)).cuda()
+    st = lib.vipmi_pca_4d_f32(ctx, cube.data_ptr(), angles.ctypes.data, nch, n, N, 2, 1, mask.data_ptr(), 1, 0,
+                              frame.data_ptr(), None)                     # temp-mean, mask, mean collapse, median over channels
+    assert st == 0, lib.vipmi_last_error().decode()
+    torch.cuda.synchronize()
+    ref = pca(cube_np, angle_list, ncomp=2, scaling="temp-mean", mask_center_px=3, collapse="mean", collapse_ifs="median",
+              full_output=True, verbose=False)[0]
+    assert np.abs(frame.cpu().numpy() - ref).max() < 2e-5
+    st = lib.vipmi_pca_4d_f32(ctx, cube.data_ptr(), angles.ctypes.data, nch, n, N, 0, 0, None, 0, 1, frame.data_ptr(), None)
+    assert st < 0 and b"PCs" in lib.vipmi_last_error()
+    lib.vipmi_destroy.argtypes = [ctypes.c_void_p]
+    assert lib.vipmi_destroy(ctx) == 0

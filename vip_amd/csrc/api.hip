@@ -158,9 +158,25 @@ void vipmi_ctx::toc(const char* stage) {
   t.open = false;
 }
 
+namespace {
+// E[b][c][i] (float32) = evecs[b][c][i] (float64 rows, c < k), zeroed where the eigenvalue is below 1e-12 of the
+// leading one (components the projection must not use: their vectors are arbitrary)
+__global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const double* __restrict__ evals, int n, int k,
+                                      float* __restrict__ E) {
+  const int b = blockIdx.y;
+  const double* ev = evals + (size_t)b * n;
+  const double lead = ev[0];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k * n; e += gridDim.x * blockDim.x) {
+    const int c = e / n;
+    const bool keep = ev[c] > lead * 1e-12;
+    E[(size_t)b * k * n + e] = keep ? (float)evecs[(size_t)b * n * n + e] : 0.f;
+  }
+}
+}  // namespace
+
 extern "C" {
 
-int vipmi_version(void) { return 100; }
+int vipmi_version(void) { return 101; }
 
 const char* vipmi_last_error(void) { return g_err; }
 
@@ -556,6 +572,68 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
     if (residuals_der) VIPMI_TRY(apply_mask_f32(ctx, der, der, n, P, mask, 0.f));
     VIPMI_TRY(apply_mask_f32(ctx, frame, frame, 1, P, mask, 0.f));
   }
+  return VIPMI_OK;
+}
+
+// 4-D cube without scale_list (psfsub/pca_fullfr.py:544-658): one full-frame ADI PCA per spectral channel with the
+// small stages batched -- ONE Gram launch and ONE eigensolver launch for all channels (a workgroup per channel), the
+// projections of all channels in two launches, ONE derotation over all nch * n residual frames, ONE collapse launch --
+// then the spectral collapse of the per-channel frames.
+int vipmi_pca_4d_f32(vipmi_ctx* ctx, const float* cube4, const double* angles_host, int64_t nch, int64_t n, int64_t N,
+                     int64_t ncomp, int scaling, const uint8_t* mask, int collapse_mode, int collapse_ifs_mode,
+                     float* frame, float* ifs_frames) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(cube4 && angles_host && frame, "pca_4d: null pointer");
+  VIPMI_REQUIRE(nch > 0 && n > 0 && N > 1, "pca_4d: bad sizes");
+  VIPMI_REQUIRE(ncomp > 0, "Number of PCs too low. It should be > 0.");
+  VIPMI_REQUIRE(collapse_mode != VIPMI_COLLAPSE_WMEAN && collapse_ifs_mode != VIPMI_COLLAPSE_WMEAN,
+                "pca_4d: weighted collapses need weights (use vipmi_collapse_f32 on the per-channel frames)");
+  const int64_t P = N * N;
+  const int64_t k = ncomp > n ? n : ncomp;          // pca_fullfr.py:876-881 (clamp, not an error)
+  VIPMI_REQUIRE(n <= 512 && k <= 64, "pca_4d: the batched eigensolver takes up to 512 frames and 64 PCs per channel "
+                "(got %ld, %ld): call vipmi_pca_fullframe_f32 per channel", (long)n, (long)k);
+  const float* M = cube4;
+  if (mask || scaling) {
+    float* scratch = nullptr;
+    VIPMI_TRY(ws(ctx, "pca4_M", (size_t)nch * n * P, &scratch));
+    for (int64_t c = 0; c < nch; ++c) {
+      const float* src = cube4 + (size_t)c * n * P;
+      float* dst = scratch + (size_t)c * n * P;
+      if (mask) {
+        VIPMI_TRY(apply_mask_f32(ctx, src, dst, n, P, mask, 0.f));
+        src = dst;
+      }
+      if (scaling) VIPMI_TRY(scale_f32(ctx, src, dst, n, P, scaling));
+    }
+    M = scratch;
+  }
+  double *G = nullptr, *evals = nullptr, *evecs = nullptr;
+  VIPMI_TRY(ws(ctx, "pca4_G", (size_t)nch * n * n, &G));
+  VIPMI_TRY(ws(ctx, "pca4_evals", (size_t)nch * n, &evals));
+  VIPMI_TRY(ws(ctx, "pca4_evecs", (size_t)nch * n * n, &evecs));
+  VIPMI_TRY(gram_batched_f32(ctx, M, nch, n, P, G));
+  VIPMI_TRY(eigh_leading(ctx, G, nch, n, k, nullptr, evals, evecs));
+  float* E = nullptr;
+  VIPMI_TRY(ws(ctx, "pca4_E", (size_t)nch * k * n, &E));
+  {
+    const unsigned gx = (unsigned)cdiv(k * n, 256);
+    hipLaunchKernelGGL(evecs_rows_f32_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)nch), dim3(256), 0, ctx->stream, evecs, evals,
+                       (int)n, (int)k, E);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  float *R = nullptr, *der = nullptr;
+  VIPMI_TRY(ws(ctx, "pca4_res", (size_t)nch * n * P, &R));
+  VIPMI_TRY(ws(ctx, "pca4_der", (size_t)nch * n * P, &der));
+  VIPMI_TRY(project_batched_f32(ctx, M, E, nch, n, k, P, R));
+  static thread_local std::vector<double> tiled;
+  tiled.resize((size_t)nch * n);
+  for (int64_t c = 0; c < nch; ++c) memcpy(tiled.data() + (size_t)c * n, angles_host, sizeof(double) * n);
+  VIPMI_TRY(derotate_f32(ctx, R, tiled.data(), nch * n, N, der, mask ? 0 : 1, mask ? 1 : 0, VIPMI_ROT_AUTO));
+  float* ifs = ifs_frames;
+  if (!ifs) VIPMI_TRY(ws(ctx, "pca4_ifs", (size_t)nch * P, &ifs));
+  VIPMI_TRY(collapse_batched_f32(ctx, der, nch, n, P, collapse_mode, nullptr, 50, ifs));
+  if (mask) VIPMI_TRY(apply_mask_f32(ctx, ifs, ifs, nch, P, mask, 0.f));     // pca_fullfr.py:985-987 per channel
+  VIPMI_TRY(collapse_f32(ctx, ifs, nch, P, collapse_ifs_mode, nullptr, 50, frame));
   return VIPMI_OK;
 }
 
