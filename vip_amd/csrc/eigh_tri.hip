@@ -35,7 +35,13 @@ using tri::sturm_count;
 // PCA: 400 problems of 200 x 200 per annulus), so that two problems share a CU -- a problem is bound by the latency
 // of its ~n dependent steps (7.6 us each at n = 200), not by throughput: 400 problems take 2.7 ms, one takes 1.5 ms.
 // The Gram-Schmidt stage holds 4 vectors per wave: k <= NT/16.
-template <int RPL, int NT>
+// RPW > 0: the matrix lives in REGISTERS during the tridiagonalisation -- wave w holds rows w, w + TNW, ... (RPW of them,
+// cyclic, so every wave keeps work as the trailing matrix shrinks), lane l the columns l, l + 64, ... (RPL of them) of
+// each: RPW * RPL doubles per thread (200 x 200 on 512 threads: 100).  Round 1 streamed the trailing triangle from L2
+// in every step: 400 problems of 200 x 200 in flight moved ~20 TB/s, the aggregate L2 bandwidth, which is what the 7.6 us
+// per step of the batched solver were (annular PCA: 24 of C3's 35 ms).  The whole (symmetric) square is kept, so A v
+// needs only column sums -- per lane, in registers, no wave reduction -- combined across the waves through LDS.
+template <int RPL, int NT, int RPW = 0>
 __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
                                                      double* __restrict__ evecs_all, double* __restrict__ scratch_all,
@@ -67,6 +73,12 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   }
   __syncthreads();
 
+#ifdef VIPMI_TRI_PROFILE
+#define TRI_STAMP(i) do { __syncthreads(); if (prob == 0 && tid == 0) evals[n - 8 + (i)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TRI_STAMP(i)
+#endif
+  TRI_STAMP(0);
   // ---------------- 1. tridiagonalisation ----------------
   // Per step: ONE global round trip (the trailing pass) over the LOWER triangle of the trailing matrix only (the
   // batch is bound by the traffic of these passes: 400 problems of 200 x 200 move 2/3 n^3 * 8 B each).  Element
@@ -75,6 +87,114 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   // sums of the waves are combined through LDS in a fixed order (deterministic).  The first batch of loads is
   // issued before the Householder vector of the step is formed; column s+1 of the updated matrix (the next
   // Householder column) is handed over through LDS (`nrow`) instead of being re-read.
+  if constexpr (RPW > 0) {
+    double* nrow = e2;                                 // [n] column s of the updated matrix (e2 is not yet in use)
+    double* pcolw = lam + 72 + n;                      // [TNW][n] per-wave column parts of A v (same place as below)
+    double areg[RPW][RPL];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int r = wave + TNW * j, c = lane + 64 * ch;
+        areg[j][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
+      }
+    for (int c = tid; c < na; c += TNT) nrow[c] = A[(size_t)c * n];  // column 0
+    __syncthreads();
+    for (int s = 0; s + 2 < na; ++s) {
+      if (wave == 0) {
+        // column s below the diagonal (already updated) is the next Householder vector
+        double nrm2 = 0.0;
+        for (int c = s + 1 + lane; c < na; c += 64) {
+          const double x = nrow[c];
+          vcur[c] = x;
+          nrm2 += x * x;
+        }
+        nrm2 = wave_sum(nrm2);
+        const double x0 = nrow[s + 1];
+        const double nrm = sqrt(nrm2);
+        const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+        const double v0 = x0 - alpha;
+        double rest = nrm2 - x0 * x0;
+        if (rest < 0.0) rest = 0.0;
+        const double vv = rest + v0 * v0;
+        const double beta = (nrm2 > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          dd[s] = nrow[s];
+          vcur[s + 1] = v0;
+          ee[s] = (nrm2 > 0.0) ? alpha : 0.0;
+          tau[s] = beta;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // kept for the back-transform, in the (otherwise unused) upper triangle: row s, columns > s
+        for (int c = s + 1 + lane; c < na; c += 64) A[(size_t)s * n + c] = vcur[c];
+      }
+      __syncthreads();
+      const double beta = tau[s];
+      // the lane's columns: pending update vectors and this step's Householder vector
+      double vpc[RPL], wpc[RPL], colacc[RPL];
+      bool live[RPL];
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int c = lane + 64 * ch;
+        live[ch] = c > s && c < na;
+        vpc[ch] = live[ch] ? vprev[c] : 0.0;
+        wpc[ch] = live[ch] ? wprev[c] : 0.0;
+        colacc[ch] = 0.0;
+      }
+      // rank-2 update of step s-1 fused with the column sums of A v for step s: rows r > s of this wave
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        const int r = wave + TNW * j;
+        if (r > s && r < na) {                         // (wave-uniform)
+          const double vr = vprev[r], wr = wprev[r], vcr = vcur[r];
+#pragma unroll
+          for (int ch = 0; ch < RPL; ++ch) {
+            const double t = areg[j][ch] - vr * wpc[ch] - wr * vpc[ch];
+            areg[j][ch] = t;
+            colacc[ch] = fma(t, vcr, colacc[ch]);
+            // row s+1 (= column s+1 by symmetry) without the still pending update of this step: the next Householder column
+            if (r == s + 1 && live[ch]) nrow[lane + 64 * ch] = t;
+          }
+        }
+      }
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int c = lane + 64 * ch;
+        if (live[ch]) pcolw[wave * n + c] = colacc[ch];
+      }
+      __syncthreads();
+      for (int r = s + 1 + tid; r < na; r += TNT) {
+        double t = 0.0;
+#pragma unroll 4
+        for (int w = 0; w < TNW; ++w) t += pcolw[w * n + r];
+        pcur[r] = beta * t;
+      }
+      __syncthreads();
+      // K = beta/2 v.p (every wave computes it: no further barrier) ; w = p - K v becomes the pending update
+      double kd = 0.0;
+      for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pcur[r];
+      const double K = 0.5 * beta * wave_sum(kd);
+      const double vs1 = vcur[s + 1], ws1 = pcur[s + 1] - K * vs1;
+      for (int r = s + 1 + tid; r < na; r += TNT) {
+        const double v = vcur[r];
+        const double w = pcur[r] - K * v;
+        wprev[r] = w;
+        vprev[r] = v;
+        nrow[r] = nrow[r] - vs1 * w - ws1 * v;      // column s+1 with its own step's update: ready for the next step
+      }
+      __syncthreads();
+    }
+    // the trailing 2 x 2 block (without the last pending update) goes back to memory for the closing formulas below
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+#pragma unroll
+      for (int ch = 0; ch < RPL; ++ch) {
+        const int r = wave + TNW * j, c = lane + 64 * ch;
+        if (na >= 2 && r >= na - 2 && r < na && c >= na - 2 && c < na) A[(size_t)r * n + c] = areg[j][ch];
+      }
+    __syncthreads();
+  } else {
   constexpr int RQ = 4;                                // rows per wave and batch
   double* nrow = e2;                                   // [n] column s of the updated matrix (e2 is not yet in use)
   double* prow = lam + 72;                             // [n] row parts of A v
@@ -184,6 +304,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
     }
     __syncthreads();
   }
+  }
   if (tid == 0) {
     if (na >= 2) {
       const int a = na - 2, b = na - 1;
@@ -198,6 +319,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   }
   __syncthreads();
 
+  TRI_STAMP(1);
   // ---------------- 2. leading eigenvalues of T (scaled to max-norm 1) ----------------
   double scale = 0.0, glo = 0.0, ghi = 0.0;
   {
@@ -242,6 +364,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   }
   __syncthreads();
 
+  TRI_STAMP(2);
   // ---------------- 3. eigenvectors of T: inverse iteration, one lane per vector ----------------
   double* __restrict__ U0 = scr;                       // [n][kp] reciprocal pivots
   double* __restrict__ U1 = scr + (size_t)n * kp;      // first superdiagonal of U
@@ -324,6 +447,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   }
   __syncthreads();
 
+  TRI_STAMP(3);
   // ---------------- 3b. modified Gram-Schmidt, one wave per vector (registers), pivot vector through LDS -------------
   constexpr int VPW = 4;                    // vectors per wave: c = wave + 16 v
   double z[VPW][RPL];
@@ -378,6 +502,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
     __syncthreads();
   }
 
+  TRI_STAMP(4);
   // ---------------- 4. back-transformation: reflectors staged through LDS in blocks, one wave per vector ------------
   {
     constexpr int RB = 6;                             // reflectors per block: RB * n doubles of LDS (vcur..ee reused;
@@ -452,6 +577,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
       if (lane == 0) evals[c] = (c < kk) ? lam[c] * scale : 0.0;
     }
   }
+  TRI_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -917,6 +1043,23 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   int nt = (int)ctx->opt("eigh_nt", 0);
   if (nt != 256 && nt != 512 && nt != 1024) nt = batch > ctx->num_cu ? 512 : 1024;   // measured: 256 never wins
   while (nt < 1024 && k > nt / 16) nt *= 2;
+  // register-resident tridiagonalisation (512 threads: 8 waves x RPW rows x RPL x 64 columns) whenever the matrix fits
+  const int rpw_need = (int)cdiv(n, 8);
+  const bool reg = ctx->opt("eigh_reg", 1) != 0 && k <= 32 && rpw_need <= 25 && (RPL == 2 || RPL == 4);
+  if (reg) {
+    const size_t lds_r = ((size_t)(9 + 8) * n + 64 + 8 + 72) * sizeof(double);
+    auto launch_reg = [&](auto kern) -> int {
+      VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_r));
+      hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
+                         all_evals);
+      VIPMI_CHECK_HIP(hipGetLastError());
+      return VIPMI_OK;
+    };
+    if (rpw_need <= 8) return launch_reg(tri_eig_kernel<RPL, 512, 8>);
+    if (rpw_need <= 16) return launch_reg(tri_eig_kernel<RPL, 512, 16>);
+    return launch_reg(tri_eig_kernel<RPL, 512, 25>);
+  }
   const size_t lds = ((size_t)(9 + nt / 64) * n + 64 + 8) * sizeof(double);     // + prow[n], pcolw[waves][n]
   const void* kern = nt == 256   ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 256>)
                      : nt == 512 ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 512>)
