@@ -440,7 +440,13 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
                      int mask_nan, int mask_zero) {
   // paddings: multiples of 2 TNA (a lane pair owns 2 TNA outputs) with at least one zero after the last input
   const int Npad = (int)cdiv(g.N + 1, 2 * TNA) * 2 * TNA, Lpad = (int)cdiv(g.Le + 1, 2 * TNA) * 2 * TNA;
-  const int64_t per_frame = (int64_t)g.N * g.Le;
+  // 129 .. 512 px: the three passes as power-of-two circular convolutions (derotate_conv.inc) on blocked intermediates
+  // (N, Le rounded up to multiples of 128); option rot_conv = 0 keeps the direct correlations
+  const bool conv = ctx->opt("rot_conv", 1) != 0 && g.N > 128 && g.N <= 512;
+  CvLayout lay;
+  lay.nbr = (int)cdiv(g.N, 128) * 64;
+  lay.nbc = (int)cdiv(g.Le, 128) * 64;
+  const int64_t per_frame = conv ? (int64_t)lay.nbr * lay.nbc * 4 : (int64_t)g.N * g.Le;
   int64_t chunk = ctx->opt("rot_batch", 0);
   if (chunk <= 0) {
     const int64_t budget = ctx->opt("rot_ws_mb", 4096) * (int64_t)(1 << 20);
@@ -494,16 +500,13 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
   int t2 = (int)cdiv((int64_t)CT * (Npad / TNA), 64) * 64;
   if (t2 > 1024) t2 = 1024;
   if (t2 < 256) t2 = 256;
-  // 129 .. 512 px: the three passes as power-of-two circular convolutions (derotate_conv.inc); option rot_conv = 0 keeps
-  // the direct correlations
-  const bool conv = ctx->opt("rot_conv", 1) != 0 && g.N > 128 && g.N <= 512;
   for (int64_t f0 = 0; f0 < n; f0 += chunk) {
     const unsigned nf = (unsigned)((n - f0) < chunk ? (n - f0) : chunk);
     if (conv) {
       if (2 * g.N - 1 <= 512)
-        VIPMI_TRY((conv_passes<fftw::Plan512>(ctx, in, d_frames, g, A1r, A2r, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
+        VIPMI_TRY((conv_passes<fftw::Plan512>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
       else
-        VIPMI_TRY((conv_passes<fftw::Plan1024>(ctx, in, d_frames, g, A1r, A2r, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
+        VIPMI_TRY((conv_passes<fftw::Plan1024>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
       continue;
     }
     ctx->tic("k_rot_s1");
