@@ -18,6 +18,8 @@ from dataclasses import dataclass
 from enum import Enum
 from typing import List, Tuple, Union
 
+import os
+
 import numpy as np
 
 from .. import backend as B
@@ -199,7 +201,6 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                                          max_frames_lib, theta_init)             # is accepted (pca_local.py:868-870)
     if verbose:
         print("N annuli = {}, FWHM = {:.3f}".format(int((y / 2 - radius_int) / asize), fwhm))
-    ctx = B.get_context(cube.device.index)
     dev = cube.device.index
     P = y * x
     cube_out = torch.zeros_like(cube) if ks is None else torch.zeros((len(ks),) + tuple(cube.shape), dtype=cube.dtype,
@@ -208,7 +209,8 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     pad_ok = scaling not in ("spat-mean", "spat-standard")
     lib_cache = plan_dev.setdefault(("libs", dev), {})
     pix_cache = plan_dev.setdefault(("pix", dev, pad_ok), {})
-    for si, seg in enumerate(plan):
+
+    def pix_of(si, seg):
         pix = pix_cache.get(si)
         if pix is None:
             pix_h = seg["pix"]
@@ -217,6 +219,23 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             if pix_h.size % 4 and pad_ok:
                 pix_h = np.concatenate([pix_h, np.full(4 - pix_h.size % 4, -1, dtype=np.int32)])
             pix = pix_cache[si] = torch.from_numpy(pix_h).to(cube.device)
+        return pix
+
+    def libs_of(seg):
+        key = (id(seg["libs"]), nref)
+        if key not in lib_cache:
+            libs = seg["libs"]
+            if nref:
+                head = np.arange(nref, dtype=np.int64)
+                libs = [np.array([r]) for r in range(nref)] + [np.concatenate((head, np.asarray(li, dtype=np.int64) + nref))
+                                                               for li in libs]
+            idx, ln, max_lib = _pack_libs(libs)
+            lib_cache[key] = (torch.from_numpy(idx).to(cube.device), torch.from_numpy(ln).to(cube.device), max_lib)
+        return lib_cache[key]
+
+    def do_segment(si, seg):
+        ctx = B.get_context(dev)                       # (one context per stream)
+        pix = pix_of(si, seg)
         npx = int(pix.numel())
         A = B.empty((n, npx), device=dev)
         ctx.call("vipmi_gather_f32", B.ptr(cube), n, P, B.ptr(pix), npx, B.ptr(A))
@@ -238,16 +257,7 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             if scaling is not None:
                 Aref = B.scale(Aref, scaling)
             A = torch.cat((Aref, A))
-        key = (id(seg["libs"]), nref)
-        if key not in lib_cache:
-            libs = seg["libs"]
-            if nref:
-                head = np.arange(nref, dtype=np.int64)
-                libs = [np.array([r]) for r in range(nref)] + [np.concatenate((head, np.asarray(li, dtype=np.int64) + nref))
-                                                               for li in libs]
-            idx, ln, max_lib = _pack_libs(libs)
-            lib_cache[key] = (torch.from_numpy(idx).to(cube.device), torch.from_numpy(ln).to(cube.device), max_lib)
-        idx_t, ln_t, max_lib = lib_cache[key]
+        idx_t, ln_t, max_lib = libs_of(seg)
         if ks is None:
             R = B.empty((nrow, npx), device=dev)
             ctx.call("vipmi_annular_residuals_f32", B.ptr(A), nrow, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib,
@@ -267,6 +277,37 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                     Rn = B.lincomb(Rn, S, 1.0, 1.0)
                 Rn = Rn.contiguous()
                 ctx.call("vipmi_scatter_f32", B.ptr(Rn), n, P, B.ptr(pix), npx, B.ptr(cube_out[nn]))
+
+    # Independent segments: issue the annuli round-robin on a few streams in asynchronous mode, so that the 400 per-frame
+    # eigenproblems of one annulus (1.6 rounds of workgroups on 256 CUs) fill the idle tail of the previous one, and
+    # one annulus' Gram / projection runs beside the other's eigensolver.  The last two annuli overlap by one pixel ring
+    # and the later one must win (pca_local.py:786-787): they share a stream, which keeps their order.
+    n_ann = plan[-1]["ann"] + 1 if plan else 0
+    pipelined = n_ann >= 3 and not B.is_async()
+    if pipelined:
+        for si, seg in enumerate(plan):               # index uploads before the fork
+            pix_of(si, seg)
+            libs_of(seg)
+        cur = torch.cuda.current_stream()
+        depth = max(2, min(int(os.environ.get("VIPMI_ANNULAR_STREAMS", "2")), n_ann - 1))
+        streams = B.side_streams(depth, dev)
+        for st in streams:
+            st.wait_stream(cur)
+        B.set_async(True)
+        try:
+            for si, seg in enumerate(plan):
+                a = seg["ann"]
+                lane = (n_ann - 2) % depth if a == n_ann - 1 else a % depth
+                with torch.cuda.stream(streams[lane]):
+                    do_segment(si, seg)
+            for st in streams:
+                cur.wait_stream(st)
+            B.check_deferred()
+        finally:
+            B.set_async(False)
+    else:
+        for si, seg in enumerate(plan):
+            do_segment(si, seg)
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
     if not mv_nan and mask_val != 0:
