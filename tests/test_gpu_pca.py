@@ -939,3 +939,21 @@ def test_raw_c_abi_pca_4d():
     assert st < 0 and b"PCs" in lib.vipmi_last_error()
     lib.vipmi_destroy.argtypes = [ctypes.c_void_p]
     assert lib.vipmi_destroy(ctx) == 0
+
+
+@pytest.mark.parametrize("N", [255, 301])
+def test_pca_odd_frame_sizes_end_to_end(N):
+    """VIP's convention is ODD frames centred on the star: the whole pipeline at sizes whose derotation runs through the
+    power-of-two convolution passes (derotate_conv.inc), with and without a central mask (mask_val = 0 restore), against
+    the oracle."""
+    from vip_amd.psfsub import pca, pca_annular
+    cube, ang = O.synth_adi(10, N, seed=8)
+    ang = np.linspace(-30, 250, 10)                      # every rot90 quadrant
+    out = pca(cube, ang, ncomp=3, full_output=True, verbose=False)
+    ref = O.pca_fullframe(cube, ang, ncomp=3, full_output=True)
+    assert np.abs(out[0] - ref[0]).max() < TOL and np.nanmax(np.abs(out[4] - ref[4])) < TOL
+    fm = pca(cube, ang, ncomp=2, mask_center_px=5, collapse="mean", verbose=False)
+    assert np.abs(fm - O.pca_fullframe(cube, ang, ncomp=2, mask_center_px=5, collapse="mean")).max() < TOL
+    if N == 255:
+        fa = pca_annular(cube, ang, ncomp=2, asize=32, fwhm=4, verbose=False)
+        assert np.nanmax(np.abs(fa - O.pca_annular(cube, ang, ncomp=2, asize=32, fwhm=4))) < TOL
