@@ -399,9 +399,9 @@ def test_rotate_masks_and_cube_direct(B):
 
 @pytest.mark.parametrize("N", [21, 101, 129, 200, 255, 256, 301, 400, 511, 512])
 def test_derotate_generic_sizes_vs_oracle(B, N):
-    """Non-power-of-two padded lengths take the real-split direct path (rot_variant 0; from 129 px its passes run as
-    power-of-two circular convolutions, derotate_conv.inc) -- every rot90 quadrant, angles whose shears land next to
-    integer shifts, NaN mask -- and the complex-field correlation (rot_variant 1) agrees."""
+    """Non-power-of-two padded lengths take the real-split direct path (from 129 px its passes run as power-of-two
+    circular convolutions, derotate_conv.inc) -- every rot90 quadrant, angles whose shears land next to integer shifts,
+    NaN mask."""
     from vip_amd.preproc import cube_derotate
     rng = np.random.default_rng(N)
     angles = np.array([10.0, 50.0, 100.0, 200.0, 300.0, 359.0, -44.9, 45.1, 180.0, 0.0])
@@ -411,17 +411,14 @@ def test_derotate_generic_sizes_vs_oracle(B, N):
     ref = O.cube_derotate(cube, angles[:n])
     ctx = B.get_context()
     try:
-        for variant in ((0, 1) if N <= 200 else (0,)):
-            ctx.set_option("rot_variant", variant)
-            got = cube_derotate(cube, angles[:n], method="direct")
-            assert np.array_equal(np.isnan(got), np.isnan(ref))
-            assert np.nanmax(np.abs(got - ref)) < (2e-5 if variant == 0 else 5e-5), variant
+        got = cube_derotate(cube, angles[:n], method="direct")
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.nanmax(np.abs(got - ref)) < 2e-5
         if 128 < N <= 512:                      # the convolution passes against the direct correlations they replace
             ctx.set_option("rot_conv", 0)
             slow = cube_derotate(cube, angles[:n], method="direct")
             assert np.nanmax(np.abs(slow - ref)) < 2e-5
     finally:
-        ctx.set_option("rot_variant", 0)
         ctx.set_option("rot_conv", 1)
 
 
@@ -538,25 +535,16 @@ def test_derotate_fft_1024_delta(B):
 
 
 @pytest.mark.parametrize("N", [128, 256, 512])
-def test_derotate_fft_variants_agree(B, N):
-    """real-split two-for-one transforms (default) vs the complex-field formulation vs the oracle."""
+def test_derotate_fft_vs_oracle_all_quadrants(B, N):
+    """real-split two-for-one transforms (pruned butterflies, canonical positions) vs the float64 oracle."""
     from vip_amd.preproc import cube_derotate
     rng = np.random.default_rng(N + 1)
     angles = np.array([7.0, -47.5, 95.0, 200.1, 333.3, 135.0])
     n = len(angles) if N < 512 else 3
     cube = (rng.standard_normal((n, N, N)) * 3).astype(np.float32)
-    ctx = B.get_context()
-    outs = {}
-    for variant in (0, 1):
-        ctx.set_option("rot_variant", variant)
-        try:
-            outs[variant] = cube_derotate(cube, angles[:n], method="fft")
-        finally:
-            ctx.set_option("rot_variant", 0)
+    got = cube_derotate(cube, angles[:n], method="fft")
     ref = O.cube_derotate(cube, angles[:n])
-    assert np.abs(outs[0] - ref).max() < 5e-5
-    assert np.abs(outs[1] - ref).max() < 5e-5
-    assert np.abs(outs[0] - outs[1]).max() < 5e-5
+    assert np.abs(got - ref).max() < 5e-5
 
 
 def test_eigh_topk_repeatable_under_load():
