@@ -10,7 +10,7 @@
 //   power-of-two Le (frames of 128 / 256 / 512 / 1024 px): wave-resident FFT shears, derotate_fft2.hip;
 //   any other size: derotate_direct2.hip (power-of-two circular convolutions from 129 px, exact correlations below).
 // (The complex-field formulations of round 1 -- one complex transform per line, 44 N^3 correlations -- are gone: they
-//  survived only as cross-checks of the real-split paths, which are tested against the float64 oracle directly.)
+//  survived only as cross-checks of the real-split paths, which are tested against the float64 CPU restatement directly.)
 #include "common.h"
 #include "rot_common.h"
 
