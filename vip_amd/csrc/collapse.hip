@@ -260,8 +260,9 @@ __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ c
   // stage: TP consecutive pixels of every frame.  The kernel is bound by this load (400 row segments of 128 bytes,
   // 1 MB apart), so each thread issues a batch of 16-byte loads (8 threads per segment, 32 frames per pass) before
   // the first LDS write: ~13 requests in flight per thread instead of one.
-  if (TP == 32 && (P & 3) == 0) {
-    const int seg = threadIdx.x & 7, r0 = threadIdx.x >> 3, RPP = blockDim.x >> 3;   // rows per pass
+  if ((TP == 32 || TP == 16) && (P & 3) == 0) {
+    const int sh = TP == 32 ? 3 : 2;                                  // TP / 4 threads cover one row segment
+    const int seg = threadIdx.x & ((1 << sh) - 1), r0 = threadIdx.x >> sh, RPP = blockDim.x >> sh;   // rows per pass
     const int64_t pc = p0 + 4 * seg;
     const bool inb = pc < P;                                     // P % 4 == 0: the whole float4 is in range
     constexpr int NB = 4;                                        // passes per batch
@@ -457,7 +458,15 @@ __global__ void colreduce_kernel(const float* __restrict__ cube0, int n, int64_t
 
 template <int RPL, bool TRIM>
 int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64_t P, float* out, int t0, int tn) {
-  int TP = 32;
+  // pixels per tile: 32 (128-byte row segments) unless 16 lets more workgroups share a CU -- after the bucket-selection
+  // rewrite the kernel waits on dependent LDS round trips, so occupancy is what counts (C2, n = 400: 53 + 12 KB -> 2
+  // workgroups per CU with 32 pixels, 27 + 12 KB -> 4 with 16: 0.39 -> 0.32 ms)
+  int TP = (int)ctx->opt("median_tp", 0);
+  if (TP != 16 && TP != 32) {
+    const size_t hb = 8 * HIST_WORDS * 4;
+    const int wg32 = (int)((160 * 1024) / ((size_t)n * 33 * 4 + hb)), wg16 = (int)((160 * 1024) / ((size_t)n * 17 * 4 + hb));
+    TP = (wg32 < 4 && wg16 > wg32) ? 16 : 32;
+  }
   const size_t hist_bytes = 8 * HIST_WORDS * 4;             // 8 waves per workgroup
   while (TP > 1 && (size_t)n * (TP + 1) * 4 + hist_bytes > 150 * 1024) TP >>= 1;
   const size_t lds = (size_t)n * (TP + 1) * 4 + hist_bytes;
