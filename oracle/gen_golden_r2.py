@@ -46,3 +46,21 @@ for i, (xy, fw, ex) in enumerate((((33.2, 29.7), 4.0, False), ((10.0, 12.5), 5.3
     g["apc_in_%d" % i] = np.array([xy[0], xy[1], fw, float(ex)])
     g["apc_yy_%d" % i], g["apc_xx_%d" % i] = yy, xx
 save("g20_pca_annulus", **g)
+
+# ---- G21: cube_derotate at 512 px (padded length 2048, the C2 shear plan) against the REAL reference in the rot90
+# quadrants the C2 pin (angles 0..90 -> q in {0, 3, 4}) never reaches: q = 1, 2 and the half-to-even cases 135 / 225.
+# Inputs are reproducible from the seed (not stored); outputs float32.
+rng = np.random.default_rng(2100)
+fr = (rng.standard_normal((5, 512, 512)) * 3).astype(np.float32)
+angs = np.array([-100.0, -135.0, -170.0, -200.1, -225.0])          # cube_derotate rotates by -angle: theta = 100 ... 225
+out = ref.cube_derotate(fr, angs, imlib="vip-fft")
+save("g21_rotate_512", angles=angs, out=np.asarray(out, dtype=np.float32),
+     checksum=np.array([float(np.abs(fr).sum())]))
+
+# ---- G22: the same at 1024 px (padded length 4096, the two-waves-per-line plan of BASELINE configs[4]), one frame per
+# rot90 quadrant; a band of 128 rows and 8 columns of every output are kept.
+rng = np.random.default_rng(2200)
+fr = (rng.standard_normal((4, 1024, 1024)) * 3).astype(np.float32)
+angs = np.array([-20.0, -100.0, -200.1, -290.0])
+out = np.asarray(ref.cube_derotate(fr, angs, imlib="vip-fft"))
+save("g22_rotate_1024", angles=angs, band=out[:, 448:576, :].astype(np.float32), cols=out[:, :, 500:508].astype(np.float32))

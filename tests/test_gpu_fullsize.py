@@ -259,3 +259,31 @@ def test_c5_eigensolver_n2000_k50_against_numpy():
     assert np.abs(Pd).max() < 1e-9
     resid = G @ ec.T - ec.T * ev[None, :]
     assert np.abs(resid).max() < 1e-10 * w_ref[0]
+
+
+def test_c2_rotation_quadrants_against_the_real_reference():
+    """The C2 pin uses angles 0..90 (quadrants 0, 3, 4 only): G21 holds the real reference's cube_derotate of 512-px frames
+    at theta = 100, 135 (half-to-even), 170, 200.1, 225 -- q = 1 and 2 on the Le = 2048 shear plan."""
+    import torch
+    from conftest import load_golden
+    from vip_amd import backend as B
+    g = load_golden("g21_rotate_512")
+    rng = np.random.default_rng(2100)
+    fr = (rng.standard_normal((5, 512, 512)) * 3).astype(np.float32)
+    got = B.derotate(torch.from_numpy(fr).cuda(), g["angles"]).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(g["out"]))
+    assert np.nanmax(np.abs(got - g["out"])) < 1e-4
+
+
+def test_c5_rotation_quadrants_against_the_real_reference():
+    """1024-px frames (Le = 4096: two waves per line) in all four rot90 quadrants against the REAL reference's cube_derotate
+    (G22: a band of 128 rows and 8 columns of each output frame)."""
+    import torch
+    from conftest import load_golden
+    from vip_amd import backend as B
+    g = load_golden("g22_rotate_1024")
+    rng = np.random.default_rng(2200)
+    fr = (rng.standard_normal((4, 1024, 1024)) * 3).astype(np.float32)
+    got = B.derotate(torch.from_numpy(fr).cuda(), g["angles"]).cpu().numpy()
+    assert np.nanmax(np.abs(got[:, 448:576, :] - g["band"])) < 1e-4
+    assert np.nanmax(np.abs(got[:, :, 500:508] - g["cols"])) < 1e-4
