@@ -31,7 +31,8 @@ __global__ void subgram_kernel(const double* __restrict__ G, int n, const int32_
   }
 }
 
-// one workgroup per frame j: C[j][lib_j[a]] = sum_{c<k'} E[c][a] * (E[c] . g_j) / lambda_c
+// one workgroup per frame j: C[j][lib_j[a]] = sum_{c<k'} E[c][a] * (E[c] . g_j) / lambda_c, stored as D = I - C (the matrix is
+// zeroed before the launch), so that the residuals are ONE product  R = D A  on the matrix cores
 __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G, int n,
                                                     const int32_t* __restrict__ idx,
                                                     const int32_t* __restrict__ len, int max_lib, int m,
@@ -63,8 +64,10 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
   for (int a = threadIdx.x; a < lj; a += blockDim.x) {
     double s = 0;
     for (int c = 0; c < kk; ++c) s += E[(size_t)c * m + a] * proj[c];
-    C[(size_t)j * n + ij[a]] = (float)s;
+    C[(size_t)j * n + ij[a]] = (float)(-s);
   }
+  __syncthreads();                       // (the frame may belong to its own library: add the identity afterwards)
+  if (threadIdx.x == 0) C[(size_t)j * n + j] += 1.0f;
 }
 
 }  // namespace
@@ -101,8 +104,9 @@ int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
     hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
                        (int)max_lib, m, evals, evecs, (int)ncomps[i], (int)npx, C);
     VIPMI_CHECK_HIP(hipGetLastError());
-    // residuals = A - C * A   (projection GEMM on the matrix cores: "components" are the n frames)
-    VIPMI_TRY(subtract_gemm_f32(ctx, A, C, A, n, n, npx, residuals + (size_t)i * n * npx, nullptr));
+    // residuals = A - C A = (I - C) A: one (n x n) x (n x npx) product on the matrix cores.  (Round 1 ran it through the
+    // skinny-k subtract kernel, k = n components: 14 TF/s, 4.7 of C3's 35 ms; the row-space kernel does it at ~60 TF/s.)
+    VIPMI_TRY(rowspace_gemm_f32(ctx, C, A, n, n, npx, nullptr, residuals + (size_t)i * n * npx));
   }
   return VIPMI_OK;
 }
