@@ -41,6 +41,9 @@ using tri::sturm_count;
 // in every step: 400 problems of 200 x 200 in flight moved ~20 TB/s, the aggregate L2 bandwidth, which is what the 7.6 us
 // per step of the batched solver were (annular PCA: 24 of C3's 35 ms).  The whole (symmetric) square is kept, so A v
 // needs only column sums -- per lane, in registers, no wave reduction -- combined across the waves through LDS.
+// workgroup barrier that orders LDS traffic only (no wait for outstanding global stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int RPL, int NT, int RPW = 0>
 __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
@@ -88,16 +91,39 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   // issued before the Householder vector of the step is formed; column s+1 of the updated matrix (the next
   // Householder column) is handed over through LDS (`nrow`) instead of being re-read.
   if constexpr (RPW > 0) {
-    double* nrow = e2;                                 // [n] column s of the updated matrix (e2 is not yet in use)
     double* pcolw = lam + 72 + n;                      // [TNW][n] per-wave column parts of A v (same place as below)
-    double areg[RPW][RPL];
+    // RPL = 4 serves 129..200 rows: a fourth register chunk would hold 8 live columns in 64 lanes (25 wasted doubles per
+    // thread: the kernel spilled inside the step loop).  Columns 192.. live in LDS instead ([n][8], a few elements per
+    // thread and step); the whole square is still represented exactly once, so A v stays a pure column sum.
+    constexpr int CH = (RPL == 4) ? 3 : RPL;
+    constexpr int NTC = (RPL == 4) ? 8 : 0;
+    double* tcol = pcolw + TNW * n;                    // [n][NTC] tail columns 64 CH .. 64 CH + NTC - 1
+    // the three vectors the row blocks read, padded to TNW RPW entries and zero outside the live rows (rows <= s of the
+    // current Householder vector, rows >= na of all three): the row blocks need no per-row masks
+    constexpr int NP = TNW * RPW;
+    double* const vprev_n = vprev;                     // the n-strided arrays: the closing formulas read them
+    double* const wprev_n = wprev;
+    double* vcur = tcol + n * NTC;                     // (shadow the n-strided arrays above)
+    double* vprev = vcur + NP;
+    double* wprev = vprev + NP;
+    double* nrow = wprev + NP;                         // [NP] column s of the updated matrix (the next Householder column)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: row conditions are scalar branches
+    for (int i = tid; i < 4 * NP; i += TNT) vcur[i] = 0.0;
+    __syncthreads();
+    double areg[RPW][CH];
 #pragma unroll
     for (int j = 0; j < RPW; ++j)
 #pragma unroll
-      for (int ch = 0; ch < RPL; ++ch) {
+      for (int ch = 0; ch < CH; ++ch) {
         const int r = wave + TNW * j, c = lane + 64 * ch;
         areg[j][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
       }
+    if constexpr (NTC > 0) {
+      for (int e = tid; e < n * NTC; e += TNT) {
+        const int r = e / NTC, c = 64 * CH + e % NTC;
+        tcol[e] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
+      }
+    }
     for (int c = tid; c < na; c += TNT) nrow[c] = A[(size_t)c * n];  // column 0
     __syncthreads();
     for (int s = 0; s + 2 < na; ++s) {
@@ -121,56 +147,102 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
           dd[s] = nrow[s];
+          vcur[s] = 0.0;
           vcur[s + 1] = v0;
           ee[s] = (nrm2 > 0.0) ? alpha : 0.0;
           tau[s] = beta;
         }
-        __builtin_amdgcn_wave_barrier();
-        // kept for the back-transform, in the (otherwise unused) upper triangle: row s, columns > s
-        for (int c = s + 1 + lane; c < na; c += 64) A[(size_t)s * n + c] = vcur[c];
       }
-      __syncthreads();
+      lds_barrier();
       const double beta = tau[s];
+      // kept for the back-transform, in the (otherwise unused) upper triangle: row s, columns > s.  The only global
+      // access of a step: the barriers inside the step loop wait for LDS only (a full __syncthreads waits for the write
+      // acknowledgement from L2, ~1.5 us per step on the critical path)
+      for (int c = s + 1 + tid; c < na; c += TNT) A[(size_t)s * n + c] = vcur[c];
       // the lane's columns: pending update vectors and this step's Householder vector
-      double vpc[RPL], wpc[RPL], colacc[RPL];
-      bool live[RPL];
+      double vpc[CH], wpc[CH], colacc[CH];
+      bool live[CH];
 #pragma unroll
-      for (int ch = 0; ch < RPL; ++ch) {
+      for (int ch = 0; ch < CH; ++ch) {
         const int c = lane + 64 * ch;
         live[ch] = c > s && c < na;
         vpc[ch] = live[ch] ? vprev[c] : 0.0;
         wpc[ch] = live[ch] ? wprev[c] : 0.0;
         colacc[ch] = 0.0;
       }
-      // rank-2 update of step s-1 fused with the column sums of A v for step s: rows r > s of this wave
+      // rank-2 update of step s-1 fused with the column sums of A v for step s: rows r > s of this wave, in groups of GR
+      // rows without branches inside a group (the 3 GR LDS reads of a group are in flight together; a branch per row
+      // serialised 25 LDS round trips per step).  Rows r <= s of a live group take a meaningless update (they are never
+      // read again) and add nothing to the column sums (vcur is zero there); rows >= na stay zero.
+      constexpr int GR = (RPW % 5 == 0) ? 5 : 4;
+      const int jcap = (wave == ((s + 1) & (TNW - 1))) ? (s + 1) / TNW : -1;     // this wave's row block that is row s+1
 #pragma unroll
-      for (int j = 0; j < RPW; ++j) {
-        const int r = wave + TNW * j;
-        if (r > s && r < na) {                         // (wave-uniform)
-          const double vr = vprev[r], wr = wprev[r], vcr = vcur[r];
+      for (int g = 0; g < RPW / GR; ++g) {
+        if (wave + TNW * (g * GR + GR - 1) > s && wave + TNW * g * GR < na) {      // (wave-uniform)
+          double vr[GR], wr[GR], vcr[GR];
 #pragma unroll
-          for (int ch = 0; ch < RPL; ++ch) {
-            const double t = areg[j][ch] - vr * wpc[ch] - wr * vpc[ch];
-            areg[j][ch] = t;
-            colacc[ch] = fma(t, vcr, colacc[ch]);
-            // row s+1 (= column s+1 by symmetry) without the still pending update of this step: the next Householder column
-            if (r == s + 1 && live[ch]) nrow[lane + 64 * ch] = t;
+          for (int i = 0; i < GR; ++i) {
+            const int r = wave + TNW * (g * GR + i);
+            vr[i] = vprev[r];
+            wr[i] = wprev[r];
+            vcr[i] = vcur[r];
+          }
+#pragma unroll
+          for (int i = 0; i < GR; ++i) {
+            const int j = g * GR + i;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+              const double t = areg[j][ch] - vr[i] * wpc[ch] - wr[i] * vpc[ch];
+              areg[j][ch] = t;
+              colacc[ch] = fma(t, vcr[i], colacc[ch]);
+            }
+          }
+          // row s+1 (= column s+1 by symmetry) without the still pending update of this step: the next Householder
+          // column (entries of dead columns are never read)
+          if (jcap >= g * GR && jcap < g * GR + GR) {
+#pragma unroll
+            for (int i = 0; i < GR; ++i)
+              if (jcap == g * GR + i) {
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) nrow[lane + 64 * ch] = areg[g * GR + i][ch];
+              }
           }
         }
       }
 #pragma unroll
-      for (int ch = 0; ch < RPL; ++ch) {
+      for (int ch = 0; ch < CH; ++ch) {
         const int c = lane + 64 * ch;
         if (live[ch]) pcolw[wave * n + c] = colacc[ch];
       }
-      __syncthreads();
+      if constexpr (NTC > 0) {
+        // tail columns: thread tid owns column 64 CH + tid % NTC in rows tid / NTC + (TNT / NTC) i
+        const int c = 64 * CH + (tid & (NTC - 1));
+        double part = 0.0;
+        if (c > s && c < na) {
+          const double vc = vprev[c], wc = wprev[c];
+          for (int r = tid / NTC; r < na; r += TNT / NTC) {
+            if (r > s) {
+              const double t = tcol[r * NTC + (tid & (NTC - 1))] - vprev[r] * wc - wprev[r] * vc;
+              tcol[r * NTC + (tid & (NTC - 1))] = t;
+              part = fma(t, vcur[r], part);
+              if (r == s + 1) nrow[c] = t;
+            }
+          }
+        }
+        // the 8 lanes of a wave that share a column: lanes equal modulo NTC
+        part += __shfl_xor(part, 8, 64);
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (lane < NTC && c > s && c < na) pcolw[wave * n + c] = part;
+      }
+      lds_barrier();
       for (int r = s + 1 + tid; r < na; r += TNT) {
         double t = 0.0;
 #pragma unroll 4
         for (int w = 0; w < TNW; ++w) t += pcolw[w * n + r];
         pcur[r] = beta * t;
       }
-      __syncthreads();
+      lds_barrier();
       // K = beta/2 v.p (every wave computes it: no further barrier) ; w = p - K v becomes the pending update
       double kd = 0.0;
       for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pcur[r];
@@ -183,16 +255,33 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         vprev[r] = v;
         nrow[r] = nrow[r] - vs1 * w - ws1 * v;      // column s+1 with its own step's update: ready for the next step
       }
-      __syncthreads();
+      lds_barrier();
     }
-    // the trailing 2 x 2 block (without the last pending update) goes back to memory for the closing formulas below
+    // the trailing 2 x 2 block (without the last pending update) goes back to memory for the closing formulas below,
+    // the pending update vectors to where those formulas read them
+    for (int i = tid; i < na; i += TNT) {
+      vprev_n[i] = vprev[i];
+      wprev_n[i] = wprev[i];
+    }
+    // the last 2x2 block goes back through LDS (global addresses of all RPW rows would stay live across the step loop)
+    double* fin = pcolw;
+    if (na >= 2) {
 #pragma unroll
-    for (int j = 0; j < RPW; ++j)
+      for (int j = 0; j < RPW; ++j)
 #pragma unroll
-      for (int ch = 0; ch < RPL; ++ch) {
-        const int r = wave + TNW * j, c = lane + 64 * ch;
-        if (na >= 2 && r >= na - 2 && r < na && c >= na - 2 && c < na) A[(size_t)r * n + c] = areg[j][ch];
+        for (int ch = 0; ch < CH; ++ch) {
+          const int r = wave + TNW * j, c = lane + 64 * ch;
+          if (r >= na - 2 && r < na && c >= na - 2 && c < na) fin[(r - (na - 2)) * 2 + (c - (na - 2))] = areg[j][ch];
+        }
+      if constexpr (NTC > 0) {
+        for (int e = tid; e < n * NTC; e += TNT) {
+          const int r = e / NTC, c = 64 * CH + e % NTC;
+          if (r >= na - 2 && r < na && c >= na - 2 && c < na) fin[(r - (na - 2)) * 2 + (c - (na - 2))] = tcol[e];
+        }
       }
+    }
+    __syncthreads();
+    if (na >= 2 && tid < 4) A[(size_t)(na - 2 + (tid >> 1)) * n + (na - 2 + (tid & 1))] = fin[tid];
     __syncthreads();
   } else {
   constexpr int RQ = 4;                                // rows per wave and batch
@@ -1047,7 +1136,7 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   const int rpw_need = (int)cdiv(n, 8);
   const bool reg = ctx->opt("eigh_reg", 1) != 0 && k <= 32 && rpw_need <= 25 && (RPL == 2 || RPL == 4);
   if (reg) {
-    const size_t lds_r = ((size_t)(9 + 8) * n + 64 + 8 + 72) * sizeof(double);
+    const size_t lds_r = ((size_t)(9 + 8 + 8) * n + 64 + 8 + 72 + 4 * 200) * sizeof(double);    // + tail columns [n][8], padded vectors
     auto launch_reg = [&](auto kern) -> int {
       VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds_r));
@@ -1056,9 +1145,12 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
       VIPMI_CHECK_HIP(hipGetLastError());
       return VIPMI_OK;
     };
-    if (rpw_need <= 8) return launch_reg(tri_eig_kernel<RPL, 512, 8>);
-    if (rpw_need <= 16) return launch_reg(tri_eig_kernel<RPL, 512, 16>);
-    return launch_reg(tri_eig_kernel<RPL, 512, 25>);
+    if constexpr (RPL == 2) {
+      if (rpw_need <= 8) return launch_reg(tri_eig_kernel<2, 512, 8>);
+      return launch_reg(tri_eig_kernel<2, 512, 16>);
+    } else {
+      return launch_reg(tri_eig_kernel<4, 512, 25>);       // 129 .. 200 rows
+    }
   }
   const size_t lds = ((size_t)(9 + nt / 64) * n + 64 + 8) * sizeof(double);     // + prow[n], pcolw[waves][n]
   const void* kern = nt == 256   ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 256>)
