@@ -126,6 +126,12 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
     }
     for (int c = tid; c < na; c += TNT) nrow[c] = A[(size_t)c * n];  // column 0
     __syncthreads();
+#ifdef VIPMI_TRI_PROFILE
+    long long seg[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define SEG(i) do { const long long tn = __builtin_amdgcn_s_memtime(); seg[i] += tn - tlast; tlast = tn; } while (0)
+#else
+#define SEG(i)
+#endif
     for (int s = 0; s + 2 < na; ++s) {
       if (wave == 0) {
         // column s below the diagonal (already updated) is the next Householder vector
@@ -153,7 +159,9 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
           tau[s] = beta;
         }
       }
+      SEG(0);
       lds_barrier();
+      SEG(1);
       const double beta = tau[s];
       // kept for the back-transform, in the (otherwise unused) upper triangle: row s, columns > s.  The only global
       // access of a step: the barriers inside the step loop wait for LDS only (a full __syncthreads waits for the write
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         part += __shfl_xor(part, 32, 64);
         if (lane < NTC && c > s && c < na) pcolw[wave * n + c] = part;
       }
+      SEG(2);
       lds_barrier();
       for (int r = s + 1 + tid; r < na; r += TNT) {
         double t = 0.0;
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         for (int w = 0; w < TNW; ++w) t += pcolw[w * n + r];
         pcur[r] = beta * t;
       }
+      SEG(3);
       lds_barrier();
       // K = beta/2 v.p (every wave computes it: no further barrier) ; w = p - K v becomes the pending update
       double kd = 0.0;
@@ -255,8 +265,12 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         vprev[r] = v;
         nrow[r] = nrow[r] - vs1 * w - ws1 * v;      // column s+1 with its own step's update: ready for the next step
       }
+      SEG(4);
       lds_barrier();
     }
+#ifdef VIPMI_TRI_PROFILE
+    if (prob == 0 && tid == 0) for (int i = 0; i < 5; ++i) evals[n - 16 + i] = (double)seg[i];
+#endif
     // the trailing 2 x 2 block (without the last pending update) goes back to memory for the closing formulas below,
     // the pending update vectors to where those formulas read them
     for (int i = tid; i < na; i += TNT) {
@@ -455,12 +469,33 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
 
   TRI_STAMP(2);
   // ---------------- 3. eigenvectors of T: inverse iteration, one lane per vector ----------------
-  double* __restrict__ U0 = scr;                       // [n][kp] reciprocal pivots
-  double* __restrict__ U1 = scr + (size_t)n * kp;      // first superdiagonal of U
-  double* __restrict__ U2 = scr + (size_t)2 * n * kp;  // second superdiagonal (row swaps)
-  double* __restrict__ Zg = scr + (size_t)3 * n * kp;  // rhs / solution, [n][kp]
-  double* __restrict__ Lm = scr + (size_t)4 * n * kp;  // multipliers of L
-  double* __restrict__ Ls = scr + (size_t)5 * n * kp;  // 1 where rows i, i+1 were swapped
+  // Scratch of the factorisation: [n][ks] arrays.  The register-resident variant keeps them in LDS (the tridiagonalisation
+  // buffers are dead by now; the launcher checks the size): the substitutions are chains of dependent loads, and with
+  // the scratch in global memory the phase cost 0.27 ms of a 1.27 ms problem in a full batch.
+  constexpr bool LSCR = RPW > 0;
+  const int ks = LSCR ? kk : kp;
+  double *U0, *U1, *U2, *Zg, *Lm, *Ls = nullptr;      // reciprocal pivots; first, second superdiagonal of U (row swaps);
+  unsigned char* Lsb = nullptr;                        // rhs / solution; multipliers of L; 1 where rows i, i+1 were swapped
+  if constexpr (LSCR) {
+    double* b = lam + 72 + n;
+    U0 = b;
+    U1 = b + (size_t)n * ks;
+    U2 = b + (size_t)2 * n * ks;
+    Zg = b + (size_t)3 * n * ks;
+    Lm = b + (size_t)4 * n * ks;
+    Lsb = reinterpret_cast<unsigned char*>(b + (size_t)5 * n * ks);
+  } else {
+    U0 = scr;
+    U1 = scr + (size_t)n * kp;
+    U2 = scr + (size_t)2 * n * kp;
+    Zg = scr + (size_t)3 * n * kp;
+    Lm = scr + (size_t)4 * n * kp;
+    Ls = scr + (size_t)5 * n * kp;
+  }
+  auto swapped = [&](int i, int c) -> bool {
+    if constexpr (LSCR) return Lsb[i * ks + c] != 0;
+    else return Ls[(size_t)i * ks + c] != 0.0;
+  };
   if (tid < kk) {
     const int c = tid;
     // distinct shifts for (nearly) equal eigenvalues; the offsets are far below the eigenvalue accuracy that matters
@@ -472,12 +507,13 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
     for (int i = 0; i + 1 < na; ++i) {
       const double sub = ee[i], nd = dd[i + 1] - lc, nu = (i + 2 < na) ? ee[i + 1] : 0.0;
       const double yn = hash_unit((unsigned)(i + 1), (unsigned)c);
-      double inv, u1, u2, yi, m, sw;
+      double inv, u1, u2, yi, m;
+      bool sw;
       if (fabs(sub) > fabs(p) && fabs(sub) >= ptiny) {         // swap rows i and i+1
         inv = fast_rcp(sub);
         u1 = nd; u2 = nu;
         m = p * inv;
-        sw = 1.0;
+        sw = true;
         yi = yn;
         yc = yc - m * yn;
         p = q - m * nd;
@@ -488,44 +524,67 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         inv = fast_rcp(p);
         u1 = q; u2 = r;
         m = sub * inv;
-        sw = 0.0;
+        sw = false;
         yi = yc;
         yc = yn - m * yc;
         p = nd - m * q;
         q = nu - m * r;
         r = 0.0;
       }
-      U0[(size_t)i * kp + c] = inv;
-      U1[(size_t)i * kp + c] = u1;
-      U2[(size_t)i * kp + c] = u2;
-      Lm[(size_t)i * kp + c] = m;
-      Ls[(size_t)i * kp + c] = sw;
-      Zg[(size_t)i * kp + c] = yi;
+      U0[(size_t)i * ks + c] = inv;
+      U1[(size_t)i * ks + c] = u1;
+      U2[(size_t)i * ks + c] = u2;
+      Lm[(size_t)i * ks + c] = m;
+      if constexpr (LSCR) Lsb[i * ks + c] = sw ? 1 : 0;
+      else Ls[(size_t)i * ks + c] = sw ? 1.0 : 0.0;
+      Zg[(size_t)i * ks + c] = yi;
     }
     if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
     const double invlast = fast_rcp(p);
     double rs = 1.0;
     for (int it = 0; it < 2; ++it) {
-      if (it > 0) {
-        // forward substitution of the previous solution (scaled to unit norm) through P L
+      if (it > 0 && na > 1) {
+        // forward substitution of the previous solution (scaled to unit norm) through P L; the operands of row i+1
+        // are fetched while row i is computed
         yc = Zg[c] * rs;
+        double ynr = Zg[(size_t)ks + c], m = Lm[c];
+        bool sw = swapped(0, c);
         for (int i = 0; i + 1 < na; ++i) {
-          const double yn = Zg[(size_t)(i + 1) * kp + c] * rs;
-          const double m = Lm[(size_t)i * kp + c];
-          const bool sw = Ls[(size_t)i * kp + c] != 0.0;
-          const double yi = sw ? yn : yc;
-          yc = sw ? (yc - m * yn) : (yn - m * yc);
-          Zg[(size_t)i * kp + c] = yi;
+          const double yn = ynr * rs, mi = m;
+          const bool swi = sw;
+          if (i + 2 < na) {
+            ynr = Zg[(size_t)(i + 2) * ks + c];
+            m = Lm[(size_t)(i + 1) * ks + c];
+            sw = swapped(i + 1, c);
+          }
+          const double yi = swi ? yn : yc;
+          yc = swi ? (yc - mi * yn) : (yn - mi * yc);
+          Zg[(size_t)i * ks + c] = yi;
         }
+      } else if (it > 0) {
+        yc = Zg[c] * rs;
       }
-      // back substitution
+      // back substitution (same prefetch)
       double x1 = yc * invlast, x2 = 0.0;
-      Zg[(size_t)(na - 1) * kp + c] = x1;
+      Zg[(size_t)(na - 1) * ks + c] = x1;
       double acc = x1 * x1;
+      double zn = 0.0, u1n = 0.0, u2n = 0.0, u0n = 0.0;
+      if (na > 1) {
+        zn = Zg[(size_t)(na - 2) * ks + c];
+        u1n = U1[(size_t)(na - 2) * ks + c];
+        u2n = U2[(size_t)(na - 2) * ks + c];
+        u0n = U0[(size_t)(na - 2) * ks + c];
+      }
       for (int i = na - 2; i >= 0; --i) {
-        const double x = (Zg[(size_t)i * kp + c] - U1[(size_t)i * kp + c] * x1 - U2[(size_t)i * kp + c] * x2) *
-                         U0[(size_t)i * kp + c];
-        Zg[(size_t)i * kp + c] = x;
+        const double z = zn, u1 = u1n, u2 = u2n, u0 = u0n;
+        if (i > 0) {
+          zn = Zg[(size_t)(i - 1) * ks + c];
+          u1n = U1[(size_t)(i - 1) * ks + c];
+          u2n = U2[(size_t)(i - 1) * ks + c];
+          u0n = U0[(size_t)(i - 1) * ks + c];
+        }
+        const double x = (z - u1 * x1 - u2 * x2) * u0;
+        Zg[(size_t)i * ks + c] = x;
         acc += x * x;
         x2 = x1;
         x1 = x;
@@ -546,7 +605,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
 #pragma unroll
     for (int rr = 0; rr < RPL; ++rr) {
       const int i = lane + 64 * rr;
-      z[v][rr] = (c < kk && i < na) ? Zg[(size_t)i * kp + c] : 0.0;
+      z[v][rr] = (c < kk && i < na) ? Zg[(size_t)i * ks + c] : 0.0;
     }
   }
   double* qv = pcur;                        // pivot vector [n]
@@ -1134,9 +1193,16 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   while (nt < 1024 && k > nt / 16) nt *= 2;
   // register-resident tridiagonalisation (512 threads: 8 waves x RPW rows x RPL x 64 columns) whenever the matrix fits
   const int rpw_need = (int)cdiv(n, 8);
-  const bool reg = ctx->opt("eigh_reg", 1) != 0 && k <= 32 && rpw_need <= 25 && (RPL == 2 || RPL == 4);
+  // LDS of the register-resident variant: the tridiagonalisation buffers (tail columns [n][8], padded vectors), later
+  // overlaid by the inverse-iteration scratch (5 double arrays and one byte array of n x min(k, n))
+  const int kk_max = k < n ? k : n;
+  const size_t lds_fixed = ((size_t)10 * n + 64 + 8 + 72) * sizeof(double);
+  const size_t lds_tri = ((size_t)(8 + 8) * n + 4 * 200) * sizeof(double);
+  const size_t lds_inv = (size_t)n * kk_max * (5 * sizeof(double) + 1) + 16;
+  const size_t lds_r = lds_fixed + (lds_tri > lds_inv ? lds_tri : lds_inv);
+  const bool reg = ctx->opt("eigh_reg", 1) != 0 && k <= 32 && rpw_need <= 25 && (RPL == 2 || RPL == 4) &&
+                   lds_r <= (size_t)160 * 1024;
   if (reg) {
-    const size_t lds_r = ((size_t)(9 + 8 + 8) * n + 64 + 8 + 72 + 4 * 200) * sizeof(double);    // + tail columns [n][8], padded vectors
     auto launch_reg = [&](auto kern) -> int {
       VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds_r));

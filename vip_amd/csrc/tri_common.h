@@ -31,38 +31,47 @@ __device__ __forceinline__ double hash_unit(unsigned a, unsigned b) {
 // the Sturm sequence p_i = (d_i - sigma) p_{i-1} - e_{i-1}^2 p_{i-2} (one dependent FMA per step instead of a
 // float64 division); the pair (p_i, p_{i-1}) is renormalised every 16 steps (|growth| <= 5 per step), the operands
 // of 16 steps are fetched from LDS up front (uniform addresses).  A zero term counts as a sign change and is given
-// the opposite sign, as LAPACK dstebz does with its pivmin clamp.
+// the opposite sign, as LAPACK dstebz does with its pivmin clamp.  The signs of a block are shifted into an integer
+// (one v_alignbit per step) and the changes counted once per block: the multisection is bound by the instruction
+// count of this loop (9 per step; 17 with a compare / select / add per step).
+__device__ __forceinline__ unsigned hi_word(double x) { return (unsigned)(__double_as_longlong(x) >> 32); }
+
+__device__ __forceinline__ double sturm_step(double dmi, double e2i, double sigma, double& pm, double p, unsigned& sg) {
+  const double t = e2i * pm;
+  double pn = fma(dmi - sigma, p, -t);
+  // +-1e-300 with the sign opposite to p (p is never zero: zeros are replaced as they appear)
+  const unsigned alt_hi = 0x01A56E1Fu | (~hi_word(p) & 0x80000000u);
+  const double alt = __longlong_as_double(((long long)alt_hi << 32) | 0xC2F8F359ll);
+  pn = (pn == 0.0) ? alt : pn;
+  sg = __builtin_amdgcn_alignbit(sg, hi_word(pn), 31);      // (sg << 1) | sign(pn)
+  pm = p;
+  return pn;
+}
+
 __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n,
                                            double sigma) {
   double pm = 1.0, p = d[0] - sigma;
-  bool neg = p < 0.0 || p == 0.0;          // effective sign of p_i (true = negative); p_0 = 1 is positive
-  if (p == 0.0) p = -1e-300;
-  int cnt = neg ? 1 : 0;
-  for (int i0 = 1; i0 < n; i0 += 16) {
+  if (p == 0.0) p = -1e-300;               // p_{-1} = 1 is positive
+  unsigned sg = hi_word(p) >> 31;          // bit 0 = sign of the newest term
+  int cnt = (int)sg;
+  int i0 = 1;
+  for (; i0 + 16 <= n; i0 += 16) {
     double db[16], eb[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int i = i0 + u;
-      db[u] = (i < n) ? d[i] : 0.0;
-      eb[u] = (i < n) ? e2[i - 1] : 0.0;
+      db[u] = d[i0 + u];
+      eb[u] = e2[i0 + u - 1];
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      if (i0 + u < n) {
-        const double t = eb[u] * pm;
-        double pn = fma(db[u] - sigma, p, -t);
-        if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
-        const bool nneg = pn < 0.0;
-        cnt += (nneg != neg) ? 1 : 0;
-        neg = nneg;
-        pm = p;
-        p = pn;
-      }
-    }
+    for (int u = 0; u < 16; ++u) p = sturm_step(db[u], eb[u], sigma, pm, p, sg);
+    cnt += __popc((sg ^ (sg >> 1)) & 0xffffu);
     const int ex = ilogb(fabs(p) > fabs(pm) ? p : pm);
     p = scalbn(p, -ex);
     pm = scalbn(pm, -ex);
   }
+  const int m = n - i0;                    // 0 .. 15 remaining steps
+  for (int u = 0; u < m; ++u) p = sturm_step(d[i0 + u], e2[i0 + u - 1], sigma, pm, p, sg);
+  cnt += __popc((sg ^ (sg >> 1)) & ((1u << m) - 1u));
   return cnt;
 }
 
