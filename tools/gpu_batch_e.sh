@@ -1,12 +1,9 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c3 -o c3 -- python tools/time_c3.py > gpurun_out/prof_c3.log 2>&1
-python - <<'PY'
-import csv, glob
-f = glob.glob('gpurun_out/prof_c3/**/*kernel_stats.csv', recursive=True)
-print(f)
-rows = list(csv.DictReader(open(f[0])))
-for r in rows[:16]:
-    print("%-90s calls %6s total_ms %9.3f avg_us %9.1f pct %s" % (r['Name'][:90], r['Calls'], float(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e3, r['Percentage']))
-PY
+cp vip_amd/libvipmi.so /tmp/libvipmi.keep
+cp vip_amd/csrc/eigh_tri.o /tmp/eigh_tri.keep
+for D in "" "-DVIPMI_EXP_NOTAIL" "-DVIPMI_EXP_NOGROUPS" "-DVIPMI_EXP_NOTAIL -DVIPMI_EXP_NOGROUPS"; do
+( cd vip_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DVIPMI_TRI_PROFILE $D -c eigh_tri.hip -o eigh_tri.o && make ) > /dev/null 2>&1
+echo "variant: $D"
+timeout 300 python tools/tri_profile.py 2>&1 | grep -v amdgpu.ids | grep "reg=1\|wave0-phase [1-9]" | head -2
+done
+cp /tmp/eigh_tri.keep vip_amd/csrc/eigh_tri.o; cp /tmp/libvipmi.keep vip_amd/libvipmi.so

@@ -93,17 +93,18 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   if constexpr (RPW > 0) {
     double* pcolw = lam + 72 + n;                      // [TNW][n] per-wave column parts of A v (same place as below)
     // RPL = 4 serves 129..200 rows: a fourth register chunk would hold 8 live columns in 64 lanes (25 wasted doubles per
-    // thread: the kernel spilled inside the step loop).  Columns 192.. live in LDS instead ([n][8], a few elements per
-    // thread and step); the whole square is still represented exactly once, so A v stays a pure column sum.
+    // thread: the kernel spilled inside the step loop).  By symmetry the entries (r, c >= 192) of rows r < 192 are the
+    // entries (c, r) of rows 192..199, which the waves hold anyway (row 192 + w is row block RPW-1 of wave w): the column
+    // sums (A v)[c >= 192] become ONE row dot product per wave, and only the 8 x 8 corner needs storage of its own
+    // (`ablk`: lanes 0..7 of wave w hold A[192 + w][192 + lane]).
     constexpr int CH = (RPL == 4) ? 3 : RPL;
-    constexpr int NTC = (RPL == 4) ? 8 : 0;
-    double* tcol = pcolw + TNW * n;                    // [n][NTC] tail columns 64 CH .. 64 CH + NTC - 1
+    constexpr bool TAIL8 = (RPL == 4);
     // the three vectors the row blocks read, padded to TNW RPW entries and zero outside the live rows (rows <= s of the
     // current Householder vector, rows >= na of all three): the row blocks need no per-row masks
     constexpr int NP = TNW * RPW;
     double* const vprev_n = vprev;                     // the n-strided arrays: the closing formulas read them
     double* const wprev_n = wprev;
-    double* vcur = tcol + n * NTC;                     // (shadow the n-strided arrays above)
+    double* vcur = pcolw + TNW * n;                    // (shadow the n-strided arrays above)
     double* vprev = vcur + NP;
     double* wprev = vprev + NP;
     double* nrow = wprev + NP;                         // [NP] column s of the updated matrix (the next Householder column)
@@ -118,11 +119,13 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         const int r = wave + TNW * j, c = lane + 64 * ch;
         areg[j][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
       }
-    if constexpr (NTC > 0) {
-      for (int e = tid; e < n * NTC; e += TNT) {
-        const int r = e / NTC, c = 64 * CH + e % NTC;
-        tcol[e] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
-      }
+    double ablk = 0.0;
+    if constexpr (TAIL8) {
+      const int r8 = 64 * CH + wave, c8 = 64 * CH + lane;
+      ablk = (lane < 8 && r8 < na && c8 < na) ? A[(size_t)r8 * n + c8] : 0.0;
+      // (A v)[192 + w] is written by wave w alone, into the slot of wave 0: the other waves' slots stay zero
+      for (int e = tid; e < TNW * 8; e += TNT)
+        if (64 * CH + (e & 7) < n) pcolw[(e >> 3) * n + 64 * CH + (e & 7)] = 0.0;
     }
     for (int c = tid; c < na; c += TNT) nrow[c] = A[(size_t)c * n];  // column 0
     __syncthreads();
@@ -178,6 +181,16 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         wpc[ch] = live[ch] ? wprev[c] : 0.0;
         colacc[ch] = 0.0;
       }
+      double vcc[CH], v8 = 0.0, w8 = 0.0, vc8 = 0.0;  // TAIL8: this step's vector at the lane's columns; the three vectors
+      if constexpr (TAIL8) {                          // at column 192 + lane (lanes 0..7)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) vcc[ch] = vcur[lane + 64 * ch];
+        if (lane < 8) {
+          v8 = vprev[64 * CH + lane];
+          w8 = wprev[64 * CH + lane];
+          vc8 = vcur[64 * CH + lane];
+        }
+      }
       // rank-2 update of step s-1 fused with the column sums of A v for step s: rows r > s of this wave, in groups of GR
       // rows without branches inside a group (the 3 GR LDS reads of a group are in flight together; a branch per row
       // serialised 25 LDS round trips per step).  Rows r <= s of a live group take a meaningless update (they are never
@@ -222,28 +235,24 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         const int c = lane + 64 * ch;
         if (live[ch]) pcolw[wave * n + c] = colacc[ch];
       }
-      if constexpr (NTC > 0) {
-        // tail columns: thread tid owns column 64 CH + tid % NTC in rows tid / NTC + (TNT / NTC) i
-        const int c = 64 * CH + (tid & (NTC - 1));
-        double part = 0.0;
-        if (c > s && c < na) {
-          const double vc = vprev[c], wc = wprev[c];
-          for (int r = tid / NTC; r < na; r += TNT / NTC) {
-            if (r > s) {
-              const double t = tcol[r * NTC + (tid & (NTC - 1))] - vprev[r] * wc - wprev[r] * vc;
-              tcol[r * NTC + (tid & (NTC - 1))] = t;
-              part = fma(t, vcur[r], part);
-              if (r == s + 1) nrow[c] = t;
-            }
-          }
+      if constexpr (TAIL8) {
+        const int r8 = 64 * CH + wave;
+        if (r8 > s && r8 < na) {                       // (wave-uniform)
+          ablk = ablk - vprev[r8] * w8 - wprev[r8] * v8;
+          double rd = ablk * vc8;
+#pragma unroll
+          for (int ch = 0; ch < CH; ++ch) rd = fma(areg[RPW - 1][ch], vcc[ch], rd);
+          rd = wave_sum(rd);
+          if (lane == 0) pcolw[r8] = rd;
+          // entry r8 of the next Householder column: A[r8][s+1] (for r8 = s+1 the diagonal entry)
+          const int cs = s + 1;
+          double val = ablk;
+          if (cs < 64) val = areg[RPW - 1][0];
+          else if (cs < 128) val = areg[RPW - 1][1];
+          else if (cs < 192) val = areg[RPW - 1][2];
+          if (lane == (cs < 192 ? (cs & 63) : cs - 192)) nrow[r8] = val;
         }
-        // the 8 lanes of a wave that share a column: lanes equal modulo NTC
-        part += __shfl_xor(part, 8, 64);
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
-        if (lane < NTC && c > s && c < na) pcolw[wave * n + c] = part;
       }
-      SEG(2);
       lds_barrier();
       for (int r = s + 1 + tid; r < na; r += TNT) {
         double t = 0.0;
@@ -287,11 +296,9 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
           const int r = wave + TNW * j, c = lane + 64 * ch;
           if (r >= na - 2 && r < na && c >= na - 2 && c < na) fin[(r - (na - 2)) * 2 + (c - (na - 2))] = areg[j][ch];
         }
-      if constexpr (NTC > 0) {
-        for (int e = tid; e < n * NTC; e += TNT) {
-          const int r = e / NTC, c = 64 * CH + e % NTC;
-          if (r >= na - 2 && r < na && c >= na - 2 && c < na) fin[(r - (na - 2)) * 2 + (c - (na - 2))] = tcol[e];
-        }
+      if constexpr (TAIL8) {
+        const int r8 = 64 * CH + wave, c8 = 64 * CH + lane;
+        if (lane < 8 && r8 >= na - 2 && r8 < na && c8 >= na - 2 && c8 < na) fin[(r8 - (na - 2)) * 2 + (c8 - (na - 2))] = ablk;
       }
     }
     __syncthreads();
@@ -1197,7 +1204,7 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   // overlaid by the inverse-iteration scratch (5 double arrays and one byte array of n x min(k, n))
   const int kk_max = k < n ? k : n;
   const size_t lds_fixed = ((size_t)10 * n + 64 + 8 + 72) * sizeof(double);
-  const size_t lds_tri = ((size_t)(8 + 8) * n + 4 * 200) * sizeof(double);
+  const size_t lds_tri = ((size_t)8 * n + 4 * 200) * sizeof(double);
   const size_t lds_inv = (size_t)n * kk_max * (5 * sizeof(double) + 1) + 16;
   const size_t lds_r = lds_fixed + (lds_tri > lds_inv ? lds_tri : lds_inv);
   const bool reg = ctx->opt("eigh_reg", 1) != 0 && k <= 32 && rpw_need <= 25 && (RPL == 2 || RPL == 4) &&
