@@ -585,6 +585,21 @@ def test_msdi_errors():
         pca(g["cube"], g["angles"], scale_list=g["scale_list"][:3], adimsdi="double", ncomp=(1, 1), verbose=False)
 
 
+def test_more_than_64_components():
+    """ncomp > 64: full-frame PCA (fused entry and svd_wrapper) through the looping matrix-in-L2 eigensolver"""
+    from vip_amd.psfsub import pca
+    from vip_amd.psfsub.svd import svd_wrapper
+    n, N, k = 160, 40, 100
+    cube, ang = O.synth_adi(n, N, seed=11)
+    got = pca(cube, ang, ncomp=k, verbose=False)
+    assert np.abs(got - O.pca_fullframe(cube, ang, ncomp=k)).max() < TOL
+    M = cube.reshape(n, -1).astype(np.float64)
+    V = svd_wrapper(M.astype(np.float32), "lapack", k, False)
+    Vr = O.svd_wrapper(M, "lapack", k)
+    # same row space (PCs of the noise floor are defined up to rotations inside near-degenerate groups)
+    assert np.abs(V.T @ (V @ M.T) - Vr.T @ (Vr @ M.T)).max() < 1e-3 * np.abs(M).max()
+
+
 def test_more_than_2048_frames():
     """beyond the LDS-resident eigensolvers (n > 2048) the front keeps the device Gram / projection kernels and takes
     the eigendecomposition from rocSOLVER (backend.eigh_beyond_lds): ADI cube and RDI reference library of 2100 frames"""

@@ -315,6 +315,12 @@ def eigh_topk(G, k, nact=None, all_evals=False):
     return (ev[0], ec[0]) if single else (ev, ec)
 
 
+def topk_native(n, k):
+    """True when the leading-k tridiagonal solvers serve (n, k): up to 512 frames and 64 vectors in LDS
+    (eigh_tri.hip), 128..2048 frames and any number of vectors with the matrix in L2 (eigh_tri_large.hip)."""
+    return 0 < k <= n and ((n <= 512 and k <= 64) or 128 <= n <= 2048)
+
+
 MAX_EIGH_N = 2048        # the hand-written eigensolvers keep their working set in LDS: matrices up to 2048 x 2048
 
 

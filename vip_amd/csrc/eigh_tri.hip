@@ -1188,6 +1188,17 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   return VIPMI_OK;
 }
 
+// LDS of the register-resident variant: the tridiagonalisation buffers (padded vectors, per-wave column sums), later
+// overlaid by the inverse-iteration scratch (5 double arrays and one byte array of n x min(k, n))
+size_t reg_variant_lds(int n, int k) {
+  const int kk_max = k < n ? k : n;
+  const size_t lds_fixed = ((size_t)10 * n + 64 + 8 + 72) * sizeof(double);
+  const size_t lds_tri = ((size_t)8 * n + 4 * 200) * sizeof(double);
+  const size_t lds_inv = (size_t)n * kk_max * (5 * sizeof(double) + 1) + 16;
+  return lds_fixed + (lds_tri > lds_inv ? lds_tri : lds_inv);
+}
+bool reg_variant_fits(int n, int k) { return k <= 32 && cdiv(n, 8) <= 25 && reg_variant_lds(n, k) <= (size_t)160 * 1024; }
+
 template <int RPL>
 int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int32_t* nact, double* evals,
                double* evecs, int all_evals) {
@@ -1200,15 +1211,8 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   while (nt < 1024 && k > nt / 16) nt *= 2;
   // register-resident tridiagonalisation (512 threads: 8 waves x RPW rows x RPL x 64 columns) whenever the matrix fits
   const int rpw_need = (int)cdiv(n, 8);
-  // LDS of the register-resident variant: the tridiagonalisation buffers (tail columns [n][8], padded vectors), later
-  // overlaid by the inverse-iteration scratch (5 double arrays and one byte array of n x min(k, n))
-  const int kk_max = k < n ? k : n;
-  const size_t lds_fixed = ((size_t)10 * n + 64 + 8 + 72) * sizeof(double);
-  const size_t lds_tri = ((size_t)8 * n + 4 * 200) * sizeof(double);
-  const size_t lds_inv = (size_t)n * kk_max * (5 * sizeof(double) + 1) + 16;
-  const size_t lds_r = lds_fixed + (lds_tri > lds_inv ? lds_tri : lds_inv);
-  const bool reg = ctx->opt("eigh_reg", 1) != 0 && k <= 32 && rpw_need <= 25 && (RPL == 2 || RPL == 4) &&
-                   lds_r <= (size_t)160 * 1024;
+  const size_t lds_r = reg_variant_lds(n, k);
+  const bool reg = ctx->opt("eigh_reg", 1) != 0 && (RPL == 2 || RPL == 4) && reg_variant_fits(n, k);
   if (reg) {
     auto launch_reg = [&](auto kern) -> int {
       VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1255,7 +1259,10 @@ int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k
   VIPMI_REQUIRE(batch > 0 && eigh_topk_supported(n, k), "eigh_topk: unsupported sizes n=%ld k=%ld", (long)n, (long)k);
   StageScope sc(ctx, "eigh");
   // a few larger problems: spread each over several CUs (LDS-resident matrix); many problems: one CU each
-  const bool multi = !nact && n >= 96 && batch <= 8 && ctx->opt("eigh_multi", 1) != 0;
+  // (up to 200 rows the register-resident single-workgroup variant is the faster one even for a lone problem:
+  // 0.31 / 0.82 ms against 0.42 / 0.93 ms at n = 100 / 200)
+  const bool reg1 = ctx->opt("eigh_reg", 1) != 0 && reg_variant_fits((int)n, (int)k);
+  const bool multi = !nact && n >= 96 && batch <= 8 && !reg1 && ctx->opt("eigh_multi", 1) != 0;
   if (multi) {
     if (n <= 128) return launch_tri_multi<2>(ctx, A, batch, (int)n, (int)k, evals, evecs, all_evals);
     if (n <= 256) return launch_tri_multi<4>(ctx, A, batch, (int)n, (int)k, evals, evecs, all_evals);

@@ -1,11 +1,11 @@
-// eigh_tri_large.hip -- leading k eigenpairs of ONE larger symmetric float64 matrix (512 < n <= 2048, k <= 64):
+// eigh_tri_large.hip -- leading k eigenpairs of ONE larger symmetric float64 matrix (128 <= n <= 2048, any k <= n):
 // the algorithm of eigh_tri.hip's multi-workgroup variant with the matrix left in global memory (a 2000 x 2000
 // float64 matrix is 32 MB: it no longer fits the LDS of the cooperating workgroups, but it does fit the L2s and the
 // Infinity Cache).  W = 64 workgroups own the rows cyclically (row r -> workgroup r mod W) and update them in place;
 // per Householder step a workgroup reads and writes its share of the trailing matrix once (all loads of a row issued
 // before the first use), then the same single counter barrier / redundant-reflector scheme as in eigh_tri.hip.
-// Afterwards workgroup c computes eigenvalue c, its eigenvector by inverse iteration (factors in LDS) and its
-// back-transformation; workgroup 0 finally orthonormalises the k vectors.
+// Afterwards workgroup c computes eigenvalues c, c + W, ..., their eigenvectors by inverse iteration (factors in LDS)
+// and their back-transformations; workgroup 0 finally orthonormalises the k vectors.
 //
 // Replaces, for C5-sized cubes (n = 2000 frames), the one-sided Jacobi kernel (140 ms) in the decomposition step of
 // svd_wrapper / get_eigenvectors (psfsub/svd.py:342-702).
@@ -205,14 +205,21 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
     glo -= margin;
     ghi += margin;
   }
-  const bool mine = wg < kk;                    // vector c = wg (the host launches W >= k workgroups)
-  const int c = wg;
+  // vectors c = wg, wg + W, ... of this workgroup, one after the other (k <= W: one each).  Phase 4 overwrites dd with
+  // the Householder scalars, so every further vector starts by restoring the scaled diagonal.
+  for (int c = wg, first = 1; first || c < kk; c += W, first = 0) {
+  const bool mine = c < kk;
+  if (!first) {
+    __syncthreads();
+    for (int i = tid; i < na; i += LNT) dd[i] = ld_shared(&gd[i]) * iscale;
+    __syncthreads();
+  }
   if (mine && wave == 0) {
     const int target = na - 1 - c;
     const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
     if (lane == 0) lamv[0] = lam_;
   }
-  if (all_evals) {                         // the rest of the spectrum (values only): waves 1.. of every workgroup
+  if (all_evals && first) {                // the rest of the spectrum (values only): waves 1.. of every workgroup
     for (int i = kk + wg * (LNW - 1) + (wave - 1); wave > 0 && i < na; i += W * (LNW - 1)) {
       const int target = na - 1 - i;
       const double lam_ = tri::multisect(dd, e2, na, target, glo, ghi, lane);
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
       if (tid == 0) st_shared(&evals[c], lamv[0] * scale);
     }
   }
+  }   // vectors of this workgroup
   bar_target += W;
   grid_barrier(bar, bar_target, W);
   if (wg != 0) return;
@@ -440,7 +448,8 @@ int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double*
 
 }  // namespace
 
-bool eigh_large_supported(int64_t n, int64_t k) { return n > 512 && n <= 2048 && k >= 1 && k <= 64; }
+// (n below 512 is served when more than 64 vectors are wanted: the LDS-resident solvers of eigh_tri.hip stop there)
+bool eigh_large_supported(int64_t n, int64_t k) { return n >= 128 && n <= 2048 && k >= 1 && k <= n; }
 
 // one problem (batch entries are solved one after the other)
 int eigh_large_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,

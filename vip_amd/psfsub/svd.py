@@ -24,7 +24,7 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
     G = B.gram(mat_t)
     if leading_only:
         evals, evecs = B.eigh_topk(G, ncomp)
-    elif n <= 2048 and 0 < ncomp <= 64:
+    elif B.topk_native(n, ncomp):
         evals, evecs = B.eigh_topk(G, ncomp, all_evals=True)       # whole spectrum, leading vectors
     elif n > B.MAX_EIGH_N:
         evals, evecs = B.eigh_beyond_lds(G)                        # more than 2048 frames (rocSOLVER, see backend)
