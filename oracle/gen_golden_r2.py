@@ -64,3 +64,24 @@ fr = (rng.standard_normal((4, 1024, 1024)) * 3).astype(np.float32)
 angs = np.array([-20.0, -100.0, -200.1, -290.0])
 out = np.asarray(ref.cube_derotate(fr, angs, imlib="vip-fft"))
 save("g22_rotate_1024", angles=angs, band=out[:, 448:576, :].astype(np.float32), cols=out[:, :, 500:508].astype(np.float32))
+
+# ---- G23: ADI+mSDI single-pass leftovers (psfsub/pca_fullfr.py:1038-1243): grid of PCs (tuple / list ncomp ->
+# pca_grid with scale_list, utils_pca.py:201-227), with and without S/N scoring at source_xy, and a reference cube ----
+if "g23" in sys.argv or len(sys.argv) == 1:
+    z_, n_, N_ = 4, 8, 32
+    c4 = np.stack([O.synth_adi(n_, N_, seed=80 + i)[0] for i in range(z_)]).astype(np.float32)
+    a4 = np.linspace(0, 70, n_)
+    sc = np.linspace(1.0, 1.2, z_)[::-1].copy()
+    cr4 = np.stack([O.synth_adi(5, N_, seed=90 + i)[0] for i in range(z_)]).astype(np.float32)
+    g = {"cube": c4, "angles": a4, "scale_list": sc, "cube_ref": cr4}
+    g["grid_frames"] = np.asarray(ref.pca(c4, a4, scale_list=sc, adimsdi="single", ncomp=(1, 4), verbose=False, nproc=1))
+    fo = ref.pca(c4, a4, scale_list=sc, adimsdi="single", ncomp=[2, 5], full_output=True, verbose=False, nproc=1)
+    g["list_frames"], g["list_pcs"] = np.asarray(fo[0]), np.asarray(fo[1])
+    g["grid_range_median"] = np.asarray(ref.pca(c4, a4, scale_list=sc, adimsdi="single", ncomp=(1, 5, 2), verbose=False,
+                                                nproc=1, ifs_collapse_range=(1, 4), collapse="mean",
+                                                scaling="temp-mean", mask_center_px=3))
+    fo = ref.pca(c4, a4, scale_list=sc, adimsdi="single", ncomp=3, cube_ref=cr4, full_output=True, verbose=False,
+                 nproc=1)
+    for nm, a in zip(("frame", "allfr", "desc", "adi"), fo):
+        g["ref_%s" % nm] = np.asarray(a)
+    save("g23_msdi_single_more", **g)

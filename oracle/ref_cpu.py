@@ -1035,15 +1035,9 @@ def pca_adimsdi_double(cube, angle_list, scale_list, ncomp, scaling=None, mask_c
     return frame
 
 
-def pca_adimsdi_single(cube, angle_list, scale_list, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
-                       collapse="median", collapse_ifs="mean", ifs_collapse_range="all", crop_ifs=True, weights=None,
-                       full_output=False):
-    """``pca(cube4d, angles, scale_list=..., adimsdi='single', ncomp=<int>)``.
-    Ref: psfsub/pca_fullfr.py:1038-1216 (_adimsdi_singlepca), :736-742 (returns)."""
+def _msdi_big_cube(cube, scale_list, crop_ifs):
+    """All channels of every multispectral frame rescaled, frame-major (pca_fullfr.py:1084-1096 / :1099-1115)."""
     z, n, y_in, x_in = cube.shape
-    mask_val = 0 if mask_center_px else np.nan
-    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
-    scale_list = np.asarray(scale_list, dtype=float)
     big = []
     for i in range(n):
         cr = cube_rescaling_wavelengths(cube[:, i], scale_list)[0]
@@ -1051,8 +1045,46 @@ def pca_adimsdi_single(cube, angle_list, scale_list, ncomp, scaling=None, mask_c
             cr = cube_crop_frames(cr, y_in)
         big.append(cr)
     big = np.array(big)
-    big = big.reshape(z * n, big.shape[2], big.shape[3])
-    res_cube = project_subtract(big, ncomp, scaling, mask_center_px, svd_mode)
+    return big.reshape(z * n, big.shape[2], big.shape[3])
+
+
+def pca_adimsdi_single(cube, angle_list, scale_list, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
+                       collapse="median", collapse_ifs="mean", ifs_collapse_range="all", crop_ifs=True, weights=None,
+                       full_output=False, cube_ref=None):
+    """``pca(cube4d, angles, scale_list=..., adimsdi='single', ncomp=<int | tuple | list>)``.
+    Ref: psfsub/pca_fullfr.py:1038-1216 (_adimsdi_singlepca: int ncomp, optional 4-D ``cube_ref`` rescaled the same way
+    and used as the PCA library, :1099-1115), :1202-1243 + psfsub/utils_pca.py:201-227 (tuple / list ncomp: grid of frames,
+    every residual cube de-scaled and collapsed with ``collapse`` -- not ``collapse_ifs`` --, no central mask after the
+    derotation; ``cube_ref`` is not passed on), :736-742 (returns)."""
+    z, n, y_in, x_in = cube.shape
+    mask_val = 0 if mask_center_px else np.nan
+    angle_list = check_pa_vector(np.asarray(angle_list, dtype=float))
+    scale_list = np.asarray(scale_list, dtype=float)
+    big = _msdi_big_cube(cube, scale_list, crop_ifs)
+    i0, i1 = (0, z) if ifs_collapse_range == "all" else ifs_collapse_range
+    if isinstance(ncomp, (tuple, list)):
+        nf = big.shape[0]
+        if isinstance(ncomp, list):
+            pclist = list(ncomp)
+            pcmax = max(pclist)
+        else:
+            pcmin, pcmax = ncomp[0], min(ncomp[1], nf)
+            pclist = list(range(pcmin, pcmax + 1, ncomp[2] if len(ncomp) == 3 else 1))
+        matrix = prepare_matrix(big, scaling, mask_center_px)
+        V = svd_wrapper(matrix, svd_mode, pcmax)
+        frames = []
+        for pc in pclist:
+            res = (matrix - np.dot(np.dot(V[:pc], matrix.T).T, V[:pc])).reshape(big.shape)
+            resh = np.zeros((n, y_in, y_in))
+            for i in range(n):
+                resh[i] = cube_rescaling_wavelengths(res[i * z + i0:i * z + i1], scale_list[i0:i1], full_output=False,
+                                                     inverse=True, y_in=y_in, x_in=x_in, collapse=collapse)
+            der = cube_derotate(resh, angle_list, mask_val=mask_val)
+            frames.append(cube_collapse(der, mode=collapse, w=weights))
+        cubeout = np.array(frames)
+        return (cubeout, pclist) if full_output else cubeout
+    big_ref = _msdi_big_cube(cube_ref, scale_list, crop_ifs) if cube_ref is not None else None
+    res_cube = project_subtract(big, ncomp, scaling, mask_center_px, svd_mode, cube_ref=big_ref)
     resadi = np.zeros((n, y_in, x_in))
     i0, i1 = (0, z) if ifs_collapse_range == "all" else ifs_collapse_range
     desc = np.zeros_like(cube[i0:i1])

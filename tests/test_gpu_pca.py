@@ -559,6 +559,36 @@ def test_msdi_single_golden(tag, kw):
         assert np.abs(a - b).max() < TOL, (tag, nm, np.abs(a - b).max())
 
 
+def test_msdi_single_grid_and_reference_cube_golden():
+    """single-pass ADI+mSDI: tuple / list ``ncomp`` (grid of frames), S/N-scored grid at ``source_xy``, 4-D ``cube_ref``
+    (RSDI and ARSDI) against the reference's own outputs (g23) resp. the oracle"""
+    from vip_amd.psfsub import pca
+    g = load_golden("g23_msdi_single_more")
+    c4, a4, sc = g["cube"], g["angles"], g["scale_list"]
+    kw = dict(scale_list=sc, adimsdi="single", verbose=False)
+    fr = pca(c4, a4, ncomp=(1, 4), **kw)
+    assert fr.shape == g["grid_frames"].shape and np.abs(fr - g["grid_frames"]).max() < TOL
+    fr, pcs = pca(c4, a4, ncomp=[2, 5], full_output=True, **kw)
+    assert list(pcs) == list(g["list_pcs"]) and np.abs(fr - g["list_frames"]).max() < TOL
+    fr = pca(c4, a4, ncomp=(1, 5, 2), ifs_collapse_range=(1, 4), collapse="mean", scaling="temp-mean", mask_center_px=3,
+             **kw)
+    assert np.abs(fr - g["grid_range_median"]).max() < TOL
+    out = pca(c4, a4, ncomp=3, cube_ref=g["cube_ref"], full_output=True, **kw)
+    for nm, a in zip(("frame", "allfr", "desc", "adi"), out):
+        assert a.shape == g["ref_" + nm].shape and np.abs(a - g["ref_" + nm]).max() < TOL, nm
+    # ARSDI: the science frames join the library (pca_fullfr.py:503-508) -- against the oracle
+    both = np.concatenate((c4, g["cube_ref"]), axis=1)
+    fr = pca(c4, a4, ncomp=3, cube_ref=g["cube_ref"], ref_strategy="ARSDI", **kw)
+    assert np.abs(fr - O.pca_adimsdi_single(c4, a4, sc, 3, cube_ref=both)).max() < TOL
+    # S/N-scored grid: table and best frame (the S/N itself is host code shared with the 3-D grid)
+    cubeout, best, table = pca(c4, a4, ncomp=(1, 4), source_xy=(20.0, 12.0), fwhm=4.0, full_output=True, **kw)
+    assert np.abs(cubeout - g["grid_frames"]).max() < TOL
+    k = int(np.argmax(table["S/Ns"].values))
+    assert np.array_equal(best, cubeout[k]) and list(table["PCs"]) == [1, 2, 3, 4]
+    with pytest.raises(NotImplementedError):
+        pca(c4, a4, ncomp=(2, 2), scale_list=sc, adimsdi="double", cube_ref=g["cube_ref"], verbose=False)
+
+
 @pytest.mark.parametrize("N", [64, 65])
 def test_msdi_larger_sizes_golden(N):
     """ADI+mSDI with 7 channels at an even and an odd frame size against the reference's outputs."""

@@ -381,9 +381,14 @@ def pca(*all_args: List, **all_kwargs: dict):
         # argument checks of the ADI+mSDI path before anything touches the GPU
         if cube.ndim != 4:
             raise TypeError("`scale_list` needs a 4d (channels, frames, y, x) cube")
+        single = _s(algo_params.adimsdi) == "single"
         for name in ("cube_ref", "source_xy", "mask_rdi", "cube_sig", "smooth_first_pass"):
+            if single and name in ("cube_ref", "source_xy"):
+                continue                      # single pass: reference cube and S/N-scored grid are accelerated
             if getattr(algo_params, name, None) is not None:
                 raise NotImplementedError("{} is outside the accelerated ADI+mSDI path".format(name))
+        if algo_params.cube_ref is not None and np.ndim(algo_params.cube_ref) != 4:
+            raise TypeError("Ref cube has wrong format for 4d input cube")
         if _s(algo_params.imlib) != "vip-fft" or _s(algo_params.imlib2) != "vip-fft":
             raise NotImplementedError("vip_amd implements imlib='vip-fft' / imlib2='vip-fft' only")
         if _s(algo_params.adimsdi) not in ("double", "single"):
@@ -443,11 +448,30 @@ def pca(*all_args: List, **all_kwargs: dict):
                 return host(frame, dt), host(rcc, dt), host(rcc_, dt)
             return host(frame, dt)
         if mode == "single":
-            allfr, desc, adi, frame = adimsdi_single(cube_t, algo_params.angle_list, algo_params.scale_list,
-                                                     algo_params.ncomp, _s(algo_params.scaling),
-                                                     algo_params.mask_center_px, collapse, algo_params.collapse_ifs,
-                                                     algo_params.ifs_collapse_range, algo_params.crop_ifs,
-                                                     algo_params.weights, mv_nan, algo_params.verbose)
+            ref_t = None
+            if algo_params.cube_ref is not None:
+                ref_t = B.to_device_f32(algo_params.cube_ref)
+                if "A" in _s(algo_params.ref_strategy):          # e.g. 'ARSDI': the science frames join the library
+                    ref_t = B._torch().cat((cube_t, ref_t), dim=1)
+            grid = isinstance(algo_params.ncomp, (tuple, list))
+            res = adimsdi_single(cube_t, algo_params.angle_list, algo_params.scale_list,
+                                 algo_params.ncomp, _s(algo_params.scaling),
+                                 algo_params.mask_center_px, collapse, algo_params.collapse_ifs,
+                                 algo_params.ifs_collapse_range, algo_params.crop_ifs,
+                                 algo_params.weights, mv_nan, algo_params.verbose, cube_ref=ref_t,
+                                 grid_args=dict(fwhm=algo_params.fwhm, source_xy=algo_params.source_xy,
+                                                full_output=algo_params.full_output, rot_options=rot_options))
+            if grid:
+                # returns of the single-pass grid (pca_fullfr.py:744-755)
+                if algo_params.source_xy is None:
+                    if algo_params.full_output:
+                        return host(res[0], np.float64), res[1]
+                    return host(res, np.float64)
+                cubeout, finalfr, table, _ = res
+                if algo_params.full_output:
+                    return host(cubeout, np.float64), host(finalfr, np.float64), table
+                return host(finalfr, np.float64)
+            allfr, desc, adi, frame = res
             if algo_params.full_output:
                 return host(frame, np.float64), host(allfr, np.float64), host(desc), host(adi, np.float64)
             return host(frame, np.float64)

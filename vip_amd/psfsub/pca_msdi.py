@@ -3,8 +3,9 @@
 
 The spectral channels are rescaled with the matrix-core zoom of ``vip_amd.preproc.rescaling`` (all frames of all
 channels in one call), the PCA stages reuse the full-frame kernels, the de-scaled channels are collapsed with the
-collapse kernel.  Not accelerated (NotImplementedError): ``cube_ref``, ``source_xy``, ``batch``, ``mask_rdi``,
-``smooth_first_pass``, tuple / list ``ncomp`` in single-pass mode (grid), ``imlib2`` other than 'vip-fft'.
+collapse kernel.  Single-pass mode also takes a 4-D ``cube_ref`` and a tuple / list ``ncomp`` (grid of frames, with S/N
+scoring at ``source_xy``).  Not accelerated (NotImplementedError): ``cube_ref`` / ``source_xy`` in double-pass mode,
+``batch``, ``mask_rdi``, ``smooth_first_pass``, ``imlib2`` other than 'vip-fft'.
 """
 import numpy as np
 
@@ -147,25 +148,53 @@ def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
 
 
 def adimsdi_single(cube, angle_list, scale_list, ncomp, scaling, mask_center_px, collapse, collapse_ifs,
-                   ifs_collapse_range, crop_ifs, weights, mv_nan, verbose):
-    """Returns (cube_allfr_residuals (z*n, Y, X), cube_desc_residuals (zc, n, y, x), cube_adi_residuals (n, y, x),
-    frame) as device tensors."""
+                   ifs_collapse_range, crop_ifs, weights, mv_nan, verbose, cube_ref=None, grid_args=None):
+    """int ``ncomp``: returns (cube_allfr_residuals (z*n, Y, X), cube_desc_residuals (zc, n, y, x), cube_adi_residuals
+    (n, y, x), frame) as device tensors; ``cube_ref`` (4-D, same channels): rescaled like the cube, its frames are the
+    PCA library (pca_fullfr.py:1099-1115).  Tuple / list ``ncomp``: the grid of final frames through
+    ``utils_pca.pca_grid`` (one decomposition, every residual cube de-scaled, collapsed, derotated; pca_fullfr.py:1202-1236)
+    -- returns what ``pca_grid`` returns; ``grid_args``: fwhm, source_xy, full_output, rot_options."""
     torch = B._torch()
     z, n, y_in, x_in = cube.shape
     angle_list, scale_list = _check(cube, angle_list, scale_list)
-    if not np.isscalar(ncomp):
-        raise NotImplementedError("tuple / list ncomp (grid) in single-pass ADI+mSDI is not accelerated")
     if isinstance(ncomp, (float, np.floating)):
         raise NotImplementedError("float ncomp (CEVR) in single-pass ADI+mSDI is not accelerated")
+    if not np.isscalar(ncomp) and not isinstance(ncomp, (tuple, list)):
+        raise TypeError("`ncomp` must be an int, float, tuple or list for single-pass PCA")
     if verbose:
         print("Rescaling the spectral channels to align the speckles")
     E = channel_operators(y_in, scale_list, crop_to=y_in if crop_ifs else None)
     big_cube = zoom_frames(_frame_major(cube), E, np.tile(np.arange(z), n))           # (n*z, Y, Y)
     Y = big_cube.shape[1]
+    big_ref = None
+    if cube_ref is not None:
+        if cube_ref.dim() != 4 or cube_ref.shape[0] != z or tuple(cube_ref.shape[2:]) != (y_in, x_in):
+            raise TypeError("Ref cube has wrong format for 4d input cube")
+        if verbose:
+            print("Rescaling the spectral channels of the reference cube..")
+        big_ref = zoom_frames(_frame_major(cube_ref), E, np.tile(np.arange(z), cube_ref.shape[1]))
     if verbose:
         print("{} total frames".format(n * z))
         print("Performing single-pass PCA")
-    res_cube = _residuals(big_cube, int(ncomp), scaling, mask_center_px)
+    if not np.isscalar(ncomp):
+        from .utils_pca import pca_grid
+        ga = dict(grid_args or {})
+        rot_options = ga.pop("rot_options", {})
+        return pca_grid(big_cube, angle_list, ga.get("fwhm"), range_pcs=ncomp, source_xy=ga.get("source_xy"),
+                        cube_ref=None, mode="fullfr", scaling=scaling, mask_center_px=mask_center_px, fmerit="mean",
+                        collapse=collapse, ifs_collapse_range=ifs_collapse_range, verbose=verbose,
+                        full_output=ga.get("full_output", False), scale_list=scale_list,
+                        initial_4dshape=tuple(cube.shape), weights=weights, **rot_options)
+    if big_ref is None:
+        res_cube = _residuals(big_cube, int(ncomp), scaling, mask_center_px)
+    else:
+        M = _prep(big_cube, scaling, mask_center_px)
+        R = _prep(big_ref, scaling, mask_center_px)
+        if ncomp > min(R.shape):
+            msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
+            msg += " Increase the size of the patches or request less PCs"
+            raise RuntimeError(msg.format(ncomp, R.shape[0], R.shape[1]))
+        res_cube = B.pca_project(M, int(ncomp), ref=R)[0].reshape(n * z, Y, Y)
     i0, i1 = (0, z) if ifs_collapse_range == "all" else ifs_collapse_range
     zc = i1 - i0
     sel = res_cube.reshape(n, z, Y, Y)[:, i0:i1].reshape(n * zc, Y, Y).contiguous()

@@ -78,8 +78,9 @@ def pca_grid(cube, angle_list, fwhm=None, range_pcs=None, source_xy=None, cube_r
     ``(cubeout, finalfr, df, opt_npc)`` -- the frame of the best S/N, the pandas table PCs / S/Ns / fluxes and the
     optimal number of PCs.  ``plot`` / ``save_plot`` are accepted and ignored (no plotting on the accelerated path)."""
     torch = B.require_gpu()
-    if scale_list is not None or initial_4dshape is not None:
-        raise NotImplementedError("pca_grid on rescaled ADI+mSDI cubes is outside the accelerated path")
+    msdi = scale_list is not None and initial_4dshape is not None
+    if msdi and mode != "fullfr":
+        raise NotImplementedError("pca_grid on rescaled ADI+mSDI cubes: mode='fullfr' only")
     if not (isinstance(cube, np.ndarray) or B.is_device_tensor(cube)) or cube.ndim != 3:
         raise TypeError("Input cube is not a 3d array")
     dev_in = B.is_device_tensor(cube)
@@ -115,6 +116,15 @@ def pca_grid(cube, angle_list, fwhm=None, range_pcs=None, source_xy=None, cube_r
         raise TypeError("mode not recognized")
     scaling = _s(scaling)
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
+    if msdi:
+        # `cube` is the frame-major stack of rescaled channels of a (z, n_adi, y, x) cube: every residual cube is de-scaled
+        # and collapsed per multispectral frame (with `collapse`, as the reference does: utils_pca.py:201-220) first
+        from ..preproc.rescaling import channel_operators, zoom_frames
+        z4, n_adi, y4, x4 = initial_4dshape
+        i0, i1 = (0, z4) if ifs_collapse_range == "all" else ifs_collapse_range
+        zc = i1 - i0
+        Einv = channel_operators(ysz, np.asarray(scale_list, dtype=np.float64)[i0:i1], inverse=True,
+                                 out_size=max(y4, x4))
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
     cube_t = B.to_device_f32(cube)
@@ -152,7 +162,11 @@ def pca_grid(cube, angle_list, fwhm=None, range_pcs=None, source_xy=None, cube_r
             C = coeff[:, :pc].contiguous()
             R = B.empty((n, npx), device=cube_t.device.index)
             ctx.call("vipmi_subtract_gemm_f32", B.ptr(M), B.ptr(C), B.ptr(V), n, int(pc), npx, B.ptr(R), None)
-            if pix_t is None:
+            if msdi:
+                sel = R.reshape(n_adi, z4, ysz, xsz)[:, i0:i1].reshape(n_adi * zc, ysz, xsz).contiguous()
+                desc = zoom_frames(sel, Einv, np.tile(np.arange(zc), n_adi))
+                res_cube = B.collapse_batched(desc.reshape(n_adi, zc, desc.shape[1], desc.shape[2]), collapse)
+            elif pix_t is None:
                 res_cube = R.reshape(n, ysz, xsz)
             else:
                 res_cube = torch.zeros((n, ysz, xsz), dtype=torch.float32, device=cube_t.device)
