@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_pca.py -x -q -m gpu -k "msdi or grid" 2>&1 | tail -15
+timeout 600 python tools/time_topk_w.py 2>&1 | grep -v amdgpu.ids

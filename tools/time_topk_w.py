@@ -1,0 +1,27 @@
+"""n = 1000 / 2000 leading-k solver (matrix in L2) against the number of cooperating workgroups."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vip_amd import backend as B
+rng = np.random.default_rng(0)
+ctx = B.get_context()
+for n, k in ((1000, 20), (2000, 50)):
+    X = rng.standard_normal((n, 3 * n)); X[:, :5] *= 10
+    Gh = X @ X.T
+    w = np.linalg.eigvalsh(Gh)[::-1][:k]
+    G = torch.from_numpy(Gh).cuda()[None]
+    evals = torch.zeros((1, n), dtype=torch.float64, device="cuda"); evecs = torch.zeros((1, n, n), dtype=torch.float64, device="cuda")
+    for W in (32, 64, 128, 256):
+        ctx.set_option("eigh_large_w", W)
+        best = 1e9
+        for rep in range(3):
+            g2 = G.clone(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ctx.call("vipmi_eigh_topk_f64", B.ptr(g2), 1, n, k, 0, B.ptr(evals), B.ptr(evecs))
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        err = np.abs(evals[0, :k].cpu().numpy() - w).max() / w[0]
+        V = evecs[0, :k].cpu().numpy()
+        res = np.abs(Gh @ V.T - V.T * evals[0, :k].cpu().numpy()).max() / w[0]
+        print("n=%d k=%d W=%d: %.3f ms  (eigenvalue error %.1e, residual %.1e)" % (n, k, W, best, err, res))

@@ -430,7 +430,10 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
 
 template <int RPL>
 int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double* evecs, int all_evals) {
-  const int W = 64;                                    // >= k: workgroup c owns vector c
+  // workgroups (all co-resident: one per CU): a step is bound by the L2 bandwidth of the CUs that take part
+  int W = (int)ctx->opt("eigh_large_w", 0);
+  if (W != 32 && W != 64 && W != 128 && W != 256) W = n > 1024 ? 128 : 64;    // n = 2000: 43.0 / 35.7 / 35.1 ms with 64 / 128 / 256,
+  if (W > ctx->num_cu) W = 64;                                                 // n = 1000: 10.6 / 10.1 / 11.2 (barrier-bound)
   double* gbuf = nullptr;
   unsigned* bars = nullptr;
   VIPMI_TRY(ws(ctx, "eigh_large_gbuf", (size_t)8 * n, &gbuf));
