@@ -222,6 +222,24 @@ int vipmi_pca_4d_f32(vipmi_ctx* ctx, const float* cube4, const double* angles_ho
                      int64_t ncomp, int scaling, const uint8_t* mask, int collapse_mode, int collapse_ifs_mode,
                      float* frame, float* ifs_frames);
 
+/* ---- one cube over several GPUs ("C2/C5 single cube"): psfsub/pca_fullfr.py:801-1007 with the pixels
+ * sharded for the decomposition and the frames sharded for the derotation.  One process per GPU; RCCL is resolved at
+ * run time (dlopen; `path` NULL = the copy already in the process, else the loader's search path).
+ *   vipmi_rccl_unique_id:    128-byte ncclUniqueId, made on one rank and handed to the others by the host program
+ *   vipmi_rccl_comm_create:  ncclCommInitRank on ctx's device; *comm is an ncclComm_t (a communicator made elsewhere
+ *                            with the SAME RCCL library may be passed to the call below instead)
+ *   vipmi_pca_fullframe_sharded_f32: every rank passes its row slab of the cube, slab[n][y1-y0][N] with
+ *       [y0, y1) = rows of rank r of `world` contiguous near-equal blocks (block r starts at r*(N/world) + min(r, N%world)),
+ *       and the whole angle vector; frame[N,N] (device) receives the final frame on EVERY rank.  Collectives on
+ *       ctx's stream: one all-reduce of n*n float64, two all-to-alls of the residual cube, one exchange of N*N floats. */
+int vipmi_rccl_load(const char* path);
+int vipmi_rccl_unique_id(void* id128);
+int vipmi_rccl_comm_create(vipmi_ctx* ctx, const void* id128, int rank, int world, void** comm);
+int vipmi_rccl_comm_destroy(void* comm);
+int vipmi_pca_fullframe_sharded_f32(vipmi_ctx* ctx, void* comm, int rank, int world, const float* slab,
+                                    const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int collapse_mode,
+                                    float* frame);
+
 #ifdef __cplusplus
 }
 #endif

@@ -786,6 +786,21 @@ def test_bench_sharded_modes_two_ranks_on_one_gpu():
         assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
 
 
+def test_sharded_c_entry_on_an_rccl_communicator_world_1():
+    """include/vipmi.h: vipmi_rccl_* + vipmi_pca_fullframe_sharded_f32 (RCCL resolved at run time, communicator created by
+    the library, all-reduce / grouped send-recv exchanges incl. the sends to self) against pca() -- one rank, which is
+    what one GPU allows; the partition logic for more ranks is the one the gloo tests run through dist.pca_single_cube"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_world1.py")], capture_output=True,
+                        text=True, timeout=300)
+    assert cp.returncode == 0 and "OK" in cp.stdout, (cp.stdout[-2000:], cp.stderr[-3000:])
+    for ln in cp.stdout.splitlines():
+        if ln.startswith("case"):
+            assert float(ln.split()[-1]) < 1e-6, ln
+
+
 # ---- SURVEY 8(f) #1 / #4 remainders: pca_annulus, the S/N-scored PCA grid, a PPPCA-shaped caller ---------------------
 
 def test_pca_annulus_golden():

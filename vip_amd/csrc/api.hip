@@ -2,6 +2,7 @@
 // the fused full-frame ADI pipeline (psfsub/pca_fullfr.py:801-1007).
 #include <stdarg.h>
 #include "common.h"
+#include "rccl_dl.h"
 #include <new>
 
 namespace vipmi {
@@ -634,6 +635,157 @@ int vipmi_pca_4d_f32(vipmi_ctx* ctx, const float* cube4, const double* angles_ho
   VIPMI_TRY(collapse_batched_f32(ctx, der, nch, n, P, collapse_mode, nullptr, 50, ifs));
   if (mask) VIPMI_TRY(apply_mask_f32(ctx, ifs, ifs, nch, P, mask, 0.f));     // pca_fullfr.py:985-987 per channel
   VIPMI_TRY(collapse_f32(ctx, ifs, nch, P, collapse_ifs_mode, nullptr, 50, frame));
+  return VIPMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-GPU variant of vipmi_pca_fullframe_f32 over an RCCL communicator: ONE cube sharded over all ranks with the data
+// path collectives of SURVEY 8(e) row "C2/C5 single cube" and nothing else --
+//   pixel rows sharded -> partial Gram -> all-reduce (n x n float64) -> identical leading eigenvectors on every rank ->
+//   local project / subtract -> all-to-all (row slabs -> whole frames, frames sharded) -> local derotation -> all-to-all
+//   back (-> row slabs of all frames) -> local collapse -> exchange of the final frame's row slabs.
+// (vip_amd/dist.py:pca_single_cube is the same partition over torch.distributed.)
+#define VIPMI_CHECK_RCCL(expr)                                                                                  \
+  do {                                                                                                          \
+    ncclResult_t _r = (expr);                                                                                   \
+    if (_r != ncclSuccess) {                                                                                    \
+      vipmi::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, vipmi::rccl_api().GetErrorString(_r));     \
+      return VIPMI_ERR_HIP;                                                                                     \
+    }                                                                                                           \
+  } while (0)
+
+static inline int64_t split_edge(int64_t total, int world, int r) {      // contiguous near-equal blocks (dist._split)
+  const int64_t base = total / world, rem = total % world;
+  return r * base + (r < rem ? r : rem);
+}
+
+int vipmi_rccl_load(const char* path) {
+  const char* why = "";
+  if (!vipmi::rccl_load(path, &why)) {
+    vipmi::set_error("RCCL could not be loaded: %s", why ? why : "?");
+    return VIPMI_ERR_UNSUPPORTED;
+  }
+  return VIPMI_OK;
+}
+
+int vipmi_rccl_unique_id(void* id128) {
+  VIPMI_REQUIRE(id128, "rccl_unique_id: null pointer");
+  VIPMI_TRY(vipmi_rccl_load(nullptr));
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  VIPMI_CHECK_RCCL(vipmi::rccl_api().GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128)));
+  return VIPMI_OK;
+}
+
+int vipmi_rccl_comm_create(vipmi_ctx* ctx, const void* id128, int rank, int world, void** comm) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(id128 && comm && world > 0 && rank >= 0 && rank < world, "rccl_comm_create: bad arguments");
+  VIPMI_TRY(vipmi_rccl_load(nullptr));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t c = nullptr;
+  VIPMI_CHECK_RCCL(vipmi::rccl_api().CommInitRank(&c, world, id, rank));
+  *comm = c;
+  return VIPMI_OK;
+}
+
+int vipmi_rccl_comm_destroy(void* comm) {
+  if (!comm) return VIPMI_OK;
+  VIPMI_REQUIRE(vipmi::rccl_api().ok(), "rccl_comm_destroy: RCCL is not loaded");
+  VIPMI_CHECK_RCCL(vipmi::rccl_api().CommDestroy(static_cast<ncclComm_t>(comm)));
+  return VIPMI_OK;
+}
+
+int vipmi_pca_fullframe_sharded_f32(vipmi_ctx* ctx, void* comm_, int rank, int world, const float* slab,
+                                    const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int collapse_mode,
+                                    float* frame) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(comm_ && slab && angles_host && frame, "pca_fullframe_sharded: null pointer");
+  VIPMI_REQUIRE(world > 0 && rank >= 0 && rank < world && n > 0 && N > 1, "pca_fullframe_sharded: bad sizes");
+  VIPMI_REQUIRE(ncomp > 0, "Number of PCs too low. It should be > 0.");
+  VIPMI_REQUIRE(collapse_mode != VIPMI_COLLAPSE_WMEAN, "pca_fullframe_sharded: weighted collapse is not offered");
+  VIPMI_REQUIRE(vipmi::rccl_api().ok(), "pca_fullframe_sharded: RCCL is not loaded (vipmi_rccl_comm_create first)");
+  const vipmi::RcclApi& nc = vipmi::rccl_api();
+  ncclComm_t comm = static_cast<ncclComm_t>(comm_);
+  hipStream_t st = ctx->stream;
+  const int64_t k = ncomp > n ? n : ncomp;
+  const int64_t y0 = split_edge(N, world, rank), y1 = split_edge(N, world, rank + 1), rl = y1 - y0;   // my pixel rows
+  const int64_t f0 = split_edge(n, world, rank), f1 = split_edge(n, world, rank + 1), fl = f1 - f0;   // my frames
+  const int64_t Pl = rl * N;
+  // 1. partial Gram of the slab [n][rl * N], all-reduce
+  double *G = nullptr, *evals = nullptr, *evecs = nullptr;
+  VIPMI_TRY(ws(ctx, "shard_G", (size_t)n * n, &G));
+  VIPMI_TRY(ws(ctx, "shard_evals", (size_t)n, &evals));
+  VIPMI_TRY(ws(ctx, "shard_evecs", (size_t)n * n, &evecs));
+  if (Pl > 0) {
+    VIPMI_TRY(gram_batched_f32(ctx, slab, 1, n, Pl, G));
+  } else {
+    VIPMI_CHECK_HIP(hipMemsetAsync(G, 0, sizeof(double) * n * n, st));
+  }
+  VIPMI_CHECK_RCCL(nc.AllReduce(G, G, (size_t)n * n, ncclDouble, ncclSum, comm, st));
+  // 2. identical decomposition on every rank, residuals of the slab
+  VIPMI_TRY(eigh_leading(ctx, G, 1, n, k, nullptr, evals, evecs));
+  float *E = nullptr, *R = nullptr;
+  VIPMI_TRY(ws(ctx, "shard_E", (size_t)k * n, &E));
+  VIPMI_TRY(ws(ctx, "shard_R", (size_t)n * (Pl > 0 ? Pl : 1), &R));
+  {
+    const unsigned gx = (unsigned)cdiv(k * n, 256);
+    hipLaunchKernelGGL(evecs_rows_f32_kernel, dim3(gx > 64 ? 64 : gx, 1), dim3(256), 0, st, evecs, evals, (int)n, (int)k, E);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  if (Pl > 0) VIPMI_TRY(project_batched_f32(ctx, slab, E, 1, n, k, Pl, R));
+  // 3. row slabs -> whole frames of my frame shard: peer p gets frames [fa, fb) of my slab (one contiguous block) and
+  //    sends its rows of my frames, placed into the frames with a strided copy
+  float *F = nullptr, *D = nullptr, *stage = nullptr;
+  const int64_t rl_max = cdiv(N, world), fl_max = cdiv(n, world);
+  VIPMI_TRY(ws(ctx, "shard_F", (size_t)(fl > 0 ? fl : 1) * N * N, &F));
+  VIPMI_TRY(ws(ctx, "shard_D", (size_t)(fl > 0 ? fl : 1) * N * N, &D));
+  VIPMI_TRY(ws(ctx, "shard_stage", (size_t)world * fl_max * rl_max * N, &stage));
+  const size_t chunk = (size_t)fl_max * rl_max * N;            // staging area per peer
+  VIPMI_CHECK_RCCL(nc.GroupStart());
+  for (int p = 0; p < world; ++p) {
+    const int64_t fa = split_edge(n, world, p), fb = split_edge(n, world, p + 1);
+    const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
+    if ((fb - fa) * Pl > 0) VIPMI_CHECK_RCCL(nc.Send(R + (size_t)fa * Pl, (size_t)(fb - fa) * Pl, ncclFloat, p, comm, st));
+    if (fl * (rb - ra) > 0) VIPMI_CHECK_RCCL(nc.Recv(stage + p * chunk, (size_t)fl * (rb - ra) * N, ncclFloat, p, comm, st));
+  }
+  VIPMI_CHECK_RCCL(nc.GroupEnd());
+  for (int p = 0; p < world && fl > 0; ++p) {
+    const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
+    if (rb > ra)
+      VIPMI_CHECK_HIP(hipMemcpy2DAsync(F + (size_t)ra * N, sizeof(float) * N * N, stage + p * chunk,
+                                       sizeof(float) * (rb - ra) * N, sizeof(float) * (rb - ra) * N, (size_t)fl,
+                                       hipMemcpyDeviceToDevice, st));
+  }
+  // 4. derotate my frames
+  if (fl > 0) VIPMI_TRY(derotate_f32(ctx, F, angles_host + f0, fl, N, D, 1, 0, VIPMI_ROT_AUTO));
+  // 5. whole frames -> row slabs of ALL frames: peer p gets its rows of my frames (packed), I get my rows of its frames
+  float* S = nullptr;
+  VIPMI_TRY(ws(ctx, "shard_S", (size_t)n * (Pl > 0 ? Pl : 1), &S));
+  for (int p = 0; p < world && fl > 0; ++p) {
+    const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
+    if (rb > ra)
+      VIPMI_CHECK_HIP(hipMemcpy2DAsync(stage + p * chunk, sizeof(float) * (rb - ra) * N, D + (size_t)ra * N,
+                                       sizeof(float) * N * N, sizeof(float) * (rb - ra) * N, (size_t)fl,
+                                       hipMemcpyDeviceToDevice, st));
+  }
+  VIPMI_CHECK_RCCL(nc.GroupStart());
+  for (int p = 0; p < world; ++p) {
+    const int64_t fa = split_edge(n, world, p), fb = split_edge(n, world, p + 1);
+    const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
+    if (fl * (rb - ra) > 0) VIPMI_CHECK_RCCL(nc.Send(stage + p * chunk, (size_t)fl * (rb - ra) * N, ncclFloat, p, comm, st));
+    if ((fb - fa) * Pl > 0) VIPMI_CHECK_RCCL(nc.Recv(S + (size_t)fa * Pl, (size_t)(fb - fa) * Pl, ncclFloat, p, comm, st));
+  }
+  VIPMI_CHECK_RCCL(nc.GroupEnd());
+  // 6. collapse my pixels over all frames, then every rank collects the row slabs of the final frame
+  if (Pl > 0) VIPMI_TRY(collapse_f32(ctx, S, n, Pl, collapse_mode, nullptr, 50, frame + (size_t)y0 * N));
+  VIPMI_CHECK_RCCL(nc.GroupStart());
+  for (int p = 0; p < world; ++p) {
+    if (p == rank) continue;
+    const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
+    if (Pl > 0) VIPMI_CHECK_RCCL(nc.Send(frame + (size_t)y0 * N, (size_t)Pl, ncclFloat, p, comm, st));
+    if (rb > ra) VIPMI_CHECK_RCCL(nc.Recv(frame + (size_t)ra * N, (size_t)(rb - ra) * N, ncclFloat, p, comm, st));
+  }
+  VIPMI_CHECK_RCCL(nc.GroupEnd());
   return VIPMI_OK;
 }
 

@@ -350,6 +350,64 @@ def pca_single_cube(cube, angle_list, ncomp, collapse="median", ops=None):
     return _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, dev)
 
 
+class RcclComm:
+    """An RCCL communicator owned by libvipmi (include/vipmi.h: vipmi_rccl_*), one rank per process / GPU.  The 128-byte
+    unique id is made on rank 0 and handed to the other ranks through the already initialised ``torch.distributed``
+    group (any backend: it is host data); with world 1 nothing is exchanged."""
+
+    def __init__(self, device=None):
+        import ctypes
+        from . import _lib, backend as B
+        self._lib = _lib
+        self.ctx = B.get_context(device)         # (imports torch first: its HIP runtime must be the one in the process)
+        lib = _lib.load()
+        rank, world = world_info()
+        self.rank, self.world = rank, world
+        ident = (ctypes.c_char * 128)()
+        if rank == 0:
+            _lib.raise_for_status(lib.vipmi_rccl_unique_id(ident), "vipmi_rccl_unique_id")
+        if world > 1:
+            box = [bytes(ident)]
+            _dist().broadcast_object_list(box, src=0)
+            ident = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        handle = ctypes.c_void_p()
+        _lib.raise_for_status(lib.vipmi_rccl_comm_create(self.ctx.handle, ident, rank, world, ctypes.byref(handle)),
+                              "vipmi_rccl_comm_create")
+        self.handle = handle
+
+    def destroy(self):
+        h, self.handle = self.handle, None
+        if h:
+            self._lib.load().vipmi_rccl_comm_destroy(h)
+
+
+def pca_single_cube_rccl(cube, angle_list, ncomp, comm, collapse="median"):
+    """``pca_single_cube`` through the C entry ``vipmi_pca_fullframe_sharded_f32``: the same partition (pixel rows for the
+    decomposition, frames for the derotation), with the collectives issued by the library itself on an RCCL communicator
+    (``RcclComm``) instead of ``torch.distributed``.  Every rank passes the same ``cube`` (only its row slab is
+    touched) or, as a cuda tensor of shape (n, y1 - y0, x), its slab; returns the final frame on every rank."""
+    from . import backend as B
+    torch = B._torch()
+    n = cube.shape[0]
+    angle_list = np.ascontiguousarray(angle_list, dtype=np.float64)
+    if angle_list.shape[0] != n:
+        raise ValueError("`angle_list` vector has wrong length. It must equal the number of frames in the cube")
+    N = cube.shape[2]
+    y0, y1 = _split(N, comm.world)[comm.rank]
+    if cube.shape[1] == N:
+        slab = B.to_device_f32(np.ascontiguousarray(cube[:, y0:y1, :]) if isinstance(cube, np.ndarray)
+                               else cube[:, y0:y1, :].contiguous())
+    elif cube.shape[1] == y1 - y0:
+        slab = B.to_device_f32(cube)
+    else:
+        raise TypeError("cube must be the whole (n, N, N) cube or this rank's (n, rows, N) slab")
+    mode = B.COLLAPSE_MODES[collapse]
+    frame = torch.empty((N, N), dtype=torch.float32, device=slab.device)
+    comm.ctx.call("vipmi_pca_fullframe_sharded_f32", comm.handle, comm.rank, comm.world, B.ptr(slab),
+                  angle_list.ctypes.data, n, N, int(ncomp), int(mode), B.ptr(frame))
+    return frame
+
+
 def _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, dev, **rot):
     """Tail shared by the sharded single-cube and annular paths: this rank holds the whole residual frames of its
     frame shard -> local derotation -> all_to_all (whole frames -> pixel-row slabs of ALL frames) -> local collapse of
