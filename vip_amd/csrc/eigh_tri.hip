@@ -48,7 +48,7 @@ template <int RPL, int NT, int RPW = 0>
 __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
                                                      double* __restrict__ evecs_all, double* __restrict__ scratch_all,
-                                                     int kp, int all_evals) {
+                                                     int kp, int all_evals, int kc) {
   constexpr int TNT = NT, TNW = NT / 64;          // (shadow the file-scope values used by tri_multi_kernel)
   extern __shared__ double sm[];
   double* vcur = sm;             // [n] Householder vector of the current step (indexed by absolute row)
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   // buffers are dead by now; the launcher checks the size): the substitutions are chains of dependent loads, and with
   // the scratch in global memory the phase cost 0.27 ms of a 1.27 ms problem in a full batch.
   constexpr bool LSCR = RPW > 0;
-  const int ks = LSCR ? kk : kp;
+  const int ks = LSCR ? kc : kp;
   double *U0, *U1, *U2, *Zg, *Lm, *Ls = nullptr;      // reciprocal pivots; first, second superdiagonal of U (row swaps);
   unsigned char* Lsb = nullptr;                        // rhs / solution; multipliers of L; 1 where rows i, i+1 were swapped
   if constexpr (LSCR) {
@@ -503,8 +503,17 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
     if constexpr (LSCR) return Lsb[i * ks + c] != 0;
     else return Ls[(size_t)i * ks + c] != 0.0;
   };
-  if (tid < kk) {
-    const int c = tid;
+  // vectors in chunks of kc (= all of them unless the LDS scratch is short: the launcher sizes the chunk); the solutions
+  // of a chunk move to registers (one wave per vector) before the next chunk reuses the scratch
+  constexpr int VPW = 4;                    // vectors per wave: c = wave + TNW v
+  double z[VPW][RPL];
+#pragma unroll
+  for (int v = 0; v < VPW; ++v)
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) z[v][rr] = 0.0;
+  for (int c0 = 0; c0 < kk; c0 += kc) {
+  if (tid < kc && c0 + tid < kk) {
+    const int c = c0 + tid, cs = tid;      // vector, scratch column
     // distinct shifts for (nearly) equal eigenvalues; the offsets are far below the eigenvalue accuracy that matters
     const double lc = lam[c] - (double)(c + 1) * 4.0 * TEPS;
     const double ptiny = 1e-3 * TEPS;      // pivot floor (scaled matrix has max-norm 1)
@@ -538,13 +547,13 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
         q = nu - m * r;
         r = 0.0;
       }
-      U0[(size_t)i * ks + c] = inv;
-      U1[(size_t)i * ks + c] = u1;
-      U2[(size_t)i * ks + c] = u2;
-      Lm[(size_t)i * ks + c] = m;
-      if constexpr (LSCR) Lsb[i * ks + c] = sw ? 1 : 0;
-      else Ls[(size_t)i * ks + c] = sw ? 1.0 : 0.0;
-      Zg[(size_t)i * ks + c] = yi;
+      U0[(size_t)i * ks + cs] = inv;
+      U1[(size_t)i * ks + cs] = u1;
+      U2[(size_t)i * ks + cs] = u2;
+      Lm[(size_t)i * ks + cs] = m;
+      if constexpr (LSCR) Lsb[i * ks + cs] = sw ? 1 : 0;
+      else Ls[(size_t)i * ks + cs] = sw ? 1.0 : 0.0;
+      Zg[(size_t)i * ks + cs] = yi;
     }
     if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
     const double invlast = fast_rcp(p);
@@ -553,45 +562,45 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
       if (it > 0 && na > 1) {
         // forward substitution of the previous solution (scaled to unit norm) through P L; the operands of row i+1
         // are fetched while row i is computed
-        yc = Zg[c] * rs;
-        double ynr = Zg[(size_t)ks + c], m = Lm[c];
-        bool sw = swapped(0, c);
+        yc = Zg[cs] * rs;
+        double ynr = Zg[(size_t)ks + cs], m = Lm[cs];
+        bool sw = swapped(0, cs);
         for (int i = 0; i + 1 < na; ++i) {
           const double yn = ynr * rs, mi = m;
           const bool swi = sw;
           if (i + 2 < na) {
-            ynr = Zg[(size_t)(i + 2) * ks + c];
-            m = Lm[(size_t)(i + 1) * ks + c];
-            sw = swapped(i + 1, c);
+            ynr = Zg[(size_t)(i + 2) * ks + cs];
+            m = Lm[(size_t)(i + 1) * ks + cs];
+            sw = swapped(i + 1, cs);
           }
           const double yi = swi ? yn : yc;
           yc = swi ? (yc - mi * yn) : (yn - mi * yc);
-          Zg[(size_t)i * ks + c] = yi;
+          Zg[(size_t)i * ks + cs] = yi;
         }
       } else if (it > 0) {
-        yc = Zg[c] * rs;
+        yc = Zg[cs] * rs;
       }
       // back substitution (same prefetch)
       double x1 = yc * invlast, x2 = 0.0;
-      Zg[(size_t)(na - 1) * ks + c] = x1;
+      Zg[(size_t)(na - 1) * ks + cs] = x1;
       double acc = x1 * x1;
       double zn = 0.0, u1n = 0.0, u2n = 0.0, u0n = 0.0;
       if (na > 1) {
-        zn = Zg[(size_t)(na - 2) * ks + c];
-        u1n = U1[(size_t)(na - 2) * ks + c];
-        u2n = U2[(size_t)(na - 2) * ks + c];
-        u0n = U0[(size_t)(na - 2) * ks + c];
+        zn = Zg[(size_t)(na - 2) * ks + cs];
+        u1n = U1[(size_t)(na - 2) * ks + cs];
+        u2n = U2[(size_t)(na - 2) * ks + cs];
+        u0n = U0[(size_t)(na - 2) * ks + cs];
       }
       for (int i = na - 2; i >= 0; --i) {
         const double z = zn, u1 = u1n, u2 = u2n, u0 = u0n;
         if (i > 0) {
-          zn = Zg[(size_t)(i - 1) * ks + c];
-          u1n = U1[(size_t)(i - 1) * ks + c];
-          u2n = U2[(size_t)(i - 1) * ks + c];
-          u0n = U0[(size_t)(i - 1) * ks + c];
+          zn = Zg[(size_t)(i - 1) * ks + cs];
+          u1n = U1[(size_t)(i - 1) * ks + cs];
+          u2n = U2[(size_t)(i - 1) * ks + cs];
+          u0n = U0[(size_t)(i - 1) * ks + cs];
         }
         const double x = (z - u1 * x1 - u2 * x2) * u0;
-        Zg[(size_t)i * ks + c] = x;
+        Zg[(size_t)i * ks + cs] = x;
         acc += x * x;
         x2 = x1;
         x1 = x;
@@ -602,19 +611,22 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   }
   __syncthreads();
 
-  TRI_STAMP(3);
-  // ---------------- 3b. modified Gram-Schmidt, one wave per vector (registers), pivot vector through LDS -------------
-  constexpr int VPW = 4;                    // vectors per wave: c = wave + 16 v
-  double z[VPW][RPL];
 #pragma unroll
   for (int v = 0; v < VPW; ++v) {
     const int c = wave + TNW * v;
+    if (c >= c0 && c < c0 + kc && c < kk) {
 #pragma unroll
-    for (int rr = 0; rr < RPL; ++rr) {
-      const int i = lane + 64 * rr;
-      z[v][rr] = (c < kk && i < na) ? Zg[(size_t)i * ks + c] : 0.0;
+      for (int rr = 0; rr < RPL; ++rr) {
+        const int i = lane + 64 * rr;
+        z[v][rr] = (i < na) ? Zg[(size_t)i * ks + (c - c0)] : 0.0;
+      }
     }
   }
+  __syncthreads();
+  }   // chunks of vectors
+
+  TRI_STAMP(3);
+  // ---------------- 3b. modified Gram-Schmidt, one wave per vector (registers), pivot vector through LDS -------------
   double* qv = pcur;                        // pivot vector [n]
   for (int c = 0; c < kk; ++c) {
     const int ow = c % TNW, ov = c / TNW;
@@ -1190,14 +1202,21 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
 
 // LDS of the register-resident variant: the tridiagonalisation buffers (padded vectors, per-wave column sums), later
 // overlaid by the inverse-iteration scratch (5 double arrays and one byte array of n x min(k, n))
-size_t reg_variant_lds(int n, int k) {
+// vectors per chunk of the inverse iteration: all of them when the scratch fits, else as many as do (at least 8)
+int reg_variant_chunk(int n, int k) {
   const int kk_max = k < n ? k : n;
   const size_t lds_fixed = ((size_t)10 * n + 64 + 8 + 72) * sizeof(double);
+  const size_t avail = (size_t)160 * 1024 - lds_fixed - 16;
+  const int fit = (int)(avail / ((size_t)n * (5 * sizeof(double) + 1)));
+  return fit >= kk_max ? kk_max : fit;
+}
+size_t reg_variant_lds(int n, int k) {
+  const size_t lds_fixed = ((size_t)10 * n + 64 + 8 + 72) * sizeof(double);
   const size_t lds_tri = ((size_t)8 * n + 4 * 200) * sizeof(double);
-  const size_t lds_inv = (size_t)n * kk_max * (5 * sizeof(double) + 1) + 16;
+  const size_t lds_inv = (size_t)n * reg_variant_chunk(n, k) * (5 * sizeof(double) + 1) + 16;
   return lds_fixed + (lds_tri > lds_inv ? lds_tri : lds_inv);
 }
-bool reg_variant_fits(int n, int k) { return k <= 32 && cdiv(n, 8) <= 25 && reg_variant_lds(n, k) <= (size_t)160 * 1024; }
+bool reg_variant_fits(int n, int k) { return k <= 32 && cdiv(n, 8) <= 25 && reg_variant_chunk(n, k) >= (k < 8 ? k : 8); }
 
 template <int RPL>
 int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int32_t* nact, double* evals,
@@ -1218,7 +1237,7 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
       VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds_r));
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
-                         all_evals);
+                         all_evals, reg_variant_chunk(n, k));
       VIPMI_CHECK_HIP(hipGetLastError());
       return VIPMI_OK;
     };
@@ -1236,13 +1255,13 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   VIPMI_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (nt == 256)
     hipLaunchKernelGGL((tri_eig_kernel<RPL, 256>), dim3((unsigned)batch), dim3(256), lds, ctx->stream, A, n, k, nact,
-                       evals, evecs, scratch, kp, all_evals);
+                       evals, evecs, scratch, kp, all_evals, k < n ? k : n);
   else if (nt == 512)
     hipLaunchKernelGGL((tri_eig_kernel<RPL, 512>), dim3((unsigned)batch), dim3(512), lds, ctx->stream, A, n, k, nact,
-                       evals, evecs, scratch, kp, all_evals);
+                       evals, evecs, scratch, kp, all_evals, k < n ? k : n);
   else
     hipLaunchKernelGGL((tri_eig_kernel<RPL, 1024>), dim3((unsigned)batch), dim3(1024), lds, ctx->stream, A, n, k, nact,
-                       evals, evecs, scratch, kp, all_evals);
+                       evals, evecs, scratch, kp, all_evals, k < n ? k : n);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
