@@ -164,6 +164,24 @@ def test_eigh_topk_more_than_64_vectors(B, n, k):
     assert np.abs(ev2.cpu().numpy() - w).max() < 1e-11 * w[0]
 
 
+@pytest.mark.parametrize("n,k", [(2049, 5), (2500, 30), (2200, 150), (3100, 20)])
+def test_eigh_topk_more_than_2048_rows(B, n, k):
+    """2048 < n <= 6144: three vectors of n doubles in LDS, gathered vectors in registers, factors of the inverse
+    iteration in global memory (eigh_tri_large.hip: tri_xl_kernel); k = 150 > 128 workgroups loops over the vectors."""
+    import torch
+    rng = np.random.default_rng(n + k)
+    M = rng.standard_normal((n, n + 50)) * np.logspace(0, -2, n + 50)
+    M[:, :4] *= 20
+    G = M @ M.T
+    ev, ec = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), k)
+    _topk_check(G, ev.cpu().numpy(), ec.cpu().numpy(), k)
+    if n <= 2500:
+        ev2, ec2 = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), k, all_evals=True)
+        assert np.array_equal(ec2.cpu().numpy(), ec.cpu().numpy())
+        w = np.linalg.eigvalsh(G)[::-1]
+        assert np.abs(ev2.cpu().numpy() - w).max() < 1e-11 * w[0]
+
+
 def test_eigh_topk_degenerate_and_padded(B):
     import torch
     rng = np.random.default_rng(5)

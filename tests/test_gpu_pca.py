@@ -630,9 +630,21 @@ def test_more_than_64_components():
     assert np.abs(V.T @ (V @ M.T) - Vr.T @ (Vr @ M.T)).max() < 1e-3 * np.abs(M).max()
 
 
+def test_more_than_6144_frames_library_fallback():
+    """beyond the hand-written leading-k solver (n > backend.MAX_EIGH_N = 6144) the front keeps the device Gram / projection
+    kernels and takes the eigendecomposition from rocSOLVER (backend.eigh_beyond_lds)"""
+    from vip_amd import backend as B
+    from vip_amd.psfsub import pca
+    n, N, k = B.MAX_EIGH_N + 56, 16, 6
+    cube, _ = O.synth_adi(n, N, seed=3)
+    ang = np.linspace(0, 170, n)
+    got = pca(cube, ang, ncomp=k, verbose=False)
+    assert np.abs(got - O.pca_fullframe(cube, ang, ncomp=k)).max() < TOL
+
+
 def test_more_than_2048_frames():
-    """beyond the LDS-resident eigensolvers (n > 2048) the front keeps the device Gram / projection kernels and takes
-    the eigendecomposition from rocSOLVER (backend.eigh_beyond_lds): ADI cube and RDI reference library of 2100 frames"""
+    """2048 < n <= 6144 frames: the 3-vector variant of the matrix-in-L2 eigensolver (eigh_tri_large.hip, tri_xl_kernel),
+    fused entry, RDI reference library and svd_wrapper: ADI cube and RDI reference library of 2100 frames"""
     from vip_amd.psfsub import pca
     n, N, k = 2100, 32, 10
     cube, _ = O.synth_adi(n, N, seed=n)

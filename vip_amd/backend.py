@@ -317,17 +317,17 @@ def eigh_topk(G, k, nact=None, all_evals=False):
 
 def topk_native(n, k):
     """True when the leading-k tridiagonal solvers serve (n, k): up to 512 frames and 64 vectors in LDS
-    (eigh_tri.hip), 128..2048 frames and any number of vectors with the matrix in L2 (eigh_tri_large.hip)."""
-    return 0 < k <= n and ((n <= 512 and k <= 64) or 128 <= n <= 2048)
+    (eigh_tri.hip), 128..6144 frames and any number of vectors with the matrix in L2 (eigh_tri_large.hip)."""
+    return 0 < k <= n and ((n <= 512 and k <= 64) or 128 <= n <= MAX_EIGH_N)
 
 
-MAX_EIGH_N = 2048        # the hand-written eigensolvers keep their working set in LDS: matrices up to 2048 x 2048
+MAX_EIGH_N = 6144        # the leading-k solver keeps three vectors of n doubles in LDS: matrices up to 6144 x 6144
 
 
 def eigh_beyond_lds(G):
     """Eigendecomposition of a Gram matrix of more than MAX_EIGH_N frames: the ONE place where a ROCm library routine is
-    used (rocSOLVER's syevd through ``torch.linalg.eigh``, on the device, float64) -- the hand-written solvers hold 9 n
-    doubles of vectors in LDS and stop at n = 2048, and such cubes are rare.  Returns (evals descending, eigenvectors as
+    used (rocSOLVER's syevd through ``torch.linalg.eigh``, on the device, float64) -- the hand-written leading-k solver
+    holds 3 n doubles of vectors in LDS and stops at n = 6144, and such cubes are rare.  Returns (evals descending, eigenvectors as
     rows, largest-magnitude component positive) like the native solvers."""
     torch = _torch()
     w, Q = torch.linalg.eigh(G.to(torch.float64))

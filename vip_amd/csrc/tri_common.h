@@ -48,6 +48,9 @@ __device__ __forceinline__ double sturm_step(double dmi, double e2i, double sigm
   return pn;
 }
 
+// SQ: `e2` holds the off-diagonals themselves and is squared as it is fetched (the solver for more than 2048 rows has
+// no LDS left for the squares; the multiplications are off the dependent chain).
+template <bool SQ = false>
 __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n,
                                            double sigma) {
   double pm = 1.0, p = d[0] - sigma;
@@ -61,6 +64,7 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const d
     for (int u = 0; u < 16; ++u) {
       db[u] = d[i0 + u];
       eb[u] = e2[i0 + u - 1];
+      if (SQ) eb[u] *= eb[u];
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) p = sturm_step(db[u], eb[u], sigma, pm, p, sg);
@@ -70,18 +74,22 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const d
     pm = scalbn(pm, -ex);
   }
   const int m = n - i0;                    // 0 .. 15 remaining steps
-  for (int u = 0; u < m; ++u) p = sturm_step(d[i0 + u], e2[i0 + u - 1], sigma, pm, p, sg);
+  for (int u = 0; u < m; ++u) {
+    const double eo = e2[i0 + u - 1];
+    p = sturm_step(d[i0 + u], SQ ? eo * eo : eo, sigma, pm, p, sg);
+  }
   cnt += __popc((sg ^ (sg >> 1)) & ((1u << m) - 1u));
   return cnt;
 }
 
 // One eigenvalue by multisection, executed by a whole wave: the 64 lanes evaluate Sturm counts at 64 interior points
 // of the bracket [a, b], which shrinks 65x per sweep.  target = ascending index of the eigenvalue.  Wave-uniform result.
+template <bool SQ = false>
 __device__ __forceinline__ double multisect(const double* __restrict__ d, const double* __restrict__ e2, int n,
                                             int target, double a, double b, int lane) {
   for (int sweep = 0; sweep < 14; ++sweep) {
     const double h = (b - a) * (1.0 / 65.0);
-    const int cnt = sturm_count(d, e2, n, a + h * (double)(lane + 1));
+    const int cnt = sturm_count<SQ>(d, e2, n, a + h * (double)(lane + 1));
     const int L = __popcll(__ballot(cnt <= target));          // sigma_l <= lambda_target for the first L lanes
     const double na = (L == 0) ? a : a + h * (double)L;
     const double nb = (L == 64) ? b : a + h * (double)(L + 1);

@@ -3,7 +3,7 @@
 Every ``svd_mode`` of the reference is an alternative back-end of the same mathematical object (the
 top-k right singular vectors of the n x P matrix).  Here all of them map onto ONE deterministic device
 algorithm: Gram matrix on the matrix cores (float64 accumulation) + a float64 eigensolver (Householder
-tridiagonalisation / multisection / inverse iteration; block Jacobi beyond n = 2048) + back-projection, i.e. the arithmetic of the reference's ``'eigen'`` mode at
+tridiagonalisation / multisection / inverse iteration up to 6144 frames) + back-projection, i.e. the arithmetic of the reference's ``'eigen'`` mode at
 LAPACK-class accuracy.  PCs are defined up to a per-row sign (sign convention: see DESIGN.md).
 """
 import numpy as np
@@ -27,7 +27,7 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
     elif B.topk_native(n, ncomp):
         evals, evecs = B.eigh_topk(G, ncomp, all_evals=True)       # whole spectrum, leading vectors
     elif n > B.MAX_EIGH_N:
-        evals, evecs = B.eigh_beyond_lds(G)                        # more than 2048 frames (rocSOLVER, see backend)
+        evals, evecs = B.eigh_beyond_lds(G)                        # more than 6144 frames (rocSOLVER, see backend)
     else:
         evals, evecs = B.eigh(G)
     sig_all = torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
@@ -121,7 +121,7 @@ class SVDecomposer:
             self.generate_matrix()
         t = B.to_device_f32(self.matrix)
         G = B.gram(t)
-        if G.shape[0] <= 2048:
+        if G.shape[0] <= B.MAX_EIGH_N:
             evals, _ = B.eigh_topk(G, 1, all_evals=True)     # values only: tridiagonalisation + multisection
         else:
             evals, _ = B.eigh_beyond_lds(G)
