@@ -94,7 +94,9 @@ def pmc_traffic(frames_per_launch, N, kernel="rs_shear2"):
     import glob
     if N != 512:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json"))
+                   if re.fullmatch(r"r\d+_pmc_hbm\.json", os.path.basename(f)))      # the round's final pass (rNN), not interim ones
     if not files:
         return None
     try:

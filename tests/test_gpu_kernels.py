@@ -327,7 +327,8 @@ def test_collapse_golden(B, n):
     assert np.abs(got - g["wmean_%d" % n]).max() < 2e-6
 
 
-@pytest.mark.parametrize("n,P", [(1, 100), (2, 100), (63, 1000), (64, 1000), (65, 333), (129, 257), (400, 4096), (1000, 70)])
+@pytest.mark.parametrize("n,P", [(1, 100), (2, 100), (63, 1000), (64, 1000), (65, 333), (129, 257), (400, 4096), (1000, 70),
+                                 (4097, 300), (6001, 130), (5000, 64)])      # (more than 4096 frames: the streaming kernel)
 def test_median_sizes_bitexact(B, n, P):
     rng = np.random.default_rng(n + P)
     cube = rng.standard_normal((n, P)).astype(np.float32)

@@ -456,6 +456,55 @@ __global__ void colreduce_kernel(const float* __restrict__ cube0, int n, int64_t
   }
 }
 
+// More than 4096 frames (64 keys per lane no longer fit the registers): one THREAD per pixel, the 32-step bitwise
+// bisection on the order-preserving keys with the samples re-read from memory in every step (consecutive threads read
+// consecutive pixels: coalesced; 34 passes over the cube -- 6000 x 512 x 512 takes ~60 ms, for cubes the eigensolver
+// needs 350 ms for).  Same value rules as the register kernel: NaN-aware, even count -> (a + b) * 0.5 in float32.
+__global__ __launch_bounds__(256) void median_stream_kernel(const float* __restrict__ cube0, int n, int64_t P,
+                                                            float* __restrict__ out0) {
+  const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;
+  float* __restrict__ out = out0 + (size_t)blockIdx.y * P;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int m = 0;
+  for (int f = 0; f < n; ++f) {
+    const float v = cube[(size_t)f * P + p];
+    m += (v == v) ? 1 : 0;
+  }
+  if (m == 0) {
+    out[p] = __uint_as_float(0x7fc00000u);
+    return;
+  }
+  const int k = (m - 1) >> 1;
+  unsigned ans = 0;                              // largest key with at most k valid keys below it = the rank-k key
+  for (int b = 31; b >= 0; --b) {
+    const unsigned cand = ans | (1u << b);
+    int c = 0;
+    for (int f = 0; f < n; ++f) {
+      const float v = cube[(size_t)f * P + p];
+      c += (v == v && f2key(v) < cand) ? 1 : 0;
+    }
+    if (c <= k) ans = cand;
+  }
+  float res = key2f(ans);
+  if ((m & 1) == 0) {
+    // upper median: the same value again when it is repeated, else the smallest key above it
+    int cle = 0;
+    unsigned nxt = 0xffffffffu;
+    for (int f = 0; f < n; ++f) {
+      const float v = cube[(size_t)f * P + p];
+      if (v == v) {
+        const unsigned kf = f2key(v);
+        cle += (kf <= ans) ? 1 : 0;
+        if (kf > ans && kf < nxt) nxt = kf;
+      }
+    }
+    const unsigned khigh = (cle >= k + 2) ? ans : nxt;
+    res = (key2f(ans) + key2f(khigh)) * 0.5f;
+  }
+  out[p] = res;
+}
+
 template <int RPL, bool TRIM>
 int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64_t P, float* out, int t0, int tn) {
   // pixels per tile: 32 (128-byte row segments) unless 16 lets more workgroups share a CU -- after the bucket-selection
@@ -525,7 +574,13 @@ int collapse_batched_f32(vipmi_ctx* ctx, const float* cube, int64_t batch, int64
       if (rpl <= 32) { VIPMI_MED(32); }
       if (rpl <= 64) { VIPMI_MED(64); }
 #undef VIPMI_MED
-      set_error("collapse(median/trimmean): more than 4096 frames not supported");
+      if (!trim) {
+        hipLaunchKernelGGL(median_stream_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)batch), dim3(256), 0, ctx->stream,
+                           cube, (int)n, P, out);
+        VIPMI_CHECK_HIP(hipGetLastError());
+        return VIPMI_OK;
+      }
+      set_error("collapse(trimmean): more than 4096 frames not supported");
       return VIPMI_ERR_UNSUPPORTED;
     }
     case VIPMI_COLLAPSE_WMEAN:
