@@ -22,6 +22,7 @@
 //    option "gram_f32" selects v_mfma_f32_16x16x4_f32 (2x MFMA rate, f32 chains per slice).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace vipmi {
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel
   A += (int64_t)blockIdx.z * batch_stride;
   B += (int64_t)blockIdx.z * batch_stride;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // in an SGPR: the tile guards are scalar branches
   const int tile = blockIdx.y * waves_per_wg + wave;
   if (tile >= ntiles) return;
   const int slice = blockIdx.x;
@@ -93,6 +94,54 @@ __global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel
     for (int j = 0; j < TB; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
   f32x4 fa[TB], fb[TB];
+  // Fast path: every block of the super-tile is live, it is not on the diagonal, and the slice is whole 16-pixel steps of
+  // aligned 16-byte loads -- no guards at all: TB*TB MFMAs per step in one basic block (with the guards, which the
+  // compiler turns into an exec-mask save / branch / restore around every MFMA, the matrix pipe was busy 55 % of the time)
+  bool full = VEC && kbeg < kend && ((kend - kbeg) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < TB; ++i) full = full && (t.x * TB + i) * 16 + 15 < na && (t.y * TB + i) * 16 + 15 < nb;
+  auto fast = [&](auto diag_c) {
+    constexpr bool DG = decltype(diag_c)::value;           // diagonal super-tile: blocks j < i are skipped (compile time)
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      fa[i] = *reinterpret_cast<const f32x4*>(pa[i] + kbeg + 4 * kq);
+      fb[i] = *reinterpret_cast<const f32x4*>(pb[i] + kbeg + 4 * kq);
+    }
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
+      f32x4 na_[TB], nb_[TB];
+      const int64_t kn = (k0 + 16 < kend) ? k0 + 16 : k0;        // (the last step re-reads its own fragment: no branch)
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        na_[i] = *reinterpret_cast<const f32x4*>(pa[i] + kn + 4 * kq);
+        nb_[i] = *reinterpret_cast<const f32x4*>(pb[i] + kn + 4 * kq);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+#pragma unroll
+          for (int j = 0; j < TB; ++j) {
+            if (DG && j < i) continue;
+            if constexpr (ACC64) {
+              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[i][c], (double)fb[j][c], acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        fa[i] = na_[i];
+        fb[i] = nb_[i];
+      }
+    }
+  };
+  if (full && !diag) {
+    fast(std::false_type{});
+  } else if (full) {
+    fast(std::true_type{});
+  } else {
   if (kbeg < kend) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
@@ -140,6 +189,7 @@ __global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel
       fb[i] = nb_[i];
     }
   }
+  }   // guarded path
 
   using sc_t = typename std::conditional<ACC64, double, float>::type;
   sc_t* partial = reinterpret_cast<sc_t*>(partial_) +
