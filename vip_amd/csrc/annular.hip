@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
   if (kk > npx) kk = npx;
   for (int a = threadIdx.x; a < m; a += blockDim.x) g[a] = (a < lj) ? G[(size_t)ij[a] * n + j] : 0.0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const double thr = ev[0] * 1e-12;
   for (int c = wave; c < kk; c += nw) {
     double s = 0;

@@ -48,7 +48,7 @@ struct BgemmArgs {
 
 template <bool VEC, int TB>       // TB x TB blocks of 16 x 16 per wave
 __global__ __launch_bounds__(256) void bgemm_abt_kernel(BgemmArgs g, int tiles_n, int ntiles) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = blockIdx.x * 4 + wave;
   if (tile >= ntiles) return;
   const int b = blockIdx.y;
@@ -139,7 +139,7 @@ constexpr int BG_LDP = 20;            // LDS row pitch of a panel in floats (80 
 template <bool VEC>
 __global__ __launch_bounds__(256) void bgemm_abt_lds_kernel(BgemmArgs g, int tiles_n) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][128 * BG_LDP];      // [buffer][A | B][row][k]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int b = blockIdx.y;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ c
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 256 histogram words per wave, then the n x (TP+1) tile
   const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;       // blockIdx.y = cube of the batch
   float* __restrict__ out = out0 + (size_t)blockIdx.y * P;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
   const int ldt = TP + 1;
   unsigned* hist = reinterpret_cast<unsigned*>(smem) + HIST_WORDS * wave;

@@ -169,7 +169,7 @@ __device__ __forceinline__ void src_map_d(int q, int Y, const RotGeom& g, int& b
 __device__ __forceinline__ float block_sum(float v, float* red) {      // sum over the workgroup (<= 16 waves)
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x + 63) >> 6;
   if ((threadIdx.x & 63) == 0) red[wave] = v;
   __syncthreads();
   float t = 0.f;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(1024) void ds_shear2(const float* __restrict__ A1r,
   }
   if (threadIdx.x < CT) xsh[threadIdx.x * CS] = 0.f;
   // kernel tables: outputs at canvas rows off + m, inputs at rows r0 + y: d0 = off - r0
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   for (int c = wave; c < CT; c += nw) {
     const double s = p.b * (double)(X0 + c - g.c);
     fill_table(T + c * TS, Npad, Npad, g.off - r0, s, g.Le, lane, 64, aux.cotab);

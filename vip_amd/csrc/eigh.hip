@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
   extern __shared__ __attribute__((aligned(16))) double lds[];   // B columns x ldn
   const int prob = prob0 + blockIdx.y;
   const int g = blockIdx.x, nwg = gridDim.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* A = Gall + (size_t)prob * n * n;   // column j = A + j*n (G symmetric)
   unsigned* bar = bars + prob;
   unsigned* cv = conv + (size_t)prob * max_sweeps;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   double* e2 = tau + n;          // [n] (scaled) squared off-diagonals
   double* lam = e2 + n;          // [64] scaled eigenvalues, descending
   const int prob = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* A = Aall + (size_t)prob * n * n;
   double* evals = evals_all + (size_t)prob * n;
   double* evecs = evecs_all + (size_t)prob * n * n;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
                                                         double* __restrict__ gbuf_all, unsigned* __restrict__ bars) {
   extern __shared__ double sm[];
   const int W = gridDim.x, wg = blockIdx.x, prob = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* rows = sm;                         // [RW][n]  row lr <-> global row lr*W + wg ; reused after phase 1
   double* vbuf0 = rows + rows_d;             // Householder vector, double buffered (rows_d >= RW*n, 6*n*VW)
   double* vbuf1 = vbuf0 + n;

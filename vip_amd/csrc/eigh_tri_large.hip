@@ -28,7 +28,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
                                                         unsigned* __restrict__ bar, int all_evals) {
   extern __shared__ double sm[];
   const int W = gridDim.x, wg = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // phase 1: six vectors of n ; later phases reuse the space (9 n doubles in total)
   double* vbuf0 = sm;
   double* vbuf1 = vbuf0 + n;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
                                                      int all_evals) {
   extern __shared__ double sm[];
   const int W = gridDim.x, wg = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* vb0 = sm;                // v_s / v_{s-1}, rotating
   double* vb1 = vb0 + n;
   double* wprev = vb1 + n;

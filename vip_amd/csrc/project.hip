@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void rowspace_kernel(const float* __restrict__
   Wt += blockIdx.z * sWt;                    // blockIdx.z = problem of the batch (strides 0 for a single one)
   M += blockIdx.z * sM;
   T += blockIdx.z * sT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   const int64_t px0 = tile * 128;
   if (px0 >= P) return;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
   R += blockIdx.y * sM;
   Ct += blockIdx.y * sCt;
   T += blockIdx.y * sT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   const int64_t px0 = tile * 128;
   if (px0 >= P) return;

@@ -52,7 +52,7 @@ __global__ void temp_apply_kernel(const float* __restrict__ in, float* __restric
 __device__ __forceinline__ double block_sum(double v, double* sh) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __syncthreads();
   if (lane == 0) sh[w] = v;
   __syncthreads();
