@@ -1,5 +1,5 @@
 """Time the Gram kernel alone:  python tools/time_gram.py n N [opt=val ...]"""
-import sys; sys.path.insert(0, ".")
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vip_amd import backend as B
 n, N = int(sys.argv[1]), int(sys.argv[2])
