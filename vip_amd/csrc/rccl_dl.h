@@ -3,6 +3,7 @@
 // executes the collectives on it.  Only the types of <rccl/rccl.h> are used at build time.
 #pragma once
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 
 namespace vipmi {
@@ -28,6 +29,8 @@ inline RcclApi& rccl_api() {
 
 // path == nullptr: the RCCL already in the process, else librccl.so.1 / librccl.so from the loader's search path
 inline bool rccl_load(const char* path, const char** why) {
+  static std::mutex mu;                      // first use may come from several host threads (one ctx per thread)
+  std::lock_guard<std::mutex> lock(mu);
   RcclApi& a = rccl_api();
   if (a.ok()) return true;
   void* h = nullptr;
