@@ -177,7 +177,7 @@ __global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const do
 
 extern "C" {
 
-int vipmi_version(void) { return 101; }
+int vipmi_version(void) { return 102; }
 
 const char* vipmi_last_error(void) { return g_err; }
 
