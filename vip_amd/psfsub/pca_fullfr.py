@@ -6,10 +6,10 @@ Same positional order (= ``PCA_Params`` field order), same kwargs (unknown kwarg
 ``rot_options``), same return tuples and shapes.  All array work runs on the MI355X through
 libvipmi.so; numpy in -> numpy out, cuda tensor in -> cuda tensors out (no host copies).
 
-Tuple/list ``ncomp`` (the ``pca_grid`` of final frames), ``source_xy`` (PA-threshold frame rejection), ``cube_ref``
-(RDI / ARDI), ``cube_sig`` and 4-D cubes with ``scale_list`` (ADI+mSDI, psfsub/pca_msdi.py) are accelerated.  Not
-accelerated (raise NotImplementedError): ``pca_grid`` scored by S/N (tuple ``ncomp`` + ``source_xy``), ``batch``
-(incremental PCA), ``left_eigv``, ``mask_rdi``, ``smooth``, ``imlib`` other than 'vip-fft' (parity path) and 'opencv' (interpolating rotation, 3-D cubes).
+Tuple/list ``ncomp`` (the ``pca_grid`` of final frames, with S/N scoring at ``source_xy``), ``source_xy`` (PA-threshold
+frame rejection), ``cube_ref`` (RDI / ARDI), ``cube_sig`` and 4-D cubes with ``scale_list`` (ADI+mSDI, psfsub/pca_msdi.py)
+are accelerated.  Not accelerated (raise NotImplementedError): ``batch`` (incremental PCA), ``left_eigv``, ``mask_rdi``,
+``smooth``, ``imlib`` other than 'vip-fft' (parity path) and 'opencv' (interpolating rotation, 3-D cubes).
 """
 from dataclasses import dataclass
 from enum import Enum
