@@ -85,3 +85,19 @@ if "g23" in sys.argv or len(sys.argv) == 1:
     for nm, a in zip(("frame", "allfr", "desc", "adi"), fo):
         g["ref_%s" % nm] = np.asarray(a)
     save("g23_msdi_single_more", **g)
+
+# ---- G24: left_eigv=True (psfsub/pca_fullfr.py:428-437,1720-1724: PCs in the temporal domain, ADI only): the residuals
+# equal those of the standard projection; full_output returns pcs = U^T (k x n) -------------------------------------
+if "g24" in sys.argv or len(sys.argv) == 1:
+    cube, ang = O.synth_adi(14, 40, seed=95)
+    g = {"cube": cube, "angles": ang}
+    fo = ref.pca(cube, ang, ncomp=3, left_eigv=True, full_output=True, verbose=False, nproc=1)
+    for nm, a in zip(("frame", "pcs", "recon", "res", "resd"), fo):
+        g["left_" + nm] = np.asarray(a)
+    g["left_frame_only"] = np.asarray(ref.pca(cube, ang, ncomp=3, left_eigv=True, verbose=False, nproc=1))
+    g["std_frame"] = np.asarray(ref.pca(cube, ang, ncomp=3, verbose=False, nproc=1))
+    from vip_hci.psfsub.svd import svd_wrapper as _svdw
+    M = cube.reshape(14, -1).astype(np.float64)
+    g["svd_left_lapack"] = _svdw(M, "lapack", 4, False, left_eigv=True)
+    g["svd_left_arpack"] = _svdw(M, "arpack", 4, False, left_eigv=True)
+    save("g24_left_eigv", **g)

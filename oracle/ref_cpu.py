@@ -136,19 +136,24 @@ def randomized_svd(M, k, n_iter=2, n_oversamples=10, seed=0):
     return U[:, :k], s[:k], Vt[:k]
 
 
-def svd_wrapper(matrix, mode, ncomp, full_output=False, seed=0):
-    """Returns V (k x P, rows = PCs) or (U, S, V).  Ref: psfsub/svd.py:342-620."""
+def svd_wrapper(matrix, mode, ncomp, full_output=False, seed=0, left_eigv=False):
+    """Returns V (k x P, rows = PCs) or (U, S, V); ``left_eigv`` (mode 'lapack'): the temporal modes, (n x k)
+    (svd.py:607-613).  Ref: psfsub/svd.py:342-620."""
     if matrix.ndim != 2:
         raise TypeError("Input matrix is not a 2d array")
     if ncomp > min(matrix.shape):
         raise RuntimeError("{} PCs cannot be obtained from a matrix with size [{},{}]."
                            .format(ncomp, matrix.shape[0], matrix.shape[1]))
+    if left_eigv and mode != "lapack":
+        raise NotImplementedError("left_eigv: mode 'lapack' only in this restatement")
     if mode == "lapack":
         # svd of M.T (P x n): left vectors of M.T are the PCs (svd.py:466-475,598,615)
         Ul, S, Vl = np.linalg.svd(matrix.T, full_matrices=False)
         V = Ul[:, :ncomp].T
         if full_output:
             return Vl[:ncomp].T, S[:ncomp], V
+        if left_eigv:
+            return Vl[:ncomp].T
         return V
     if mode == "eigen":
         # svd.py:447-464
@@ -181,7 +186,7 @@ def cevr_to_ncomp(cube, cevr, scaling=None, svd_mode="lapack"):
 
 
 def project_subtract(cube, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
-                     cube_ref=None, full_output=False, seed=0, cube_sig=None):
+                     cube_ref=None, full_output=False, seed=0, cube_sig=None, left_eigv=False):
     """Whole-matrix branch of ``_project_subtract``.  Ref: psfsub/pca_fullfr.py:1649-1737.
     ``cube_sig`` (estimated signal, :1652-1662): the PCs are learnt from and the projection is taken of the
     "empty" matrix ``matrix - reshape(cube_sig)`` (cube_sig is neither masked nor scaled), but the model is
@@ -194,9 +199,14 @@ def project_subtract(cube, ncomp, scaling=None, mask_center_px=None, svd_mode="l
     matrix = prepare_matrix(cube, scaling, mask_center_px)
     matrix_emp = matrix if cube_sig is None else matrix - np.reshape(cube_sig, (cube_sig.shape[0], -1))
     ref_lib = matrix_emp if cube_ref is None else prepare_matrix(cube_ref, scaling, mask_center_px)
-    V = svd_wrapper(ref_lib, svd_mode, ncomp, seed=seed)
-    transformed = V @ matrix_emp.T
-    reconstructed = transformed.T @ V
+    if left_eigv:                                  # temporal modes (pca_fullfr.py:1720-1724): same subspace projection
+        V = svd_wrapper(ref_lib, svd_mode, ncomp, seed=seed, left_eigv=True)
+        transformed = matrix_emp.T @ V
+        reconstructed = V @ transformed.T
+    else:
+        V = svd_wrapper(ref_lib, svd_mode, ncomp, seed=seed)
+        transformed = V @ matrix_emp.T
+        reconstructed = transformed.T @ V
     residuals = (matrix - reconstructed).reshape(n, y, x)
     if full_output:
         return residuals, reconstructed, V
@@ -521,9 +531,11 @@ def get_annulus_segments(shape, inner_radius, width, nsegm=1, theta_init=0):
 
 def pca_fullframe(cube, angle_list, ncomp=1, svd_mode="lapack", scaling=None,
                   mask_center_px=None, collapse="median", cube_ref=None, weights=None,
-                  full_output=False, seed=0, rot_options=None, cube_sig=None):
+                  full_output=False, seed=0, rot_options=None, cube_sig=None, left_eigv=False):
     """3-D ADI / RDI branch of ``pca``.  Ref: psfsub/pca_fullfr.py:412-415,661-701,
-    801-1007,759-793."""
+    801-1007,759-793; ``left_eigv`` (ADI only, :428-437): pcs = V.T, (k x n) (:905)."""
+    if left_eigv and cube_ref is not None:
+        raise NotImplementedError("left_eigv is not compatible with 'mask_rdi' nor 'batch'")
     if cube.ndim != 3:
         raise TypeError("`cube` must be a 3d numpy ndarray")
     n = cube.shape[0]
@@ -541,9 +553,10 @@ def pca_fullframe(cube, angle_list, ncomp=1, svd_mode="lapack", scaling=None,
     elif ncomp <= 0:
         raise ValueError("Number of PCs too low. It should be > 0.")
     res, recon, V = project_subtract(cube, ncomp, scaling, mask_center_px, svd_mode,
-                                     cube_ref=cube_ref, full_output=True, seed=seed, cube_sig=cube_sig)
+                                     cube_ref=cube_ref, full_output=True, seed=seed, cube_sig=cube_sig,
+                                     left_eigv=left_eigv)
     y, x = cube.shape[1:]
-    pcs = V.reshape(V.shape[0], y, x)
+    pcs = V.T if left_eigv else V.reshape(V.shape[0], y, x)
     recon = recon.reshape(n, y, x)
     res_der = cube_derotate(res, angle_list, mask_val=mask_val)
     frame = cube_collapse(res_der, mode=collapse, w=weights)

@@ -151,7 +151,9 @@ def test_argument_errors_raise_before_touching_the_gpu():
     with pytest.raises(ValueError):
         pca(cube, np.zeros(4), svd_mode="nope", verbose=False)
     with pytest.raises(NotImplementedError):
-        pca(cube, np.zeros(4), left_eigv=True, verbose=False)
+        pca(cube, np.zeros(4), left_eigv=True, cube_ref=cube, verbose=False)          # (pca_fullfr.py:428-437)
+    with pytest.raises(NotImplementedError):
+        pca(cube, np.zeros(4), batch=2, verbose=False)
     with pytest.raises(TypeError):
         svd_wrapper(np.zeros((2, 3, 4)), "lapack", 1, False)
     with pytest.raises(RuntimeError):

@@ -615,6 +615,31 @@ def test_msdi_errors():
         pca(g["cube"], g["angles"], scale_list=g["scale_list"][:3], adimsdi="double", ncomp=(1, 1), verbose=False)
 
 
+def test_left_eigv_golden():
+    """pca(left_eigv=True) against the reference (g24): same frame / cubes as the standard projection, pcs = temporal
+    modes (k x n); svd_wrapper(left_eigv=True) -> (n x k); the reference's incompatibilities raise"""
+    from vip_amd.psfsub import pca
+    from vip_amd.psfsub.svd import svd_wrapper
+    g = load_golden("g24_left_eigv")
+    cube, ang = g["cube"], g["angles"]
+    out = pca(cube, ang, ncomp=3, left_eigv=True, full_output=True, verbose=False)
+    assert len(out) == 5
+    for nm, a in zip(("frame", "pcs", "recon", "res", "resd"), out):
+        b = g["left_" + nm]
+        assert a.shape == b.shape, (nm, a.shape, b.shape)
+        if nm == "pcs":
+            a = a * np.sign(np.sum(a * b, axis=1, keepdims=True))
+        assert np.nanmax(np.abs(a - b)) < TOL, nm
+    fr = pca(cube, ang, ncomp=3, left_eigv=True, verbose=False)
+    assert np.abs(fr - g["left_frame_only"]).max() < TOL
+    M = cube.reshape(14, -1)
+    for mode, key in (("lapack", "svd_left_lapack"), ("arpack", "svd_left_arpack")):
+        U = svd_wrapper(M, mode, 4, False, left_eigv=True)
+        assert U.shape == (14, 4) and np.abs(np.abs(U.T @ g[key]) - np.eye(4)).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        pca(cube, ang, ncomp=3, left_eigv=True, cube_ref=cube, verbose=False)
+
+
 def test_more_than_64_components():
     """ncomp > 64: full-frame PCA (fused entry and svd_wrapper) through the looping matrix-in-L2 eigensolver"""
     from vip_amd.psfsub import pca

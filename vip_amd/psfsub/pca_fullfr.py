@@ -8,7 +8,7 @@ libvipmi.so; numpy in -> numpy out, cuda tensor in -> cuda tensors out (no host 
 
 Tuple/list ``ncomp`` (the ``pca_grid`` of final frames, with S/N scoring at ``source_xy``), ``source_xy`` (PA-threshold
 frame rejection), ``cube_ref`` (RDI / ARDI), ``cube_sig`` and 4-D cubes with ``scale_list`` (ADI+mSDI, psfsub/pca_msdi.py)
-are accelerated.  Not accelerated (raise NotImplementedError): ``batch`` (incremental PCA), ``left_eigv``, ``mask_rdi``,
+are accelerated, ``left_eigv`` for plain ADI.  Not accelerated (raise NotImplementedError): ``batch`` (incremental PCA), ``mask_rdi``,
 ``smooth``, ``imlib`` other than 'vip-fft' (parity path) and 'opencv' (interpolating rotation, 3-D cubes).
 """
 from dataclasses import dataclass
@@ -203,8 +203,10 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
     """ADI / ADI+RDI full-frame PCA on device tensors; returns device tensors."""
     if batch is not None:
         raise NotImplementedError("batch (incremental PCA) is outside the accelerated path")
-    if mask_rdi is not None or left_eigv or smooth is not None:
-        raise NotImplementedError("mask_rdi / left_eigv / smooth are outside the accelerated path")
+    if mask_rdi is not None or smooth is not None:
+        raise NotImplementedError("mask_rdi / smooth are outside the accelerated path")
+    if left_eigv and (cube_ref is not None or source_xy is not None or not isinstance(ncomp, (int, np.integer))):
+        raise NotImplementedError("left_eigv: plain ADI with an integer ncomp only")
     if cube_sig is not None and tuple(cube_sig.shape) != tuple(cube.shape):
         raise TypeError("`cube_sig` must have the shape of `cube`")
     B.check_imlib(imlib, interpolation)         # 'vip-fft' or 'opencv'; the decorator selects the rotation
@@ -268,6 +270,20 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
             return recon_cube, residuals_cube, residuals_cube_, frame
         return frame
 
+    def left_pcs():
+        """pcs of ``left_eigv=True``: the temporal modes as rows, (ncomp x n) (pca_fullfr.py:905) -- the residuals are
+        those of the ordinary projection, U U^T M = M V^T V for the leading k triplets of M itself."""
+        from .svd import svd_wrapper
+        m = cube.reshape(n, -1)
+        if mask_center_px:
+            mk = B.to_device_f32(center_mask_u8((y, x), mask_center_px).astype(np.float32)).to(B._torch().uint8)
+            m = B.apply_mask(m, mk.reshape(-1), 0.0)
+        if scaling is not None:
+            m = B.scale(m, scaling)
+        if cube_sig is not None:
+            m = B.lincomb(m, cube_sig.reshape(n, -1), 1.0, -1.0)
+        return svd_wrapper(m, svd_mode, min(int(ncomp), n), False, left_eigv=True).t().contiguous()
+
     fused_ok = (cube_ref is None and cube_sig is None and n <= B.MAX_EIGH_N and _s(imlib) == "vip-fft" and isinstance(ncomp, (int, np.integer)) and collapse in
                 ("median", "mean", "sum", "max", "absmean") and (bool(mask_center_px) != mv_nan))
     if fused_ok:
@@ -281,6 +297,8 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
             print("Done PCA, de-rotating and combining on MI355X")
         if full_output:
             frame, pcs, recon, residuals_cube, residuals_cube_ = out
+            if left_eigv:
+                pcs = left_pcs()
             return pcs, recon, residuals_cube, residuals_cube_, frame
         return out
 
@@ -288,7 +306,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
                             cube_sig_t=cube_sig)
     if full_output:
         residuals_cube, recon, pcs = res
-        pcs = pcs.reshape(pcs.shape[0], y, x)
+        pcs = left_pcs() if left_eigv else pcs.reshape(pcs.shape[0], y, x)
         recon = recon.reshape(n, y, x)
     else:
         residuals_cube = res
@@ -374,7 +392,10 @@ def pca(*all_args: List, **all_kwargs: dict):
     if cube.ndim not in (3, 4):
         raise TypeError("`cube` must be a 3 or 4d numpy ndarray")
     if algo_params.left_eigv:
-        raise NotImplementedError("left_eigv is outside the accelerated path")
+        if algo_params.batch is not None or algo_params.mask_rdi is not None or algo_params.cube_ref is not None:
+            raise NotImplementedError("left_eigv is not compatible with 'mask_rdi' nor 'batch'")      # (pca_fullfr.py:428-437)
+        if algo_params.scale_list is not None or cube.ndim == 4:
+            raise NotImplementedError("left_eigv with 4-D cubes is outside the accelerated path")
     if _s(algo_params.svd_mode) not in SVD_MODES:
         raise ValueError("The SVD `mode` is not recognized")
     if algo_params.scale_list is not None:

@@ -61,8 +61,9 @@ def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=No
     mode = str(getattr(mode, "value", mode))
     if mode not in SVD_MODES:
         raise ValueError("The SVD `mode` is not recognized")
-    if left_eigv:
-        raise NotImplementedError("left_eigv is outside the accelerated path")
+    if left_eigv and mode in ("eigen", "eigencupy", "eigenpytorch"):
+        # (the reference's eigen family returns rows of the eigenvector matrix scaled column-wise here, svd.py:460-462)
+        raise NotImplementedError("left_eigv with the 'eigen' modes is outside the accelerated path")
     dev_in = B.is_device_tensor(matrix)
     t = B.to_device_f32(matrix)
     sig, E, V = _decompose(t, int(ncomp))
@@ -76,6 +77,9 @@ def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=No
             return x
         return x.cpu().numpy().astype(out_dtype, copy=False)
 
+    if left_eigv and not full_output:
+        # temporal modes, (n x ncomp) (svd.py:607-613: V.T of the SVD of matrix.T for 'lapack', U for the SVD of matrix)
+        return fin(E.T.contiguous().to(B._torch().float32))
     if full_output:
         U = E.T.contiguous() if mode == "lapack" else E
         # the reference truncates S to ncomp except in the eigen-family modes (svd.py:454-459,473)
