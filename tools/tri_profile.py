@@ -22,6 +22,6 @@ for n, k, batch in ((200, 10, 1), (200, 10, 400), (200, 10, 1600)):
         st = evals[0, n - 8:n - 2].cpu().numpy()
         d = np.diff(st) / 100.0      # s_memtime ticks at 100 MHz -> us
         sg = evals[0, n - 16:n - 11].cpu().numpy()
-        print("   step-loop segments of wave 0 (cycles/step): wave0-phase %.0f | barrier1 %.0f | update+tail %.0f | barrier2+reduce %.0f | barrier3+K+final %.0f" % tuple(sg / (n - 2)))
+        print("   step-loop segments of wave 0 (cycles/step): update+corner %.0f | barrier %.0f | vector phases (p, K, w, norms) %.0f | reflector %.0f | (unused %.0f)" % tuple(sg / (n - 2)))
         print("n=%d k=%d batch=%d reg=%d: %.3f ms | us: tridiag %.0f  eigenvalues %.0f  inverse-iteration %.0f  gram-schmidt %.0f  back-transform %.0f" % (
             n, k, batch, reg, e0.elapsed_time(e1), *d))

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
     double* vprev = vcur + NP;
     double* wprev = vprev + NP;
     double* nrow = wprev + NP;                         // [NP] column s of the updated matrix (the next Householder column)
+    double* xch = nrow + NP;                           // [16] per-wave partial sums and broadcast values of the vector phases
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: row conditions are scalar branches
     for (int i = tid; i < 4 * NP; i += TNT) vcur[i] = 0.0;
     __syncthreads();
@@ -135,36 +136,52 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
 #else
 #define SEG(i)
 #endif
-    for (int s = 0; s + 2 < na; ++s) {
-      if (wave == 0) {
-        // column s below the diagonal (already updated) is the next Householder vector
-        double nrm2 = 0.0;
-        for (int c = s + 1 + lane; c < na; c += 64) {
-          const double x = nrow[c];
-          vcur[c] = x;
-          nrm2 += x * x;
-        }
-        nrm2 = wave_sum(nrm2);
-        const double x0 = nrow[s + 1];
-        const double nrm = sqrt(nrm2);
-        const double alpha = (x0 >= 0.0) ? -nrm : nrm;
-        const double v0 = x0 - alpha;
-        double rest = nrm2 - x0 * x0;
-        if (rest < 0.0) rest = 0.0;
-        const double vv = rest + v0 * v0;
-        const double beta = (nrm2 > 0.0 && vv > 0.0) ? 2.0 / vv : 0.0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-          dd[s] = nrow[s];
-          vcur[s] = 0.0;
-          vcur[s + 1] = v0;
-          ee[s] = (nrm2 > 0.0) ? alpha : 0.0;
-          tau[s] = beta;
-        }
+    // The vector phases of a step are spread over the first NV = ceil(n / 64) waves (one element per lane: element
+    // r = base + 64 wave + lane), partial sums and the few broadcast values go through `xch`.  Reflector of step s1 from
+    // the (updated) column s1 (x = its element r = s1 + 64 wave + lane): called by waves < NV between two barriers.
+    constexpr int NV = RPL;                               // waves that take part (RPL * 64 >= n)
+    // phase A (before a barrier): partial norms and the two leading entries; phase B (after it): the vector itself
+    auto reflector_a = [&](int s1, double x) {
+      const int r = s1 + 64 * wave + lane;
+      const double part = wave_sum((r > s1 && r < na) ? x * x : 0.0);
+      if (lane == 0) xch[8 + wave] = part;
+      if (wave == 0 && lane == 0) xch[12] = x;            // diagonal entry
+      if (wave == 0 && lane == 1) xch[13] = x;            // first entry below it
+    };
+    auto reflector_b = [&](int s1, double x) {
+      double nrm2 = xch[8];
+#pragma unroll
+      for (int w = 1; w < NV; ++w) nrm2 += xch[8 + w];
+      const double xd = xch[12], x0 = xch[13];
+      // (square root and reciprocal from the hardware seeds + Newton; tiny or huge norms take the IEEE sequence)
+      const bool easy = nrm2 > 1e-280 && nrm2 < 1e280;
+      const double nrm = easy ? tri::fast_sqrt_pos(nrm2) : sqrt(nrm2);
+      const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+      const double v0 = x0 - alpha;
+      double rest = nrm2 - x0 * x0;
+      if (rest < 0.0) rest = 0.0;
+      const double vv = rest + v0 * v0;
+      const double beta = (nrm2 > 0.0 && vv > 0.0) ? (easy ? 2.0 * tri::fast_rcp(vv) : 2.0 / vv) : 0.0;
+      const int r = s1 + 64 * wave + lane;
+      if (r < na) vcur[r] = (r == s1) ? 0.0 : ((r == s1 + 1) ? v0 : x);
+      if (wave == 0 && lane == 0) {
+        dd[s1] = xd;
+        ee[s1] = (nrm2 > 0.0) ? alpha : 0.0;
+        tau[s1] = beta;
       }
-      SEG(0);
+    };
+    {
+      const int r = 64 * wave + lane;
+      const double x = (wave < NV && r < na) ? nrow[r] : 0.0;
+      if (wave < NV && na > 2) reflector_a(0, x);
       lds_barrier();
-      SEG(1);
+      if (wave < NV && na > 2) reflector_b(0, x);
+      lds_barrier();
+    }
+    // Four barriers per step: (1) all waves: pending rank-2 update fused with the column sums of A v, capture of row s+1;
+    // (2) waves < NV, one element per lane: p = beta A v from the per-wave sums (all loads of an element issued together),
+    // partial v.p; (3) K, w = p - K v, column s+1 with its own step's update, partial norms; (4) the next reflector.
+    for (int s = 0; s + 2 < na; ++s) {
       const double beta = tau[s];
       // kept for the back-transform, in the (otherwise unused) upper triangle: row s, columns > s.  The only global
       // access of a step: the barriers inside the step loop wait for LDS only (a full __syncthreads waits for the write
@@ -253,29 +270,51 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
           if (lane == (cs < 192 ? (cs & 63) : cs - 192)) nrow[r8] = val;
         }
       }
+      SEG(0);                                    // profile build: update + corner
       lds_barrier();
-      for (int r = s + 1 + tid; r < na; r += TNT) {
-        double t = 0.0;
-#pragma unroll 4
-        for (int w = 0; w < TNW; ++w) t += pcolw[w * n + r];
-        pcur[r] = beta * t;
+      SEG(1);                                    // wait at the barrier
+      double pv = 0.0, vl = 0.0, xl = 0.0;
+      const int rv = s + 1 + 64 * wave + lane;   // this lane's element in the vector phases
+      const bool okv = wave < NV && rv < na;
+      if (wave < NV) {
+        const int rr = okv ? rv : na - 1;
+        double q[TNW];
+#pragma unroll
+        for (int w = 0; w < TNW; ++w) q[w] = pcolw[w * n + rr];
+        const double v_ = vcur[rr], x_ = nrow[rr];
+        double t = q[0];
+#pragma unroll
+        for (int w = 1; w < TNW; ++w) t += q[w];
+        pv = okv ? beta * t : 0.0;
+        vl = okv ? v_ : 0.0;
+        xl = okv ? x_ : 0.0;
+        const double part = wave_sum(vl * pv);
+        if (lane == 0) xch[wave] = part;
+        if (wave == 0 && lane == 0) {
+          xch[4] = vl;                             // v[s+1], p[s+1]
+          xch[5] = pv;
+        }
       }
+      lds_barrier();
+      if (wave < NV) {
+        double kd = xch[0];
+#pragma unroll
+        for (int w = 1; w < NV; ++w) kd += xch[w];
+        const double K = 0.5 * beta * kd;
+        const double vs1 = xch[4], ws1 = xch[5] - K * vs1;
+        const double w = pv - K * vl;
+        if (okv) {
+          wprev[rv] = w;
+          vprev[rv] = vl;
+        }
+        xl = xl - vs1 * w - ws1 * vl;              // column s+1 with its own step's update
+        if (s + 3 < na) reflector_a(s + 1, xl);
+      }
+      SEG(2);                                    // vector phases
+      lds_barrier();
+      if (wave < NV && s + 3 < na) reflector_b(s + 1, xl);
+      lds_barrier();
       SEG(3);
-      lds_barrier();
-      // K = beta/2 v.p (every wave computes it: no further barrier) ; w = p - K v becomes the pending update
-      double kd = 0.0;
-      for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pcur[r];
-      const double K = 0.5 * beta * wave_sum(kd);
-      const double vs1 = vcur[s + 1], ws1 = pcur[s + 1] - K * vs1;
-      for (int r = s + 1 + tid; r < na; r += TNT) {
-        const double v = vcur[r];
-        const double w = pcur[r] - K * v;
-        wprev[r] = w;
-        vprev[r] = v;
-        nrow[r] = nrow[r] - vs1 * w - ws1 * v;      // column s+1 with its own step's update: ready for the next step
-      }
-      SEG(4);
-      lds_barrier();
     }
 #ifdef VIPMI_TRI_PROFILE
     if (prob == 0 && tid == 0) for (int i = 0; i < 5; ++i) evals[n - 16 + i] = (double)seg[i];
@@ -1212,7 +1251,7 @@ int reg_variant_chunk(int n, int k) {
 }
 size_t reg_variant_lds(int n, int k) {
   const size_t lds_fixed = ((size_t)10 * n + 64 + 8 + 72) * sizeof(double);
-  const size_t lds_tri = ((size_t)8 * n + 4 * 200) * sizeof(double);
+  const size_t lds_tri = ((size_t)8 * n + 4 * 200 + 16) * sizeof(double);
   const size_t lds_inv = (size_t)n * reg_variant_chunk(n, k) * (5 * sizeof(double) + 1) + 16;
   return lds_fixed + (lds_tri > lds_inv ? lds_tri : lds_inv);
 }
