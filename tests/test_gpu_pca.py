@@ -823,6 +823,38 @@ def test_bench_sharded_modes_two_ranks_on_one_gpu():
         assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
 
 
+def test_c_client_of_the_c_abi(tmp_path):
+    """The boundary is a C ABI: a plain C program (tests/helpers/cabi_client.c: gcc, the HIP runtime for the device
+    buffers, libvipmi.so -- no Python, no PyTorch in that process) runs vipmi_pca_fullframe_f32 and must write the frame
+    that pca() returns."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    from vip_amd.psfsub import pca
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler on this box")
+    exe = str(tmp_path / "cabi_client")
+    libdir = os.path.join(ROOT, "vip_amd")
+    cp = subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                         os.path.join(ROOT, "tests", "helpers", "cabi_client.c"), "-o", exe, "-L", libdir, "-lvipmi",
+                         "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    n, N, k = 30, 64, 4
+    cube, ang = O.synth_adi(n, N, seed=17)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([n, N, k], dtype=np.int64).tofile(f)
+        cube.astype(np.float32).tofile(f)
+        np.asarray(ang, dtype=np.float64).tofile(f)
+    cp = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, (cp.stdout, cp.stderr[-2000:])
+    got = np.fromfile(fout, dtype=np.float32).reshape(N, N)
+    ref = pca(cube, ang, ncomp=k, verbose=False)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert np.nanmax(np.abs(got - O.pca_fullframe(cube, ang, ncomp=k))) < TOL
+
+
 def test_sharded_c_entry_on_an_rccl_communicator_world_1():
     """include/vipmi.h: vipmi_rccl_* + vipmi_pca_fullframe_sharded_f32 (RCCL resolved at run time, communicator created by
     the library, all-reduce / grouped send-recv exchanges incl. the sends to self) against pca() -- one rank, which is
