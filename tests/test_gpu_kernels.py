@@ -432,6 +432,30 @@ def test_rotate_masks_and_cube_direct(B):
     assert np.abs(got - g["derot_128"]).max() < 5e-5
 
 
+@pytest.mark.parametrize("N", [513, 577, 640, 801, 1001, 1023])
+def test_derotate_513_to_1023_px_vs_oracle(B, N):
+    """513 .. 1023 px: the convolution passes take every line in two parts (derotate_conv.inc) -- against the float64
+    restatement of the reference and against the direct correlations; all four rot90 quadrants, NaN mask."""
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(N)
+    angles = np.array([10.0, 100.0, 200.0, 300.0])
+    cube = rng.standard_normal((4, N, N)).astype(np.float32)
+    cube[1, 3:6, 4] = np.nan
+    cube[2, N - 5, N - 7:] = np.nan
+    ref = O.cube_derotate(cube, angles)
+    ctx = B.get_context()
+    try:
+        got = cube_derotate(cube, angles, method="direct")
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.nanmax(np.abs(got - ref)) < 4e-5
+        if N in (513, 801):
+            ctx.set_option("rot_conv", 0)
+            slow = cube_derotate(cube, angles, method="direct")
+            assert np.nanmax(np.abs(slow - got)) < 4e-5
+    finally:
+        ctx.set_option("rot_conv", 1)
+
+
 @pytest.mark.parametrize("N", [21, 101, 129, 200, 255, 256, 301, 400, 511, 512])
 def test_derotate_generic_sizes_vs_oracle(B, N):
     """Non-power-of-two padded lengths take the real-split direct path (from 129 px its passes run as power-of-two
