@@ -456,6 +456,29 @@ def test_derotate_513_to_1023_px_vs_oracle(B, N):
         ctx.set_option("rot_conv", 1)
 
 
+@pytest.mark.parametrize("N", [1025, 1100, 1537])
+def test_derotate_beyond_1024_px(B, N):
+    """1025 .. 2048 px: three or four parts per line on the 1024-point convolutions, against the direct correlations
+    (and the float64 restatement at 1100 px)"""
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(N)
+    angles = np.array([33.0, 250.0])
+    cube = rng.standard_normal((2, N, N)).astype(np.float32)
+    cube[1, 3:6, 4] = np.nan
+    ctx = B.get_context()
+    try:
+        got = cube_derotate(cube, angles, method="direct")
+        ctx.set_option("rot_conv", 0)
+        slow = cube_derotate(cube, angles, method="direct")
+        assert np.array_equal(np.isnan(got), np.isnan(slow))
+        assert np.nanmax(np.abs(slow - got)) < 6e-5
+        if N == 1100:
+            ref = O.cube_derotate(cube, angles)
+            assert np.nanmax(np.abs(got - ref)) < 6e-5
+    finally:
+        ctx.set_option("rot_conv", 1)
+
+
 @pytest.mark.parametrize("N", [21, 101, 129, 200, 255, 256, 301, 400, 511, 512])
 def test_derotate_generic_sizes_vs_oracle(B, N):
     """Non-power-of-two padded lengths take the real-split direct path (from 129 px its passes run as power-of-two

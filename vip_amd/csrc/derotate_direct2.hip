@@ -442,7 +442,7 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
   const int Npad = (int)cdiv(g.N + 1, 2 * TNA) * 2 * TNA, Lpad = (int)cdiv(g.Le + 1, 2 * TNA) * 2 * TNA;
   // 129 .. 512 px: the three passes as power-of-two circular convolutions (derotate_conv.inc) on blocked intermediates
   // (N, Le rounded up to multiples of 128); option rot_conv = 0 keeps the direct correlations
-  const bool conv = ctx->opt("rot_conv", 1) != 0 && g.N > 128 && g.N <= 1024;       // (513 .. 1024 px: two parts per line)
+  const bool conv = ctx->opt("rot_conv", 1) != 0 && g.N > 128 && g.N <= 2048;       // (from 513 px: up to four parts per line)
   CvLayout lay;
   lay.nbr = (int)cdiv(g.N, 128) * 64;
   lay.nbc = (int)cdiv(g.Le, 128) * 64;
