@@ -1070,14 +1070,15 @@ def test_raw_c_abi_pca_4d():
     assert lib.vipmi_destroy(ctx) == 0
 
 
-@pytest.mark.parametrize("N", [255, 301])
+@pytest.mark.parametrize("N", [255, 301, 601])
 def test_pca_odd_frame_sizes_end_to_end(N):
     """VIP's convention is ODD frames centred on the star: the whole pipeline at sizes whose derotation runs through the
     power-of-two convolution passes (derotate_conv.inc), with and without a central mask (mask_val = 0 restore), against
     the oracle."""
     from vip_amd.psfsub import pca, pca_annular
-    cube, ang = O.synth_adi(10, N, seed=8)
-    ang = np.linspace(-30, 250, 10)                      # every rot90 quadrant
+    nfr = 10 if N < 500 else 6                           # (601 px: two parts per line in the convolution passes)
+    cube, ang = O.synth_adi(nfr, N, seed=8)
+    ang = np.linspace(-30, 250, nfr)                     # every rot90 quadrant
     out = pca(cube, ang, ncomp=3, full_output=True, verbose=False)
     ref = O.pca_fullframe(cube, ang, ncomp=3, full_output=True)
     assert np.abs(out[0] - ref[0]).max() < TOL and np.nanmax(np.abs(out[4] - ref[4])) < TOL
