@@ -240,44 +240,55 @@ __global__ __launch_bounds__(256) void ds_bf(const RotFrame* __restrict__ fr, Ro
 
 // K[m] = Re sum_k Bhat[k] g[k] e^{2 pi i k (off + m)/Le},  Bhat[k] = sum_y beta[y] e^{-2 pi i k (r0 + y)/Le},
 // g(k) = sum_X exp(-2 pi i ks b (X - c)/Le)/Le in closed form (ks = signed frequency; Nyquist: real part).
-__global__ __launch_bounds__(1024) void ds_aux_k(const RotFrame* __restrict__ fr, RotGeom g, AuxD aux, int f0) {
+// Two launches over a grid (frames, S): phase 1 writes the spectrum H of a frame in S slices to global memory, phase 2
+// computes S slices of K from the whole H.  (One workgroup per frame did both: 0.6 ms for a 2048-pixel frame, a third of
+// the derotation of a handful of such frames.)
+__global__ __launch_bounds__(1024) void ds_aux_k(const RotFrame* __restrict__ fr, RotGeom g, AuxD aux, int f0, int phase,
+                                                 float2* __restrict__ Hg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float2* root = reinterpret_cast<float2*>(smem);          // [Le] e^{+2 pi i t/Le}
   float2* H = root + g.Le;                                  // [Le]
   float* beta = reinterpret_cast<float*>(H + g.Le);         // [N]
-  const int fl = blockIdx.x;
+  const int fl = blockIdx.x, S = gridDim.y, sl = blockIdx.y;
   const RotFrame p = fr[f0 + fl];
   const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
   const int Le = g.Le;
+  float2* Hf = Hg + (size_t)fl * Le;
   for (int t = threadIdx.x; t < Le; t += blockDim.x) {
     float sn, cs;
     sincospif(2.0f * (float)t / (float)Le, &sn, &cs);
     root[t] = make_float2(cs, sn);
   }
-  for (int y = threadIdx.x; y < g.N; y += blockDim.x) beta[y] = aux.beta[fl * g.N + y];
-  __syncthreads();
-  for (int k = threadIdx.x; k < Le; k += blockDim.x) {
-    float re = 0.f, im = 0.f;
-    int idx = (int)(((long long)k * r0) % Le);             // k (r0 + y) mod Le, advanced by k per step
-    for (int y = 0; y < g.N; ++y) {
-      const float2 w = root[idx];
-      re += beta[y] * w.x;                                  // e^{-i phi} = (cos, -sin)
-      im -= beta[y] * w.y;
-      idx += k;
-      if (idx >= Le) idx -= Le;
+  if (phase == 1) {
+    for (int y = threadIdx.x; y < g.N; y += blockDim.x) beta[y] = aux.beta[fl * g.N + y];
+    __syncthreads();
+    const int per = (Le + S - 1) / S, k0 = sl * per, k1 = (k0 + per < Le) ? k0 + per : Le;
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+      float re = 0.f, im = 0.f;
+      int idx = (int)(((long long)k * r0) % Le);             // k (r0 + y) mod Le, advanced by k per step
+      for (int y = 0; y < g.N; ++y) {
+        const float2 w = root[idx];
+        re += beta[y] * w.x;                                  // e^{-i phi} = (cos, -sin)
+        im -= beta[y] * w.y;
+        idx += k;
+        if (idx >= Le) idx -= Le;
+      }
+      const int ks = (k < Le / 2) ? k : k - Le;
+      const double kbv = (double)ks * p.b;
+      const double den = sinpi(kbv / (double)Le);
+      const double ratio = (fabs(den) < 1e-300) ? (double)Le : sinpi(kbv) / den;
+      double sn, cs;
+      sincospi(-2.0 * kbv * (0.5 * (double)(Le - 1) - (double)g.c) / (double)Le, &sn, &cs);
+      float gre = (float)(ratio * cs / (double)Le), gim = (float)(ratio * sn / (double)Le);
+      if (k == Le / 2) gim = 0.f;
+      Hf[k] = make_float2(re * gre - im * gim, re * gim + im * gre);
     }
-    const int ks = (k < Le / 2) ? k : k - Le;
-    const double kbv = (double)ks * p.b;
-    const double den = sinpi(kbv / (double)Le);
-    const double ratio = (fabs(den) < 1e-300) ? (double)Le : sinpi(kbv) / den;
-    double sn, cs;
-    sincospi(-2.0 * kbv * (0.5 * (double)(Le - 1) - (double)g.c) / (double)Le, &sn, &cs);
-    float gre = (float)(ratio * cs / (double)Le), gim = (float)(ratio * sn / (double)Le);
-    if (k == Le / 2) gim = 0.f;
-    H[k] = make_float2(re * gre - im * gim, re * gim + im * gre);
+    return;
   }
+  for (int k = threadIdx.x; k < Le; k += blockDim.x) H[k] = Hf[k];
   __syncthreads();
-  for (int m = threadIdx.x; m < g.N; m += blockDim.x) {
+  const int per = (g.N + S - 1) / S, m0 = sl * per, m1 = (m0 + per < g.N) ? m0 + per : g.N;
+  for (int m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
     const int Yo = g.off + m;
     float re = 0.f;
     int idx = 0;
@@ -432,6 +443,16 @@ __global__ __launch_bounds__(1024) void ds_shear3(const float* __restrict__ A2r,
   }
 }
 
+// K vectors of a batch of frames: the frames times S slices of workgroups (few large frames would leave the chip empty)
+static void launch_aux_k(vipmi_ctx* ctx, unsigned nf, size_t ldsk, const RotFrame* d_frames, const RotGeom& g, const AuxD& aux,
+                         int f0, float2* Hg) {
+  int S = nf > 0 ? (int)(ctx->num_cu / nf) : 1;
+  if (S < 1) S = 1;
+  if (S > 8) S = 8;
+  hipLaunchKernelGGL(ds_aux_k, dim3(nf, S), dim3(1024), ldsk, ctx->stream, d_frames, g, aux, f0, 1, Hg);
+  hipLaunchKernelGGL(ds_aux_k, dim3(nf, S), dim3(1024), ldsk, ctx->stream, d_frames, g, aux, f0, 2, Hg);
+}
+
 #include "derotate_conv.inc"
 
 }  // namespace
@@ -464,6 +485,8 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
   VIPMI_TRY(ws(ctx, "rot_kv", (size_t)(chunk * g.N), &aux.kv));
   VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * g.Le), &aux.gam));
   VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
+  float2* aux_H = nullptr;
+  VIPMI_TRY(ws(ctx, "rot_auxH", (size_t)(chunk * g.Le), &aux_H));
   float* cotab = nullptr;
   VIPMI_TRY(ws(ctx, "rot_cotab", (size_t)g.Le, &cotab));
   hipLaunchKernelGGL(ds_cotab_kernel, dim3((unsigned)cdiv(g.Le, 256)), dim3(256), 0, ctx->stream, cotab, g.Le);
@@ -504,9 +527,9 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
     const unsigned nf = (unsigned)((n - f0) < chunk ? (n - f0) : chunk);
     if (conv) {
       if (2 * g.N - 1 <= 512)
-        VIPMI_TRY((conv_passes<fftw::Plan512>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
+        VIPMI_TRY((conv_passes<fftw::Plan512>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk, aux_H)));
       else
-        VIPMI_TRY((conv_passes<fftw::Plan1024>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk)));
+        VIPMI_TRY((conv_passes<fftw::Plan1024>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk, aux_H)));
       continue;
     }
     ctx->tic("k_rot_s1");
@@ -515,7 +538,7 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
     ctx->toc("k_rot_s1");
     ctx->tic("k_rot_aux");
     hipLaunchKernelGGL(ds_bf, dim3(nf), dim3(256), 0, ctx->stream, d_frames, g, aux, (int)f0);
-    hipLaunchKernelGGL(ds_aux_k, dim3(nf), dim3(1024), ldsk, ctx->stream, d_frames, g, aux, (int)f0);
+    launch_aux_k(ctx, nf, ldsk, d_frames, g, aux, (int)f0, aux_H);
     ctx->toc("k_rot_aux");
     ctx->tic("k_rot_s2");
     {
