@@ -825,21 +825,13 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
                   float* out, int mask_nan, int mask_zero) {
   switch (g.Le) {
     case 512: return run_plan2<Plan512>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-    case 1024:
-      // rot_wpb=4: 4-wave workgroups (three per CU at <= 168 VGPRs); a stand-alone derotation gains 4 % (shear 1: 12 %),
-      // but with two calls in flight (4-D cubes, pca_many) the other call's eigensolver finds no free CU: C4 +11 %
-      if (ctx->opt("rot_wpb", 8) == 4) return run_plan2<Plan1024w4>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-      return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-    case 2048:
-      // rot_wpb = waves per workgroup: 8 (default) = one wave per line, 2 waves/SIMD with a 256-VGPR budget;
-      // 12 / 16 = two waves per line (more waves, but workgroup barriers and 1.5x the instructions per line)
-      if (ctx->opt("rot_wpb", 8) == 8 || ctx->opt("rot_wpb", 8) == 4)
-        return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-      if (ctx->opt("rot_wpb", 8) == 12) return run_plan2<Plan2048w12>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-      return run_plan2<Plan2048>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-    case 4096:
-      if (ctx->opt("rot_wpb", 8) == 8) return run_plan2<Plan4096w2>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-      return run_plan2<Plan4096>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    // one plan per padded length.  Measured and dropped from the build (NOTES.md): 4-wave workgroups at Le = 1024 (+4 %
+    // stand-alone, but with two calls in flight the other call's eigensolver finds no free CU: C4 +11 %); two waves per
+    // line at Le = 2048 with 12 or 16 waves per workgroup (3 waves per SIMD, but workgroup barriers and 1.5x the
+    // instructions per line: 6.2 against 3.8 ms at C2); four waves per line at Le = 4096.
+    case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 2048: return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 4096: return run_plan2<Plan4096w2>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     default:
       set_error("derotate(fft2): unsupported padded length %d", g.Le);
       return VIPMI_ERR_UNSUPPORTED;

@@ -235,11 +235,7 @@ struct Plan {
 // keeps the kernels under 128 VGPRs (4 waves/SIMD, no spills); the exchanges then need a workgroup barrier.
 using Plan512 = Plan<8, 8, 8, 72, 72, 9, 8, 1>;
 using Plan1024 = Plan<16, 8, 8, 72, 72, 9, 8, 1, true>;
-using Plan1024w4 = Plan<16, 8, 8, 72, 72, 9, 4, 1>;        // 4-wave workgroups: 3 of them per CU (<= 168 VGPRs)
-using Plan2048 = Plan<16, 16, 8, 136, 152, 9, 16, 2>;
-using Plan2048w12 = Plan<16, 16, 8, 136, 152, 9, 12, 2>;   // 3 waves/SIMD, 170-VGPR budget
 using Plan2048w1 = Plan<16, 16, 8, 136, 152, 9, 8, 1, true>;   // one wave per line: no workgroup barriers, 2 waves/SIMD
-using Plan4096 = Plan<16, 16, 16, 272, 272, 17, 16, 4>;
 using Plan4096w2 = Plan<16, 16, 16, 272, 272, 17, 8, 2>;    // two waves per line, 2 waves/SIMD, 256-VGPR budget
 
 // exp(-2 pi i j/64), j = 0..63
