@@ -377,7 +377,8 @@ def test_median_bucket_selection_hard_cases(B, n):
 
 
 @pytest.mark.parametrize("n,P,tn", [(7, 50, 3), (8, 50, 3), (8, 64, 4), (7, 33, 9), (7, 33, 50), (65, 333, 20),
-                                    (400, 1024, 100), (129, 100, 129), (10, 40, 1)])
+                                    (400, 1024, 100), (129, 100, 129), (10, 40, 1),
+                                    (4100, 70, 50), (5001, 40, 1001)])      # (more than 4096 frames: the streaming kernel)
 def test_trimmean_sizes(B, n, P, tn):
     rng = np.random.default_rng(n * 7 + P + tn)
     cube = rng.standard_normal((n, P)).astype(np.float32)

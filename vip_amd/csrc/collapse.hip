@@ -460,6 +460,64 @@ __global__ void colreduce_kernel(const float* __restrict__ cube0, int n, int64_t
 // bisection on the order-preserving keys with the samples re-read from memory in every step (consecutive threads read
 // consecutive pixels: coalesced; 34 passes over the cube -- 6000 x 512 x 512 takes ~60 ms, for cubes the eigensolver
 // needs 350 ms for).  Same value rules as the register kernel: NaN-aware, even count -> (a + b) * 0.5 in float32.
+// rank-k key of a pixel's valid samples, read from memory (32-step bitwise bisection)
+__device__ __forceinline__ unsigned stream_select(const float* __restrict__ cube, int n, int64_t P, int64_t p, int k) {
+  unsigned ans = 0;
+  for (int b = 31; b >= 0; --b) {
+    const unsigned cand = ans | (1u << b);
+    int c = 0;
+    for (int f = 0; f < n; ++f) {
+      const float v = cube[(size_t)f * P + p];
+      c += (v == v && f2key(v) < cand) ? 1 : 0;
+    }
+    if (c <= k) ans = cand;
+  }
+  return ans;
+}
+
+// trimmed mean of more than 4096 frames: the two order statistics that bound the slice by streaming bisections, then
+// one pass for the sum between them (the value rules of the register kernel: NaNs dropped, ties counted)
+__global__ __launch_bounds__(256) void trimmean_stream_kernel(const float* __restrict__ cube0, int n, int64_t P,
+                                                              float* __restrict__ out0, int t0, int tn) {
+  const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;
+  float* __restrict__ out = out0 + (size_t)blockIdx.y * P;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int m = 0;
+  for (int f = 0; f < n; ++f) {
+    const float v = cube[(size_t)f * P + p];
+    m += (v == v) ? 1 : 0;
+  }
+  int hi_end = t0 + tn;
+  if (hi_end > n) hi_end = n;
+  if (hi_end > m) hi_end = m;
+  if (t0 >= hi_end) {
+    out[p] = __uint_as_float(0x7fc00000u);
+    return;
+  }
+  const unsigned klo = stream_select(cube, n, P, p, t0), khi = stream_select(cube, n, P, p, hi_end - 1);
+  int cle_lo = 0, clt_hi = 0;
+  double mid = 0.0;
+  for (int f = 0; f < n; ++f) {
+    const float v = cube[(size_t)f * P + p];
+    if (v == v) {
+      const unsigned kf = f2key(v);
+      cle_lo += (kf <= klo) ? 1 : 0;
+      clt_hi += (kf < khi) ? 1 : 0;
+      if (kf > klo && kf < khi) mid += (double)v;
+    }
+  }
+  double tot;
+  if (klo == khi) {
+    tot = (double)key2f(klo) * (double)(hi_end - t0);
+  } else {
+    const int nlo = (cle_lo < hi_end ? cle_lo : hi_end) - t0;
+    const int nhi = hi_end - clt_hi;
+    tot = mid + (double)key2f(klo) * nlo + (double)key2f(khi) * nhi;
+  }
+  out[p] = (float)(tot / (double)(hi_end - t0));
+}
+
 __global__ __launch_bounds__(256) void median_stream_kernel(const float* __restrict__ cube0, int n, int64_t P,
                                                             float* __restrict__ out0) {
   const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;
@@ -476,16 +534,7 @@ __global__ __launch_bounds__(256) void median_stream_kernel(const float* __restr
     return;
   }
   const int k = (m - 1) >> 1;
-  unsigned ans = 0;                              // largest key with at most k valid keys below it = the rank-k key
-  for (int b = 31; b >= 0; --b) {
-    const unsigned cand = ans | (1u << b);
-    int c = 0;
-    for (int f = 0; f < n; ++f) {
-      const float v = cube[(size_t)f * P + p];
-      c += (v == v && f2key(v) < cand) ? 1 : 0;
-    }
-    if (c <= k) ans = cand;
-  }
+  const unsigned ans = stream_select(cube, n, P, p, k);       // largest key with at most k valid keys below it
   float res = key2f(ans);
   if ((m & 1) == 0) {
     // upper median: the same value again when it is repeated, else the smallest key above it
@@ -574,14 +623,14 @@ int collapse_batched_f32(vipmi_ctx* ctx, const float* cube, int64_t batch, int64
       if (rpl <= 32) { VIPMI_MED(32); }
       if (rpl <= 64) { VIPMI_MED(64); }
 #undef VIPMI_MED
-      if (!trim) {
+      if (!trim)
         hipLaunchKernelGGL(median_stream_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)batch), dim3(256), 0, ctx->stream,
                            cube, (int)n, P, out);
-        VIPMI_CHECK_HIP(hipGetLastError());
-        return VIPMI_OK;
-      }
-      set_error("collapse(trimmean): more than 4096 frames not supported");
-      return VIPMI_ERR_UNSUPPORTED;
+      else
+        hipLaunchKernelGGL(trimmean_stream_kernel, dim3((unsigned)cdiv(P, 256), (unsigned)batch), dim3(256), 0, ctx->stream,
+                           cube, (int)n, P, out, t0, tn);
+      VIPMI_CHECK_HIP(hipGetLastError());
+      return VIPMI_OK;
     }
     case VIPMI_COLLAPSE_WMEAN:
       VIPMI_REQUIRE(w != nullptr, "Weights have to be provided for weighted mean mode");
