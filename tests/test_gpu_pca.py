@@ -655,6 +655,18 @@ def test_more_than_64_components():
     assert np.abs(V.T @ (V @ M.T) - Vr.T @ (Vr @ M.T)).max() < 1e-3 * np.abs(M).max()
 
 
+def test_annular_libraries_beyond_512_frames_are_refused_clearly():
+    """PCA libraries of more than 512 frames per annulus (max_frames_lib raised far above the reference's default 200):
+    a clear NotImplementedError instead of the non-convergence of the fallback solver; 512 itself works."""
+    from vip_amd.psfsub import pca_annular
+    cube, _ = O.synth_adi(560, 32, seed=2)
+    ang = np.linspace(0, 300, 560)
+    with pytest.raises(NotImplementedError, match="512 frames"):
+        pca_annular(cube, ang, asize=8, ncomp=3, fwhm=4, delta_rot=(0.1, 1), max_frames_lib=540, verbose=False)
+    fr = pca_annular(cube, ang, asize=8, ncomp=3, fwhm=4, delta_rot=(0.1, 1), max_frames_lib=512, verbose=False)
+    assert np.isfinite(fr[np.isfinite(fr)]).all() and np.isfinite(fr).sum() > 100
+
+
 def test_more_than_6144_frames_library_fallback():
     """beyond the hand-written leading-k solver (n > backend.MAX_EIGH_N = 6144) the front keeps the device Gram / projection
     kernels and takes the eigendecomposition from rocSOLVER (backend.eigh_beyond_lds)"""

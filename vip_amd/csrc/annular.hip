@@ -80,6 +80,13 @@ int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
   VIPMI_REQUIRE(A && lib_idx && lib_len && residuals && ncomps, "annular_residuals: null pointer");
   VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && nk > 0, "annular_residuals: bad sizes");
   VIPMI_REQUIRE(max_lib <= n, "annular_residuals: max_lib > n");
+  if (max_lib > 512) {
+    // (the batched leading-k eigensolver holds a library's Gram matrix per workgroup: up to 512 frames; the one-sided
+    // Jacobi fallback does not converge on the graded spectra of larger libraries)
+    set_error("annular_residuals: PCA libraries of more than 512 frames (max_frames_lib = %ld) are not supported: "
+              "lower max_frames_lib (the reference's default is 200)", (long)max_lib);
+    return VIPMI_ERR_UNSUPPORTED;
+  }
   int64_t kmax = 0;
   for (int64_t i = 0; i < nk; ++i) {
     VIPMI_REQUIRE(ncomps[i] > 0, "annular_residuals: ncomp must be positive");
