@@ -70,7 +70,9 @@ int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key);   /* -1 if unset */
  * vipmi_stage_ms: total elapsed ms of all intervals of the named stage since the last
  * vipmi_reset_timers (synchronises; <0 if none); vipmi_stage_count: number of intervals.
  * Stages: "gram","eigh","project","derotate","collapse","scale"; single kernels:
- * "k_gram","k_rowspace","k_subtract","k_rot_s1","k_rot_s2","k_rot_s3","k_median". */
+ * "k_gram","k_rowspace","k_subtract","k_rot_s1","k_rot_s2","k_rot_s3","k_median".
+ * "timing"=3: no events; vipmi_stage_ms returns the HOST wall time spent inside each stage (enqueue cost; includes
+ * waiting for a staging slot when the host runs ahead of the GPU) -- tools/time_small_calls.py. */
 float vipmi_stage_ms(vipmi_ctx* ctx, const char* stage);
 int vipmi_stage_count(vipmi_ctx* ctx, const char* stage);
 int vipmi_reset_timers(vipmi_ctx* ctx);

@@ -140,6 +140,11 @@ void vipmi_ctx::tic(const char* stage) {
   if (!timing || (timing == 2 && strcmp(stage, "k_rot_s2") != 0)) return;
   StageTimer& t = timers[stage];
   if (t.open) return;
+  if (timing == 3) {
+    t.host_t0 = std::chrono::steady_clock::now();
+    t.open = true;
+    return;
+  }
   if (t.used == (int)t.ev.size()) {
     hipEvent_t a = nullptr, b = nullptr;
     (void)hipEventCreate(&a);
@@ -154,6 +159,12 @@ void vipmi_ctx::toc(const char* stage) {
   if (!timing || (timing == 2 && strcmp(stage, "k_rot_s2") != 0)) return;
   StageTimer& t = timers[stage];
   if (!t.open) return;
+  if (timing == 3) {
+    t.host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t.host_t0).count();
+    t.host_count++;
+    t.open = false;
+    return;
+  }
   (void)hipEventRecord(t.ev[t.used].second, stream);
   t.used++;
   t.open = false;
@@ -253,6 +264,7 @@ int64_t vipmi_get_option(vipmi_ctx* ctx, const char* key) {
 float vipmi_stage_ms(vipmi_ctx* ctx, const char* stage) {
   if (!ctx || !stage) return -1.f;
   auto it = ctx->timers.find(stage);
+  if (it != ctx->timers.end() && ctx->timing == 3) return it->second.host_count ? (float)it->second.host_ms : -1.f;
   if (it == ctx->timers.end() || it->second.used == 0) return -1.f;
   StageTimer& t = it->second;
   if (hipEventSynchronize(t.ev[t.used - 1].second) != hipSuccess) return -1.f;
@@ -276,6 +288,8 @@ int vipmi_reset_timers(vipmi_ctx* ctx) {
   for (auto& kv : ctx->timers) {
     kv.second.used = 0;
     kv.second.open = false;
+    kv.second.host_ms = 0.0;
+    kv.second.host_count = 0;
   }
   return VIPMI_OK;
 }

@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <vector>
 #include "../../include/vipmi.h"
 
@@ -48,6 +49,9 @@ struct StageTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   int used = 0;
   bool open = false;
+  double host_ms = 0.0;            // option timing = 3: host wall time spent enqueuing the stage (no events)
+  int host_count = 0;
+  std::chrono::steady_clock::time_point host_t0;
 };
 
 }  // namespace vipmi
@@ -81,6 +85,16 @@ struct vipmi_ctx {
   // returns a device buffer of at least `bytes` (contents undefined)
   int get(const char* name, size_t bytes, void** out);
   // device copy of a small host table, re-uploaded only when `key` changes (synchronous upload)
+  // true (and *out set) when workspace `name` already holds the upload tagged `key` -- lets callers skip building the
+  // host table at all (the twiddle tables cost ~0.1 ms of host time per call otherwise)
+  bool cached(const char* name, const std::string& key, void** out) {
+    auto it = upload_keys.find(name);
+    if (it == upload_keys.end() || it->second != key) return false;
+    auto b = buffers.find(name);
+    if (b == buffers.end() || !b->second.ptr) return false;
+    *out = b->second.ptr;
+    return true;
+  }
   int upload_cached(const char* name, const std::string& key, const void* host, size_t bytes,
                     void** out);
   // asynchronous H2D of a small host table through a ring of pinned staging buffers (never blocks the

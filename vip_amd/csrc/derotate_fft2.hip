@@ -750,12 +750,14 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   VIPMI_REQUIRE(lds <= 160 * 1024, "derotate(fft2): LDS budget exceeded (%zu)", lds);
   cf* twtab = nullptr;
   {
-    std::vector<cf> tab;
-    Twiddles<P>::fill_table(tab);
     char key[32];
     snprintf(key, sizeof key, "L%d", P::L);
     void* pt = nullptr;
-    VIPMI_TRY(ctx->upload_cached("rot_twiddles", key, tab.data(), tab.size() * sizeof(cf), &pt));
+    if (!ctx->cached("rot_twiddles", key, &pt)) {
+      std::vector<cf> tab;
+      Twiddles<P>::fill_table(tab);
+      VIPMI_TRY(ctx->upload_cached("rot_twiddles", key, tab.data(), tab.size() * sizeof(cf), &pt));
+    }
     twtab = reinterpret_cast<cf*>(pt);
   }
   auto k1 = rs_shear1<P>;
