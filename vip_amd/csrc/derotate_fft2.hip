@@ -582,16 +582,36 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
   tasks.init(counters, lds_all);
   constexpr int TPG = 8;                          // 8 block columns = one 128-byte line of every block row
   const int ntask = nf * B::NBC;
+  constexpr bool PR = P::CAN_PRUNE;
+  // Software pipeline over the tasks of a wave (plans with ONE wave per SIMD only: nothing else covers the load latency
+  // at the head of a task there; with two waves per SIMD it changed nothing, NOTES.md): the input blocks, the frame
+  // record and Bf of task i+1 are requested before the transforms of task i.  Tokens then run two ahead.
+  constexpr bool PIPE = P::WPB <= 4;
+  float4 nblk[B::NG];
+  RotFrame pn;
+  float bfn = 0.f;
+  auto fetch = [&](int t) {
+    if (t < ntask) {
+      const int fl = t / B::NBC, u = t % B::NBC;
+      const float4* src = reinterpret_cast<const float4*>(A1r) + (int64_t)fl * B::NB * B::NBC + u;
+#pragma unroll
+      for (int G = 0; G < B::NG; ++G) nblk[G] = src[(int64_t)(64 * G + lane) * B::NBC];
+      pn = fr[f0 + fl];
+      bfn = aux.bf[fl];
+    }
+  };
   tasks.request();
-  for (int task = tasks.template take<TPG>(); task < ntask; task = tasks.template take<TPG>()) {
-    tasks.request();
-    const int fl = task / B::NBC, u = task % B::NBC, f = f0 + fl;
+  int task = tasks.template take<TPG>();
+  tasks.request();
+  if constexpr (PIPE) fetch(task);
+  while (task < ntask) {
+    if constexpr (!PIPE) fetch(task);
+    const int fl = task / B::NBC, u = task % B::NBC;
     const int X1 = 128 * (u / 64) + (u % 64), X2 = X1 + 64;
-    const RotFrame p = fr[f];
+    const RotFrame p = pn;
+    const float bf0 = bfn;
     const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
     const int dr = r0 - g.off;                     // the data rows sit at the canonical positions: displacement -> shift
-    const float4* src = reinterpret_cast<const float4*>(A1r) + (int64_t)fl * B::NB * B::NBC + u;
-    constexpr bool PR = P::CAN_PRUNE;
     cf v[P::VL];
     if constexpr (!PR) {
 #pragma unroll
@@ -599,16 +619,22 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
     }
 #pragma unroll
     for (int G = 0; G < B::NG; ++G) {
-      const float4 blk = src[(int64_t)(64 * G + lane) * B::NBC];
+      const float4 blk = nblk[G];
       v[B::reg(B::OFF + 128 * G)] = mkcf(blk.x, blk.z);
       v[B::reg(B::OFF + 128 * G + 64)] = mkcf(blk.y, blk.w);
+    }
+    int next = ntask;
+    if constexpr (PIPE) {
+      next = tasks.template take<TPG>();
+      tasks.request();
+      fetch(next);
     }
     const double s1 = p.b * (double)(X1 - g.c) + (double)dr, s2 = p.b * (double)(X2 - g.c) + (double)dr;
     float alt1, alt2, sn1, sn2;
     pair_shift<P, PR, PR, true>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2,
                           aux.dph + ((int64_t)fl * 2 + 1) * DPH_STRIDE);
     // rank-one correction  - sin(pi s_X) (-1)^X Bf/L (-1)^Y  on the output rows Y = off + m;  sn = sin(pi(s+dr))/L
-    const float bfl = (dr & 1) ? -aux.bf[fl] : aux.bf[fl];
+    const float bfl = (dr & 1) ? -bf0 : bf0;
     const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
     const float k2c = sn2 * ((X2 & 1) ? -bfl : bfl);
     float4* dst = reinterpret_cast<float4*>(A2r) + (int64_t)fl * B::NB * B::NBC + u;
@@ -622,6 +648,12 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
     if (lane == 0) {
       aux.gam[fl * P::L + X1] = ((X1 & 1) ? -sn1 : sn1) * alt1;
       aux.gam[fl * P::L + X2] = ((X2 & 1) ? -sn2 : sn2) * alt2;
+    }
+    if constexpr (PIPE) {
+      task = next;
+    } else {
+      task = tasks.template take<TPG>();
+      tasks.request();
     }
   }
 }
@@ -760,8 +792,13 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     }
     twtab = reinterpret_cast<cf*>(pt);
   }
+  // (the one-line-per-frame K kernel of the one-wave Le = 4096 plan would spill: it runs on the two-wave plan of the same
+  // radices -- same twiddle table, same LDS footprint, same number of lines per workgroup)
+  using PA = typename std::conditional<std::is_same<P, Plan4096w1>::value, Plan4096w2, P>::type;
+  static_assert(PA::LPB == P::LPB && PA::LDS_ELEMS == P::LDS_ELEMS && Twiddles<PA>::LDS_ELEMS == Twiddles<P>::LDS_ELEMS,
+                "rs_aux_k: substitute plan must share the launch geometry");
   auto k1 = rs_shear1<P>;
-  auto ka = rs_aux_k<P>;
+  auto ka = rs_aux_k<PA>;
   auto k2 = rs_shear2<P>;
   auto k3 = rs_shear3<P>;
   for (const void* f : {reinterpret_cast<const void*>(k1), reinterpret_cast<const void*>(ka),
@@ -795,7 +832,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     ctx->toc("k_rot_s1");
     ctx->tic("k_rot_aux");
     hipLaunchKernelGGL(rs_bf_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_frames, g, aux, (int)f0);
-    hipLaunchKernelGGL(ka, dim3(ga), blk, lds, ctx->stream, d_frames, g, aux, (int)f0, nf, twtab);
+    hipLaunchKernelGGL(ka, dim3(ga), dim3(64 * PA::WPB), lds, ctx->stream, d_frames, g, aux, (int)f0, nf, twtab);
     ctx->toc("k_rot_aux");
     ctx->tic("k_rot_s2");
     if constexpr (P::WPL == 1) {
@@ -833,7 +870,11 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
     // instructions per line: 6.2 against 3.8 ms at C2); four waves per line at Le = 4096.
     case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     case 2048: return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-    case 4096: return run_plan2<Plan4096w2>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 4096:
+      // one wave per line and per SIMD (512-VGPR budget), column shear software-pipelined: 200 frames of 1024 px
+      // 10.85 -> 9.4 ms against the two-wave plan (kept behind rot_4096_w1=0)
+      if (ctx->opt("rot_4096_w1", 1)) return run_plan2<Plan4096w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      return run_plan2<Plan4096w2>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
     default:
       set_error("derotate(fft2): unsupported padded length %d", g.Le);
       return VIPMI_ERR_UNSUPPORTED;

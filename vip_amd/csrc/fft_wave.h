@@ -237,6 +237,7 @@ using Plan512 = Plan<8, 8, 8, 72, 72, 9, 8, 1>;
 using Plan1024 = Plan<16, 8, 8, 72, 72, 9, 8, 1, true>;
 using Plan2048w1 = Plan<16, 16, 8, 136, 152, 9, 8, 1, true>;   // one wave per line: no workgroup barriers, 2 waves/SIMD
 using Plan4096w2 = Plan<16, 16, 16, 272, 272, 17, 8, 2>;    // two waves per line, 2 waves/SIMD, 256-VGPR budget
+using Plan4096w1 = Plan<16, 16, 16, 272, 272, 17, 4, 1, true>;   // one wave per line, ONE wave per SIMD (512-VGPR budget)
 
 // exp(-2 pi i j/64), j = 0..63
 __device__ const float ROOT64_C[64] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 6.123233996e-17f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, -1.836970199e-16f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f};
