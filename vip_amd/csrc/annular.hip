@@ -80,13 +80,6 @@ int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
   VIPMI_REQUIRE(A && lib_idx && lib_len && residuals && ncomps, "annular_residuals: null pointer");
   VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && nk > 0, "annular_residuals: bad sizes");
   VIPMI_REQUIRE(max_lib <= n, "annular_residuals: max_lib > n");
-  if (max_lib > 512) {
-    // (the batched leading-k eigensolver holds a library's Gram matrix per workgroup: up to 512 frames; the one-sided
-    // Jacobi fallback does not converge on the graded spectra of larger libraries)
-    set_error("annular_residuals: PCA libraries of more than 512 frames (max_frames_lib = %ld) are not supported: "
-              "lower max_frames_lib (the reference's default is 200)", (long)max_lib);
-    return VIPMI_ERR_UNSUPPORTED;
-  }
   int64_t kmax = 0;
   for (int64_t i = 0; i < nk; ++i) {
     VIPMI_REQUIRE(ncomps[i] > 0, "annular_residuals: ncomp must be positive");
@@ -104,7 +97,16 @@ int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
   hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, G, (int)n, lib_idx, lib_len,
                      (int)max_lib, m, H);
   VIPMI_CHECK_HIP(hipGetLastError());
-  VIPMI_TRY(eigh_leading(ctx, H, n, m, kmax < m ? kmax : m, lib_len, evals, evecs));
+  if (m > ctx->opt("ann_large_min", 512)) {      // (option: A/B and test switch, at least 127)
+    // libraries of more than 512 frames (max_frames_lib raised far above the reference's default 200) are beyond the
+    // batched solver (one library per workgroup): the matrix-in-L2 solver takes them one after the other.  It has no
+    // active-size argument and needs none: the sub-Gram matrices are zero padded, so the padding only adds zero
+    // eigenvalues, which coeff_kernel skips, and the leading vectors are zero there.  (~5 ms per library of 600 frames.)
+    VIPMI_REQUIRE(eigh_large_supported(m, kmax < m ? kmax : m), "annular_residuals: libraries of %d frames are not supported", m);
+    VIPMI_TRY(eigh_large_f64(ctx, H, n, m, kmax < m ? kmax : m, evals, evecs));
+  } else {
+    VIPMI_TRY(eigh_leading(ctx, H, n, m, kmax < m ? kmax : m, lib_len, evals, evecs));
+  }
   const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
   for (int64_t i = 0; i < nk; ++i) {
     VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
