@@ -171,3 +171,67 @@ def test_pca_feature_combinations_random(seed):
               O.pca_adimsdi_double(c4, a4, scal, (1, 2)), 5e-4, what="msdi double")
         close(pca(c4, a4, scale_list=scal, ncomp=2, adimsdi="single", verbose=False),
               O.pca_adimsdi_single(c4, a4, scal, 2), 5e-4, what="msdi single")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_annular_feature_combinations_random(seed):
+    """pca_annular with list / per-annulus ncomp, reference cubes and cube_sig, pca_annulus (ADI / RDI), and the
+    PA-threshold frame rejection of pca(source_xy=...) -- one feature per seed (seed % 6), random shapes."""
+    from vip_amd.psfsub import pca, pca_annular, pca_annulus
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(14, 36))
+    N = int(rng.integers(44, 80))
+    cube = _cube(rng, n, N)
+    ang = np.linspace(0, float(rng.uniform(80, 220)), n)
+    feat = seed % 6
+
+    def close(a, b, tol=2e-4, what=""):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape, (seed, feat, what, a.shape, b.shape)
+        ok = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), ok), (seed, feat, what)
+        assert np.abs(a[ok] - b[ok]).max() < tol, (seed, feat, what, n, N, np.abs(a[ok] - b[ok]).max())
+
+    base = dict(asize=int(rng.integers(5, 11)), fwhm=4, delta_rot=(0.1, float(rng.uniform(0.5, 1.0))),
+                n_segments=int(rng.integers(1, 3)), radius_int=int(rng.integers(0, 5)))
+    if feat == 0:                                             # several truncations at once
+        ks = sorted(set(int(k) for k in rng.integers(1, 6, 3)))
+        a = pca_annular(cube, ang, ncomp=ks, full_output=True, verbose=False, **base)
+        b = O.pca_annular(cube, ang, ncomp=ks, full_output=True, **base)
+        close(a[0], b[0], what="list cube_out")
+        close(a[1], b[1], what="list cube_der")
+        close(np.stack(a[2]), np.stack(b[2]), what="list frames")
+    elif feat == 1:                                           # one ncomp per annulus
+        ref = O.pca_annular(cube, ang, ncomp=1, full_output=True, **base)
+        n_annuli = int((N / 2 - base["radius_int"]) / base["asize"])
+        ks = tuple(int(k) for k in rng.integers(1, 5, n_annuli))
+        close(pca_annular(cube, ang, ncomp=ks, verbose=False, **base), O.pca_annular(cube, ang, ncomp=ks, **base),
+              what="tuple ncomp")
+        assert ref[2].shape == (N, N)
+    elif feat == 2:                                           # reference cube stacked on every library
+        ref_cube = _cube(rng, int(rng.integers(4, 12)), N)
+        close(pca_annular(cube, ang, ncomp=2, cube_ref=ref_cube, verbose=False, **base),
+              O.pca_annular(cube, ang, ncomp=2, cube_ref=ref_cube, **base), what="annular cube_ref")
+    elif feat == 3:                                           # cube_sig
+        sig = (0.05 * np.abs(_cube(rng, n, N))).astype(np.float32)
+        close(pca_annular(cube, ang, ncomp=2, cube_sig=sig, verbose=False, **base),
+              O.pca_annular(cube, ang, ncomp=2, cube_sig=sig, **base), what="annular cube_sig")
+    elif feat == 4:                                           # one annulus around a guessed radius, ADI and RDI
+        width, rg = int(rng.integers(4, 9)), float(rng.uniform(8, N / 2 - 8))
+        k = int(rng.integers(1, 5))
+        close(pca_annulus(cube, ang, k, width, rg), O.pca_annulus(cube, ang, k, width, rg), what="pca_annulus")
+        ref_cube = _cube(rng, int(rng.integers(k + 1, 14)), N)
+        close(pca_annulus(cube, ang, k, width, rg, cube_ref=ref_cube, collapse="mean"),
+              O.pca_annulus(cube, ang, k, width, rg, cube_ref=ref_cube, collapse="mean"), what="pca_annulus rdi")
+    else:                                                     # frame rejection around source_xy
+        r = float(rng.uniform(10, N / 2 - 6))
+        th = float(rng.uniform(0, 2 * np.pi))
+        xy = (float(round(N / 2 + r * np.cos(th))), float(round(N / 2 + r * np.sin(th))))
+        kw = dict(ncomp=int(rng.integers(1, 4)), source_xy=xy, fwhm=4.0, delta_rot=float(rng.uniform(0.3, 1.0)))
+        try:
+            ref = O.pca_pa_rejection(cube, ang, kw["ncomp"], xy, 4.0, kw["delta_rot"])
+        except Exception as e:                                # (too few frames left for this geometry: both sides must refuse)
+            with pytest.raises(type(e)):
+                pca(cube, ang, verbose=False, **kw)
+            return
+        close(pca(cube, ang, verbose=False, **kw), ref if not isinstance(ref, tuple) else ref[0], what="pa rejection")
