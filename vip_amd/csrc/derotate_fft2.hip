@@ -583,10 +583,10 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
   constexpr int TPG = 8;                          // 8 block columns = one 128-byte line of every block row
   const int ntask = nf * B::NBC;
   constexpr bool PR = P::CAN_PRUNE;
-  // Software pipeline over the tasks of a wave (plans with ONE wave per SIMD only: nothing else covers the load latency
-  // at the head of a task there; with two waves per SIMD it changed nothing, NOTES.md): the input blocks, the frame
+  // Software pipeline over the tasks of a wave (the plan with ONE wave per SIMD -- nothing else covers the load latency
+  // at the head of a task there -- and Le = 1024, -2.6 %; at Le = 2048 it changed nothing, NOTES.md): the input blocks, the frame
   // record and Bf of task i+1 are requested before the transforms of task i.  Tokens then run two ahead.
-  constexpr bool PIPE = P::WPB <= 4;
+  constexpr bool PIPE = P::WPB <= 4 || P::L == 1024;
   float4 nblk[B::NG];
   RotFrame pn;
   float bfn = 0.f;
