@@ -872,6 +872,12 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   __syncthreads();
 
   // ---------------- 1. tridiagonalisation ----------------
+#ifdef VIPMI_TRI_PROFILE      // s_memtime segments of wave 0 of workgroup 0 (tools/multi_profile.py)
+  unsigned long long seg_t[6] = {0, 0, 0, 0, 0, 0}, seg_c = __builtin_amdgcn_s_memtime();
+#define MSEG(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_t[i] += t_ - seg_c; seg_c = t_; } while (0)
+#else
+#define MSEG(i)
+#endif
   for (int s = 0; s + 2 < na; ++s) {
     const int par = s & 1;
     const double beta = tau[s];
@@ -906,13 +912,16 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
         if (lane == (dl & 63)) st_shared(&Db[r], dval);
       }
     }
+    MSEG(0);
     bar_target += W;
     grid_barrier(bar, bar_target, W);
+    MSEG(1);
     for (int c = s + 1 + tid; c < na; c += TNT) {
       pfull[c] = ld_shared(&Pb[par * n + c]);
       cfull[c] = ld_shared(&Cb[par * n + c]);
     }
     __syncthreads();
+    MSEG(2);
     double kd = 0.0;
     for (int r = s + 1 + lane; r < na; r += 64) kd += vcur[r] * pfull[r];
     const double K = 0.5 * beta * wave_sum(kd);
@@ -925,6 +934,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
       cfull[r] = cfull[r] - vs1 * w - ws1 * v;          // row s+1 with this step's update
     }
     __syncthreads();
+    MSEG(3);
     if (s + 3 < na) {
       form_reflector(s + 1, vnext);
       double* t = vcur;
@@ -932,7 +942,12 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
       vnext = t;
     }
     __syncthreads();
+    MSEG(4);
   }
+#ifdef VIPMI_TRI_PROFILE
+  if (wg == 0 && tid == 0 && prob == 0)
+    for (int i = 0; i < 5; ++i) evals[n - 8 + i] = (double)seg_t[i];
+#endif
   if (tid == 0) {
     // trailing 2 x 2 block: cfull holds row na-2 (fully updated) ; the last diagonal entry came through Db
     const int a = na - 2, b = na - 1;
