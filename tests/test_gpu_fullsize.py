@@ -217,8 +217,9 @@ def test_c5_projection_properties(c5):
 
 
 def test_c5_derotation_quadrants_and_median_against_the_oracle(c5):
-    """1024-px frames use the two-waves-per-line Le = 4096 shear plan: oracle (float64 restatement of rotate_fft) on
-    frames in all four rot90 quadrants, the in-pipeline derotation on sampled frames, the median bit-exact on a row band."""
+    """1024-px frames use the Le = 4096 shear plans (default: one wave per line and per SIMD; option rot_4096_w1=0: two
+    cooperating waves): oracle (float64 restatement of rotate_fft) on frames in all four rot90 quadrants with both plans,
+    the in-pipeline derotation on sampled frames, the median bit-exact on a row band."""
     import torch
     from vip_amd import backend as B
     cube_t, ang, (frame, pcs, recon, res, res_der) = c5
@@ -230,11 +231,17 @@ def test_c5_derotation_quadrants_and_median_against_the_oracle(c5):
         assert np.nanmax(np.abs(got - exp)) < 1e-4, i
     angles = np.array([-20.0, 47.5, 95.0, 135.0, 200.1, 290.0])  # q = 0, 1 (half-even at 47.5 -> 1), 1, 2 (135 -> 2), 2, 3
     src = res[100:100 + len(angles)].contiguous()
-    got = B.derotate(src, angles).cpu().numpy()
-    for j, a in enumerate(angles):
-        exp = O.frame_rotate_fft(src[j].cpu().numpy().astype(np.float64), -a)
-        assert np.array_equal(np.isnan(got[j]), np.isnan(exp))
-        assert np.nanmax(np.abs(got[j] - exp)) < 1e-4, a
+    exps = [O.frame_rotate_fft(src[j].cpu().numpy().astype(np.float64), -a) for j, a in enumerate(angles)]
+    ctx = B.get_context()
+    for w1 in (1, 0):
+        ctx.set_option("rot_4096_w1", w1)
+        try:
+            got = B.derotate(src, angles).cpu().numpy()
+        finally:
+            ctx.set_option("rot_4096_w1", 1)
+        for j, a in enumerate(angles):
+            assert np.array_equal(np.isnan(got[j]), np.isnan(exps[j]))
+            assert np.nanmax(np.abs(got[j] - exps[j])) < 1e-4, (w1, a)
     rows = slice(500, 508)
     exp = np.nanmedian(res_der[:, rows].cpu().numpy(), axis=0)
     assert np.array_equal(frame[rows].cpu().numpy(), exp)       # median of 2000 samples per pixel: bit-exact
@@ -276,7 +283,7 @@ def test_c2_rotation_quadrants_against_the_real_reference():
 
 
 def test_c5_rotation_quadrants_against_the_real_reference():
-    """1024-px frames (Le = 4096: two waves per line) in all four rot90 quadrants against the REAL reference's cube_derotate
+    """1024-px frames (Le = 4096, both shear plans) in all four rot90 quadrants against the REAL reference's cube_derotate
     (G22: a band of 128 rows and 8 columns of each output frame)."""
     import torch
     from conftest import load_golden
@@ -284,6 +291,12 @@ def test_c5_rotation_quadrants_against_the_real_reference():
     g = load_golden("g22_rotate_1024")
     rng = np.random.default_rng(2200)
     fr = (rng.standard_normal((4, 1024, 1024)) * 3).astype(np.float32)
-    got = B.derotate(torch.from_numpy(fr).cuda(), g["angles"]).cpu().numpy()
-    assert np.nanmax(np.abs(got[:, 448:576, :] - g["band"])) < 1e-4
-    assert np.nanmax(np.abs(got[:, :, 500:508] - g["cols"])) < 1e-4
+    ctx = B.get_context()
+    for w1 in (1, 0):
+        ctx.set_option("rot_4096_w1", w1)
+        try:
+            got = B.derotate(torch.from_numpy(fr).cuda(), g["angles"]).cpu().numpy()
+        finally:
+            ctx.set_option("rot_4096_w1", 1)
+        assert np.nanmax(np.abs(got[:, 448:576, :] - g["band"])) < 1e-4, w1
+        assert np.nanmax(np.abs(got[:, :, 500:508] - g["cols"])) < 1e-4, w1

@@ -585,14 +585,21 @@ def test_derotate_fft_golden_128(B):
     assert np.abs(got0 - g["derot_128"]).max() < 5e-5      # no exact zeros in this cube
 
 
-def test_derotate_fft_1024_vs_oracle(B):
-    """Le = 4096 (two waves per line, blocked intermediates): the oracle on three frames in different rot90 quadrants."""
+@pytest.mark.parametrize("w1", [1, 0])
+def test_derotate_fft_1024_vs_oracle(B, w1):
+    """Le = 4096, both plans (one wave per line and per SIMD with blocked intermediates / two cooperating waves with the
+    tiled column shear): the oracle on three frames in different rot90 quadrants."""
     from vip_amd.preproc import cube_derotate
     rng = np.random.default_rng(1024)
     angles = np.array([17.3, 100.0, 250.5])
     cube = rng.standard_normal((3, 1024, 1024)).astype(np.float32)
     cube[1, 7:9, 11] = np.nan
-    got = cube_derotate(cube, angles, method="fft")
+    ctx = B.get_context()
+    ctx.set_option("rot_4096_w1", w1)
+    try:
+        got = cube_derotate(cube, angles, method="fft")
+    finally:
+        ctx.set_option("rot_4096_w1", 1)
     ref = O.cube_derotate(cube, angles)
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     assert np.nanmax(np.abs(got - ref)) < 3e-5
