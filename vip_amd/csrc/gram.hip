@@ -406,8 +406,11 @@ int gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, i
     const int64_t nb_ = (batch - b0) < 65535 ? (batch - b0) : 65535;
     const float* Mb = M + (size_t)b0 * n * P;
     double* Gb = G + (size_t)b0 * n * n;
-    if (n <= 16) VIPMI_TRY((launch<1, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
-    else if (n <= 32) VIPMI_TRY((launch<2, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
+    int tb = (int)ctx->opt("gram_tb", 0);
+    if (tb <= 0) tb = n <= 16 ? 1 : (n <= 32 ? 2 : 4);
+    if (tb == 1) VIPMI_TRY((launch<1, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
+    else if (tb == 2) VIPMI_TRY((launch<2, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
+    else if (tb == 3) VIPMI_TRY((launch<3, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
     else VIPMI_TRY((launch<4, true>(ctx, Mb, n, Mb, n, P, P, Gb, true, nb_)));
   }
   return VIPMI_OK;
