@@ -185,6 +185,15 @@ int vipmi_annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
 int vipmi_annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
                                       const int32_t* lib_idx, const int32_t* lib_len, int64_t max_lib,
                                       const int32_t* ncomps_host, int64_t nk, float* residuals);
+/* The same computation in stages, so that a caller can solve the libraries of ALL segments of a frame set in ONE
+ * vipmi_eigh_topk_f64 call (do_pca_patch of every segment, pca_local.py:830-909; 3200 eigenproblems at BASELINE C3):
+ * subgrams: G[n,n] = A A^T (float64) and the zero-padded library sub-Gram matrices H[n][m][m], m >= max_lib;
+ * apply: residuals[nk][n][npx] from the leading eigenpairs evals[n][m], evecs[n][m][m] (rows = vectors, descending). */
+int vipmi_annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                               const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H);
+int vipmi_annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                            const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
+                            const double* evecs, const int32_t* ncomps_host, int64_t nk, float* residuals);
 /* gather / scatter of annulus pixels: A[n,npx] = cube[n, pix[j]] and back. */
 int vipmi_gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
                      int64_t npx, float* A);

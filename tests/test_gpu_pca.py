@@ -655,6 +655,30 @@ def test_more_than_64_components():
     assert np.abs(V.T @ (V @ M.T) - Vr.T @ (Vr @ M.T)).max() < 1e-3 * np.abs(M).max()
 
 
+def test_annular_staged_eigensolve_matches_the_per_segment_route(monkeypatch):
+    """With 512+ libraries in a call the annular path solves the libraries of ALL segments in one batched launch
+    (Gram / sub-Gram stage, one eigensolve, coefficient / residual stage); below that, and with VIPMI_ANNULAR_STAGED=0,
+    segment by segment.  Same frames from both (list ncomp, reference cube and two segments per annulus included), and
+    the float64 restatement of the reference agrees."""
+    from vip_amd.psfsub import pca_annular
+    cube, _ = O.synth_adi(130, 56, seed=11)
+    ang = np.linspace(0, 160, 130)
+    ref_cube, _ = O.synth_adi(6, 56, seed=12)
+    for kw in (dict(asize=6, ncomp=3, fwhm=4, delta_rot=(0.1, 1)),
+               dict(asize=8, ncomp=[1, 4], fwhm=4, delta_rot=0.5, n_segments=2, max_frames_lib=60),
+               dict(asize=6, ncomp=(1, 2, 3, 2), fwhm=4, delta_rot=1, cube_ref=ref_cube, scaling="temp-mean")):
+        monkeypatch.setenv("VIPMI_ANNULAR_STAGED", "1")
+        a = pca_annular(cube, ang, full_output=True, verbose=False, **kw)
+        monkeypatch.setenv("VIPMI_ANNULAR_STAGED", "0")
+        b = pca_annular(cube, ang, full_output=True, verbose=False, **kw)
+        ref = O.pca_annular(cube, ang, full_output=True, **kw)
+        for x, y, z in zip(a, b, ref):
+            x, y, z = (np.stack(t) if isinstance(t, list) else t for t in (x, y, z))
+            assert np.array_equal(np.isfinite(x), np.isfinite(y))
+            assert np.nanmax(np.abs(x - y)) < 2e-5
+            assert np.nanmax(np.abs(x - z)) < TOL
+
+
 def test_annular_libraries_beyond_512_frames():
     """PCA libraries of more than 512 frames per annulus (max_frames_lib raised far above the reference's default 200)
     leave the batched eigensolver for the matrix-in-L2 one, library after library (zero-padded sub-Gram matrices, no

@@ -72,6 +72,49 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
 
 }  // namespace
 
+// The three stages of a segment.  annular_residuals_multi_f32 below runs them back to back; the Python front runs stage 1
+// for ALL segments, then ONE batched eigensolve over the libraries of all segments (3200 problems at C3: enough to run
+// the tridiagonalisation and the rest of the solve as two launches with four problems per CU in the second), then
+// stage 3 per segment.
+// stage 1: G = A A^T (n x n) and the zero-padded sub-Gram matrices H[j] (m x m, m >= max_lib) of the n libraries
+int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                         const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H) {
+  VIPMI_REQUIRE(A && lib_idx && lib_len && G && H, "annular_subgrams: null pointer");
+  VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && max_lib <= n && m >= max_lib, "annular_subgrams: bad sizes");
+  VIPMI_TRY(gram_f32(ctx, A, n, A, n, npx, npx, G));
+  hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, G, (int)n, lib_idx, lib_len,
+                     (int)max_lib, (int)m, H);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+// stage 3: residuals[i] = (I - C_i) A for every truncation rank ncomps[i] (HOST array), from the leading eigenpairs of the
+// libraries (evals[j][m], evecs[j][m][m]: rows = vectors, as the top-k eigensolver returns them)
+int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                      const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
+                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals) {
+  VIPMI_REQUIRE(A && lib_idx && lib_len && G && evals && evecs && ncomps && residuals, "annular_apply: null pointer");
+  VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && m >= max_lib && nk > 0, "annular_apply: bad sizes");
+  int64_t kmax = 0;
+  for (int64_t i = 0; i < nk; ++i) {
+    VIPMI_REQUIRE(ncomps[i] > 0, "annular_residuals: ncomp must be positive");
+    if (ncomps[i] > kmax) kmax = ncomps[i];
+  }
+  float* C = nullptr;
+  VIPMI_TRY(ws(ctx, "ann_C", (size_t)n * n, &C));
+  const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
+  for (int64_t i = 0; i < nk; ++i) {
+    VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
+    hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
+                       (int)max_lib, (int)m, evals, evecs, (int)ncomps[i], (int)npx, C);
+    VIPMI_CHECK_HIP(hipGetLastError());
+    // residuals = A - C A = (I - C) A: one (n x n) x (n x npx) product on the matrix cores.  (Round 1 ran it through the
+    // skinny-k subtract kernel, k = n components: 14 TF/s, 4.7 of C3's 35 ms; the row-space kernel does it at ~60 TF/s.)
+    VIPMI_TRY(rowspace_gemm_f32(ctx, C, A, n, n, npx, nullptr, residuals + (size_t)i * n * npx));
+  }
+  return VIPMI_OK;
+}
+
 // ncomps: HOST array of nk truncation ranks (the reference's list `ncomp`, pca_local.py:665-668,892-902: one
 // decomposition with max(ncomp), residuals for every V[:k]); residuals: [nk][n][npx].
 int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
@@ -87,16 +130,11 @@ int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
   }
   const int m = (int)max_lib;
   double *G = nullptr, *H = nullptr, *evals = nullptr, *evecs = nullptr;
-  float* C = nullptr;
   VIPMI_TRY(ws(ctx, "ann_G", (size_t)n * n, &G));
   VIPMI_TRY(ws(ctx, "ann_H", (size_t)n * m * m, &H));
   VIPMI_TRY(ws(ctx, "ann_evals", (size_t)n * m, &evals));
   VIPMI_TRY(ws(ctx, "ann_evecs", (size_t)n * m * m, &evecs));
-  VIPMI_TRY(ws(ctx, "ann_C", (size_t)n * n, &C));
-  VIPMI_TRY(gram_f32(ctx, A, n, A, n, npx, npx, G));
-  hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, G, (int)n, lib_idx, lib_len,
-                     (int)max_lib, m, H);
-  VIPMI_CHECK_HIP(hipGetLastError());
+  VIPMI_TRY(annular_subgrams_f64(ctx, A, n, npx, lib_idx, lib_len, max_lib, m, G, H));
   if (m > ctx->opt("ann_large_min", 512)) {      // (option: A/B and test switch, at least 127)
     // libraries of more than 512 frames (max_frames_lib raised far above the reference's default 200) are beyond the
     // batched solver (one library per workgroup): the matrix-in-L2 solver takes them one after the other.  It has no
@@ -107,17 +145,7 @@ int annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
   } else {
     VIPMI_TRY(eigh_leading(ctx, H, n, m, kmax < m ? kmax : m, lib_len, evals, evecs));
   }
-  const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
-  for (int64_t i = 0; i < nk; ++i) {
-    VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
-    hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
-                       (int)max_lib, m, evals, evecs, (int)ncomps[i], (int)npx, C);
-    VIPMI_CHECK_HIP(hipGetLastError());
-    // residuals = A - C A = (I - C) A: one (n x n) x (n x npx) product on the matrix cores.  (Round 1 ran it through the
-    // skinny-k subtract kernel, k = n components: 14 TF/s, 4.7 of C3's 35 ms; the row-space kernel does it at ~60 TF/s.)
-    VIPMI_TRY(rowspace_gemm_f32(ctx, C, A, n, n, npx, nullptr, residuals + (size_t)i * n * npx));
-  }
-  return VIPMI_OK;
+  return annular_apply_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, m, G, evals, evecs, ncomps, nk, residuals);
 }
 
 int annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,

@@ -246,7 +246,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
-  static const char* known[] = {"timing", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
+  static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
                                 "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
@@ -491,6 +491,19 @@ int vipmi_annular_residuals_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64
                                 int64_t ncomp, float* residuals) {
   CTX_GUARD();
   return annular_residuals_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, ncomp, residuals);
+}
+
+int vipmi_annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                               const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  return annular_subgrams_f64(ctx, A, n, npx, lib_idx, lib_len, max_lib, m, G, H);
+}
+
+int vipmi_annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                            const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
+                            const double* evecs, const int32_t* ncomps_host, int64_t nk, float* residuals) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  return annular_apply_f32(ctx, A, n, npx, lib_idx, lib_len, max_lib, m, G, evals, evecs, ncomps_host, nk, residuals);
 }
 
 int vipmi_annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,

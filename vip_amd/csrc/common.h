@@ -150,6 +150,11 @@ int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float*
 bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,
                    bool all_evals = false);
+int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                         const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H);
+int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
+                      const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
+                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals);
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                  double* evals, double* evecs, bool all_evals = false);
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,

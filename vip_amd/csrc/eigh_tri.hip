@@ -48,7 +48,12 @@ template <int RPL, int NT, int RPW = 0>
 __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
                                                      double* __restrict__ evecs_all, double* __restrict__ scratch_all,
-                                                     int kp, int all_evals, int kc) {
+                                                     int kp, int all_evals, int kc, int phase = 0,
+                                                     double* __restrict__ det_all = nullptr) {
+  // phase: 0 = the whole solve; 1 = tridiagonalisation only (d, e, tau -> det_all[prob][3][n], reflectors in A);
+  // 2 = everything after it from those arrays.  Big batches run the two halves as two launches: the second half is a
+  // chain of latencies on a few waves, so it runs with 256 threads and four problems per CU while the register-
+  // resident first half (one problem per CU) already works on the next libraries.
   constexpr int TNT = NT, TNW = NT / 64;          // (shadow the file-scope values used by tri_multi_kernel)
   extern __shared__ double sm[];
   double* vcur = sm;             // [n] Householder vector of the current step (indexed by absolute row)
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
   int na = nact ? nact[prob] : n;
   if (na > n) na = n;
   const int kk = k < na ? k : na;
+  double* det = det_all ? det_all + (size_t)prob * 3 * n : nullptr;
   for (int i = tid; i < n; i += TNT) {
     vprev[i] = 0.0;
     wprev[i] = 0.0;
@@ -82,6 +88,13 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
 #define TRI_STAMP(i)
 #endif
   TRI_STAMP(0);
+  if (phase == 2) {
+    for (int i = tid; i < n; i += TNT) {
+      dd[i] = det[i];
+      ee[i] = det[n + i];
+      tau[i] = det[2 * n + i];
+    }
+  } else {
   // ---------------- 1. tridiagonalisation ----------------
   // Per step: ONE global round trip (the trailing pass) over the LOWER triangle of the trailing matrix only (the
   // batch is bound by the traffic of these passes: 400 problems of 200 x 200 move 2/3 n^3 * 8 B each).  Element
@@ -466,7 +479,16 @@ __global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, 
       ee[0] = 0.0;
     }
   }
+  }   // phase != 2
   __syncthreads();
+  if (phase == 1) {
+    for (int i = tid; i < n; i += TNT) {
+      det[i] = dd[i];
+      det[n + i] = ee[i];
+      det[2 * n + i] = tau[i];
+    }
+    return;
+  }
 
   TRI_STAMP(1);
   // ---------------- 2. leading eigenvalues of T (scaled to max-norm 1) ----------------
@@ -1290,8 +1312,26 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
     auto launch_reg = [&](auto kern) -> int {
       VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds_r));
+      // big batches: tridiagonalisation and the rest as two launches (see the kernel); option eigh_split = 0 / 1 forces
+      const int64_t split_opt = ctx->opt("eigh_split", -1);
+      const bool split = (split_opt < 0 ? batch >= ctx->num_cu : split_opt != 0) && k <= 16;
+      if (!split) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch,
+                           kp, all_evals, reg_variant_chunk(n, k), 0, (double*)nullptr);
+        VIPMI_CHECK_HIP(hipGetLastError());
+        return VIPMI_OK;
+      }
+      double* det = nullptr;
+      VIPMI_TRY(ws(ctx, "eigh_tri_det", (size_t)batch * 3 * n, &det));
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
-                         all_evals, reg_variant_chunk(n, k));
+                         all_evals, reg_variant_chunk(n, k), 1, det);
+      VIPMI_CHECK_HIP(hipGetLastError());
+      const size_t lds2 = ((size_t)(9 + 256 / 64) * n + 64 + 8) * sizeof(double);
+      auto kern2 = tri_eig_kernel<RPL, 256>;
+      VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds2));
+      hipLaunchKernelGGL(kern2, dim3((unsigned)batch), dim3(256), lds2, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
+                         all_evals, k < n ? k : n, 2, det);
       VIPMI_CHECK_HIP(hipGetLastError());
       return VIPMI_OK;
     };

@@ -233,6 +233,36 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             lib_cache[key] = (torch.from_numpy(idx).to(cube.device), torch.from_numpy(ln).to(cube.device), max_lib)
         return lib_cache[key]
 
+    def seg_matrix(si, seg):
+        """Gathered / scaled segment matrix (+ cube_sig part, reference rows): everything before the decomposition."""
+        ctx = B.get_context(dev)                       # (one context per stream)
+        pix = pix_of(si, seg)
+        npx = int(pix.numel())
+        A = B.empty((n, npx), device=dev)
+        ctx.call("vipmi_gather_f32", B.ptr(cube), n, P, B.ptr(pix), npx, B.ptr(A))
+        if scaling is not None:
+            A = B.scale(A, scaling)
+        S = None
+        if cube_sig is not None:
+            S = B.empty((n, npx), device=dev)
+            ctx.call("vipmi_gather_f32", B.ptr(cube_sig), n, P, B.ptr(pix), npx, B.ptr(S))
+            A = B.lincomb(A, S, 1.0, -1.0)
+        if nref:
+            Aref = B.empty((nref, npx), device=dev)
+            ctx.call("vipmi_gather_f32", B.ptr(cube_ref), nref, P, B.ptr(pix), npx, B.ptr(Aref))
+            if scaling is not None:
+                Aref = B.scale(Aref, scaling)
+            A = torch.cat((Aref, A))
+        return A, S, pix, npx
+
+    def seg_scatter(R, S, pix, npx, dst):
+        ctx = B.get_context(dev)
+        R = R[nref:]
+        if S is not None:
+            R = B.lincomb(R, S, 1.0, 1.0)
+        R = R.contiguous()
+        ctx.call("vipmi_scatter_f32", B.ptr(R), n, P, B.ptr(pix), npx, B.ptr(dst))
+
     def do_segment(si, seg):
         ctx = B.get_context(dev)                       # (one context per stream)
         pix = pix_of(si, seg)
@@ -291,15 +321,59 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         cur = torch.cuda.current_stream()
         depth = max(2, min(int(os.environ.get("VIPMI_ANNULAR_STREAMS", "2")), n_ann - 1))
         streams = B.side_streams(depth, dev)
+        lane_of = lambda a: (n_ann - 2) % depth if a == n_ann - 1 else a % depth
+        # Staged variant: the libraries of ALL segments in ONE batched eigensolve between the per-segment Gram / sub-Gram
+        # stage and the per-segment coefficient / residual stage.  With thousands of problems in one launch the solver runs
+        # its latency-bound second half four problems per CU beside the register-resident tridiagonalisations of the
+        # next ones (csrc/eigh_tri.hip); per-segment launches of ~400 problems cannot do that.  C3: 18.5 -> see NOTES.
+        nrow = n + nref
+        total = nrow * len(plan)
+        m_all = max(libs_of(seg)[2] for seg in plan)
+        k_all = min(m_all, max(int(seg["ncomp"]) for seg in plan) if ks is None else int(ks.max()))
+        staged = (os.environ.get("VIPMI_ANNULAR_STAGED", "1") != "0" and total >= 512 and m_all <= 512 and k_all <= 64
+                  and total * m_all * m_all * 16 <= 8e9)
+        ctx0 = B.get_context(dev)
+        if staged:
+            H_all = torch.empty((total, m_all, m_all), dtype=torch.float64, device=cube.device)
+            ev_all = torch.empty((total, m_all), dtype=torch.float64, device=cube.device)
+            ec_all = torch.empty((total, m_all, m_all), dtype=torch.float64, device=cube.device)
+            nact_all = torch.cat([libs_of(seg)[1] for seg in plan]).contiguous()
         for st in streams:
             st.wait_stream(cur)
         B.set_async(True)
         try:
-            for si, seg in enumerate(plan):
-                a = seg["ann"]
-                lane = (n_ann - 2) % depth if a == n_ann - 1 else a % depth
-                with torch.cuda.stream(streams[lane]):
-                    do_segment(si, seg)
+            if not staged:
+                for si, seg in enumerate(plan):
+                    with torch.cuda.stream(streams[lane_of(seg["ann"])]):
+                        do_segment(si, seg)
+            else:
+                states = []
+                for si, seg in enumerate(plan):
+                    with torch.cuda.stream(streams[lane_of(seg["ann"])]):
+                        A, S, pix, npx = seg_matrix(si, seg)
+                        idx_t, ln_t, max_lib = libs_of(seg)
+                        G = torch.empty((nrow, nrow), dtype=torch.float64, device=cube.device)
+                        B.get_context(dev).call("vipmi_annular_subgrams_f64", B.ptr(A), nrow, npx, B.ptr(idx_t), B.ptr(ln_t),
+                                                max_lib, m_all, B.ptr(G), B.ptr(H_all[si * nrow:(si + 1) * nrow]))
+                        states.append((A, S, pix, npx, G))
+                for st in streams:
+                    cur.wait_stream(st)
+                ctx0.call("vipmi_eigh_topk_f64", B.ptr(H_all), total, m_all, k_all, B.ptr(nact_all), B.ptr(ev_all),
+                          B.ptr(ec_all))
+                for st in streams:
+                    st.wait_stream(cur)
+                for si, seg in enumerate(plan):
+                    with torch.cuda.stream(streams[lane_of(seg["ann"])]):
+                        A, S, pix, npx, G = states[si]
+                        idx_t, ln_t, max_lib = libs_of(seg)
+                        kk_ = np.array([int(seg["ncomp"])], dtype=np.int32) if ks is None else ks
+                        R = B.empty((len(kk_), nrow, npx), device=dev)
+                        B.get_context(dev).call("vipmi_annular_apply_f32", B.ptr(A), nrow, npx, B.ptr(idx_t), B.ptr(ln_t),
+                                                max_lib, m_all, B.ptr(G), B.ptr(ev_all[si * nrow:(si + 1) * nrow]),
+                                                B.ptr(ec_all[si * nrow:(si + 1) * nrow]),
+                                                kk_.ctypes.data_as(ctypes.c_void_p), len(kk_), B.ptr(R))
+                        for nn in range(len(kk_)):
+                            seg_scatter(R[nn], S, pix, npx, cube_out if ks is None else cube_out[nn])
             for st in streams:
                 cur.wait_stream(st)
             B.check_deferred()
