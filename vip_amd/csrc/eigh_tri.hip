@@ -44,8 +44,10 @@ using tri::sturm_count;
 // workgroup barrier that orders LDS traffic only (no wait for outstanding global stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// (256 threads: capped at 80 VGPRs so that six workgroups share a CU -- that variant runs the latency-bound second half of
+// split batches; 3200 problems 7.10 -> 6.83 ms against four workgroups per CU, eight are slower again)
 template <int RPL, int NT, int RPW = 0>
-__global__ __launch_bounds__(NT) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
+__global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
                                                      double* __restrict__ evecs_all, double* __restrict__ scratch_all,
                                                      int kp, int all_evals, int kc, int phase = 0,
@@ -1314,7 +1316,8 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
                                           (int)lds_r));
       // big batches: tridiagonalisation and the rest as two launches (see the kernel); option eigh_split = 0 / 1 forces
       const int64_t split_opt = ctx->opt("eigh_split", -1);
-      const bool split = (split_opt < 0 ? batch >= ctx->num_cu : split_opt != 0) && k <= 16;
+      // (measured, 200 x 200, k = 10: 400 problems 1.47 ms in one launch / 1.57 split, 1600: 4.33 / 3.70, 3200: 8.33 / 6.83)
+      const bool split = (split_opt < 0 ? batch >= 4 * ctx->num_cu : split_opt != 0) && k <= 16;
       if (!split) {
         hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch,
                            kp, all_evals, reg_variant_chunk(n, k), 0, (double*)nullptr);
