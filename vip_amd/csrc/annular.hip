@@ -17,17 +17,22 @@ namespace {
 
 // H[j][a][b] = G[idx[j][a]][idx[j][b]] for a,b < len[j], 0 elsewhere (zero padding only adds null
 // eigenvalues, sorted last)
-__global__ void subgram_kernel(const double* __restrict__ G, int n, const int32_t* __restrict__ idx,
-                               const int32_t* __restrict__ len, int max_lib, int m, double* __restrict__ H) {
+__global__ __launch_bounds__(256) void subgram_kernel(const double* __restrict__ G, int n, const int32_t* __restrict__ idx,
+                                                      const int32_t* __restrict__ len, int max_lib, int m, double* __restrict__ H) {
+  // one workgroup per library: the index list once into LDS, then row a by wave (a = wave, wave + 4, ...), columns by lane
+  // -- no integer division per element, 512-byte row segments of H per store instruction
+  extern __shared__ int32_t sidx[];
   const int j = blockIdx.x;
   const int lj = len[j];
   const int32_t* ij = idx + (size_t)j * max_lib;
   double* Hj = H + (size_t)j * m * m;
-  for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
-    const int a = e / m, b = e % m;
-    double v = 0.0;
-    if (a < lj && b < lj) v = G[(size_t)ij[a] * n + ij[b]];
-    Hj[e] = v;
+  for (int a = threadIdx.x; a < lj; a += blockDim.x) sidx[a] = ij[a];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  for (int a = wave; a < m; a += nw) {
+    const bool rowlive = a < lj;
+    const double* Ga = G + (size_t)(rowlive ? sidx[a] : 0) * n;
+    for (int b = lane; b < m; b += 64) Hj[(size_t)a * m + b] = (rowlive && b < lj) ? Ga[sidx[b]] : 0.0;
   }
 }
 
@@ -82,8 +87,8 @@ int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
   VIPMI_REQUIRE(A && lib_idx && lib_len && G && H, "annular_subgrams: null pointer");
   VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && max_lib <= n && m >= max_lib, "annular_subgrams: bad sizes");
   VIPMI_TRY(gram_f32(ctx, A, n, A, n, npx, npx, G));
-  hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, G, (int)n, lib_idx, lib_len,
-                     (int)max_lib, (int)m, H);
+  hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), sizeof(int32_t) * (size_t)max_lib, ctx->stream, G, (int)n,
+                     lib_idx, lib_len, (int)max_lib, (int)m, H);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
