@@ -210,6 +210,41 @@ __global__ __launch_bounds__(64 * gram_max_waves<TB>()) void gram_partial_kernel
     }
 }
 
+// COOP adjacent lanes share an output element: lane q sums the slices q, q + COOP, ... and the lanes are combined by a fixed
+// butterfly (deterministic).  Small problems only: one thread per element is a chain of `nslices` dependent loads on a few
+// thousand threads (62 us for the 50 x 16384 Gram of C1, 5 times the partial products themselves).
+template <int TB, bool ACC64, int COOP>
+__global__ void gram_reduce_coop_kernel(const void* __restrict__ partial_, const int2* __restrict__ tiles,
+                                        int ntiles, int nslices, int na, int nb, int symmetric,
+                                        double* __restrict__ G) {
+  using sc_t = typename std::conditional<ACC64, double, float>::type;
+  const int64_t per_tile = TB * TB * 256;
+  const int64_t total = (int64_t)ntiles * per_tile;
+  const sc_t* partial = reinterpret_cast<const sc_t*>(partial_) + (int64_t)blockIdx.y * nslices * total;   // batch
+  G += (int64_t)blockIdx.y * na * nb;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (grid covers total * COOP threads exactly or more)
+  const int64_t e = gid / COOP;
+  const int q = (int)(gid % COOP);
+  double s = 0.0;
+  if (e < total)
+    for (int sl = q; sl < nslices; sl += COOP) s += (double)partial[(int64_t)sl * total + e];
+#pragma unroll
+  for (int off = 1; off < COOP; off <<= 1) s += __shfl_xor(s, off, 64);
+  if (e >= total || q != 0) return;
+  const int tile = (int)(e / per_tile);
+  const int rem = (int)(e % per_tile);
+  const int blk = rem >> 8, idx = rem & 255;
+  const int bi = blk / TB, bj = blk % TB;
+  const int2 t = tiles[tile];
+  if (t.x < 0) return;
+  const int gi = (t.x * TB + bi) * 16 + (idx >> 4);
+  const int gj = (t.y * TB + bj) * 16 + (idx & 15);
+  if (gi >= na || gj >= nb) return;
+  if (symmetric && t.x == t.y && bj < bi) return;
+  G[(int64_t)gi * nb + gj] = s;
+  if (symmetric) G[(int64_t)gj * nb + gi] = s;
+}
+
 template <int TB, bool ACC64>
 __global__ void gram_reduce_kernel(const void* __restrict__ partial_, const int2* __restrict__ tiles,
                                    int ntiles, int nslices, int na, int nb, int symmetric,
@@ -357,6 +392,12 @@ static int launch(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, in
                        (int)na, (int)nb, P, ld, d_tiles, ntiles, wpw, klen, (int)symmetric, partial, bstride, nslices);
   VIPMI_CHECK_HIP(hipGetLastError());
   int64_t total = (int64_t)ntiles * TB * TB * 256;
+  if (total * batch <= 65536 && nslices >= 32) {          // small outputs, long slice chains: 8 lanes per element
+    hipLaunchKernelGGL((gram_reduce_coop_kernel<TB, ACC64, 8>), dim3((unsigned)cdiv(total * 8, 256), (unsigned)batch), dim3(256),
+                       0, ctx->stream, partial, d_tiles, ntiles, nslices, (int)na, (int)nb, (int)symmetric, G);
+    VIPMI_CHECK_HIP(hipGetLastError());
+    return VIPMI_OK;
+  }
   int rb = (int)cdiv(total, 256);
   if (rb > 4096) rb = 4096;
   if (batch > 1 && rb > 64) rb = 64;
