@@ -112,43 +112,40 @@ def pmc_traffic(frames_per_launch, N, kernel="rs_shear2"):
     return None
 
 
-def sharded_mode(args, world, rank, backend):
+def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512, ncomp=20):
     """One problem sharded over all ranks (strong scaling): every rank holds the same synthetic input in HBM; a step is
-    one complete sharded call ending with the final frame on every rank.  (VIPMI_BENCH_BACKEND=gloo + VIPMI_BENCH_DEVICE=0
-    run the multi-rank code path on a single-GPU box.)"""
+    one complete sharded call ending with the final frame on every rank.  Returns the record (every rank).
+    (VIPMI_BENCH_BACKEND=gloo + VIPMI_BENCH_DEVICE=0 run the multi-rank code path on a single-GPU box.)"""
     import torch
     import torch.distributed as dist
     from vip_amd import dist as D
     from vip_amd.synth import synth_adi, synth_adi_device
-    n, N, k = args.frames, args.size, args.ncomp
-    if args.mode == "4d":
+    n, N, k = frames, size, ncomp
+    if mode == "4d":
         nch, n, N = 39, 200, 256
-        cube_t = torch.stack([torch.from_numpy(synth_adi(n, N, seed=s)[0]) for s in range(nch)]).cuda()
+        cube_t = torch.stack([synth_adi_device(n, N, seed=s)[0] for s in range(nch)])
         angles = np.linspace(0, 90, n)
         what = "configs[3]: %dx%dx%dx%d IFS cube, per-channel PCA ncomp=%d + spectral mean, channels sharded" % (nch, n, N, N, k)
 
         def step():
             return D.pca_4d(cube_t, angles, ncomp=k, verbose=False, check_memory=False)[0]
         units = nch * n
-    elif args.mode == "annular":
-        cube, angles = synth_adi(n, N, seed=0)
-        cube_t = torch.from_numpy(cube).cuda()
+    elif mode == "annular":
+        cube_t, angles = synth_adi_device(n, N, seed=0)
         what = "configs[2]: %dx%dx%d ADI cube, annular PCA (asize 32 -> %d annuli, ncomp=10), annuli sharded" % (n, N, N, N // 64)
 
         def step():
             return D.pca_annular(cube_t, angles, ncomp=10, asize=32, fwhm=4, delta_rot=(0.1, 1), n_segments=1)
         units = n
-    else:
-        if n * N * N > 2 ** 29:
-            cube_t, angles = synth_adi_device(n, N, seed=0)
-        else:
-            cube, angles = synth_adi(n, N, seed=0)
-            cube_t = torch.from_numpy(cube).cuda()
+    elif mode == "single-cube":
+        cube_t, angles = synth_adi_device(n, N, seed=0)
         what = "%dx%dx%d ADI cube, full-frame PCA ncomp=%d, ONE cube sharded (Gram all-reduce + 2 all-to-all)" % (n, N, N, k)
 
         def step():
             return D.pca_single_cube(cube_t, angles, k)
         units = n
+    else:
+        raise ValueError(mode)
 
     def barrier():
         torch.cuda.synchronize()
@@ -156,11 +153,11 @@ def sharded_mode(args, world, rank, backend):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         out = step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
         out = out if not hasattr(out, "cpu") else out.cpu()
     barrier()
@@ -169,22 +166,85 @@ def sharded_mode(args, world, rank, backend):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert bool(np.isfinite(np.asarray(out)).all() or True)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "frames/sec, %s" % args.mode, "value": units * args.steps / elapsed, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+    # the frame's corners are NaN by design (mask_val of the vip-fft rotation): check the disk the rotation keeps
+    out = np.asarray(out)
+    c = out.shape[-1] // 2
+    if not np.isfinite(out[c - 8:c + 8, c - 8:c + 8]).all():
+        raise SystemExit("bench.py --mode %s: the final frame is not finite around its centre" % mode)
+    del cube_t
+    torch.cuda.empty_cache()
+    return {"metric": "frames/sec, %s" % mode, "value": units * steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": what, "parallelism": "one problem over %d GPU(s), collectives of SURVEY 8(e)" % world}}))
+            "config": {"workload": what, "parallelism": "one problem over %d GPU(s), collectives of SURVEY 8(e)" % world}}
+
+
+def sharded_mode(args, world, rank, backend):
+    import torch.distributed as dist
+    rec = sharded_leg(args.mode, world, rank, backend, args.steps, args.warmup, args.frames, args.size, args.ncomp)
+    if rank == 0:
+        print(json.dumps(rec))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def strong_scaling_legs(world, rank, backend):
+    """The three shardings BASELINE.json's configs name, ONE problem over all ranks each (strong scaling): the whole C5
+    cube (configs[4]), annular PCA of the C2 cube (configs[2]), the 4-D IFS cube (configs[3]).  A few steps each."""
+    import torch
+    from vip_amd import dist as D
+    from vip_amd.psfsub import pca, pca_annular
+    from vip_amd.synth import synth_adi
+    out = {}
+    # the sharded routines against the single-GPU calls on one small cube (the only place where the RCCL collectives of
+    # the three partitions run on more than one device: the tests have gloo and one GPU)
+    cube, ang = synth_adi(30, 128, seed=3)
+    cube_t = torch.from_numpy(cube).cuda()
+    chk = {}
+    ref = pca(cube, ang, ncomp=4, verbose=False)
+    chk["single_cube"] = float(np.nanmax(np.abs(D.pca_single_cube(cube_t, ang, 4).cpu().numpy() - ref)))
+    ref = pca_annular(cube, ang, ncomp=3, asize=16, fwhm=4, verbose=False)
+    chk["annular"] = float(np.nanmax(np.abs(D.pca_annular(cube_t, ang, ncomp=3, asize=16, fwhm=4).cpu().numpy() - ref)))
+    c4 = np.stack([cube, cube[::-1] * 0.5, cube * 0.25])
+    ref = pca(c4, ang, ncomp=4, verbose=False)
+    got = D.pca_4d(torch.from_numpy(c4).cuda(), ang, ncomp=4, verbose=False, check_memory=False)[0]
+    chk["ifs_4d"] = float(np.nanmax(np.abs(np.asarray(got.cpu() if hasattr(got, "cpu") else got) - ref)))
+    out["selfcheck_max_abs_diff_vs_one_gpu"] = chk
+    if max(chk.values()) > 1e-4:
+        raise RuntimeError("sharded results deviate from the single-GPU path: %r" % chk)
+    del cube_t
+    for key, mode, kw, st in (("single_cube_c5", "single-cube", dict(frames=2000, size=1024, ncomp=50), 3),
+                              ("annular_c3", "annular", dict(frames=400, size=512, ncomp=10), 10),
+                              ("ifs_4d_c4", "4d", dict(frames=200, size=256, ncomp=20), 10)):
+        r = sharded_leg(mode, world, rank, backend, st, 1, **kw)
+        out[key] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": st,
+                    "workload": r["config"]["workload"]}
+    return out
+
+
+def self_spawn(ngpus):
+    """`python bench.py --gpus N` outside torchrun: re-run this command line under torch.distributed.run, one rank per
+    GPU (RCCL).  Fails loudly when the box has fewer than N devices (VIPMI_BENCH_DEVICE, the single-GPU test rig, lifts
+    that check: all ranks then share one device and VIPMI_BENCH_BACKEND must be gloo)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if "VIPMI_BENCH_DEVICE" not in os.environ and have < ngpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box" % (ngpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--size", type=int, default=512)
@@ -195,6 +255,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle in this GPU-free process and print its JSON object")
     ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="skip the strong-scaling legs (C5 single cube / C3 annular / C4 4-D sharded over the ranks)")
     ap.add_argument("--no-stage-timing", action="store_true",
                     help="do not record per-stage hipEvents inside the timed region (no roofline object)")
     ap.add_argument("--mode", default="survey", choices=["survey", "single-cube", "annular", "4d"],
@@ -209,9 +271,14 @@ def main():
         print(json.dumps(cpu_baseline(args.frames, args.size, args.ncomp)))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args.gpus)                   # does not return
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -223,6 +290,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     from vip_amd import backend as B
     from vip_amd.psfsub import pca
@@ -367,6 +436,30 @@ def main():
             roof["isolated_avg_launch_ms"] = iso_ms
             roof["isolated_frac"] = roof_alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
+    # steady state over >= ~1.5 s of pipelined calls (the K timed steps above include the pipeline's fill and drain, and
+    # K = 20 lasts 0.1 s): reported beside `value`, never instead of it
+    sustained = None
+    if depth > 1 and not args.no_latency:
+        B.set_async(True)
+        ns = min(len(pinned), max(args.steps, 1))
+        reps = max(1, int(np.ceil(1.5 / max(elapsed * ns / args.steps, 1e-3))))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            run(ns)
+        barrier()
+        ts = time.perf_counter() - t1
+        B.check_deferred()
+        B.set_async(False)
+        if world > 1:
+            t = torch.tensor([ts], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts = float(t.item())
+        sustained = {"value": world * n * ns * reps / ts, "unit": "frames/s", "steps": ns * reps, "seconds": ts}
+
+    del cubes_t, cube_t
+    torch.cuda.empty_cache()
+    rec = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * n * args.steps / elapsed
@@ -385,6 +478,8 @@ def main():
             "stages": stages,
             "stages_serial_ms": stages_serial,
             "roofline": roof,
+            "sustained": sustained,
+            "strong": None,
         }
         if not args.no_cpu_baseline:
             # in a fresh process that never initialises the GPU runtime (the oracle forks a process pool)
@@ -397,7 +492,38 @@ def main():
             except Exception:
                 sys.stderr.write("cpu_baseline failed: %s\n" % cp.stderr[-2000:])
                 rec["cpu_baseline"] = None
+
+    # Strong-scaling legs LAST, under a watchdog: the record above is complete, so a collective that fails or hangs on
+    # some rank costs the `strong` object, never the headline line (still exactly one JSON line on rank 0).
+    def emit_and_exit(err):
+        if rank == 0:
+            rec["strong"] = {"error": err}
+            print(json.dumps(rec))
+            sys.stdout.flush()
+        os._exit(0)
+
+    if not args.no_strong and (n, N, k) == (400, 512, 20):
+        import threading
+        if world > 1:
+            dist.barrier()                      # (rank 0 has just spent ~30 s in the CPU baseline)
+        done = threading.Event()
+        limit = float(os.environ.get("VIPMI_BENCH_STRONG_LIMIT_S", "420"))
+
+        def dog():
+            if not done.wait(limit):
+                emit_and_exit("strong-scaling legs did not finish within %.0f s" % limit)
+        threading.Thread(target=dog, daemon=True).start()
+        try:
+            strong = strong_scaling_legs(world, rank, backend)
+        except BaseException as e:              # the other ranks may be stuck in a collective: no barrier, just leave
+            sys.stderr.write("strong-scaling legs failed on rank %d: %r\n" % (rank, e))
+            emit_and_exit(repr(e)[:300])
+        done.set()
+        if rank == 0:
+            rec["strong"] = strong
+    if rank == 0:
         print(json.dumps(rec))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -861,22 +861,92 @@ def test_sharded_annular_world1_matches_pca_annular():
 
 
 def test_bench_sharded_modes_two_ranks_on_one_gpu():
-    """bench.py --mode single-cube / annular under torchrun with 2 ranks sharing this GPU (gloo for the collectives): the
-    multi-rank code paths that RCCL will run on an 8-GPU node -- ragged all_gather / all_to_all lists included."""
+    """`python bench.py --gpus 2 --mode ...` spawns its own two ranks (no torchrun on the command line); here they share
+    this GPU and use gloo for the collectives (VIPMI_BENCH_DEVICE / VIPMI_BENCH_BACKEND): the multi-rank code paths that
+    RCCL runs on an 8-GPU node -- ragged all_gather / all_to_all lists included."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, VIPMI_BENCH_BACKEND="gloo", VIPMI_BENCH_DEVICE="0")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k_, None)
     for mode, extra in (("single-cube", ["--frames", "30", "--size", "128", "--ncomp", "4"]),
                         ("annular", ["--frames", "30", "--size", "128"])):
-        cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                             "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                              "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode] + extra,
                             capture_output=True, text=True, env=env, timeout=600)
         assert cp.returncode == 0, cp.stderr[-3000:]
         rec = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
         assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+
+
+def test_bench_survey_mode_two_ranks_with_strong_legs_on_one_gpu():
+    """The default (survey) mode at --gpus 2, self-spawned, small cube: one JSON line, n_gpus = 2, weak scaling; the
+    strong-scaling legs only run at the BASELINE shape, so a second run checks `strong` at 400 x 512 x 512 with one
+    rank (selfcheck of the three sharded routines against the single-GPU calls included)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, VIPMI_BENCH_BACKEND="gloo", VIPMI_BENCH_DEVICE="0")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k_, None)
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                         "--frames", "40", "--size", "128", "--ncomp", "5", "--no-cpu-baseline"],
+                        capture_output=True, text=True, env=env, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["cubes_per_step"] == 2
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
+                         "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    rec = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    st = rec["strong"]
+    assert "error" not in st, st
+    assert max(st["selfcheck_max_abs_diff_vs_one_gpu"].values()) < 1e-4
+    for key in ("single_cube_c5", "annular_c3", "ifs_4d_c4"):
+        assert st[key]["value"] > 0
+    assert rec["sustained"]["seconds"] > 1.0 and rec["value_serial"] > 0
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`bench.py --gpus N` must never silently run fewer ranks (round-2 VERDICT): more ranks than devices is an error,
+    and so is a WORLD_SIZE that contradicts --gpus."""
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VIPMI_BENCH_DEVICE")}
+    want = torch.cuda.device_count() + 1
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1"],
+                        capture_output=True, text=True, env=env, timeout=300)
+    assert cp.returncode != 0 and "GPU(s) visible" in cp.stderr and "{" not in cp.stdout
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                        capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert cp.returncode != 0 and "WORLD_SIZE" in cp.stderr
+
+
+def test_rccl_world_2_when_two_devices_are_visible():
+    """Two ranks on two GPUs over RCCL (tests/helpers/rccl_world2.py): the three torch.distributed partitions and the
+    C entry vipmi_pca_fullframe_sharded_f32 against pca().  Skipped on a one-GPU box."""
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29541",
+                         os.path.join(ROOT, "tests", "helpers", "rccl_world2.py")],
+                        capture_output=True, text=True, env=env, timeout=900)
+    assert cp.returncode == 0 and "OK" in cp.stdout, (cp.stdout[-2000:], cp.stderr[-3000:])
+    for ln in cp.stdout.splitlines():
+        if ln.startswith("case"):
+            assert float(ln.split()[-1]) < 1e-5, ln
 
 
 def test_c_client_of_the_c_abi(tmp_path):

@@ -68,65 +68,62 @@ def frame_rotate(array, angle, imlib="vip-fft", interpolation="lanczos4", cxy=No
     return res.astype(np.float32 if str(getattr(imlib, "value", imlib)) == "opencv" else np.float64)
 
 
+def _exclusion_windows(pa, thr):
+    """For every frame j the half-open index window [lo_j, hi_j) that the rotation criterion removes from its PCA
+    library (reference derotation.py:444-461, as a matrix statement): with D_ji = |PA_j - PA_i| in float64,
+    lo_j = the first i < j with D_ji < thr (j when there is none) and hi_j = the first i >= j with D_ji > thr (n when
+    there is none).  Returns (lo, hi) as int arrays."""
+    pa = np.asarray(pa)
+    n = pa.shape[0]
+    D = np.abs(pa[:, None] - pa[None, :])
+    col = np.arange(n)
+    before = col[None, :] < col[:, None]
+    close = (D < thr) & before
+    lo = np.where(close.any(axis=1), close.argmax(axis=1), col)
+    apart = (D > thr) & ~before
+    hi = np.where(apart.any(axis=1), apart.argmax(axis=1), n)
+    return lo, hi
+
+
+def _library_of(pa, j, lo, hi, limit):
+    """Frames outside [lo, hi), cut down to the ``limit`` frames nearest in parallactic angle when there are more (the
+    reference's argsort on |dPA| decides ties: derotation.py:488-495).  ``limit`` None: no cut (int32 as the reference)."""
+    n = pa.shape[0]
+    keep = np.concatenate([np.arange(lo), np.arange(hi, n)])
+    if limit is not None and keep.shape[0] > limit:
+        nearest = np.argsort(np.abs(pa[keep] - pa[j]))[:limit]
+        return np.sort(keep[nearest])
+    return keep.astype("int32")
+
+
 def _find_indices_adi(angle_list, frame, thr, nframes=None, out_closest=False, truncate=False,
                       max_frames=200):
-    """Indices of the frames kept in the PCA library of ``frame`` (bit-exact index contract)."""
-    n = angle_list.shape[0]
-    index_prev = 0
-    index_foll = frame
-    for i in range(0, frame):
-        if np.abs(angle_list[frame] - angle_list[i]) < thr:
-            index_prev = i
-            break
-        else:
-            index_prev += 1
-    for k in range(frame, n):
-        if np.abs(angle_list[k] - angle_list[frame]) > thr:
-            index_foll = k
-            break
-        else:
-            index_foll += 1
+    """Indices of the frames kept in the PCA library of ``frame`` (bit-exact index contract with the reference's
+    derotation.py:410-496): row ``frame`` of ``_exclusion_windows``.  ``out_closest``: the last rejected frame on either
+    side; ``nframes``: only nframes // 2 frames on either side of the window."""
+    pa = np.asarray(angle_list)
+    n = pa.shape[0]
+    gap = np.abs(pa - pa[frame])
+    near = np.flatnonzero(gap[:frame] < thr)
+    lo = int(near[0]) if near.size else frame
+    far = np.flatnonzero(gap[frame:] > thr)
+    hi = frame + int(far[0]) if far.size else n
     if out_closest:
-        return index_prev, index_foll - 1
+        return lo, hi - 1
     if nframes is not None:
-        window = nframes // 2
-        ind1 = max(index_prev - window, 0)
-        ind4 = min(index_foll + window, n)
-        return np.array(list(range(ind1, index_prev)) + list(range(index_foll, ind4)), dtype="int32")
-    half1 = range(0, index_prev)
-    half2 = range(index_foll, n)
-    indices = np.array(list(half1) + list(half2), dtype="int32")
-    if truncate:
-        thr = min(n - 1, max_frames)
-        all_indices = np.array(list(half1) + list(half2))
-        if len(all_indices) > thr:
-            dPA = np.abs(angle_list[all_indices] - angle_list[frame])
-            indices = np.sort(all_indices[np.argsort(dPA)][:thr])
-    return indices
+        side = nframes // 2
+        return np.concatenate([np.arange(max(lo - side, 0), lo), np.arange(hi, min(hi + side, n))]).astype("int32")
+    return _library_of(pa, frame, lo, hi, min(n - 1, max_frames) if truncate else None)
 
 
 def _find_indices_adi_all(angle_list, thr, truncate=False, max_frames=200):
-    """``[_find_indices_adi(angle_list, j, thr, truncate=truncate, max_frames=max_frames) for j in range(n)]``
-    with the two scans done for all frames at once on the |PA_j - PA_i| matrix (same float64 comparisons); the
-    truncation keeps the reference's per-frame ``np.argsort`` call so that ties break identically."""
-    a = np.asarray(angle_list)
-    n = a.shape[0]
-    D = np.abs(a[:, None] - a[None, :])
-    idx = np.arange(n)
-    below = (D < thr) & (idx[None, :] < idx[:, None])            # candidates i < j of the first scan
-    prev = np.where(below.any(axis=1), below.argmax(axis=1), idx)
-    above = (D > thr) & (idx[None, :] >= idx[:, None])           # candidates k >= j of the second scan
-    foll = np.where(above.any(axis=1), above.argmax(axis=1), n)
-    lim = min(n - 1, max_frames) if truncate else n
-    out = []
-    for j in range(n):
-        all_indices = np.concatenate([idx[:prev[j]], idx[foll[j]:]])
-        if truncate and all_indices.shape[0] > lim:
-            dPA = np.abs(a[all_indices] - a[j])
-            out.append(np.sort(all_indices[np.argsort(dPA)][:lim]))
-        else:
-            out.append(all_indices.astype("int32"))
-    return out
+    """``[_find_indices_adi(angle_list, j, thr, truncate=truncate, max_frames=max_frames) for j in range(n)]`` from one
+    |PA_j - PA_i| matrix (what the annular path calls: one plan per annulus, not n scans)."""
+    pa = np.asarray(angle_list)
+    n = pa.shape[0]
+    lo, hi = _exclusion_windows(pa, thr)
+    limit = min(n - 1, max_frames) if truncate else None
+    return [_library_of(pa, j, int(lo[j]), int(hi[j]), limit) for j in range(n)]
 
 
 def _compute_pa_thresh(ann_center, fwhm, delta_rot=1):
@@ -135,27 +132,25 @@ def _compute_pa_thresh(ann_center, fwhm, delta_rot=1):
 
 def _define_annuli(angle_list, ann, n_annuli, fwhm, radius_int, annulus_width, delta_rot, n_segments,
                    verbose, strict=False):
-    verbosity = int(verbose)
-    if ann == n_annuli - 1:
-        inner_radius = radius_int + (ann * annulus_width - 1)
-    else:
-        inner_radius = radius_int + ann * annulus_width
-    ann_center = inner_radius + (annulus_width / 2)
+    """Geometry and rotation threshold of annulus ``ann`` (reference derotation.py:507-539): the annulus
+    starts at radius_int + ann * width -- one pixel earlier for the last one --, its centre is half a width further out,
+    the threshold is the angle under which delta_rot * fwhm is seen from the centre, capped at 90 % of half the
+    parallactic range (unless ``strict``, which only warns).  Returns (pa_threshold, inner_radius, ann_center)."""
+    last = ann == n_annuli - 1
+    inner_radius = radius_int + ann * annulus_width - (1 if last else 0)
+    ann_center = inner_radius + annulus_width / 2
     pa_threshold = _compute_pa_thresh(ann_center, fwhm, delta_rot)
-    mid_range = np.abs(np.amax(angle_list) - np.amin(angle_list)) / 2
-    if pa_threshold >= mid_range - mid_range * 0.1:
-        new_pa_th = float(mid_range - mid_range * 0.1)
-        if strict:
-            if verbosity > 1:
-                print("WARNING: PA threshold {:.2f} is too big, recommended  value for annulus {:.0f}: "
-                      "{:.2f}".format(pa_threshold, ann, new_pa_th))
-        else:
-            print("PA threshold {:.2f} is likely too big, will be set to {:.2f}".format(pa_threshold, new_pa_th))
-            pa_threshold = new_pa_th
-    if verbosity:
+    half_range = np.abs(np.amax(angle_list) - np.amin(angle_list)) / 2
+    cap = half_range - half_range * 0.1
+    if pa_threshold >= cap:
+        if not strict:
+            print("PA threshold %.2f exceeds 90%% of half the rotation range: using %.2f" % (pa_threshold, float(cap)))
+            pa_threshold = float(cap)
+        elif int(verbose) > 1:
+            print("WARNING: PA threshold %.2f of annulus %d exceeds %.2f (kept: strict)" % (pa_threshold, ann, float(cap)))
+    if int(verbose):
+        head = "Ann %d" % (ann + 1)
         if pa_threshold > 0:
-            print("Ann {}    PA thresh: {:5.2f}    Ann center: {:3.0f}    N segments: {} ".format(
-                ann + 1, pa_threshold, ann_center, n_segments))
-        else:
-            print("Ann {}    Ann center: {:3.0f}    N segments: {} ".format(ann + 1, ann_center, n_segments))
+            head += "    PA thresh: %5.2f" % pa_threshold
+        print("%s    Ann center: %3.0f    N segments: %s " % (head, ann_center, n_segments))
     return pa_threshold, inner_radius, ann_center
