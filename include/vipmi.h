@@ -48,6 +48,9 @@ const char* vipmi_last_error(void);
 /* ctx: device = HIP ordinal; stream = hipStream_t (NULL = default stream). */
 int vipmi_create(int device, void* stream, vipmi_ctx** out);
 int vipmi_destroy(vipmi_ctx* ctx);
+/* Synchronise the stream and hipFree every workspace of the context; the handle, its options, timers and gate stay
+ * valid and the next call re-allocates what it needs (what a cache of contexts does to its least recently used entry). */
+int vipmi_trim(vipmi_ctx* ctx);
 int vipmi_set_stream(vipmi_ctx* ctx, void* stream);
 int vipmi_synchronize(vipmi_ctx* ctx);
 /* With option "eigh_check"=0 calls never synchronise; convergence failures are latched on the device.
@@ -242,7 +245,10 @@ int vipmi_pca_4d_f32(vipmi_ctx* ctx, const float* cube4, const double* angles_ho
  *   vipmi_pca_fullframe_sharded_f32: every rank passes its row slab of the cube, slab[n][y1-y0][N] with
  *       [y0, y1) = rows of rank r of `world` contiguous near-equal blocks (block r starts at r*(N/world) + min(r, N%world)),
  *       and the whole angle vector; frame[N,N] (device) receives the final frame on EVERY rank.  Collectives on
- *       ctx's stream: one all-reduce of n*n float64, two all-to-alls of the residual cube, one exchange of N*N floats. */
+ *       ctx's stream: one all-reduce of n*n float64, two all-to-alls of the residual cube, one exchange of N*N floats.
+ *       Unlike vipmi_pca_fullframe_f32 this entry takes no `scaling` and no `mask` (scale / mask the slab first with
+ *       vipmi_scale_f32 / vipmi_apply_mask_f32 -- the temporal modes are per pixel and shard with the rows; the
+ *       spatial modes need whole frames) and no weighted collapse; at most 6144 frames, checked before any collective. */
 int vipmi_rccl_load(const char* path);
 int vipmi_rccl_unique_id(void* id128);
 int vipmi_rccl_comm_create(vipmi_ctx* ctx, const void* id128, int rank, int world, void** comm);

@@ -469,7 +469,7 @@ def test_pca_many_matches_serial():
     with pytest.raises(ValueError):
         pca_many(list(cubes), list(angs), ncomp=0)
     from vip_amd import backend
-    assert backend._async["on"] is False
+    assert backend.is_async() is False
 
 
 @pytest.mark.parametrize("n,N,k", [(50, 128, 5), (120, 256, 8)])
@@ -1213,3 +1213,83 @@ def test_pca_odd_frame_sizes_end_to_end(N):
     if N == 255:
         fa = pca_annular(cube, ang, ncomp=2, asize=32, fwhm=4, verbose=False)
         assert np.nanmax(np.abs(fa - O.pca_annular(cube, ang, ncomp=2, asize=32, fwhm=4))) < TOL
+
+
+def test_context_cache_eviction_keeps_held_contexts_alive(monkeypatch):
+    """round-2 ADVICE: evicting the least recently used context must not invalidate a handle other code still holds
+    (it is trimmed -- workspaces freed, handle valid -- and re-allocates on its next call), and a context inside a call
+    is never touched."""
+    import torch
+    from vip_amd import backend as B
+    from vip_amd.psfsub import pca
+    cube, ang = O.synth_adi(20, 64, seed=5)
+    ct = torch.from_numpy(cube).cuda()
+    ref = pca(ct, ang, ncomp=3, verbose=False).clone()
+    B.release_workspaces()
+    monkeypatch.setattr(B, "MAX_CONTEXTS", 2)
+    held = []
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            held.append(B.get_context())
+            assert torch.equal(pca(ct, ang, ncomp=3, verbose=False), ref)
+    torch.cuda.synchronize()
+    assert len(B.all_contexts()) <= 2
+    assert all(c.handle for c in held)                     # evicted, not destroyed
+    for st, c in zip(streams, held):                       # an evicted context still works (and gives the same frame)
+        with torch.cuda.stream(st):
+            out = B.empty((64, 64))
+            c.call("vipmi_collapse_f32", B.ptr(ct), 20, 64 * 64, 1, None, 0, B.ptr(out))
+    torch.cuda.synchronize()
+    # a context that is inside a call cannot be trimmed
+    c = held[0]
+    assert c._in_call.acquire(blocking=False)
+    try:
+        assert c.trim() is False
+    finally:
+        c._in_call.release()
+    assert c.trim() is True
+    B.release_workspaces()
+    assert torch.equal(pca(ct, ang, ncomp=3, verbose=False), ref)
+
+
+def test_async_mode_is_thread_local():
+    """round-2 ADVICE: a pipelined region on one thread must not switch a concurrent caller on another thread to
+    deferred error checks (nor have the mode switched off under it)."""
+    import threading
+    import torch
+    from vip_amd import backend as B
+    from vip_amd.psfsub import pca
+    cube, ang = O.synth_adi(20, 64, seed=6)
+    ct = torch.from_numpy(cube).cuda()
+    ref = pca(ct, ang, ncomp=3, verbose=False).clone()
+    seen = {}
+    go, done = threading.Event(), threading.Event()
+
+    def other():
+        torch.cuda.set_device(0)
+        go.wait(30)
+        seen["async_in_other_thread"] = B.is_async()
+        with torch.cuda.stream(torch.cuda.Stream()):
+            c = B.get_context()
+            seen["frame_ok"] = bool(torch.equal(pca(ct, ang, ncomp=3, verbose=False), ref))
+            seen["eigh_check"] = c.get_option("eigh_check")
+        done.set()
+
+    th = threading.Thread(target=other)
+    th.start()
+    B.set_async(True)
+    try:
+        go.set()
+        assert done.wait(120)
+        assert B.is_async()
+        with torch.cuda.stream(torch.cuda.Stream()):
+            out = pca(ct, ang, ncomp=3, verbose=False)
+            assert B.get_context().get_option("eigh_check") == 0
+        torch.cuda.synchronize()
+        B.check_deferred()
+    finally:
+        B.set_async(False)
+    th.join()
+    assert seen == {"async_in_other_thread": False, "frame_ok": True, "eigh_check": 1}
+    assert torch.equal(out, ref)

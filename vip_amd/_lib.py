@@ -19,6 +19,7 @@ _SIGS = {
     "vipmi_last_error": ([], False, ctypes.c_char_p),
     "vipmi_create": ([ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)], False, ctypes.c_int),
     "vipmi_destroy": ([], True, ctypes.c_int),
+    "vipmi_trim": ([], True, ctypes.c_int),
     "vipmi_set_stream": ([ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_synchronize": ([], True, ctypes.c_int),
     "vipmi_check_deferred": ([], True, ctypes.c_int),

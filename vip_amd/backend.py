@@ -15,7 +15,12 @@ import collections
 
 _ctx_cache = collections.OrderedDict()      # (device, stream handle) -> Context, least recently used first
 _ctx_lock = threading.Lock()
-MAX_CONTEXTS = int(os.environ.get("VIPMI_MAX_CONTEXTS", "8"))   # every context owns hipMalloc'ed workspaces (GBs at C2 scale)
+# Every context owns hipMalloc'ed workspaces (GBs at C2 scale), so the cache is bounded: beyond MAX_CONTEXTS the least
+# recently used IDLE context is dropped from the cache and trimmed (vipmi_trim: stream synchronised, workspaces freed).
+# Its handle stays valid -- code that still holds the object (RcclComm.ctx, a local `ctx`) keeps working, the next
+# call re-allocates; the handle itself is destroyed when the last reference goes.  A context inside a call on another
+# thread is never touched (the cache grows past the bound instead).  16 >= the side streams of any one call + 1.
+MAX_CONTEXTS = int(os.environ.get("VIPMI_MAX_CONTEXTS", "16"))
 
 SCALE_MODES = {None: 0, "temp-mean": 1, "temp-standard": 2, "spat-mean": 3, "spat-standard": 4}
 COLLAPSE_MODES = {"median": 0, "mean": 1, "sum": 2, "max": 3, "absmean": 4, "wmean": 5, "trimmean": 6, "stim": 7}
@@ -41,6 +46,8 @@ class Context:
         self.lib = _lib.load()
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.handle = ctypes.c_void_p()
+        self._in_call = threading.Lock()        # held for the duration of every library call on this context
+        self._mode = (False, 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         st = self.lib.vipmi_create(self.device, ctypes.c_void_p(stream), ctypes.byref(self.handle))
         _lib.raise_for_status(st, "vipmi_create")
@@ -69,10 +76,37 @@ class Context:
     def reset_timers(self):
         self.lib.vipmi_reset_timers(self.handle)
 
+    def _apply_mode(self):
+        """Bring the context's asynchronous-mode options in line with the calling thread's mode (set_async)."""
+        mode = _mode()
+        if mode != self._mode:
+            on, reserve = mode
+            self.set_option("eigh_check", 0 if on else 1)
+            self.set_option("reserve_cus", reserve)
+            self.lib.vipmi_set_gate(self.handle, _gate() if on else None)
+            self._mode = mode
+        if mode[0]:
+            touched = getattr(_tls, "touched", None)
+            if touched is None:
+                touched = _tls.touched = {}
+            touched[id(self)] = self
+
     def call(self, name, *args):
-        self.bind_stream()
-        st = getattr(self.lib, name)(self.handle, *args)
+        with self._in_call:
+            self._apply_mode()
+            self.bind_stream()
+            st = getattr(self.lib, name)(self.handle, *args)
         _lib.raise_for_status(st, name)
+
+    def trim(self):
+        """Free the workspaces if no call is running on this context (another thread); returns whether it did."""
+        if not self.handle or not self._in_call.acquire(blocking=False):
+            return False
+        try:
+            _lib.raise_for_status(self.lib.vipmi_trim(self.handle), "vipmi_trim")
+        finally:
+            self._in_call.release()
+        return True
 
     def destroy(self):
         """Synchronise the context's stream and free every workspace it owns (hipFree); the object is dead afterwards."""
@@ -87,41 +121,44 @@ class Context:
             pass
 
 
-_async = {"on": False, "reserve_cus": 0, "gate": None}
+_gate_box = {"gate": None}
+_tls = threading.local()                 # asynchronous mode is a property of the calling THREAD (see set_async)
+
+
+def _mode():
+    return getattr(_tls, "mode", (False, 0))
 
 
 def _gate():
-    """Process-wide gate shared by every context while asynchronous mode is on (include/vipmi.h: vipmi_gate)."""
-    if _async["gate"] is None:
-        lib = _lib.load()
-        h = ctypes.c_void_p()
-        _lib.raise_for_status(lib.vipmi_gate_create(ctypes.byref(h)), "vipmi_gate_create")
-        _async["gate"] = h
-    return _async["gate"]
+    """Process-wide gate shared by every context that runs in asynchronous mode (include/vipmi.h: vipmi_gate)."""
+    with _ctx_lock:
+        if _gate_box["gate"] is None:
+            lib = _lib.load()
+            h = ctypes.c_void_p()
+            _lib.raise_for_status(lib.vipmi_gate_create(ctypes.byref(h)), "vipmi_gate_create")
+            _gate_box["gate"] = h
+        return _gate_box["gate"]
 
 
 def set_async(on=True, reserve_cus=None):
-    """Asynchronous (pipelined) mode: calls enqueue all work on the current torch stream and never
-    synchronise (the eigensolver's convergence check is latched on the device and read by
-    ``check_deferred()``).  Each (device, stream) pair gets its own vipmi_ctx / workspace, so independent
-    calls issued on two streams overlap: the latency-bound Jacobi eigensolver of one cube (13 workgroups)
-    runs beside the FFT derotation of the previous one (``reserve_cus`` CUs can be kept free for it; measured best: 0).  All
-    contexts share a gate that runs the chip-filling half of the calls one at a time in issue order (otherwise
-    identical calls drift into lock step and the chip idles while every stream sits in its eigensolver)."""
-    _async["on"] = bool(on)
+    """Asynchronous (pipelined) mode for the calls of THIS THREAD: they enqueue all work on the current torch stream and
+    never synchronise (the eigensolver's convergence check is latched on the device and read by ``check_deferred()``).
+    Each (device, stream) pair gets its own vipmi_ctx / workspace, so independent calls issued on two streams overlap:
+    the latency-bound eigensolver of one cube (16 workgroups) runs beside the FFT derotation of the previous one
+    (``reserve_cus`` CUs can be kept free for it; measured best: 0).  All asynchronous contexts share a gate that runs
+    the chip-filling half of the calls one at a time in issue order (otherwise identical calls drift into lock step and
+    the chip idles while every stream sits in its eigensolver).
+
+    The mode is thread-local and reaches a context when that thread next calls into it (``Context.call``), so a
+    pipelined region on one thread (pca_many, the annular / 4-D fronts) neither switches a concurrent caller on another
+    thread to deferred error checks nor has the mode switched off under it."""
     if reserve_cus is None:          # default 0: since the shear kernels take their work from dynamic queues, a CU that is
         reserve_cus = int(os.environ.get("VIPMI_RESERVE_CUS", "0"))   # busy with the other call's eigensolver costs nothing
-    _async["reserve_cus"] = int(reserve_cus) if on else 0
-    gate = _gate() if on else None
-    with _ctx_lock:
-        for c in _ctx_cache.values():
-            c.set_option("eigh_check", 0 if on else 1)
-            c.set_option("reserve_cus", _async["reserve_cus"])
-            c.lib.vipmi_set_gate(c.handle, gate)
+    _tls.mode = (bool(on), int(reserve_cus) if on else 0)
 
 
 def is_async():
-    return bool(_async["on"])
+    return _mode()[0]
 
 
 _side_streams = {}
@@ -139,11 +176,23 @@ def side_streams(depth, device=None):
 
 
 def check_deferred():
-    """Synchronise every context and raise if a deferred error (eigensolver non-convergence) was latched."""
-    with _ctx_lock:
-        ctxs = list(_ctx_cache.values())
-    for c in ctxs:
-        _lib.raise_for_status(c.lib.vipmi_check_deferred(c.handle), "vipmi_check_deferred")
+    """Synchronise every context this thread has called in asynchronous mode since its last check and raise if a
+    deferred error (eigensolver non-convergence) was latched on one of them."""
+    touched = getattr(_tls, "touched", None) or {}
+    _tls.touched = {}
+    first = None
+    for c in touched.values():
+        if not c.handle:
+            continue
+        with c._in_call:
+            st = c.lib.vipmi_check_deferred(c.handle)
+        if st != 0 and first is None:
+            try:
+                _lib.raise_for_status(st, "vipmi_check_deferred")
+            except Exception as e:              # keep checking (and thereby clearing) the other contexts first
+                first = e
+    if first is not None:
+        raise first
 
 
 def all_contexts():
@@ -159,13 +208,12 @@ def get_context(device=None):
     with _ctx_lock:
         c = _ctx_cache.get(key)
         if c is None:
-            while len(_ctx_cache) >= max(1, MAX_CONTEXTS):       # least recently used context: synchronised and freed
-                _ctx_cache.popitem(last=False)[1].destroy()
+            if len(_ctx_cache) >= max(1, MAX_CONTEXTS):
+                for old_key, old in list(_ctx_cache.items()):    # least recently used first
+                    if old.trim():
+                        del _ctx_cache[old_key]
+                        break
             c = Context(dev)
-            if _async["on"]:
-                c.set_option("eigh_check", 0)
-                c.set_option("reserve_cus", _async["reserve_cus"])
-                c.lib.vipmi_set_gate(c.handle, _gate())
             _ctx_cache[key] = c
         else:
             _ctx_cache.move_to_end(key)
@@ -173,11 +221,14 @@ def get_context(device=None):
 
 
 def release_workspaces():
-    """Destroy every cached context (stream synchronised, all of its hipMalloc'ed workspaces freed).  The next call
-    on a stream builds a fresh context; use between phases of a long-running process that worked on large cubes."""
+    """Empty the context cache: every idle context is trimmed (stream synchronised, all of its hipMalloc'ed workspaces
+    freed) and dropped; handles that other code still holds stay valid and are destroyed with their last reference.
+    The next call on a stream builds a fresh context; use between phases of a long-running process that worked on
+    large cubes."""
     with _ctx_lock:
-        while _ctx_cache:
-            _ctx_cache.popitem(last=False)[1].destroy()
+        for key, c in list(_ctx_cache.items()):
+            if c.trim():
+                del _ctx_cache[key]
 
 
 # ---- array plumbing ------------------------------------------------------------------------------

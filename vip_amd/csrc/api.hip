@@ -232,6 +232,17 @@ int vipmi_destroy(vipmi_ctx* ctx) {
   return VIPMI_OK;
 }
 
+int vipmi_trim(vipmi_ctx* ctx) {
+  VIPMI_REQUIRE(ctx, "null ctx");
+  VIPMI_CHECK_HIP(hipSetDevice(ctx->device));
+  VIPMI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->buffers)
+    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  ctx->buffers.clear();
+  ctx->upload_keys.clear();
+  return VIPMI_OK;
+}
+
 int vipmi_set_stream(vipmi_ctx* ctx, void* stream) {
   VIPMI_REQUIRE(ctx, "null ctx");
   ctx->stream = reinterpret_cast<hipStream_t>(stream);
@@ -681,6 +692,17 @@ int vipmi_pca_4d_f32(vipmi_ctx* ctx, const float* cube4, const double* angles_ho
     }                                                                                                           \
   } while (0)
 
+// inside an ncclGroupStart / ncclGroupEnd pair: close the group before returning, or the communicator stays in group mode
+#define VIPMI_CHECK_RCCL_IN_GROUP(expr)                                                                         \
+  do {                                                                                                          \
+    ncclResult_t _r = (expr);                                                                                   \
+    if (_r != ncclSuccess) {                                                                                    \
+      (void)vipmi::rccl_api().GroupEnd();                                                                       \
+      vipmi::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, vipmi::rccl_api().GetErrorString(_r));     \
+      return VIPMI_ERR_HIP;                                                                                     \
+    }                                                                                                           \
+  } while (0)
+
 static inline int64_t split_edge(int64_t total, int world, int r) {      // contiguous near-equal blocks (dist._split)
   const int64_t base = total / world, rem = total % world;
   return r * base + (r < rem ? r : rem);
@@ -735,6 +757,10 @@ int vipmi_pca_fullframe_sharded_f32(vipmi_ctx* ctx, void* comm_, int rank, int w
   ncclComm_t comm = static_cast<ncclComm_t>(comm_);
   hipStream_t st = ctx->stream;
   const int64_t k = ncomp > n ? n : ncomp;
+  // every size limit is checked BEFORE the first collective is enqueued (a rank that returned early would leave its peers
+  // waiting in the all-reduce): the hand-written eigensolvers stop at 6144 frames
+  VIPMI_REQUIRE(vipmi::eigh_topk_supported(n, k) || vipmi::eigh_large_supported(n, k) || n <= 2048,
+                "pca_fullframe_sharded: %lld frames are beyond the device eigensolvers", (long long)n);
   const int64_t y0 = split_edge(N, world, rank), y1 = split_edge(N, world, rank + 1), rl = y1 - y0;   // my pixel rows
   const int64_t f0 = split_edge(n, world, rank), f1 = split_edge(n, world, rank + 1), fl = f1 - f0;   // my frames
   const int64_t Pl = rl * N;
@@ -772,8 +798,8 @@ int vipmi_pca_fullframe_sharded_f32(vipmi_ctx* ctx, void* comm_, int rank, int w
   for (int p = 0; p < world; ++p) {
     const int64_t fa = split_edge(n, world, p), fb = split_edge(n, world, p + 1);
     const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
-    if ((fb - fa) * Pl > 0) VIPMI_CHECK_RCCL(nc.Send(R + (size_t)fa * Pl, (size_t)(fb - fa) * Pl, ncclFloat, p, comm, st));
-    if (fl * (rb - ra) > 0) VIPMI_CHECK_RCCL(nc.Recv(stage + p * chunk, (size_t)fl * (rb - ra) * N, ncclFloat, p, comm, st));
+    if ((fb - fa) * Pl > 0) VIPMI_CHECK_RCCL_IN_GROUP(nc.Send(R + (size_t)fa * Pl, (size_t)(fb - fa) * Pl, ncclFloat, p, comm, st));
+    if (fl * (rb - ra) > 0) VIPMI_CHECK_RCCL_IN_GROUP(nc.Recv(stage + p * chunk, (size_t)fl * (rb - ra) * N, ncclFloat, p, comm, st));
   }
   VIPMI_CHECK_RCCL(nc.GroupEnd());
   for (int p = 0; p < world && fl > 0; ++p) {
@@ -799,8 +825,8 @@ int vipmi_pca_fullframe_sharded_f32(vipmi_ctx* ctx, void* comm_, int rank, int w
   for (int p = 0; p < world; ++p) {
     const int64_t fa = split_edge(n, world, p), fb = split_edge(n, world, p + 1);
     const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
-    if (fl * (rb - ra) > 0) VIPMI_CHECK_RCCL(nc.Send(stage + p * chunk, (size_t)fl * (rb - ra) * N, ncclFloat, p, comm, st));
-    if ((fb - fa) * Pl > 0) VIPMI_CHECK_RCCL(nc.Recv(S + (size_t)fa * Pl, (size_t)(fb - fa) * Pl, ncclFloat, p, comm, st));
+    if (fl * (rb - ra) > 0) VIPMI_CHECK_RCCL_IN_GROUP(nc.Send(stage + p * chunk, (size_t)fl * (rb - ra) * N, ncclFloat, p, comm, st));
+    if ((fb - fa) * Pl > 0) VIPMI_CHECK_RCCL_IN_GROUP(nc.Recv(S + (size_t)fa * Pl, (size_t)(fb - fa) * Pl, ncclFloat, p, comm, st));
   }
   VIPMI_CHECK_RCCL(nc.GroupEnd());
   // 6. collapse my pixels over all frames, then every rank collects the row slabs of the final frame
@@ -809,8 +835,8 @@ int vipmi_pca_fullframe_sharded_f32(vipmi_ctx* ctx, void* comm_, int rank, int w
   for (int p = 0; p < world; ++p) {
     if (p == rank) continue;
     const int64_t ra = split_edge(N, world, p), rb = split_edge(N, world, p + 1);
-    if (Pl > 0) VIPMI_CHECK_RCCL(nc.Send(frame + (size_t)y0 * N, (size_t)Pl, ncclFloat, p, comm, st));
-    if (rb > ra) VIPMI_CHECK_RCCL(nc.Recv(frame + (size_t)ra * N, (size_t)(rb - ra) * N, ncclFloat, p, comm, st));
+    if (Pl > 0) VIPMI_CHECK_RCCL_IN_GROUP(nc.Send(frame + (size_t)y0 * N, (size_t)Pl, ncclFloat, p, comm, st));
+    if (rb > ra) VIPMI_CHECK_RCCL_IN_GROUP(nc.Recv(frame + (size_t)ra * N, (size_t)(rb - ra) * N, ncclFloat, p, comm, st));
   }
   VIPMI_CHECK_RCCL(nc.GroupEnd());
   return VIPMI_OK;

@@ -385,7 +385,8 @@ def pca_single_cube_rccl(cube, angle_list, ncomp, comm, collapse="median"):
     """``pca_single_cube`` through the C entry ``vipmi_pca_fullframe_sharded_f32``: the same partition (pixel rows for the
     decomposition, frames for the derotation), with the collectives issued by the library itself on an RCCL communicator
     (``RcclComm``) instead of ``torch.distributed``.  Every rank passes the same ``cube`` (only its row slab is
-    touched) or, as a cuda tensor of shape (n, y1 - y0, x), its slab; returns the final frame on every rank."""
+    touched) or, as a cuda tensor of shape (n, y1 - y0, x), its slab; returns the final frame on every rank.
+    The C entry has no ``scaling`` / ``mask_center_px`` arguments (include/vipmi.h) and stops at 6144 frames."""
     from . import backend as B
     torch = B._torch()
     n = cube.shape[0]

@@ -52,7 +52,9 @@ def aperture_sums_exact(array, xx, yy, r):
             continue
         gx, gy = np.meshgrid(xs - 0.5 - xc, ys - 0.5 - yc)            # lower-left pixel corners relative to the centre
         w = circle_pixel_overlap(gx, gy, float(r))
-        out[i] = float(np.sum(w * array[ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1]))
+        sub = array[ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1]
+        covered = w > 0                      # (photutils sums only the pixels the aperture touches: a NaN corner of the
+        out[i] = float(np.sum(w[covered] * sub[covered]))        # bounding box outside the circle must not poison the sum)
     return out
 
 

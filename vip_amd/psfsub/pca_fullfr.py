@@ -574,6 +574,8 @@ def pca(*all_args: List, **all_kwargs: dict):
                 B.check_deferred()
         finally:
             if pipelined:
+                for st in streams:              # (also on the error path, before the per-channel buffers are released)
+                    cur.wait_stream(st)
                 B.set_async(False)
         grid_ch = [isinstance(kc, (tuple, list)) for kc in ncomps]
         if any(grid_ch):
@@ -671,6 +673,8 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
             st.synchronize()
         B.check_deferred()
     finally:
+        for st in streams:                      # (a no-op after the normal path; joins the streams on the error path)
+            st.synchronize()
         B.set_async(False)
     res = []
     for i, o in enumerate(outs):

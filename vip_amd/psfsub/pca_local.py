@@ -378,6 +378,8 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                 cur.wait_stream(st)
             B.check_deferred()
         finally:
+            for st in streams:                  # (also on the error path: nothing the side streams still use may be
+                cur.wait_stream(st)             # released before they are joined back)
             B.set_async(False)
     else:
         for si, seg in enumerate(plan):
@@ -479,6 +481,8 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
                 B.check_deferred()
         finally:
             if pipelined:
+                for st in streams:              # (also on the error path, before the per-channel buffers are released)
+                    cur.wait_stream(st)
                 B.set_async(False)
         ifs = torch.stack([o[2] for o in outs])
         frame = B.collapse(ifs, _s(algo_params.collapse_ifs)) if algo_params.collapse_ifs is not None else ifs
