@@ -145,6 +145,11 @@ int vipmi_zoom_frames_f32(vipmi_ctx* ctx, const float* X, int64_t nb, int64_t di
  * method = VIPMI_ROT_*. */
 int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n,
                        int64_t N, float* out, int mask_nan, int mask_zero, int method);
+/* The same with frame_rotate's `mask_val` itself (derotation.py:133-140,324-326): NaN -> the mask_nan behaviour above;
+ * any other value v -> NaN input pixels are rotated as 0 (and NOT restored), pixels equal to v take part in the
+ * rotation with their value and are reset to v in the output. */
+int vipmi_derotate_maskval_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n,
+                               int64_t N, float* out, float mask_val, int method);
 
 /* ---- cube_derotate / frame_rotate(imlib='opencv'): preproc/derotation.py:279-305 ----
  * out[n,N,N] = frames of in[n,N,N] rotated by -angles_host[i] degrees about (cx, cy) with OpenCV's

@@ -1293,3 +1293,62 @@ def test_async_mode_is_thread_local():
     th.join()
     assert seen == {"async_in_other_thread": False, "frame_ok": True, "eigh_check": True}
     assert torch.equal(out, ref)
+
+
+def test_mask_val_other_than_nan_or_zero_golden():
+    """G25 (round 3; round-2 VERDICT missing #4): frame_rotate's ``mask_val`` as any number on the device path --
+    pixels equal to it take part in the rotation and are reset afterwards, NaNs are rotated as 0 and stay finite
+    (preproc/derotation.py:133-140,324-326); through cube_derotate, frame_rotate, pca(rot_options) and median_sub."""
+    from vip_amd.preproc import cube_derotate, frame_rotate
+    from vip_amd.psfsub import pca, median_sub
+    g = load_golden("g25_mask_val")
+
+    def close(a, b, tol):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.nanmax(np.abs(a.astype(np.float64) - b), initial=0.0) < tol
+
+    for N in (40, 128, 45):
+        fr, angs = g["in_%d" % N], g["angles_%d" % N]
+        for method in ("auto", "direct"):
+            close(cube_derotate(fr, angs, mask_val=5.0, method=method), g["out5_%d" % N], 3e-5)
+            close(cube_derotate(fr, angs, mask_val=-1.5, method=method), g["outm_%d" % N], 3e-5)
+        out = cube_derotate(fr, angs, mask_val=5.0)
+        assert np.array_equal(out == 5.0, g["out5_%d" % N] == 5.0)            # the reset pixels, bit-exact
+        close(frame_rotate(fr[0], 33.0, mask_val=5.0), g["fr5_%d" % N], 3e-5)
+    close(cube_derotate(g["in_01"], np.array([20.0, -50.0]), mask_val=0.1), g["out_01"], 3e-5)
+    cube, ang = g["cube"], g["angles"]
+    fo = pca(cube, ang, ncomp=3, mask_center_px=5, mask_val=2.5, full_output=True, verbose=False)
+    close(fo[0], g["pca_frame"], TOL)
+    close(fo[4], g["pca_resder"], TOL)
+    close(pca(cube, ang, ncomp=2, mask_val=7.0, verbose=False), g["pca_nomask"], TOL)
+    close(median_sub(cube, ang, mask_val=1e3, verbose=False), g["medsub"], TOL)
+
+
+def test_pca_grid_scored_by_snr_on_a_4d_cube():
+    """round-2 VERDICT missing #5: the S/N-scored grid on a 4-D cube without scale_list (reference
+    psfsub/pca_fullfr.py:604-612,619-623,779-786): a grid per channel, the channel's frame = its best-S/N frame, the
+    final frame = spectral collapse of those; full_output -> (per-channel grid cubes, frame, tables, ifs_adi_frames)."""
+    from vip_amd.psfsub import pca
+    chans = [_cube_with_companion(seed=9 + i, flux=3.0 - 0.5 * i) for i in range(3)]
+    c4 = np.stack([c[0] for c in chans])
+    ang = chans[0][1]
+    sx, sy = chans[0][2]
+    xy = (float(round(sx)), float(round(sy)))
+    refs = [O.pca_grid_snr(c4[ch], ang, (1, 5, 1), xy, 4.0) for ch in range(3)]
+    out = pca(c4, ang, ncomp=(1, 5, 1), source_xy=xy, fwhm=4.0, full_output=True, verbose=False)
+    assert len(out) == 4
+    cubes, frame, tables, ifs = out
+    assert cubes.shape == (3, 5, 48, 48) and ifs.shape == (3, 48, 48) and len(tables) == 3
+    for ch in range(3):
+        assert np.nanmax(np.abs(cubes[ch] - refs[ch][0])) < TOL
+        assert list(tables[ch]["PCs"]) == refs[ch][2]
+        assert np.nanmax(np.abs(ifs[ch] - refs[ch][1])) < TOL
+    exp = O.cube_collapse(np.stack([r[1] for r in refs]), "mean")
+    assert frame.dtype == np.float64 and np.nanmax(np.abs(frame - exp)) < TOL
+    only = pca(c4, ang, ncomp=(1, 5, 1), source_xy=xy, fwhm=4.0, verbose=False, collapse_ifs="median")
+    assert np.nanmax(np.abs(only - O.cube_collapse(np.stack([r[1] for r in refs]), "median"))) < TOL
+    # the per-channel grid cubes are those of the unscored grid, which the reference-generated fixtures pin
+    # (a list ncomp whose length differs from the number of channels is a grid for every channel, :548-551)
+    fo = pca(c4, ang, ncomp=[1, 2, 3, 4, 5], full_output=True, verbose=False)
+    assert np.nanmax(np.abs(fo[2] - cubes)) < 1e-6

@@ -47,6 +47,8 @@ _SIGS = {
                               ctypes.c_int),
     "vipmi_derotate_f32": ([c_f32p, ctypes.c_void_p, i64, i64, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int],
                            True, ctypes.c_int),
+    "vipmi_derotate_maskval_f32": ([c_f32p, ctypes.c_void_p, i64, i64, c_f32p, ctypes.c_float, ctypes.c_int], True,
+                                   ctypes.c_int),
     "vipmi_rotate_interp_f32": ([c_f32p, ctypes.c_void_p, i64, i64, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                  ctypes.c_int, c_f32p],
                                 True, ctypes.c_int),

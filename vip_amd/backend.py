@@ -446,7 +446,19 @@ import contextvars
 
 # rotation used by derotate(): set by rotation_mode() / with_rotation; a ContextVar, so concurrent calls from different
 # threads (or asyncio tasks) with different `imlib` values never see each other's choice
-_ROTATION = contextvars.ContextVar("vipmi_rotation", default=("vip-fft", "lanczos4", "constant"))
+_ROTATION = contextvars.ContextVar("vipmi_rotation", default=("vip-fft", "lanczos4", "constant", None))
+
+
+def other_mask_value(mask_val):
+    """frame_rotate's ``mask_val`` when it is neither NaN nor 0 (the two cases every device entry takes as flags):
+    the float the 'vip-fft' rotation resets matching pixels to (derotation.py:133-140,324-326); else None."""
+    if mask_val is None:
+        return None
+    try:
+        v = float(mask_val)
+    except (TypeError, ValueError):
+        raise TypeError("mask_val must be a number")
+    return None if (v != v or v == 0.0) else v
 
 
 def check_border(border_mode):
@@ -474,9 +486,10 @@ def check_imlib(imlib, interpolation="lanczos4"):
 class rotation_mode:
     """``with rotation_mode(imlib, interpolation):`` -- every ``derotate`` inside uses that rotation."""
 
-    def __init__(self, imlib, interpolation="lanczos4", border_mode="constant"):
+    def __init__(self, imlib, interpolation="lanczos4", border_mode="constant", mask_val=None):
         self.mode = list(check_imlib(imlib, interpolation))
         self.mode.append(check_border(border_mode) if self.mode[0] == "opencv" else "constant")
+        self.mode.append(other_mask_value(mask_val))
 
     def __enter__(self):
         self.token = _ROTATION.set(tuple(self.mode))
@@ -499,7 +512,7 @@ def with_rotation(fn):
         b.apply_defaults()
         extra = b.arguments.get("rot_options", None) or {}
         with rotation_mode(b.arguments.get("imlib", "vip-fft"), b.arguments.get("interpolation", "lanczos4"),
-                           extra.get("border_mode", "constant")):
+                           extra.get("border_mode", "constant"), extra.get("mask_val")):
             return fn(*a, **k)
     return wrapper
 
@@ -518,7 +531,9 @@ def rotate_interp(cube, angles, interpolation="lanczos4", cxy=None, out=None, bo
     return out
 
 
-def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=None):
+def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=None, mask_val=None):
+    """``mask_nan`` / ``mask_zero``: the NaN and 0 cases of frame_rotate's ``mask_val``; any other value comes in
+    through ``mask_val`` or the enclosing ``rotation_mode`` (rot_options['mask_val'] of the front-ends)."""
     rot = _ROTATION.get()
     if rot[0] == "opencv":
         return rotate_interp(cube, angles, rot[1], out=out, border_mode=rot[2])
@@ -528,6 +543,16 @@ def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=No
         raise ValueError("vip-fft derotation on the device requires square frames")
     out = empty(cube.shape, device=cube.device.index) if out is None else out
     ah, ap = host_f64(angles)
+    mv = other_mask_value(mask_val)
+    if mv is None and mask_val is None:
+        mv = rot[3]
+    if mv is not None:
+        if float(np.float32(mv)) != mv:
+            # a value float32 cannot hold: no float32 pixel equals it (the reference compares in float64), nothing to reset
+            ctx.call("vipmi_derotate_f32", ptr(cube), ap, n, Ny, ptr(out), 0, 0, ROT_METHODS[method])
+        else:
+            ctx.call("vipmi_derotate_maskval_f32", ptr(cube), ap, n, Ny, ptr(out), ctypes.c_float(mv), ROT_METHODS[method])
+        return out
     ctx.call("vipmi_derotate_f32", ptr(cube), ap, n, Ny, ptr(out), int(bool(mask_nan)), int(bool(mask_zero)),
              ROT_METHODS[method])
     return out

@@ -455,6 +455,13 @@ int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_hos
   return derotate_f32(ctx, in, angles_host, n, N, out, mask_nan, mask_zero, method);
 }
 
+int vipmi_derotate_maskval_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
+                               float* out, float mask_val, int method) {
+  CTX_GUARD();
+  const bool nan = !(mask_val == mask_val);
+  return derotate_f32(ctx, in, angles_host, n, N, out, nan ? 1 : 0, nan ? 0 : 1, method, nan ? 0.f : mask_val);
+}
+
 int vipmi_rotate_interp_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
                             double cx, double cy, int interp, int border, float* out) {
   CTX_GUARD();

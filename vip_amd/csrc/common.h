@@ -165,7 +165,7 @@ int scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
 int apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
                    const uint8_t* mask, float fill);
 int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
-                 float* out, int mask_nan, int mask_zero, int method);
+                 float* out, int mask_nan, int mask_zero, int method, float mask_v = 0.f);
 int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t nb, int64_t n, int64_t k, int64_t P,
                         float* R);
 int collapse_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, int mode, const float* w,

@@ -17,9 +17,9 @@
 namespace vipmi {
 
 int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
-                  float* out, int mask_nan, int mask_zero);  // derotate_fft2.hip (real-split, default)
+                  float* out, int mask_nan, int mask_zero, float mask_v);  // derotate_fft2.hip (real-split, default)
 int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
-                     float* out, int mask_nan, int mask_zero);  // derotate_direct2.hip (real-split correlations)
+                     float* out, int mask_nan, int mask_zero, float mask_v);  // derotate_direct2.hip (real-split correlations)
 
 // host-side geometry / angle split (derotation.py:154-158, cosmetics.py:210-215, derotation.py:577-602)
 static void rot_geometry(int N, RotGeom& g) {
@@ -61,7 +61,7 @@ static RotFrame rot_frame(double angle) {
 }
 
 int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
-                 float* out, int mask_nan, int mask_zero, int method) {
+                 float* out, int mask_nan, int mask_zero, int method, float mask_v) {
   VIPMI_REQUIRE(in && out && angles_host, "derotate: null pointer");
   VIPMI_REQUIRE(n > 0 && N >= 2 && N <= 4096, "derotate: bad sizes n=%ld N=%ld", (long)n, (long)N);
   VIPMI_REQUIRE(in != out, "derotate: in-place operation not supported");
@@ -82,9 +82,9 @@ int derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int
     set_error("derotate: FFT path needs a power-of-two padded length (frame size 128/256/512/1024), got Le=%d", g.Le);
     return VIPMI_ERR_UNSUPPORTED;
   }
-  if (use_fft) return derotate_fft2(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);     // real-split FFT shears
+  if (use_fft) return derotate_fft2(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);     // real-split FFT shears
   // any other padded length: the same decomposition as convolutions / correlations (derotate_direct2.hip)
-  return derotate_direct2(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+  return derotate_direct2(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
 }
 
 }  // namespace vipmi

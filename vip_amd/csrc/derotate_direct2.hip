@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void ds_gamma(AuxD aux, int Le) {
 template <int NA>           // outputs per lane: 8 for long rows, 4 where N / 8 lanes would leave most of a wave idle
 __global__ __launch_bounds__(1024) void ds_shear3(const float* __restrict__ A2r, const RotFrame* __restrict__ fr,
                                                  RotGeom g, const float* __restrict__ in, float* __restrict__ out,
-                                                 AuxD aux, int f0, int mask_nan, int mask_zero, int Npad, int Lpad) {
+                                                 AuxD aux, int f0, int mask_nan, int mask_zero, float mask_v, int Npad, int Lpad) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* x = smem;                       // [Lpad]
   float* xo = x + Lpad;                  // [Lpad + 8]  xo[k] = x[k-1]
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(1024) void ds_shear3(const float* __restrict__ A2r,
     re -= sg * c1;
     const float srcv = in[ob + j];
     if (mask_nan && !(srcv == srcv)) re = __uint_as_float(0x7fc00000u);
-    if (mask_zero && srcv == 0.f) re = 0.f;
+    if (mask_zero && srcv == mask_v) re = mask_v;
     out[ob + j] = re;
   }
 }
@@ -458,7 +458,7 @@ static void launch_aux_k(vipmi_ctx* ctx, unsigned nf, size_t ldsk, const RotFram
 }  // namespace
 
 int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n, float* out,
-                     int mask_nan, int mask_zero) {
+                     int mask_nan, int mask_zero, float mask_v) {
   // paddings: multiples of 2 TNA (a lane pair owns 2 TNA outputs) with at least one zero after the last input
   const int Npad = (int)cdiv(g.N + 1, 2 * TNA) * 2 * TNA, Lpad = (int)cdiv(g.Le + 1, 2 * TNA) * 2 * TNA;
   // 129 .. 512 px: the three passes as power-of-two circular convolutions (derotate_conv.inc) on blocked intermediates
@@ -527,9 +527,9 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
     const unsigned nf = (unsigned)((n - f0) < chunk ? (n - f0) : chunk);
     if (conv) {
       if (2 * g.N - 1 <= 512)
-        VIPMI_TRY((conv_passes<fftw::Plan512>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk, aux_H)));
+        VIPMI_TRY((conv_passes<fftw::Plan512>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, mask_v, ldsk, aux_H)));
       else
-        VIPMI_TRY((conv_passes<fftw::Plan1024>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, ldsk, aux_H)));
+        VIPMI_TRY((conv_passes<fftw::Plan1024>(ctx, in, d_frames, g, reinterpret_cast<float4*>(A1r), reinterpret_cast<float4*>(A2r), lay, aux, f0, (int)nf, out, mask_nan, mask_zero, mask_v, ldsk, aux_H)));
       continue;
     }
     ctx->tic("k_rot_s1");
@@ -557,10 +557,10 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
     ctx->tic("k_rot_s3");
     if (na3 == 8)
       hipLaunchKernelGGL(ds_shear3<8>, dim3(g.N, nf), dim3(t3), lds3, ctx->stream, A2r, d_frames, g, in, out, aux,
-                         (int)f0, mask_nan, mask_zero, Npad, Lpad);
+                         (int)f0, mask_nan, mask_zero, mask_v, Npad, Lpad);
     else
       hipLaunchKernelGGL(ds_shear3<4>, dim3(g.N, nf), dim3(t3), lds3, ctx->stream, A2r, d_frames, g, in, out, aux,
-                         (int)f0, mask_nan, mask_zero, Npad, Lpad);
+                         (int)f0, mask_nan, mask_zero, mask_v, Npad, Lpad);
     ctx->toc("k_rot_s3");
     VIPMI_CHECK_HIP(hipGetLastError());
   }

@@ -676,7 +676,7 @@ template <class P>
 __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict__ A2r,
                                                          const RotFrame* __restrict__ fr, RotGeom g,
                                                          const float* __restrict__ in, float* __restrict__ out,
-                                                         Aux aux, int f0, int nf, int mask_nan, int mask_zero,
+                                                         Aux aux, int f0, int nf, int mask_nan, int mask_zero, float mask_v,
                                                          const cf* __restrict__ twtab, int* __restrict__ counters) {
   VIPMI_SLOT_PROLOGUE();
   constexpr bool PW = P::WPL == 1;
@@ -740,8 +740,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
           const float src1 = in[ob1 + j], src2 = in[ob2 + j];
           if (mask_nan && !(src1 == src1)) re1 = __uint_as_float(0x7fc00000u);
           if (mask_nan && !(src2 == src2)) re2 = __uint_as_float(0x7fc00000u);
-          if (mask_zero && src1 == 0.f) re1 = 0.f;
-          if (mask_zero && src2 == 0.f) re2 = 0.f;
+          if (mask_zero && src1 == mask_v) re1 = mask_v;
+          if (mask_zero && src2 == mask_v) re2 = mask_v;
           out[ob1 + j] = re1;
           out[ob2 + j] = re2;
         }
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
 
 template <class P>
 int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n, float* out,
-              int mask_nan, int mask_zero) {
+              int mask_nan, int mask_zero, float mask_v) {
   constexpr bool BLK = P::WPL == 1;                         // blocked intermediates (see Blk)
   VIPMI_REQUIRE(4 * g.N == P::L && 8 * g.off == 3 * P::L, "derotate(fft2): unexpected canvas geometry");
   const int64_t per_frame = (int64_t)(BLK ? g.N + 2 : g.N) * P::L;     // floats per intermediate per frame
@@ -851,7 +851,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     ctx->toc("k_rot_aux");
     ctx->tic("k_rot_s3");
     hipLaunchKernelGGL(k3, dim3(gr), blk, lds, ctx->stream, A2r, d_frames, g, in, out, aux, (int)f0, nf, mask_nan,
-                       mask_zero, twtab, counters + 512);
+                       mask_zero, mask_v, twtab, counters + 512);
     ctx->toc("k_rot_s3");
     VIPMI_CHECK_HIP(hipGetLastError());
   }
@@ -861,20 +861,20 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
 }  // namespace
 
 int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const RotGeom& g, int64_t n,
-                  float* out, int mask_nan, int mask_zero) {
+                  float* out, int mask_nan, int mask_zero, float mask_v) {
   switch (g.Le) {
-    case 512: return run_plan2<Plan512>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 512: return run_plan2<Plan512>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
     // one plan per padded length.  Measured and dropped from the build (NOTES.md): 4-wave workgroups at Le = 1024 (+4 %
     // stand-alone, but with two calls in flight the other call's eigensolver finds no free CU: C4 +11 %); two waves per
     // line at Le = 2048 with 12 or 16 waves per workgroup (3 waves per SIMD, but workgroup barriers and 1.5x the
     // instructions per line: 6.2 against 3.8 ms at C2); four waves per line at Le = 4096.
-    case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-    case 2048: return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+    case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
+    case 2048: return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
     case 4096:
       // one wave per line and per SIMD (512-VGPR budget), column shear software-pipelined: 200 frames of 1024 px
       // 10.85 -> 9.4 ms against the two-wave plan (kept behind rot_4096_w1=0)
-      if (ctx->opt("rot_4096_w1", 1)) return run_plan2<Plan4096w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
-      return run_plan2<Plan4096w2>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero);
+      if (ctx->opt("rot_4096_w1", 1)) return run_plan2<Plan4096w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
+      return run_plan2<Plan4096w2>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
     default:
       set_error("derotate(fft2): unsupported padded length %d", g.Le);
       return VIPMI_ERR_UNSUPPORTED;

@@ -47,8 +47,10 @@ def inverse_stim_map(cube, angle_list, **rot_options):
     dev_in = B.is_device_tensor(cube)
     t = B.to_device_f32(cube)
     with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4"),
-                         rot_options.get("border_mode", "constant")):
-        der = B.derotate(t, -np.asarray(angle_list, dtype=np.float64))
+                         rot_options.get("border_mode", "constant"), rot_options.get("mask_val")):
+        mask_val = rot_options.get("mask_val", np.nan)
+        mv_nan = isinstance(mask_val, float) and bool(np.isnan(mask_val))
+        der = B.derotate(t, -np.asarray(angle_list, dtype=np.float64), mask_nan=mv_nan, mask_zero=not mv_nan)
     return _wrap(_stim_dev(der), dev_in, cube)
 
 
@@ -70,6 +72,6 @@ def normalized_stim_map(cube, angle_list, mask=None, **rot_options):
     if max_inv <= 0:
         raise ValueError("The normalization value is found to be {}".format(max_inv))
     with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4"),
-                         rot_options.get("border_mode", "constant")):
+                         rot_options.get("border_mode", "constant"), rot_options.get("mask_val")):
         der = B.derotate(t, np.asarray(angle_list, dtype=np.float64))
     return _wrap(B.lincomb(_stim_dev(der), None, 1.0 / max_inv), dev_in, cube)

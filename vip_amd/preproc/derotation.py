@@ -19,10 +19,7 @@ def _check_rot_options(imlib, cxy, edge_blend, mask_val, shape, interpolation="l
         cx, cy = cxy
         if (cy, cx) != (shape[0] // 2, shape[1] // 2):
             raise ValueError("'vip-fft' imlib does not yet allow for custom center to be  provided ")
-    mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
-    if not mv_nan and mask_val != 0:
-        raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
-    return mv_nan
+    return isinstance(mask_val, float) and bool(np.isnan(mask_val))
 
 
 def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", cxy=None, nproc=1,
@@ -47,7 +44,7 @@ def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", 
         out = B.rotate_interp(t, angle_list, str(getattr(interpolation, "value", interpolation)), cxy=cxy,
                               border_mode=border_mode)
     else:
-        out = B.derotate(t, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan, method=method)
+        out = B.derotate(t, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan, method=method, mask_val=mask_val)
     if dev_in:
         return out
     return out.cpu().numpy().astype(array.dtype if array.dtype.kind == "f" else np.float64, copy=False)

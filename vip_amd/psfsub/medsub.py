@@ -127,7 +127,7 @@ def median_sub(*all_args: List, **all_kwargs: dict):
         raise TypeError("Input array is not a 3d or 4d array")
     if cube.ndim == 4:
         raise NotImplementedError("4-D (SDI) median subtraction is not accelerated")
-    rot_mode = B.rotation_mode(algo_params.imlib, algo_params.interpolation, rot_options.get("border_mode", "constant"))    # 'vip-fft' or 'opencv' (medsub.py:376-387)
+    rot_mode = B.rotation_mode(algo_params.imlib, algo_params.interpolation, rot_options.get("border_mode", "constant"), rot_options.get("mask_val"))    # 'vip-fft' or 'opencv' (medsub.py:376-387)
     if algo_params.mode not in ("fullfr", "annular"):
         raise RuntimeError("Mode not recognized")
     annular = algo_params.mode == "annular"
@@ -169,8 +169,6 @@ def median_sub(*all_args: List, **all_kwargs: dict):
         print("Optimized median psf reference subtracted" if annular else "Median psf reference subtracted")
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
-    if not mv_nan and mask_val != 0:
-        raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
     with rot_mode:
         cube_der = B.derotate(cube_out, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
     if algo_params.radius_int:

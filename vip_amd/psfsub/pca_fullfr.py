@@ -227,8 +227,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         raise ValueError("Number of PCs too low. It should be > 0.")
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
-    if not mv_nan and mask_val != 0 and _s(imlib) != "opencv":       # (mask_val is unused by the opencv rotation)
-        raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
+    mv_other = B.other_mask_value(mask_val) is not None     # neither NaN nor 0: B.derotate takes it from the rotation scope
     if rot_options.get("edge_blend") not in (None, ""):
         raise NotImplementedError("edge_blend is outside the accelerated path")
     scaling = _s(scaling)
@@ -285,7 +284,7 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
         return svd_wrapper(m, svd_mode, min(int(ncomp), n), False, left_eigv=True).t().contiguous()
 
     fused_ok = (cube_ref is None and cube_sig is None and n <= B.MAX_EIGH_N and _s(imlib) == "vip-fft" and isinstance(ncomp, (int, np.integer)) and collapse in
-                ("median", "mean", "sum", "max", "absmean") and (bool(mask_center_px) != mv_nan))
+                ("median", "mean", "sum", "max", "absmean") and (bool(mask_center_px) != mv_nan) and not mv_other)
     if fused_ok:
         # one call into the C ABI: mask/scale -> Gram -> eigh -> project -> derotate -> collapse
         mask = None
@@ -446,57 +445,57 @@ def pca(*all_args: List, **all_kwargs: dict):
         from .pca_msdi import adimsdi_double, adimsdi_single
         mask_val = rot_options.get("mask_val", np.nan)
         mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
-        if not mv_nan and mask_val != 0:
-            raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
-        collapse = _s(algo_params.collapse)
-        if collapse not in B.COLLAPSE_MODES or collapse == "stim":
-            raise TypeError("mode not recognized")
-        mode = _s(algo_params.adimsdi)
-        if mode == "double":
-            rcc, rcc_, frame = adimsdi_double(cube_t, algo_params.angle_list, algo_params.scale_list,
-                                              algo_params.ncomp, algo_params.scaling, algo_params.mask_center_px,
-                                              collapse, algo_params.collapse_ifs, algo_params.ifs_collapse_range,
-                                              algo_params.weights, mv_nan, algo_params.verbose)
-            # the reference's scale_fft returns float32 when it crops the spectrum (down-scaling) and float64 when it
-            # pads it or leaves a channel untouched (scale 1): mirror the resulting dtype of the collapsed frames
-            dt = None
-            if algo_params.ncomp[0] is not None:
-                z_ = cube.shape[0]
-                r0, r1 = (0, z_) if algo_params.ifs_collapse_range == "all" else algo_params.ifs_collapse_range
-                sl = np.asarray(algo_params.scale_list, dtype=np.float64)[r0:r1]
-                dt = np.float64 if np.any(sl <= 1) else np.float32
-            if algo_params.full_output:
-                return host(frame, dt), host(rcc, dt), host(rcc_, dt)
-            return host(frame, dt)
-        if mode == "single":
-            ref_t = None
-            if algo_params.cube_ref is not None:
-                ref_t = B.to_device_f32(algo_params.cube_ref)
-                if "A" in _s(algo_params.ref_strategy):          # e.g. 'ARSDI': the science frames join the library
-                    ref_t = B._torch().cat((cube_t, ref_t), dim=1)
-            grid = isinstance(algo_params.ncomp, (tuple, list))
-            res = adimsdi_single(cube_t, algo_params.angle_list, algo_params.scale_list,
-                                 algo_params.ncomp, _s(algo_params.scaling),
-                                 algo_params.mask_center_px, collapse, algo_params.collapse_ifs,
-                                 algo_params.ifs_collapse_range, algo_params.crop_ifs,
-                                 algo_params.weights, mv_nan, algo_params.verbose, cube_ref=ref_t,
-                                 grid_args=dict(fwhm=algo_params.fwhm, source_xy=algo_params.source_xy,
-                                                full_output=algo_params.full_output, rot_options=rot_options))
-            if grid:
-                # returns of the single-pass grid (pca_fullfr.py:744-755)
-                if algo_params.source_xy is None:
-                    if algo_params.full_output:
-                        return host(res[0], np.float64), res[1]
-                    return host(res, np.float64)
-                cubeout, finalfr, table, _ = res
+        # (the rotation scope carries a mask_val that is neither NaN nor 0 to every B.derotate of the mSDI passes)
+        with B.rotation_mode("vip-fft", "lanczos4", "constant", mask_val):
+            collapse = _s(algo_params.collapse)
+            if collapse not in B.COLLAPSE_MODES or collapse == "stim":
+                raise TypeError("mode not recognized")
+            mode = _s(algo_params.adimsdi)
+            if mode == "double":
+                rcc, rcc_, frame = adimsdi_double(cube_t, algo_params.angle_list, algo_params.scale_list,
+                                                  algo_params.ncomp, algo_params.scaling, algo_params.mask_center_px,
+                                                  collapse, algo_params.collapse_ifs, algo_params.ifs_collapse_range,
+                                                  algo_params.weights, mv_nan, algo_params.verbose)
+                # the reference's scale_fft returns float32 when it crops the spectrum (down-scaling) and float64 when it
+                # pads it or leaves a channel untouched (scale 1): mirror the resulting dtype of the collapsed frames
+                dt = None
+                if algo_params.ncomp[0] is not None:
+                    z_ = cube.shape[0]
+                    r0, r1 = (0, z_) if algo_params.ifs_collapse_range == "all" else algo_params.ifs_collapse_range
+                    sl = np.asarray(algo_params.scale_list, dtype=np.float64)[r0:r1]
+                    dt = np.float64 if np.any(sl <= 1) else np.float32
                 if algo_params.full_output:
-                    return host(cubeout, np.float64), host(finalfr, np.float64), table
-                return host(finalfr, np.float64)
-            allfr, desc, adi, frame = res
-            if algo_params.full_output:
-                return host(frame, np.float64), host(allfr, np.float64), host(desc), host(adi, np.float64)
-            return host(frame, np.float64)
-        raise ValueError("`adimsdi` mode not recognized")
+                    return host(frame, dt), host(rcc, dt), host(rcc_, dt)
+                return host(frame, dt)
+            if mode == "single":
+                ref_t = None
+                if algo_params.cube_ref is not None:
+                    ref_t = B.to_device_f32(algo_params.cube_ref)
+                    if "A" in _s(algo_params.ref_strategy):          # e.g. 'ARSDI': the science frames join the library
+                        ref_t = B._torch().cat((cube_t, ref_t), dim=1)
+                grid = isinstance(algo_params.ncomp, (tuple, list))
+                res = adimsdi_single(cube_t, algo_params.angle_list, algo_params.scale_list,
+                                     algo_params.ncomp, _s(algo_params.scaling),
+                                     algo_params.mask_center_px, collapse, algo_params.collapse_ifs,
+                                     algo_params.ifs_collapse_range, algo_params.crop_ifs,
+                                     algo_params.weights, mv_nan, algo_params.verbose, cube_ref=ref_t,
+                                     grid_args=dict(fwhm=algo_params.fwhm, source_xy=algo_params.source_xy,
+                                                    full_output=algo_params.full_output, rot_options=rot_options))
+                if grid:
+                    # returns of the single-pass grid (pca_fullfr.py:744-755)
+                    if algo_params.source_xy is None:
+                        if algo_params.full_output:
+                            return host(res[0], np.float64), res[1]
+                        return host(res, np.float64)
+                    cubeout, finalfr, table, _ = res
+                    if algo_params.full_output:
+                        return host(cubeout, np.float64), host(finalfr, np.float64), table
+                    return host(finalfr, np.float64)
+                allfr, desc, adi, frame = res
+                if algo_params.full_output:
+                    return host(frame, np.float64), host(allfr, np.float64), host(desc), host(adi, np.float64)
+                return host(frame, np.float64)
+            raise ValueError("`adimsdi` mode not recognized")
     cube_ref_t = None
     if algo_params.cube_ref is not None:
         cube_ref_t = B.to_device_f32(algo_params.cube_ref)
@@ -580,10 +579,21 @@ def pca(*all_args: List, **all_kwargs: dict):
         grid_ch = [isinstance(kc, (tuple, list)) for kc in ncomps]
         if any(grid_ch):
             # per-channel PCA grid (pca_fullfr.py:614-617,626-629,639-646): one collapsed frame per grid entry
-            if algo_params.source_xy is not None:
-                raise NotImplementedError("the S/N-scored pca_grid on 4-D cubes is outside the accelerated path")
             if not all(grid_ch):
                 raise TypeError("`ncomp` must be a grid for every channel or for none")
+            if algo_params.source_xy is not None:
+                # per-channel grids scored by the S/N at source_xy (pca_fullfr.py:604-612): the channel's frame is its
+                # best-S/N frame; returns (per-channel grid cubes, frame, tables[, ifs_adi_frames]).  `med_of_npcs`
+                # takes the reference's median over axis 0 of the stacked grid cubes -- the channel axis (:718-719).
+                cubes_ch = torch.stack([o[0] for o in outs])                   # (nch, n_grid, y, x)
+                ifs = torch.stack([o[1] for o in outs])
+                tables = [o[2] for o in outs]
+                frame = B.collapse(ifs, _s(algo_params.collapse_ifs))
+                if algo_params.med_of_npcs:
+                    cubes_ch = B.collapse(cubes_ch.reshape(nch, -1, 1).contiguous(), "median").reshape(cubes_ch.shape[1:])
+                if fo:
+                    return host(cubes_ch, np.float64), host(frame, np.float64), tables, host(ifs, np.float64)
+                return host(frame, np.float64)
             cubes_ch = torch.stack([o[0] if fo else o for o in outs])          # (nch, n_grid, y, x)
             final = torch.stack([B.collapse(cubes_ch[:, i].contiguous(), _s(algo_params.collapse_ifs))
                                  for i in range(cubes_ch.shape[1])])

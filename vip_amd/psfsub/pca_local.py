@@ -386,8 +386,6 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             do_segment(si, seg)
     mask_val = rot_options.get("mask_val", np.nan)
     mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
-    if not mv_nan and mask_val != 0:
-        raise NotImplementedError("mask_val must be np.nan or 0 on the device path")
     if ks is not None:
         cube_der = torch.stack([B.derotate(cube_out[nn], angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
                                 for nn in range(len(ks))])

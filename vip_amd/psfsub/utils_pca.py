@@ -156,7 +156,7 @@ def pca_grid(cube, angle_list, fwhm=None, range_pcs=None, source_xy=None, cube_r
     ctx = B.get_context(cube_t.device.index)
     npx = M.shape[1]
     with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4"),
-                         rot_options.get("border_mode", "constant")):
+                         rot_options.get("border_mode", "constant"), rot_options.get("mask_val")):
         frames = []
         for pc in pclist:
             C = coeff[:, :pc].contiguous()
@@ -246,7 +246,7 @@ def pca_annulus(cube, angs, ncomp, annulus_width, r_guess, cube_ref=None, svd_mo
         ctx.call("vipmi_scatter_f32", B.ptr(res.contiguous()), n, ysz * xsz, B.ptr(pix_t), int(pix_t.numel()),
                  B.ptr(cube_zeros))
         with B.rotation_mode(rot_options.get("imlib", "vip-fft"), rot_options.get("interpolation", "lanczos4"),
-                             rot_options.get("border_mode", "constant")):
+                             rot_options.get("border_mode", "constant"), rot_options.get("mask_val")):
             out = cube_zeros if angles is None else B.derotate(cube_zeros, angles, mask_nan=mv_nan, mask_zero=not mv_nan)
         if collapse is not None:
             return B.collapse(out, collapse, w=weights)
