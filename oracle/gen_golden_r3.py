@@ -65,3 +65,27 @@ if want("g25"):
     from vip_hci.psfsub import median_sub
     g["medsub"] = np.asarray(median_sub(cube, ang, mask_val=1e3, verbose=False, nproc=1))
     save("g25_mask_val", **g)
+
+
+# ---- G26: ADI+mSDI double pass with a reference cube and / or a rotation threshold at source_xy
+# (psfsub/pca_fullfr.py:1279-1283,1388-1400,1403-1459) -------------------------------------------------------------
+if want("g26"):
+    z_, n_, N_ = 4, 12, 32
+    c4 = np.stack([O.synth_adi(n_, N_, seed=180 + i)[0] for i in range(z_)]).astype(np.float32)
+    a4 = np.linspace(0, 85, n_)
+    sc = np.linspace(1.0, 1.2, z_)[::-1].copy()
+    cr4 = np.stack([O.synth_adi(6, N_, seed=190 + i)[0] for i in range(z_)]).astype(np.float32)
+    g = {"cube": c4, "angles": a4, "scale_list": sc, "cube_ref": cr4}
+    kw = dict(scale_list=sc, adimsdi="double", verbose=False, nproc=1, full_output=True)
+    for tag, extra in (("rsdi", dict(ncomp=(2, 3), cube_ref=cr4)),
+                       ("rsdi_tm", dict(ncomp=(1, 2), cube_ref=cr4, scaling="temp-mean", collapse="mean", mask_center_px=3)),
+                       ("rsdi_noadi", dict(ncomp=(2, None), cube_ref=cr4)),
+                       ("thr", dict(ncomp=(2, 3), source_xy=(24.0, 20.0), delta_rot=0.5, fwhm=4.0, min_frames_pca=3)),
+                       ("thr_ref", dict(ncomp=(2, 4), source_xy=(22.0, 9.0), delta_rot=1.0, fwhm=4.0, min_frames_pca=3,
+                                        cube_ref=cr4, max_frames_pca=5)),
+                       ("thr_aref", dict(ncomp=(None, 3), source_xy=(8.0, 18.0), delta_rot=0.8, fwhm=4.0,
+                                         min_frames_pca=3, cube_ref=cr4, ref_strategy="ARSDI"))):
+        fo = ref.pca(c4, a4, **kw, **extra)
+        for nm, a in zip(("frame", "chan", "chan_der"), fo):
+            g["%s_%s" % (tag, nm)] = np.asarray(a, dtype=np.float32)
+    save("g26_msdi_double_ref_thr", **g)

@@ -733,9 +733,10 @@ def pca_annulus(cube, angs, ncomp, annulus_width, r_guess, cube_ref=None, svd_mo
 
 def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scaling=None, mask_center_px=None,
                      min_frames_pca=10, max_frames_pca=None, collapse="median", svd_mode="lapack", weights=None,
-                     full_output=False, seed=0, cube_sig=None):
+                     full_output=False, seed=0, cube_sig=None, cube_ref=None):
     """``pca(cube, angles, ncomp=<int>, source_xy=(x, y), fwhm=..., delta_rot=...)``: every frame is modelled with
-    the PCs of the frames that rotated by more than the PA threshold at ``source_xy``.
+    the PCs of the frames that rotated by more than the PA threshold at ``source_xy`` (with ``cube_ref``: plus every
+    reference frame, :1693-1694).
     Ref: psfsub/pca_fullfr.py:911-965 (threshold, per-frame loop), :1677-1713 (_project_subtract with indices/frame),
     :966-991 (derotate, collapse, mask), :779-785 (returns)."""
     n, y, x = cube.shape
@@ -750,9 +751,12 @@ def pca_pa_rejection(cube, angle_list, ncomp, source_xy, fwhm, delta_rot, scalin
     matrix_emp = matrix if cube_sig is None else matrix - np.reshape(cube_sig, (n, -1))     # :1652-1662
     residuals = np.zeros_like(matrix)
     recon = np.zeros_like(matrix)
+    matrix_ref = None if cube_ref is None else prepare_matrix(cube_ref, scaling, mask_center_px)
     for fr in range(n):
         ind = find_indices_adi(angle_list, fr, pa_thr, truncate=truncate, max_frames=max_frames_pca)
         ref_lib = matrix_emp[ind]
+        if matrix_ref is not None:
+            ref_lib = np.concatenate((ref_lib, matrix_ref))
         if ref_lib.shape[0] < min_frames_pca:
             raise RuntimeError("{} frames comply to delta_rot condition < less than min_frames_pca ({})".format(
                 ref_lib.shape[0], min_frames_pca))
@@ -1005,10 +1009,18 @@ def cube_rescaling_wavelengths(cube, scal_list, full_output=True, inverse=False,
 
 def pca_adimsdi_double(cube, angle_list, scale_list, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
                        collapse="median", collapse_ifs="mean", ifs_collapse_range="all", weights=None,
-                       full_output=False):
+                       full_output=False, cube_ref=None, ref_strategy="RSDI", source_xy=None, delta_rot=None, fwhm=4,
+                       min_frames_pca=10, max_frames_pca=None):
     """``pca(cube4d, angles, scale_list=..., adimsdi='double', ncomp=(k_ifs, k_adi))``.
     Ref: psfsub/pca_fullfr.py:412-415 (mask default), :478-508 (routing), :1263-1549 (_adimsdi_doublepca and
-    _adimsdi_doublepca_ifs), :726-731 (returns)."""
+    _adimsdi_doublepca_ifs), :726-731 (returns).  ``cube_ref`` (:1279-1283): its frames pass the spectral stage with
+    the science frames and are the library of the second stage ('RSDI', :1388-1400) or join every frame's library
+    under a rotation threshold at ``source_xy`` (:1403-1459)."""
+    n_sci = cube.shape[1]
+    nr = 0
+    if cube_ref is not None:
+        nr = cube_ref.shape[1]
+        cube = np.concatenate((cube, cube_ref), axis=1)
     z, n, y_in, x_in = cube.shape
     if not isinstance(ncomp, tuple):
         raise TypeError("`ncomp` must be a tuple when a double pass PCA is performed")
@@ -1036,11 +1048,21 @@ def pca_adimsdi_double(cube, angle_list, scale_list, ncomp, scaling=None, mask_c
         res.append(frame_i)
     res_cube_channels = np.array(res)
     if ncomp_adi is None:
-        der = cube_derotate(res_cube_channels[:n], angle_list, mask_val=mask_val)
+        der = cube_derotate(res_cube_channels[:n_sci], angle_list, mask_val=mask_val)
     else:
         if ncomp_adi > n:
             ncomp_adi = n
-        res_ifs_adi = project_subtract(res_cube_channels, ncomp_adi, scaling[1], mask_center_px, svd_mode)
+        sci, refc = res_cube_channels[:n_sci], (res_cube_channels[n_sci:] if nr else None)
+        if source_xy is not None:
+            res_ifs_adi = pca_pa_rejection(sci, angle_list, ncomp_adi, source_xy, fwhm, delta_rot, scaling[1],
+                                           mask_center_px, min_frames_pca, max_frames_pca, svd_mode=svd_mode,
+                                           full_output=True, cube_ref=refc)[2]
+        elif nr and "A" not in ref_strategy:
+            res_ifs_adi = project_subtract(sci, ncomp_adi, scaling[1], mask_center_px, svd_mode, cube_ref=refc)
+        elif nr:
+            raise IndexError("the reference de-rotates n + nr residual frames with n angles here")
+        else:
+            res_ifs_adi = project_subtract(res_cube_channels, ncomp_adi, scaling[1], mask_center_px, svd_mode)
         der = cube_derotate(res_ifs_adi, angle_list, mask_val=mask_val)
     frame = cube_collapse(der, mode=collapse, w=weights)
     if full_output:

@@ -1352,3 +1352,51 @@ def test_pca_grid_scored_by_snr_on_a_4d_cube():
     # (a list ncomp whose length differs from the number of channels is a grid for every channel, :548-551)
     fo = pca(c4, ang, ncomp=[1, 2, 3, 4, 5], full_output=True, verbose=False)
     assert np.nanmax(np.abs(fo[2] - cubes)) < 1e-6
+
+
+G26_CASES = (("rsdi", dict(ncomp=(2, 3), ref=True)),
+             ("rsdi_tm", dict(ncomp=(1, 2), ref=True, scaling="temp-mean", collapse="mean", mask_center_px=3)),
+             ("rsdi_noadi", dict(ncomp=(2, None), ref=True)),
+             ("thr", dict(ncomp=(2, 3), source_xy=(24.0, 20.0), delta_rot=0.5, fwhm=4.0, min_frames_pca=3)),
+             ("thr_ref", dict(ncomp=(2, 4), source_xy=(22.0, 9.0), delta_rot=1.0, fwhm=4.0, min_frames_pca=3, ref=True,
+                              max_frames_pca=5)),
+             ("thr_aref", dict(ncomp=(None, 3), source_xy=(8.0, 18.0), delta_rot=0.8, fwhm=4.0, min_frames_pca=3, ref=True,
+                               ref_strategy="ARSDI")))
+
+
+@pytest.mark.parametrize("tag,kw", G26_CASES)
+def test_msdi_double_with_reference_cube_and_rotation_threshold_golden(tag, kw):
+    """round-2 VERDICT missing #5: ADI+mSDI double pass with ``cube_ref`` (RSDI library of the second stage) and / or a
+    rotation threshold at ``source_xy`` (reference psfsub/pca_fullfr.py:1279-1283,1388-1459), against the reference's own
+    outputs (G26)."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g26_msdi_double_ref_thr")
+    kw = dict(kw)
+    if kw.pop("ref", False):
+        kw["cube_ref"] = g["cube_ref"]
+    fo = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", full_output=True, verbose=False, **kw)
+    assert len(fo) == 3
+    for nm, a in zip(("frame", "chan", "chan_der"), fo):
+        exp = g["%s_%s" % (tag, nm)]
+        assert a.shape == exp.shape, (tag, nm, a.shape, exp.shape)
+        assert np.array_equal(np.isnan(a), np.isnan(exp)), (tag, nm)
+        assert np.nanmax(np.abs(a - exp)) < TOL, (tag, nm, np.nanmax(np.abs(a - exp)))
+    only = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", verbose=False, **kw)
+    assert np.array_equal(only, fo[0], equal_nan=True)
+
+
+def test_pca_3d_rotation_threshold_with_a_reference_cube():
+    """source_xy + cube_ref in the 3-D branch (pca_fullfr.py:911-965 with _project_subtract's indices + cube_ref mode,
+    :1693-1694): every frame's library = its rotation-compliant frames + all reference frames; against the oracle, whose
+    per-frame mode G26 pins through the double pass."""
+    from vip_amd.psfsub import pca
+    cube, ang = O.synth_adi(16, 40, seed=260)
+    cref = O.synth_adi(7, 40, seed=261)[0]
+    for kw in (dict(ncomp=3), dict(ncomp=4, scaling="temp-standard", max_frames_pca=6)):
+        exp = O.pca_pa_rejection(cube, ang, source_xy=(28.0, 24.0), fwhm=4.0, delta_rot=0.7, min_frames_pca=3,
+                                 cube_ref=cref, full_output=True, **kw)
+        out = pca(cube, ang, source_xy=(28.0, 24.0), fwhm=4.0, delta_rot=0.7, min_frames_pca=3, cube_ref=cref,
+                  full_output=True, verbose=False, **kw)
+        # (frame, recon_cube, residuals_cube, residuals_cube_)
+        for a, b in zip(out, exp):
+            assert a.shape == b.shape and np.nanmax(np.abs(a - b)) < TOL

@@ -147,11 +147,12 @@ def _prepared_matrices(cube_t, cube_ref_t, scaling, mask_center_px):
 
 
 def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scaling, mask_center_px, min_frames_pca,
-                      max_frames_pca, verbose, cube_sig=None):
+                      max_frames_pca, verbose, cube_sig=None, cube_ref=None):
     """Device version of the ``source_xy`` branch (reference pca_fullfr.py:911-965 + the per-frame mode of
     ``_project_subtract``, :1677-1713): frame j is modelled with the PCs of the frames that have rotated by more than
-    the PA threshold at ``source_xy``.  All n per-frame decompositions come from sub-blocks of ONE Gram matrix
-    (the identity used for annular PCA).  Returns (residuals (n, P), M (n, P), library sizes)."""
+    the PA threshold at ``source_xy`` -- plus, with ``cube_ref``, every reference frame (:1693-1694).  All n per-frame
+    decompositions come from sub-blocks of ONE Gram matrix (the identity used for annular PCA).
+    Returns (residuals (n, P), M (n, P), library sizes)."""
     torch = B._torch()
     n, y, x = cube.shape
     if delta_rot is None or fwhm is None:
@@ -162,37 +163,46 @@ def _pca_pa_rejection(cube, angle_list, ncomp, source_xy, delta_rot, fwhm, scali
     pa_thr = _compute_pa_thresh(ann_center, fwhm, delta_rot)
     truncate = max_frames_pca is not None
     libs = _find_indices_adi_all(angle_list, pa_thr, truncate=truncate, max_frames=max_frames_pca)
+    nr = 0 if cube_ref is None else int(cube_ref.shape[0])
     msg = "{} frames comply to delta_rot condition < less than "
     for li in libs:
-        if li.shape[0] < min_frames_pca:
+        if li.shape[0] + nr < min_frames_pca:
             raise RuntimeError((msg + "min_frames_pca ({}). Try decreasing delta_rot or min_frames_pca").format(
-                li.shape[0], min_frames_pca))
-        if li.shape[0] < ncomp:
+                li.shape[0] + nr, min_frames_pca))
+        if li.shape[0] + nr < ncomp:
             raise RuntimeError((msg + "ncomp ({}). Try decreasing the parameter delta_rot or ncomp").format(
-                li.shape[0], ncomp))
-    M, _ = _prepared_matrices(cube, None, scaling, mask_center_px)
+                li.shape[0] + nr, ncomp))
+    M, Mref = _prepared_matrices(cube, cube_ref, scaling, mask_center_px)
     S = None
     if cube_sig is not None:                      # libraries and projections from M - S (see _project_subtract)
         S = cube_sig.reshape(n, -1)
         M_full, M = M, B.lincomb(M, S, 1.0, -1.0)
     P = y * x
-    max_lib = max(li.shape[0] for li in libs)
-    idx = np.zeros((n, max_lib), dtype=np.int32)
-    ln = np.zeros(n, dtype=np.int32)
+    A = M if nr == 0 else torch.cat((M, Mref)).contiguous()        # rows n .. n + nr - 1: the reference frames
+    ntot = n + nr
+    max_lib = max(li.shape[0] for li in libs) + nr
+    idx = np.zeros((ntot, max_lib), dtype=np.int32)
+    ln = np.zeros(ntot, dtype=np.int32)
+    refrows = np.arange(n, ntot, dtype=np.int32)
     for j, li in enumerate(libs):
+        m = li.shape[0] + nr
         idx[j, :li.shape[0]] = li
-        ln[j] = li.shape[0]
+        idx[j, li.shape[0]:m] = refrows
+        ln[j] = m
+    idx[n:] = idx[0]                              # (the reference rows need some valid library; their residuals are dropped)
+    ln[n:] = ln[0]
     idx_t = torch.from_numpy(idx).to(cube.device)
     ln_t = torch.from_numpy(ln).to(cube.device)
-    R = B.empty((n, P), device=cube.device.index)
+    R = B.empty((ntot, P), device=cube.device.index)
     ctx = B.get_context(cube.device.index)
-    ctx.call("vipmi_annular_residuals_f32", B.ptr(M), n, P, B.ptr(idx_t), B.ptr(ln_t), int(max_lib), int(ncomp), B.ptr(R))
+    ctx.call("vipmi_annular_residuals_f32", B.ptr(A), ntot, P, B.ptr(idx_t), B.ptr(ln_t), int(max_lib), int(ncomp), B.ptr(R))
+    R = R[:n]
     if S is not None:
-        R = B.lincomb(R, S, 1.0, 1.0)
+        R = B.lincomb(R.contiguous(), S, 1.0, 1.0)
         M = M_full
     if verbose:
-        print("Size LIB: min={} max={} mean={:.1f}".format(int(ln.min()), int(ln.max()), float(ln.mean())))
-    return R, M, ln
+        print("Size LIB: min={} max={} mean={:.1f}".format(int(ln[:n].min()), int(ln[:n].max()), float(ln[:n].mean())))
+    return R, M, ln[:n]
 
 
 @B.with_rotation
@@ -248,12 +258,11 @@ def _adi_rdi_pca(cube, cube_ref, angle_list, ncomp, batch, source_xy, delta_rot,
                         collapse=collapse, verbose=verbose, full_output=full_output, debug=False, plot=False,
                         weights=weights, imlib=imlib, interpolation=interpolation, **rot_options)
     if source_xy is not None:
-        if cube_ref is not None:
-            raise NotImplementedError("source_xy together with cube_ref is outside the accelerated path")
         if not isinstance(ncomp, (int, np.integer)):
             raise NotImplementedError("source_xy needs an integer ncomp on the device path")
         R, M, _ln = _pca_pa_rejection(cube, angle_list, int(ncomp), source_xy, delta_rot, fwhm, scaling,
-                                      mask_center_px, min_frames_pca, max_frames_pca, verbose, cube_sig=cube_sig)
+                                      mask_center_px, min_frames_pca, max_frames_pca, verbose, cube_sig=cube_sig,
+                                      cube_ref=cube_ref)
         residuals_cube = R.reshape(n, y, x)
         residuals_cube_ = B.derotate(residuals_cube, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
         frame = B.collapse(residuals_cube_, collapse, w=weights)
@@ -401,10 +410,7 @@ def pca(*all_args: List, **all_kwargs: dict):
         # argument checks of the ADI+mSDI path before anything touches the GPU
         if cube.ndim != 4:
             raise TypeError("`scale_list` needs a 4d (channels, frames, y, x) cube")
-        single = _s(algo_params.adimsdi) == "single"
-        for name in ("cube_ref", "source_xy", "mask_rdi", "cube_sig", "smooth_first_pass"):
-            if single and name in ("cube_ref", "source_xy"):
-                continue                      # single pass: reference cube and S/N-scored grid are accelerated
+        for name in ("mask_rdi", "cube_sig", "smooth_first_pass"):
             if getattr(algo_params, name, None) is not None:
                 raise NotImplementedError("{} is outside the accelerated ADI+mSDI path".format(name))
         if algo_params.cube_ref is not None and np.ndim(algo_params.cube_ref) != 4:
@@ -455,7 +461,13 @@ def pca(*all_args: List, **all_kwargs: dict):
                 rcc, rcc_, frame = adimsdi_double(cube_t, algo_params.angle_list, algo_params.scale_list,
                                                   algo_params.ncomp, algo_params.scaling, algo_params.mask_center_px,
                                                   collapse, algo_params.collapse_ifs, algo_params.ifs_collapse_range,
-                                                  algo_params.weights, mv_nan, algo_params.verbose)
+                                                  algo_params.weights, mv_nan, algo_params.verbose,
+                                                  cube_ref=(None if algo_params.cube_ref is None
+                                                            else B.to_device_f32(algo_params.cube_ref)),
+                                                  ref_strategy=_s(algo_params.ref_strategy),
+                                                  source_xy=algo_params.source_xy, delta_rot=algo_params.delta_rot,
+                                                  fwhm=algo_params.fwhm, min_frames_pca=algo_params.min_frames_pca,
+                                                  max_frames_pca=algo_params.max_frames_pca)
                 # the reference's scale_fft returns float32 when it crops the spectrum (down-scaling) and float64 when it
                 # pads it or leaves a channel untouched (scale 1): mirror the resulting dtype of the collapsed frames
                 dt = None

@@ -4,7 +4,7 @@
 The spectral channels are rescaled with the matrix-core zoom of ``vip_amd.preproc.rescaling`` (all frames of all
 channels in one call), the PCA stages reuse the full-frame kernels, the de-scaled channels are collapsed with the
 collapse kernel.  Single-pass mode also takes a 4-D ``cube_ref`` and a tuple / list ``ncomp`` (grid of frames, with S/N
-scoring at ``source_xy``).  Not accelerated (NotImplementedError): ``cube_ref`` / ``source_xy`` in double-pass mode,
+scoring at ``source_xy``).  Double-pass mode takes ``cube_ref`` (RSDI) and a rotation threshold at ``source_xy`` as well.  Not accelerated (NotImplementedError):
 ``batch``, ``mask_rdi``, ``smooth_first_pass``, ``imlib2`` other than 'vip-fft'.
 """
 import numpy as np
@@ -90,14 +90,25 @@ def _frame_major(cube4):
 
 
 def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px, collapse, collapse_ifs,
-                   ifs_collapse_range, weights, mv_nan, verbose):
-    """Returns (res_cube_channels (n, y, x), residuals_cube_channels_ (n, y, x), frame) as device tensors."""
+                   ifs_collapse_range, weights, mv_nan, verbose, cube_ref=None, ref_strategy="RSDI", source_xy=None,
+                   delta_rot=None, fwhm=4, min_frames_pca=10, max_frames_pca=None):
+    """Returns (res_cube_channels (n + nr, y, x), residuals_cube_channels_ (n, y, x), frame) as device tensors.
+    ``cube_ref`` (z, nr, y, x): its multispectral frames go through the first (spectral) stage with the science frames
+    and form the library of the second stage (pca_fullfr.py:1279-1283,1388-1400) -- or join every frame's library when a
+    rotation threshold is applied at ``source_xy`` (:1403-1459)."""
     torch = B._torch()
     z, n, y_in, x_in = cube.shape
     if not isinstance(ncomp, tuple):
         raise TypeError("`ncomp` must be a tuple when a double pass PCA is performed")
     ncomp_ifs, ncomp_adi = ncomp
     angle_list, scale_list = _check(cube, angle_list, scale_list)
+    nr = 0
+    if cube_ref is not None:
+        if cube_ref.ndim != 4 or cube_ref.shape[0] != z or tuple(cube_ref.shape[2:]) != (y_in, x_in):
+            raise TypeError("Ref cube has wrong format for 4d input cube")
+        nr = int(cube_ref.shape[1])
+        cube = torch.cat((cube, cube_ref), dim=1)
+    n_sci, n = n, n + nr                         # every multispectral frame, science first (pca_fullfr.py:1279-1281)
     if type(scaling) is not tuple:
         scaling = (scaling, scaling)
     if verbose:
@@ -131,17 +142,42 @@ def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
             res_cube_channels = B.apply_mask(res_cube_channels.reshape(n, -1), mask.reshape(-1), 0.0).reshape(n, ys, ys)
     if ncomp_adi is None:
         if verbose:
-            print("{} ADI frames".format(n))
+            print("{} ADI frames".format(n_sci))
             print("De-rotating and combining frames (skipping PCA)")
-        src = res_cube_channels
+        src = res_cube_channels[:n_sci]
     else:
         if ncomp_adi > n:
             ncomp_adi = n
-            print("Number of PCs too high, using  maximum of {} PCs instead".format(n))
+            print("Number of PCs too high, using  maximum of {} PCs instead".format(n_sci))
         if verbose:
-            print("{} ADI frames".format(n))
+            print("{} ADI frames".format(n_sci))
+            if nr:
+                print("+ {} reference frames".format(nr))
             print("Second PCA stage exploiting rotational variability")
-        src = _residuals(res_cube_channels, int(ncomp_adi), scaling[1], mask_center_px)
+        sci, ref = res_cube_channels[:n_sci], (res_cube_channels[n_sci:] if nr else None)
+        ys = res_cube_channels.shape[-1]
+        if source_xy is not None:
+            # rotation threshold at source_xy: per-frame libraries (+ every reference frame), pca_fullfr.py:1403-1459
+            from .pca_fullfr import _pca_pa_rejection
+            R, _M, _ln = _pca_pa_rejection(sci.contiguous(), angle_list, int(ncomp_adi), source_xy, delta_rot, fwhm,
+                                           scaling[1], mask_center_px, min_frames_pca, max_frames_pca, False,
+                                           cube_ref=None if ref is None else ref.contiguous())
+            src = R.reshape(n_sci, ys, ys)
+        elif nr and "A" in str(ref_strategy):
+            # the reference projects all n + nr frames here and then de-rotates them with the n angles (:1388-1399,
+            # :1462-1465): an IndexError in cube_derotate.  Said clearly instead.
+            raise IndexError("ADI+mSDI double pass: ref_strategy %r with cube_ref needs source_xy (the reference de-rotates "
+                             "%d residual frames with %d angles here)" % (ref_strategy, n, n_sci))
+        elif nr:
+            M = _prep(sci.contiguous(), scaling[1], mask_center_px)
+            Mr = _prep(ref.contiguous(), scaling[1], mask_center_px)
+            if ncomp_adi > min(Mr.shape):
+                msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
+                msg += " Increase the size of the patches or request less PCs"
+                raise RuntimeError(msg.format(ncomp_adi, Mr.shape[0], Mr.shape[1]))
+            src = B.pca_project(M, int(ncomp_adi), ref=Mr)[0].reshape(n_sci, ys, ys)
+        else:
+            src = _residuals(res_cube_channels, int(ncomp_adi), scaling[1], mask_center_px)
     der = B.derotate(src, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
     frame = B.collapse(der, _s(collapse), w=weights)
     return res_cube_channels, der, frame
