@@ -585,8 +585,8 @@ def test_msdi_single_grid_and_reference_cube_golden():
     assert np.abs(cubeout - g["grid_frames"]).max() < TOL
     k = int(np.argmax(table["S/Ns"].values))
     assert np.array_equal(best, cubeout[k]) and list(table["PCs"]) == [1, 2, 3, 4]
-    with pytest.raises(NotImplementedError):
-        pca(c4, a4, ncomp=(2, 2), scale_list=sc, adimsdi="double", cube_ref=g["cube_ref"], verbose=False)
+    with pytest.raises(NotImplementedError):             # (still outside the accelerated path; cube_ref / source_xy: G26)
+        pca(c4, a4, ncomp=(2, 2), scale_list=sc, adimsdi="double", smooth_first_pass=2, verbose=False)
 
 
 @pytest.mark.parametrize("N", [64, 65])

@@ -547,11 +547,9 @@ def derotate(cube, angles, mask_nan=True, mask_zero=False, method="auto", out=No
     if mv is None and mask_val is None:
         mv = rot[3]
     if mv is not None:
-        if float(np.float32(mv)) != mv:
-            # a value float32 cannot hold: no float32 pixel equals it (the reference compares in float64), nothing to reset
-            ctx.call("vipmi_derotate_f32", ptr(cube), ap, n, Ny, ptr(out), 0, 0, ROT_METHODS[method])
-        else:
-            ctx.call("vipmi_derotate_maskval_f32", ptr(cube), ap, n, Ny, ptr(out), ctypes.c_float(mv), ROT_METHODS[method])
+        # (the reference compares its float32 frames with the Python float in float32 -- numpy's scalar promotion --, so a
+        # mask_val such as 0.1 matches the float32 pixels that hold float32(0.1): the kernel's comparison exactly)
+        ctx.call("vipmi_derotate_maskval_f32", ptr(cube), ap, n, Ny, ptr(out), ctypes.c_float(mv), ROT_METHODS[method])
         return out
     ctx.call("vipmi_derotate_f32", ptr(cube), ap, n, Ny, ptr(out), int(bool(mask_nan)), int(bool(mask_zero)),
              ROT_METHODS[method])
