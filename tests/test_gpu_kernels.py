@@ -21,6 +21,20 @@ def dev(B, a):
     return B.to_device_f32(a)
 
 
+@pytest.fixture(autouse=True)
+def _exact_eigensolvers(request, B):
+    """The test_eigh_topk* tests pin the EXACT tridiagonal kernels (bit-identical vectors with and without the whole
+    spectrum, projector accuracy at 1e-10 across gaps of 1e-6): the verified fast path (eigh_chfsi.hip, n >= 600) is
+    switched off for them and has its own tests below."""
+    exact = request.node.name.startswith("test_eigh_topk")
+    ctx = B.get_context()
+    if exact:
+        ctx.set_option("eigh_fast", 0)
+    yield
+    if exact:
+        ctx.set_option("eigh_fast", 1)
+
+
 # ---- Gram -------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n,P", [(5, 77), (16, 256), (50, 16384), (33, 10201), (100, 4096), (400, 8192)])
@@ -797,3 +811,89 @@ def test_rotate_opencv_style_borders(border, interp):
             assert np.abs(got[i] - ref).max() < 5e-6 * max(1.0, np.abs(ref).max()), (N, i)
         const = cube_derotate(cube, ang, imlib="opencv", interpolation=interp)
         assert not np.array_equal(got, const)
+
+
+# ---- verified fast path of the leading-k eigensolver (eigh_chfsi.hip) -----------------------------------------------
+
+def _spectrum_matrix(n, lam, seed=0):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    G = (Q * lam) @ Q.T
+    return 0.5 * (G + G.T)
+
+
+def _baseline_like(n, seed=0):
+    """A few geometric modes above a narrow noise bulk: the spectrum of the BASELINE generator."""
+    rng = np.random.default_rng(seed)
+    lam = 0.024 * (1.0 + 0.08 * np.sort(rng.uniform(-1, 1, n))[::-1] ** 3 + 0.06 * np.linspace(1, -1, n))
+    lam[:10] += 2.0 ** (-1.2 * np.arange(10))
+    return np.sort(lam)[::-1]
+
+
+@pytest.mark.parametrize("n,k,kind", [(700, 20, "bulk"), (1000, 30, "bulk"), (2000, 50, "bulk"), (777, 17, "decay"),
+                                      (640, 12, "repeated")])
+def test_eigh_fast_path_is_verified_and_deterministic(B, n, k, kind):
+    """Chebyshev-filtered subspace iteration: every returned pair has ||G q - theta q|| <= 1e-12 theta_1 (gate 1e-13 at the
+    Ritz level), eigenvalues and orthogonality at round-off, the leading subspace to residual / gap, the sign convention of
+    the exact solvers; two runs are bit-identical (fixed start block, fixed reduction orders)."""
+    import torch
+    lam = {"bulk": _baseline_like(n, seed=n), "decay": (1.0 + np.arange(n)) ** -1.5,
+           "repeated": np.r_[np.repeat([5.0, 3.0, 2.0], 4), 0.5 * 0.97 ** np.arange(n - 12)]}[kind]
+    G = _spectrum_matrix(n, lam, seed=n + k)
+    ctx = B.get_context()
+    ctx.set_option("eigh_fast", 1)
+    Gt = torch.from_numpy(G).cuda()
+    ev, ec = B.eigh_topk(Gt.clone(), k)
+    info = [ctx.get_option("eigh_fast_last_" + s) for s in ("products", "rounds", "locked", "reason")]
+    assert info[3] == 0 and info[2] == k, info                       # converged on the fast path, not by fall-back
+    assert torch.equal(Gt, torch.from_numpy(G).cuda())               # the matrix is left untouched
+    ev2, ec2 = B.eigh_topk(Gt.clone(), k)
+    assert torch.equal(ev, ev2) and torch.equal(ec, ec2)
+    ev, X = ev.cpu().numpy(), ec.cpu().numpy().T
+    w, v = np.linalg.eigh(G)
+    w, v = w[::-1], v[:, ::-1]
+    assert np.abs(ev - w[:k]).max() < 1e-12 * w[0] and np.all(np.diff(ev) <= 0)
+    assert np.abs(X.T @ X - np.eye(k)).max() < 1e-12
+    assert np.linalg.norm(G @ X - X * ev, axis=0).max() < 1e-12 * w[0]
+    assert np.all(X[np.abs(X).argmax(axis=0), np.arange(k)] > 0)
+    gap = (w[k - 1] - w[k]) / w[0]
+    sin = np.linalg.svd(v[:, k:].T @ X, compute_uv=False).max()
+    assert sin < max(1e-9, 1e-12 / gap), (sin, gap)
+
+
+def test_eigh_fast_path_gives_up_and_the_exact_path_takes_over(B):
+    """A spectrum without a gap behind the k-th pair (flat bulk), a rank-deficient matrix and an indefinite one: the fast
+    path reports why it stopped, leaves the matrix alone, and the call returns the exact solver's result."""
+    import torch
+    n, k = 700, 20
+    ctx = B.get_context()
+    ctx.set_option("eigh_fast", 1)
+    cases = {"flat": (1.0 + 1e-4 * np.linspace(1, 0, n), 1), "rank 30": (np.r_[2.0 ** -np.arange(30.0), np.zeros(n - 30)], 3)}
+    for name, (lam, why) in cases.items():
+        G = _spectrum_matrix(n, lam, seed=5)
+        ev, ec = B.eigh_topk(torch.from_numpy(G).cuda(), k)
+        reason = ctx.get_option("eigh_fast_last_reason")
+        assert reason == why, (name, reason)
+        ctx.set_option("eigh_fast", 0)
+        ev0, ec0 = B.eigh_topk(torch.from_numpy(G).cuda(), k)
+        ctx.set_option("eigh_fast", 1)
+        assert torch.equal(ev, ev0) and torch.equal(ec, ec0), name        # (bit-identical: the exact kernels ran on the same G)
+
+
+def test_pca_with_and_without_the_fast_eigensolver(B):
+    """pca() at a size where the fast path runs (n = 640 frames): frames with eigh_fast = 1 / 0 agree far inside the
+    parity tolerance, and the asynchronous (pipelined) mode never takes the fast path (it reads Ritz values back)."""
+    import torch
+    from vip_amd.psfsub import pca
+    from vip_amd.synth import synth_adi_device
+    cube, ang = synth_adi_device(640, 64, seed=3)
+    ang = np.linspace(0, 120, 640)
+    ctx = B.get_context()
+    ctx.set_option("eigh_fast", 1)
+    f1 = pca(cube, ang, ncomp=12, verbose=False)
+    assert ctx.get_option("eigh_fast_last_reason") == 0 and ctx.get_option("eigh_fast_last_locked") == 12
+    ctx.set_option("eigh_fast", 0)
+    f0 = pca(cube, ang, ncomp=12, verbose=False)
+    ctx.set_option("eigh_fast", 1)
+    ok = torch.isfinite(f0)
+    assert torch.equal(ok, torch.isfinite(f1)) and float((f1[ok] - f0[ok]).abs().max()) < 2e-6

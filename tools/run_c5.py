@@ -16,3 +16,5 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     print("rep", rep, "%.1f ms  %.0f frames/s" % (dt * 1e3, n / dt), {s: round(ctx.stage_ms(s), 2) for s in ("gram", "eigh", "project", "derotate", "collapse") if ctx.stage_count(s)},
           "sweeps", ctx.get_option("eigh_last_sweeps"), "finite", bool(torch.isfinite(fr).all()), "mem GB", round(torch.cuda.max_memory_allocated() / 1e9, 1))
+print("fast path of the eigensolver (products, rounds, locked, reason):",
+      [ctx.get_option("eigh_fast_last_" + s) for s in ("products", "rounds", "locked", "reason")])

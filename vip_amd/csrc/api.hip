@@ -26,6 +26,30 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
 
 using namespace vipmi;
 
+int vipmi_ctx::host_scratch(size_t bytes, void** out) {
+  if (host_pinned_bytes < bytes) {
+    if (host_pinned) {
+      hipError_t e = hipStreamSynchronize(stream);          // a read-back into the old block may still be in flight
+      if (e != hipSuccess) {
+        set_error("host scratch sync failed: %s", hipGetErrorString(e));
+        return VIPMI_ERR_HIP;
+      }
+      (void)hipHostFree(host_pinned);
+      host_pinned = nullptr;
+      host_pinned_bytes = 0;
+    }
+    hipError_t e = hipHostMalloc(&host_pinned, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      host_pinned = nullptr;
+      set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      return VIPMI_ERR_NOMEM;
+    }
+    host_pinned_bytes = bytes;
+  }
+  *out = host_pinned;
+  return VIPMI_OK;
+}
+
 int vipmi_ctx::get(const char* name, size_t bytes, void** out) {
   Buffer& b = buffers[name];
   if (bytes == 0) bytes = 16;
@@ -228,6 +252,7 @@ int vipmi_destroy(vipmi_ctx* ctx) {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
     }
+  if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
   delete ctx;
   return VIPMI_OK;
 }
@@ -258,7 +283,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);

@@ -79,6 +79,8 @@ struct vipmi_ctx {
   };
   std::map<std::string, std::vector<PinnedSlot>> pinned;   // small rings of pinned staging buffers
   std::map<std::string, int> pinned_next;
+  void* host_pinned = nullptr;     // grow-only pinned scratch for small read-backs (host_scratch)
+  size_t host_pinned_bytes = 0;
   int num_cu = 256;
   int timing = 0;                 // 0 off, 1 every stage / kernel, 2 only the roofline kernel (k_rot_s2)
 
@@ -100,6 +102,8 @@ struct vipmi_ctx {
   // asynchronous H2D of a small host table through a ring of pinned staging buffers (never blocks the
   // host unless the ring wraps onto a copy that is still in flight)
   int upload_async(const char* name, const void* host, size_t bytes, void* dst);
+  // pinned host memory of at least `bytes` (contents undefined; valid until the next call that asks for more)
+  int host_scratch(size_t bytes, void** out);
   int64_t opt(const char* key, int64_t dflt) const {
     auto it = options.find(key);
     return it == options.end() ? dflt : it->second;
@@ -157,6 +161,10 @@ int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, co
                       const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals);
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                  double* evals, double* evecs, bool all_evals = false);
+// verified fast path for the leading pairs of ONE positive semi-definite matrix (eigh_chfsi.hip); G is not modified
+bool eigh_chfsi_supported(int64_t n, int64_t k);
+int eigh_chfsi_f64(vipmi_ctx* ctx, const double* G, int64_t n, int64_t k, double* evals, double* evecs, int* converged,
+                   int* info);
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,
                       const float* rowscale, float* B);
 int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,

@@ -1391,6 +1391,22 @@ int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k
 
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact, double* evals,
                  double* evecs, bool all_evals) {
+  // One larger problem, leading pairs only, synchronous mode (the fast path reads Ritz values back every round): the
+  // verified Chebyshev-filtered subspace iteration first (eigh_chfsi.hip); it leaves G untouched, so when the spectrum does
+  // not allow it within its budget the exact path below runs as if nothing had happened.
+  if (batch == 1 && !nact && !all_evals && ctx->opt("eigh_fast", 1) != 0 && ctx->opt("eigh_check", 1) != 0 &&
+      ctx->opt("eigh_method", 0) != 1 && n >= ctx->opt("eigh_fast_min", 600) && eigh_chfsi_supported(n, k)) {
+    int conv = 0, info[4];
+    {
+      StageScope sc(ctx, "eigh");
+      VIPMI_TRY(eigh_chfsi_f64(ctx, G, n, k, evals, evecs, &conv, info));
+    }
+    ctx->options["eigh_fast_last_products"] = info[0];
+    ctx->options["eigh_fast_last_rounds"] = info[1];
+    ctx->options["eigh_fast_last_locked"] = info[2];
+    ctx->options["eigh_fast_last_reason"] = info[3];
+    if (conv) return VIPMI_OK;
+  }
   if (ctx->opt("eigh_method", 0) != 1 && eigh_topk_supported(n, k))
     return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs, all_evals);
   if (ctx->opt("eigh_method", 0) != 1 && !nact && batch <= 4 && eigh_large_supported(n, k))
