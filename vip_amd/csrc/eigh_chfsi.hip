@@ -12,7 +12,7 @@
 //   repeat
 //     lock the leading Ritz pairs whose residual is below tol * theta_1 (at most k), deflate them out of a copy of G
 //     unwanted interval [0, bb], bb = smallest Ritz value of the block (G is positive semi-definite: 0 is a safe lower end)
-//     degree m limited by the dynamic range the filter may create inside the block: T_m(x_top) / T_m(x_k) <= 1e6
+//     degree m limited by the dynamic range the filter may create inside the block: T_m(x_top) <= 2e7 (= against T_m(1))
 //     Y <- T_m((Gd - c) / e) Q   by the scaled three-term recurrence (one launch per degree)
 //     Y <- Y - L (L^T Y);  Cholesky-QR twice;  H = Q^T G Q;  Jacobi;  Q <- Q W;  residual norms
 //   until k pairs are locked, or the forecast of the remaining products exceeds the budget (-> not converged)
@@ -563,7 +563,7 @@ int eigh_chfsi_f64(vipmi_ctx* ctx, const double* G, int64_t n64, int64_t k64, do
   S.nsplit = (int)cdiv(n, S.rows_per);
   S.nrb = (int)cdiv(n, 16);
   const double tol = 1e-13 * (double)std::max<int64_t>(1, ctx->opt("eigh_fast_tol", 1));     // residual gate, in units of theta_1
-  const double dyn = 1e6;            // largest amplification ratio the filter may create inside the block
+  const double dyn = 2e7;            // largest amplification the filter may create inside the block (T_m(x_top) against T_m(1) = 1)
   const int mmax = 240;
   const int budget = (int)ctx->opt("eigh_fast_budget", n <= 512 ? 260 : 700);
   const size_t nb = (size_t)n * b;
@@ -644,7 +644,10 @@ int eigh_chfsi_f64(vipmi_ctx* ctx, const double* G, int64_t n64, int64_t k64, do
     if (!(bb > 0.0)) { reason = 4; break; }
     const double c = 0.5 * bb, e = 0.5 * bb;
     const double xt = std::max(1.0, (th[0] - c) / e), xe = std::max(1.0, (th[kk - 1] - c) / e);
-    const double ge = std::acosh(xe), gap = std::acosh(xt) - ge;
+    // degree limit: the filter may amplify the top of the block by at most `dyn` over the directions it leaves alone
+    // (x = 1: where the padding columns of the block live) -- beyond that the filtered block is rank deficient in float64
+    // and the Cholesky-QR loses it (a cluster of k well separated pairs above a gap is exactly that case)
+    const double ge = std::acosh(xe), gap = std::acosh(xt);
     int m = (gap > 1e-12) ? (int)std::floor(std::log(dyn) / gap) : mmax;
     m = std::max(1, std::min(mmax, m));
     // degrees still needed for the slowest wanted pair (its error shrinks like 1 / T_m(x_k))
