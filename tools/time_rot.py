@@ -1,5 +1,5 @@
 """Time cube_derotate alone (device-resident) for a few shapes / options:  python tools/time_rot.py N n [opt=val ...]"""
-import sys; sys.path.insert(0, ".")
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vip_amd import backend as B
 N, n = int(sys.argv[1]), int(sys.argv[2])

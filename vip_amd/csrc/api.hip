@@ -152,7 +152,11 @@ int vipmi_ctx::gate_leave() {
     gate->ring.push_back(e);
     gate->next = (int)gate->ring.size() - 1;
   } else {
+    // ring full: the slot about to be re-recorded marks the end of the section issued 64 sections ago.  A stream may still
+    // hold a wait on it; the host blocks until that old section has finished (it has, unless more than 64 gated sections
+    // are in flight) so that no pending wait ever sees a re-recorded event.
     gate->next = (gate->next + 1) % (int)gate->ring.size();
+    VIPMI_CHECK_HIP(hipEventSynchronize(gate->ring[gate->next]));
   }
   hipEvent_t e = gate->ring[gate->next];
   VIPMI_CHECK_HIP(hipEventRecord(e, stream));
