@@ -110,6 +110,14 @@ int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* 
  * truncated decompositions of svd_wrapper (svd.py:342-620). */
 int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                         double* evals, double* evecs);
+/* Verified fast path alone (Chebyshev-filtered block subspace iteration on the float64 matrix cores, csrc/eigh_chfsi.hip;
+ * replaces the truncated decompositions of psfsub/svd.py:447-491,705-808 where the spectrum allows): leading k pairs of ONE
+ * symmetric positive semi-definite G[n,n] (not modified).  *converged = 1: evals[0..k) descending, evecs[k,n] rows, every pair
+ * with ||G q - theta q|| <= 1e-13 theta_1; *converged = 0: nothing written -- no usable gap behind the k-th eigenvalue, or
+ * sizes outside 256 <= n <= 16384, k + max(12, k/4) <= 64, 4k <= n.  vipmi_eigh_topk_f64 tries it by itself for one matrix of
+ * 600 .. 6144 rows (option "eigh_fast", default 1) and falls back on the exact tridiagonal path. */
+int vipmi_eigh_topk_fast_f64(vipmi_ctx* ctx, const double* G, int64_t n, int64_t k, double* evals, double* evecs,
+                             int* converged);
 
 /* All n eigenvalues (descending) and the leading k eigenvectors: what SVDecomposer.get_cevr (psfsub/svd.py:216-339) and
  * svd_wrapper(..., full_output=True) in the 'eigen' modes (svd.py:454-462) need.  Same layout as vipmi_eigh_f64. */

@@ -711,16 +711,23 @@ def test_annular_libraries_beyond_512_frames():
     assert 0.2 < np.abs(big[ok]).std() / np.abs(small[ok]).std() < 5.0
 
 
-def test_more_than_6144_frames_library_fallback():
-    """beyond the hand-written leading-k solver (n > backend.MAX_EIGH_N = 6144) the front keeps the device Gram / projection
-    kernels and takes the eigendecomposition from rocSOLVER (backend.eigh_beyond_lds)"""
+def test_more_than_6144_frames(monkeypatch):
+    """beyond the exact leading-k solvers (n > backend.MAX_EIGH_N = 6144) the front keeps the device Gram / projection
+    kernels; the decomposition comes from the verified fast path (csrc/eigh_chfsi.hip, up to 16384 frames) when it
+    converges -- no library call at all -- and from rocSOLVER (backend.eigh_beyond_lds) when it does not."""
     from vip_amd import backend as B
     from vip_amd.psfsub import pca
     n, N, k = B.MAX_EIGH_N + 56, 16, 6
     cube, _ = O.synth_adi(n, N, seed=3)
     ang = np.linspace(0, 170, n)
+    ref = O.pca_fullframe(cube, ang, ncomp=k)
     got = pca(cube, ang, ncomp=k, verbose=False)
-    assert np.abs(got - O.pca_fullframe(cube, ang, ncomp=k)).max() < TOL
+    assert np.abs(got - ref).max() < TOL
+    ctx = B.get_context()
+    assert ctx.get_option("eigh_fast_last_reason") == 0 and ctx.get_option("eigh_fast_last_locked") == k
+    monkeypatch.setattr(B, "eigh_topk_fast", lambda G, k_: None)          # the fast path gives up: the library routine
+    got2 = pca(cube, ang, ncomp=k, verbose=False)
+    assert np.abs(got2 - ref).max() < TOL and np.abs(got2 - got).max() < 2e-6
 
 
 def test_more_than_2048_frames():

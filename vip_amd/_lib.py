@@ -40,6 +40,8 @@ _SIGS = {
     "vipmi_eigh_spectrum_f64": ([ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_eigh_topk_f64": ([ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p], True,
                             ctypes.c_int),
+    "vipmi_eigh_topk_fast_f64": ([ctypes.c_void_p, i64, i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)],
+                                 True, ctypes.c_int),
     "vipmi_rowspace_gemm_f32": ([c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p], True, ctypes.c_int),
     "vipmi_subtract_gemm_f32": ([c_f32p, c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p], True, ctypes.c_int),
     "vipmi_lincomb_f32": ([c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, i64, c_f32p], True, ctypes.c_int),

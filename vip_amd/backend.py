@@ -375,12 +375,32 @@ def topk_native(n, k):
 MAX_EIGH_N = 6144        # the leading-k solver keeps three vectors of n doubles in LDS: matrices up to 6144 x 6144
 
 
-def eigh_beyond_lds(G):
+def eigh_topk_fast(G, k):
+    """Leading k eigenpairs of ONE positive semi-definite (n, n) float64 cuda tensor through the verified fast path alone
+    (csrc/eigh_chfsi.hip).  Returns (evals (k,) descending, evecs (k, n) rows) or None when it does not converge within its
+    budget / the sizes are outside its range; G is not modified."""
+    torch = _torch()
+    ctx = get_context(G.device.index)
+    n = G.shape[0]
+    G = G.contiguous()
+    evals = torch.zeros((n,), dtype=torch.float64, device=G.device)
+    evecs = torch.zeros((int(k), n), dtype=torch.float64, device=G.device)
+    conv = ctypes.c_int(0)
+    ctx.call("vipmi_eigh_topk_fast_f64", ptr(G), n, int(k), ptr(evals), ptr(evecs), ctypes.byref(conv))
+    return (evals[:k], evecs) if conv.value else None
+
+
+def eigh_beyond_lds(G, k=None):
     """Eigendecomposition of a Gram matrix of more than MAX_EIGH_N frames: the ONE place where a ROCm library routine is
     used (rocSOLVER's syevd through ``torch.linalg.eigh``, on the device, float64) -- the hand-written leading-k solver
     holds 3 n doubles of vectors in LDS and stops at n = 6144, and such cubes are rare.  Returns (evals descending, eigenvectors as
-    rows, largest-magnitude component positive) like the native solvers."""
+    rows, largest-magnitude component positive) like the native solvers.  With ``k`` (only the leading k pairs are needed)
+    the verified fast path is tried first: (evals (k,), evecs (k, n)) without any library call when it converges."""
     torch = _torch()
+    if k is not None:
+        fast = eigh_topk_fast(G.to(torch.float64), k)
+        if fast is not None:
+            return fast
     w, Q = torch.linalg.eigh(G.to(torch.float64))
     w = w.flip(0).contiguous()
     E = Q.flip(1).t().contiguous()                                   # rows = eigenvectors, descending eigenvalue
@@ -398,7 +418,7 @@ def _pca_project_large(M, k, ref, want_recon, want_pcs, want_evals):
     dev = M.device.index
     refm = M if ref is None else ref
     nref = refm.shape[0]
-    w, E = eigh_beyond_lds(gram(refm))
+    w, E = eigh_beyond_lds(gram(refm), None if want_evals else k)
     ev = w[:k]
     keep = (ev > ev[0] * 1e-12)
     Ek = (E[:k] * keep[:, None]).to(torch.float32).contiguous()       # (k, nref)

@@ -484,6 +484,23 @@ int vipmi_derotate_f32(vipmi_ctx* ctx, const float* in, const double* angles_hos
   return derotate_f32(ctx, in, angles_host, n, N, out, mask_nan, mask_zero, method);
 }
 
+// Only the verified fast path (eigh_chfsi.hip): *converged = 1 -> evals[0..k) / evecs[k][n] hold the leading pairs, each with
+// ||G q - theta q|| <= 1e-13 theta_1; 0 -> nothing written (spectrum without a usable gap, or sizes outside 256 <= n <= 16384,
+// k + max(12, k/4) <= 64, 4 k <= n).  G is not modified.  What the Python front tries before rocSOLVER above 6144 frames.
+int vipmi_eigh_topk_fast_f64(vipmi_ctx* ctx, const double* G, int64_t n, int64_t k, double* evals, double* evecs,
+                             int* converged) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(G && evals && evecs && converged && n > 0 && k > 0, "eigh_topk_fast: bad arguments");
+  int info[4];
+  StageScope sc(ctx, "eigh");
+  VIPMI_TRY(vipmi::eigh_chfsi_f64(ctx, G, n, k, evals, evecs, converged, info));
+  ctx->options["eigh_fast_last_products"] = info[0];
+  ctx->options["eigh_fast_last_rounds"] = info[1];
+  ctx->options["eigh_fast_last_locked"] = info[2];
+  ctx->options["eigh_fast_last_reason"] = info[3];
+  return VIPMI_OK;
+}
+
 int vipmi_derotate_maskval_f32(vipmi_ctx* ctx, const float* in, const double* angles_host, int64_t n, int64_t N,
                                float* out, float mask_val, int method) {
   CTX_GUARD();

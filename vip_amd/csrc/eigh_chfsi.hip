@@ -536,7 +536,7 @@ struct Chfsi {
 }  // namespace
 
 bool eigh_chfsi_supported(int64_t n, int64_t k) {
-  if (n < 256 || n > 8192 || k < 1) return false;
+  if (n < 256 || n > 16384 || k < 1) return false;
   const int64_t want = k + std::max<int64_t>(12, k / 4);
   return want <= BMAX && 4 * k <= n;
 }
