@@ -53,8 +53,9 @@ __global__ __launch_bounds__(64 * NW) void cheb_step_kernel(const double* __rest
   const bool rok = r0 + r < n;
   const double* gcol = G + r0 + r;                // A[row r][k] = G[r0 + r][k] = G[k][r0 + r]: 128 contiguous bytes per k
   const double* xcol = X + c0 + r;
-  for (int ks = ks0; ks < ks1; ks += KU) {
-    double a[KU], bv[KU][NT];
+  // two register sets of KU contraction steps each: the loads of one set are in flight while the MFMAs of the other issue
+  double a0[KU], b0[KU][NT], a1[KU], b1[KU][NT];
+  auto load_set = [&](int ks, double (&a)[KU], double (&bv)[KU][NT]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int kk = (ks + u) * 4 + kq;
@@ -63,10 +64,19 @@ __global__ __launch_bounds__(64 * NW) void cheb_step_kernel(const double* __rest
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[u][t] = kok ? xcol[(size_t)kk * LDB + 16 * t] : 0.0;
     }
+  };
+  auto mma_set = [&](const double (&a)[KU], const double (&bv)[KU][NT]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv[u][t], acc[t], 0, 0, 0);
+  };
+  load_set(ks0, a0, b0);
+  for (int ks = ks0; ks < ks1; ks += 2 * KU) {
+    load_set(ks + KU, a1, b1);          // (past the end: zeros, the MFMAs below then add nothing)
+    mma_set(a0, b0);
+    load_set(ks + 2 * KU, a0, b0);
+    mma_set(a1, b1);
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
