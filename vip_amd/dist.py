@@ -512,6 +512,14 @@ def pca_annular(cube, angle_list, ncomp=1, asize=4, fwhm=4, radius_int=0, n_segm
     every rank."""
     from .psfsub.pca_local import cached_annulus_plan
     from .preproc.parangles import check_pa_vector
+    rank, world = world_info()
+    if world == 1 and ops is None and _is_cuda(cube):
+        # one rank: nothing to shard -- the single-GPU front (all annuli through ONE batched eigensolve, DESIGN 3.2) is the
+        # same arithmetic and 1.4x faster than the per-segment path below
+        from .psfsub import pca_annular as _pca_annular
+        return _pca_annular(cube, angle_list, ncomp=ncomp, asize=asize, fwhm=fwhm, radius_int=radius_int,
+                            n_segments=n_segments, delta_rot=delta_rot, min_frames_lib=min_frames_lib,
+                            max_frames_lib=max_frames_lib, collapse=collapse, theta_init=theta_init, verbose=False)
     ops = ops or DeviceOps()
     angle_list = check_pa_vector(np.asarray(angle_list, dtype=np.float64))
     n, y, x = cube.shape
