@@ -830,7 +830,7 @@ def _baseline_like(n, seed=0):
     return np.sort(lam)[::-1]
 
 
-@pytest.mark.parametrize("n,k,kind", [(700, 20, "bulk"), (1000, 30, "bulk"), (2000, 50, "bulk"), (777, 17, "decay"),
+@pytest.mark.parametrize("n,k,kind", [(700, 20, "bulk"), (1000, 30, "bulk"), (2000, 50, "bulk"), (900, 50, "bulk"), (777, 17, "decay"),
                                       (640, 12, "repeated")])
 def test_eigh_fast_path_is_verified_and_deterministic(B, n, k, kind):
     """Chebyshev-filtered subspace iteration: every returned pair has ||G q - theta q|| <= 1e-12 theta_1 (gate 1e-13 at the

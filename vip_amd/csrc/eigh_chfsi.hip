@@ -477,7 +477,8 @@ struct Chfsi {
   hipLaunchKernelGGL((cheb_step_kernel<NT_, NW_, LDB_>), grid, dim3(64 * NW_), (size_t)NW_ * NT_ * 256 * sizeof(double), \
                      ctx->stream, Gm, n, Xin, Zp, Yout, alpha, cshift, beta)
     if (ntg == NT) {
-      if (NT == 2) VIPMI_CHF_LAUNCH(2, 8, 32); else if (NT == 3) VIPMI_CHF_LAUNCH(3, 8, 48); else VIPMI_CHF_LAUNCH(4, 8, 64);
+      // (four column tiles: four waves, 32 KB of LDS for the partial tiles -- eight would need all 64 KB of the default limit)
+      if (NT == 2) VIPMI_CHF_LAUNCH(2, 8, 32); else if (NT == 3) VIPMI_CHF_LAUNCH(3, 8, 48); else VIPMI_CHF_LAUNCH(4, 4, 64);
     } else {
       if (NT == 2) VIPMI_CHF_LAUNCH(2, 8, 32); else VIPMI_CHF_LAUNCH(2, 8, 64);
     }
