@@ -4,10 +4,15 @@ import numpy as np, torch
 from vip_amd import backend as B
 N, n = int(sys.argv[1]), int(sys.argv[2])
 ctx = B.get_context()
+amax = 90.0
 for kv in sys.argv[3:]:
-    k, v = kv.split("="); ctx.set_option(k, int(v))
+    k, v = kv.split("=")
+    if k == "amax":                     # angles 0 .. amax (amax <= 44: no quarter turn, every gather of shear 1 is row-wise)
+        amax = float(v)
+    else:
+        ctx.set_option(k, int(v))
 cube = torch.randn(n, N, N, device="cuda")
-ang = np.linspace(0, 90, n)
+ang = np.linspace(0, amax, n)
 for _ in range(2): B.derotate(cube, ang)
 torch.cuda.synchronize()
 ctx.set_option("timing", 1); ctx.reset_timers()

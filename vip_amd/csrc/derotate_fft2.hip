@@ -127,6 +127,10 @@ struct Aux {          // per-batch auxiliary arrays (device)
   float* gam;         // [nf][L]   (-1)^X gamma_X
   float* gsum;        // [nf]      Gam
   cf* dph;            // [nf][2][DPH_STRIDE] phase factors of the 64-line increments (rs_phase_delta), blocked plans only
+  // measurement probe (option "rot_fuse_probe" = k): shear 1 additionally gathers k "component images" per sample
+  // and subtracts 1e-30 of them -- the instruction and memory stream a fused project-subtract would add, at no visible change
+  int probe_k;
+  const float* probe_T;
 };
 
 #define VIPMI_SLOT_PROLOGUE()                                                     \
@@ -345,7 +349,17 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
 #pragma unroll
         for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
           const int X = P::M1 * n1 + lane + 64 * ul + dc;           // canvas column of canonical position M1 n1 + ...
-          const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
+          float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
+          if (aux.probe_k > 0) {
+            float q1 = 0.f, q2 = 0.f;
+            for (int c = 0; c < aux.probe_k; ++c) {
+              const float* Tc = aux.probe_T + (int64_t)c * g.N * g.N;
+              q1 = fmaf(1e-30f, Tc[b1 + X * st1], q1);
+              q2 = fmaf(1e-30f, Tc[b2 + X * st2], q2);
+            }
+            t1 -= q1;
+            t2 -= q2;
+          }
           v[ul * P::R1 + n1] = mkcf((t1 == t1) ? t1 : 0.f, (t2 == t2) ? t2 : 0.f);
         }
       const double s1 = p.a * (double)(Y1 - g.c) + (double)dc, s2 = p.a * (double)(Y2 - g.c) + (double)dc;
@@ -773,6 +787,8 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * P::L), &aux.gam));
   VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
   VIPMI_TRY(ws(ctx, "rot_dph", (size_t)chunk * 2 * DPH_STRIDE, &aux.dph));
+  aux.probe_k = (int)std::min<int64_t>(ctx->opt("rot_fuse_probe", 0), n);
+  aux.probe_T = in;
   int* counters = nullptr;                       // 3 kernels x 8 task queues, one 128-byte line each
   VIPMI_TRY(ws(ctx, "rot_counters", (size_t)3 * 256, &counters));
   size_t lds = (size_t)P::LPB * P::LDS_ELEMS * sizeof(cf);
