@@ -89,3 +89,26 @@ if want("g26"):
         for nm, a in zip(("frame", "chan", "chan_der"), fo):
             g["%s_%s" % (tag, nm)] = np.asarray(a, dtype=np.float32)
     save("g26_msdi_double_ref_thr", **g)
+
+
+# ---- G27: ADI+mSDI double pass with `cube_sig` (the estimate of the signal goes to the second, ADI stage:
+# psfsub/pca_fullfr.py:1395,1409,1447), plain, with a reference cube (RSDI) and under a rotation threshold ------------------
+if want("g27"):
+    z_, n_, N_ = 4, 12, 32
+    c4 = np.stack([O.synth_adi(n_, N_, seed=280 + i)[0] for i in range(z_)]).astype(np.float32)
+    a4 = np.linspace(0, 85, n_)
+    sc = np.linspace(1.0, 1.2, z_)[::-1].copy()
+    cr4 = np.stack([O.synth_adi(6, N_, seed=290 + i)[0] for i in range(z_)]).astype(np.float32)
+    rng = np.random.default_rng(2700)
+    yy, xx = np.mgrid[:N_, :N_]
+    sig = np.stack([0.4 * np.exp(-((yy - 16 - 7 * np.sin(t)) ** 2 + (xx - 16 - 7 * np.cos(t)) ** 2) / 4.0)
+                    for t in np.deg2rad(a4)]).astype(np.float32)
+    g = {"cube": c4, "angles": a4, "scale_list": sc, "cube_ref": cr4, "cube_sig": sig}
+    kw = dict(scale_list=sc, adimsdi="double", verbose=False, nproc=1, full_output=True, cube_sig=sig)
+    for tag, extra in (("plain", dict(ncomp=(2, 3))),
+                       ("rsdi", dict(ncomp=(2, 3), cube_ref=cr4, scaling="temp-mean")),
+                       ("thr", dict(ncomp=(1, 3), source_xy=(23.0, 16.0), delta_rot=0.6, fwhm=4.0, min_frames_pca=3))):
+        fo = ref.pca(c4, a4, **kw, **extra)
+        for nm, a in zip(("frame", "chan", "chan_der"), fo):
+            g["%s_%s" % (tag, nm)] = np.asarray(a, dtype=np.float32)
+    save("g27_msdi_double_sig", **g)

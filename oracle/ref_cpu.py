@@ -1010,7 +1010,7 @@ def cube_rescaling_wavelengths(cube, scal_list, full_output=True, inverse=False,
 def pca_adimsdi_double(cube, angle_list, scale_list, ncomp, scaling=None, mask_center_px=None, svd_mode="lapack",
                        collapse="median", collapse_ifs="mean", ifs_collapse_range="all", weights=None,
                        full_output=False, cube_ref=None, ref_strategy="RSDI", source_xy=None, delta_rot=None, fwhm=4,
-                       min_frames_pca=10, max_frames_pca=None):
+                       min_frames_pca=10, max_frames_pca=None, cube_sig=None):
     """``pca(cube4d, angles, scale_list=..., adimsdi='double', ncomp=(k_ifs, k_adi))``.
     Ref: psfsub/pca_fullfr.py:412-415 (mask default), :478-508 (routing), :1263-1549 (_adimsdi_doublepca and
     _adimsdi_doublepca_ifs), :726-731 (returns).  ``cube_ref`` (:1279-1283): its frames pass the spectral stage with
@@ -1056,13 +1056,15 @@ def pca_adimsdi_double(cube, angle_list, scale_list, ncomp, scaling=None, mask_c
         if source_xy is not None:
             res_ifs_adi = pca_pa_rejection(sci, angle_list, ncomp_adi, source_xy, fwhm, delta_rot, scaling[1],
                                            mask_center_px, min_frames_pca, max_frames_pca, svd_mode=svd_mode,
-                                           full_output=True, cube_ref=refc)[2]
+                                           full_output=True, cube_ref=refc, cube_sig=cube_sig)[2]
         elif nr and "A" not in ref_strategy:
-            res_ifs_adi = project_subtract(sci, ncomp_adi, scaling[1], mask_center_px, svd_mode, cube_ref=refc)
+            res_ifs_adi = project_subtract(sci, ncomp_adi, scaling[1], mask_center_px, svd_mode, cube_ref=refc,
+                                           cube_sig=cube_sig)
         elif nr:
             raise IndexError("the reference de-rotates n + nr residual frames with n angles here")
         else:
-            res_ifs_adi = project_subtract(res_cube_channels, ncomp_adi, scaling[1], mask_center_px, svd_mode)
+            res_ifs_adi = project_subtract(res_cube_channels, ncomp_adi, scaling[1], mask_center_px, svd_mode,
+                                           cube_sig=cube_sig)
         der = cube_derotate(res_ifs_adi, angle_list, mask_val=mask_val)
     frame = cube_collapse(der, mode=collapse, w=weights)
     if full_output:

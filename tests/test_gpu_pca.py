@@ -1407,3 +1407,24 @@ def test_pca_3d_rotation_threshold_with_a_reference_cube():
         # (frame, recon_cube, residuals_cube, residuals_cube_)
         for a, b in zip(out, exp):
             assert a.shape == b.shape and np.nanmax(np.abs(a - b)) < TOL
+
+
+G27_CASES = (("plain", dict(ncomp=(2, 3))), ("rsdi", dict(ncomp=(2, 3), ref=True, scaling="temp-mean")),
+             ("thr", dict(ncomp=(1, 3), source_xy=(23.0, 16.0), delta_rot=0.6, fwhm=4.0, min_frames_pca=3)))
+
+
+@pytest.mark.parametrize("tag,kw", G27_CASES)
+def test_msdi_double_with_cube_sig_golden(tag, kw):
+    """``cube_sig`` in the ADI+mSDI double pass (handed to the second stage's ``_project_subtract``, reference
+    psfsub/pca_fullfr.py:1395,1409,1447) against the reference's own outputs (G27)."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g27_msdi_double_sig")
+    kw = dict(kw)
+    if kw.pop("ref", False):
+        kw["cube_ref"] = g["cube_ref"]
+    fo = pca(g["cube"], g["angles"], scale_list=g["scale_list"], adimsdi="double", full_output=True, verbose=False,
+             cube_sig=g["cube_sig"], **kw)
+    for nm, a in zip(("frame", "chan", "chan_der"), fo):
+        exp = g["%s_%s" % (tag, nm)]
+        assert a.shape == exp.shape and np.array_equal(np.isnan(a), np.isnan(exp)), (tag, nm)
+        assert np.nanmax(np.abs(a - exp)) < TOL, (tag, nm, np.nanmax(np.abs(a - exp)))

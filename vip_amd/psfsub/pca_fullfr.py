@@ -411,6 +411,8 @@ def pca(*all_args: List, **all_kwargs: dict):
         if cube.ndim != 4:
             raise TypeError("`scale_list` needs a 4d (channels, frames, y, x) cube")
         for name in ("mask_rdi", "cube_sig", "smooth_first_pass"):
+            if name == "cube_sig" and _s(algo_params.adimsdi) == "double":
+                continue                      # double pass: handed to the second (ADI) stage
             if getattr(algo_params, name, None) is not None:
                 raise NotImplementedError("{} is outside the accelerated ADI+mSDI path".format(name))
         if algo_params.cube_ref is not None and np.ndim(algo_params.cube_ref) != 4:
@@ -467,7 +469,9 @@ def pca(*all_args: List, **all_kwargs: dict):
                                                   ref_strategy=_s(algo_params.ref_strategy),
                                                   source_xy=algo_params.source_xy, delta_rot=algo_params.delta_rot,
                                                   fwhm=algo_params.fwhm, min_frames_pca=algo_params.min_frames_pca,
-                                                  max_frames_pca=algo_params.max_frames_pca)
+                                                  max_frames_pca=algo_params.max_frames_pca,
+                                                  cube_sig=(None if algo_params.cube_sig is None
+                                                            else B.to_device_f32(algo_params.cube_sig)))
                 # the reference's scale_fft returns float32 when it crops the spectrum (down-scaling) and float64 when it
                 # pads it or leaves a channel untouched (scale 1): mirror the resulting dtype of the collapsed frames
                 dt = None

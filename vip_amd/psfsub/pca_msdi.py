@@ -91,11 +91,12 @@ def _frame_major(cube4):
 
 def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px, collapse, collapse_ifs,
                    ifs_collapse_range, weights, mv_nan, verbose, cube_ref=None, ref_strategy="RSDI", source_xy=None,
-                   delta_rot=None, fwhm=4, min_frames_pca=10, max_frames_pca=None):
+                   delta_rot=None, fwhm=4, min_frames_pca=10, max_frames_pca=None, cube_sig=None):
     """Returns (res_cube_channels (n + nr, y, x), residuals_cube_channels_ (n, y, x), frame) as device tensors.
     ``cube_ref`` (z, nr, y, x): its multispectral frames go through the first (spectral) stage with the science frames
     and form the library of the second stage (pca_fullfr.py:1279-1283,1388-1400) -- or join every frame's library when a
-    rotation threshold is applied at ``source_xy`` (:1403-1459)."""
+    rotation threshold is applied at ``source_xy`` (:1403-1459).  ``cube_sig`` (n, y, x): estimate of the signal in the
+    frames the SECOND stage works on, handed to its ``_project_subtract`` (:1395,1409,1447)."""
     torch = B._torch()
     z, n, y_in, x_in = cube.shape
     if not isinstance(ncomp, tuple):
@@ -161,7 +162,7 @@ def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
             from .pca_fullfr import _pca_pa_rejection
             R, _M, _ln = _pca_pa_rejection(sci.contiguous(), angle_list, int(ncomp_adi), source_xy, delta_rot, fwhm,
                                            scaling[1], mask_center_px, min_frames_pca, max_frames_pca, False,
-                                           cube_ref=None if ref is None else ref.contiguous())
+                                           cube_sig=cube_sig, cube_ref=None if ref is None else ref.contiguous())
             src = R.reshape(n_sci, ys, ys)
         elif nr and "A" in str(ref_strategy):
             # the reference projects all n + nr frames here and then de-rotates them with the n angles (:1388-1399,
@@ -175,7 +176,16 @@ def adimsdi_double(cube, angle_list, scale_list, ncomp, scaling, mask_center_px,
                 msg = "{} PCs cannot be obtained from a matrix with size [{},{}]."
                 msg += " Increase the size of the patches or request less PCs"
                 raise RuntimeError(msg.format(ncomp_adi, Mr.shape[0], Mr.shape[1]))
-            src = B.pca_project(M, int(ncomp_adi), ref=Mr)[0].reshape(n_sci, ys, ys)
+            if cube_sig is not None:                                # (PCs from the reference frames; M - S is projected, S added back)
+                from .pca_fullfr import _project_subtract
+                src = _project_subtract(sci.contiguous(), ref.contiguous(), int(ncomp_adi), scaling[1], mask_center_px, "lapack",
+                                        False, False, cube_sig_t=cube_sig)
+            else:
+                src = B.pca_project(M, int(ncomp_adi), ref=Mr)[0].reshape(n_sci, ys, ys)
+        elif cube_sig is not None:
+            from .pca_fullfr import _project_subtract
+            src = _project_subtract(res_cube_channels.contiguous(), None, int(ncomp_adi), scaling[1], mask_center_px, "lapack",
+                                    False, False, cube_sig_t=cube_sig)
         else:
             src = _residuals(res_cube_channels, int(ncomp_adi), scaling[1], mask_center_px)
     der = B.derotate(src, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan)
