@@ -237,10 +237,10 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(const double* __rest
   __shared__ double cs[BMAX / 2], sn[BMAX / 2];
   __shared__ int pa[BMAX / 2], pb[BMAX / 2];
   __shared__ int rank[BMAX];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;        // 256 threads up to 32 columns (cheaper barriers), 1024 above
   load_partials(H, part, nsplit, p, p);
   __syncthreads();
-  for (int e = tid; e < BMAX * BMAX; e += 1024) {
+  for (int e = tid; e < BMAX * BMAX; e += nthr) {
     const int i = e / BMAX, j = e % BMAX;
     V[i][j] = (i == j) ? 1.0 : 0.0;
     if (i < j && j < p) {                          // symmetrise (the two halves differ in round-off)
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(const double* __rest
   __shared__ int rotated, finite, round_rot[2];
   if (tid == 0) finite = 1;
   __syncthreads();
-  for (int e = tid; e < p * p; e += 1024) {
+  for (int e = tid; e < p * p; e += nthr) {
     const double h = H[e / p][e % p];
     if (!(h == h) || fabs(h) > 1e300) finite = 0;
   }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(const double* __rest
           H[b1][b2] = s1 * tb + c1 * ub;
         }
       }
-      for (int e = tid; e < half * BMAX; e += 1024) {       // columns a, b of V
+      for (int e = tid; e < half * BMAX; e += nthr) {       // columns a, b of V
         const int q = e / BMAX, i = e % BMAX;
         const double s_ = sn[q];
         if (s_ == 0.0 || i >= p) continue;
@@ -347,11 +347,11 @@ __global__ __launch_bounds__(1024) void jacobi_small_kernel(const double* __rest
     rank[tid] = rk;
     theta[rk] = finite ? d : __longlong_as_double(0x7ff8000000000000ll);
   }
-  for (int e = tid; e < BMAX; e += 1024) if (e >= p) theta[e] = 0.0;
+  for (int e = tid; e < BMAX; e += nthr) if (e >= p) theta[e] = 0.0;
   __syncthreads();
-  for (int e = tid; e < BMAX * BMAX; e += 1024) W[e] = 0.0;
+  for (int e = tid; e < BMAX * BMAX; e += nthr) W[e] = 0.0;
   __syncthreads();
-  for (int e = tid; e < p * p; e += 1024) {
+  for (int e = tid; e < p * p; e += nthr) {
     const int i = e / p, j = e % p;
     W[i * BMAX + rank[j]] = V[i][j];
   }
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
 struct Chfsi {
   vipmi_ctx* ctx;
   const double* G;
-  int n, k, b, NT, NW, nsplit, rows_per, nrb;
+  int n, k, b, NT, nsplit, rows_per, nrb;
   double *Gd, *X[3], *Z, *T1, *L, *part, *Rinv, *W, *theta_d, *rpart, *lth_d;
   int* status_d;
   double* host;              // pinned: theta[64], rpart[nrb][64], status
@@ -521,7 +521,7 @@ struct Chfsi {
     }
     VIPMI_TRY(step(G, cur, nullptr, Z, 1.0, 0.0, 0.0));              // Z = G Q~   (the ORIGINAL matrix)
     VIPMI_TRY(tn(cur, b, bact, Z, b, bact));                          // H = Q~^T Z
-    hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, nsplit, bact, W, theta_d);
+    hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(bact <= 32 ? 256 : 1024), 0, ctx->stream, part, nsplit, bact, W, theta_d);
     VIPMI_CHECK_HIP(hipGetLastError());
     // Q = Q~ W, ZW = Z W (into `oth`), residual partial sums
     VIPMI_TRY(nn(cur, b, bact, W, 1, bact, nullptr, Qout, Z, oth, true));
@@ -569,7 +569,6 @@ int eigh_chfsi_f64(vipmi_ctx* ctx, const double* G, int64_t n64, int64_t k64, do
   const int want = k + std::max(12, k / 4);
   const int b = S.b = (int)cdiv(want, 16) * 16;
   S.NT = b / 16;
-  S.NW = n > 1024 ? 8 : 4;
   S.rows_per = n > 1024 ? 64 : 50;
   S.nsplit = (int)cdiv(n, S.rows_per);
   S.nrb = (int)cdiv(n, 16);
