@@ -52,7 +52,9 @@ __device__ __forceinline__ void strow4(float* __restrict__ base, int64_t row, in
 }
 
 // T[k,P] = Wt[n,kld]^T . M[n,P];  Wt row f holds W[0..k)[f] (kld >= 32*groups, zero padded).
-template <bool VEC>
+// NG groups of 32 output rows per wave: with more than 32 components (C5: k = 50) one pass over M serves 64 of them
+// (the streamed operand is the expensive one: 8.4 GB at C5; same accumulation order per output element as NG = 1).
+template <bool VEC, int NG>
 __global__ __launch_bounds__(256) void rowspace_kernel(const float* __restrict__ Wt, int kld,
                                                        const float* __restrict__ M, int k, int n,
                                                        int64_t P, const float* __restrict__ rowscale,
@@ -64,40 +66,47 @@ __global__ __launch_bounds__(256) void rowspace_kernel(const float* __restrict__
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   const int64_t px0 = tile * 128;
   if (px0 >= P) return;
-  const int grp = blockIdx.y;               // group of 32 output rows
+  const int grp0 = blockIdx.y * NG;         // first group of 32 output rows
   const int jl = lane & 31, kh = lane >> 5;
   const int64_t px = px0 + 4 * jl;
-  f32x16 acc[4];
+  f32x16 acc[NG][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  const float* wrow = Wt + grp * 32 + jl;   // A operand: W[grp*32 + i][f], i = lane&31
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][c][r] = 0.f;
+  const float* wrow = Wt + grp0 * 32 + jl;  // A operand: W[grp*32 + i][f], i = lane&31
   constexpr int U = 4;
   for (int f0 = 0; f0 < n; f0 += 2 * U) {
     f32x4 b[U];
-    float a[U];
+    float a[NG][U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int f = f0 + 2 * u + kh;
       b[u] = ldrow4<VEC>(M, f, n, P, px);
-      a[u] = (f < n) ? wrow[(int64_t)f * kld] : 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) a[g][u] = (f < n && (grp0 + g) * 32 < kld) ? wrow[(int64_t)f * kld + 32 * g] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][c], acc[c], 0, 0, 0);
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[g][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u], b[u][c], acc[g][c], 0, 0, 0);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    if (i < k) {
-      const float s = rowscale ? rowscale[i] : 1.f;
-      f32x4 v = {acc[0][r] * s, acc[1][r] * s, acc[2][r] * s, acc[3][r] * s};
-      strow4<VEC>(T, i, k, P, px, v);
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (grp0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (i < k) {
+        const float s = rowscale ? rowscale[i] : 1.f;
+        f32x4 v = {acc[g][0][r] * s, acc[g][1][r] * s, acc[g][2][r] * s, acc[g][3][r] * s};
+        strow4<VEC>(T, i, k, P, px, v);
+      }
     }
-  }
 }
 
 // R[n,P] = M - Ct[k,nld]^T . T[k,P];  Ct row c holds C[0..n)[c] (nld >= n rounded to 32).
@@ -191,13 +200,17 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n,
                     int64_t P, const float* rowscale, float* T) {
   const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(T);
-  dim3 grid((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(k, 32)), block(256);
-  if (vec)
-    hipLaunchKernelGGL(rowspace_kernel<true>, grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P,
-                       rowscale, T, (int64_t)0, (int64_t)0, (int64_t)0);
-  else
-    hipLaunchKernelGGL(rowspace_kernel<false>, grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P,
-                       rowscale, T, (int64_t)0, (int64_t)0, (int64_t)0);
+  const int groups = (int)cdiv(k, 32), ng = groups >= 2 ? 2 : 1;     // two groups of 32 components per pass over M from 33 on
+  dim3 grid((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(groups, ng)), block(256);
+#define LAUNCH(V, G)                                                                                          \
+  hipLaunchKernelGGL((rowspace_kernel<V, G>), grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P, rowscale, T, \
+                     (int64_t)0, (int64_t)0, (int64_t)0)
+  if (vec) {
+    if (ng == 2) LAUNCH(true, 2); else LAUNCH(true, 1);
+  } else {
+    if (ng == 2) LAUNCH(false, 2); else LAUNCH(false, 1);
+  }
+#undef LAUNCH
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -273,12 +286,12 @@ int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t 
     hipLaunchKernelGGL(pad_cols_kernel, dim3(8, (unsigned)cb), dim3(256), 0, ctx->stream, Eb, (int)k, (int)n, Ct, nld);
     dim3 g1((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(k, 32), (unsigned)cb), g2((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cb);
     if (vec) {
-      hipLaunchKernelGGL(rowspace_kernel<true>, g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
+      hipLaunchKernelGGL((rowspace_kernel<true, 1>), g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
                          (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
       hipLaunchKernelGGL((subtract_kernel<true, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
                          (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
     } else {
-      hipLaunchKernelGGL(rowspace_kernel<false>, g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
+      hipLaunchKernelGGL((rowspace_kernel<false, 1>), g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
                          (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
       hipLaunchKernelGGL((subtract_kernel<false, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
                          (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
