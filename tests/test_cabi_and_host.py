@@ -177,3 +177,20 @@ def test_find_indices_adi_all_matches_per_frame_scan():
             ref = [_find_indices_adi(a, j, thr, truncate=tr, max_frames=mf) for j in range(len(a))]
             got = _find_indices_adi_all(a, thr, truncate=tr, max_frames=mf)
             assert all(np.array_equal(r, g) and r.dtype == g.dtype for r, g in zip(ref, got))
+
+
+def test_bench_refuses_gpus_it_does_not_have_on_a_gpu_less_box():
+    """round-2 VERDICT: `bench.py --gpus N` must never silently run fewer ranks.  Without any GPU it refuses before it
+    spawns anything (and a WORLD_SIZE that contradicts --gpus is an error as well)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU variant of this test is in test_gpu_pca.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VIPMI_BENCH_DEVICE")}
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                        capture_output=True, text=True, env=env, timeout=300)
+    assert cp.returncode != 0 and "GPU(s) visible" in cp.stderr and "{" not in cp.stdout
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                        capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert cp.returncode != 0 and "WORLD_SIZE" in cp.stderr
