@@ -127,6 +127,14 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
   const int jl = lane & 31, kh = lane >> 5;
   const int64_t px = px0 + 4 * jl;
   constexpr int KS = 16;                       // component pairs held in registers per chunk
+  // up to 32 components: the wave's tile of T (its 128 pixels, every component) stays in registers for all frame blocks --
+  // it was re-read from L1 / L2 for every block of 32 frames (13 times at C2)
+  const bool hoist = k <= 2 * KS;
+  f32x4 bh[KS];
+  if (hoist) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bh[s] = ldrow4<VEC>(T, 2 * s + kh, k, P, px);
+  }
   for (int fb = 0; fb < n; fb += 32) {
     f32x16 acc[4];
 #pragma unroll
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int comp = c0 + 2 * s + kh;
-        b[s] = ldrow4<VEC>(T, comp, k, P, px);
+        b[s] = hoist ? bh[s] : ldrow4<VEC>(T, comp, k, P, px);
         a[s] = (comp < k) ? Ct[(int64_t)comp * nld + fb + jl] : 0.f;
       }
 #pragma unroll
