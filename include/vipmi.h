@@ -115,7 +115,7 @@ int vipmi_eigh_topk_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int
  * symmetric positive semi-definite G[n,n] (not modified).  *converged = 1: evals[0..k) descending, evecs[k,n] rows, every pair
  * with ||G q - theta q|| <= 1e-13 theta_1; *converged = 0: nothing written -- no usable gap behind the k-th eigenvalue, or
  * sizes outside 256 <= n <= 16384, k + max(12, k/4) <= 64, 4k <= n.  vipmi_eigh_topk_f64 tries it by itself for one matrix of
- * 600 .. 6144 rows (option "eigh_fast", default 1) and falls back on the exact tridiagonal path. */
+ * 700 .. 6144 rows -- from 800 / 1000 for blocks of 48 / 64 vectors -- (option "eigh_fast", default 1) and falls back on the exact tridiagonal path. */
 int vipmi_eigh_topk_fast_f64(vipmi_ctx* ctx, const double* G, int64_t n, int64_t k, double* evals, double* evecs,
                              int* converged);
 

@@ -24,15 +24,20 @@ def dev(B, a):
 @pytest.fixture(autouse=True)
 def _exact_eigensolvers(request, B):
     """The test_eigh_topk* tests pin the EXACT tridiagonal kernels (bit-identical vectors with and without the whole
-    spectrum, projector accuracy at 1e-10 across gaps of 1e-6): the verified fast path (eigh_chfsi.hip, n >= 600) is
+    spectrum, projector accuracy at 1e-10 across gaps of 1e-6): the verified fast path (eigh_chfsi.hip, n >= 700) is
     switched off for them and has its own tests below."""
     exact = request.node.name.startswith("test_eigh_topk")
+    fast = "fast" in request.node.name
     ctx = B.get_context()
     if exact:
         ctx.set_option("eigh_fast", 0)
+    if fast:
+        ctx.set_option("eigh_fast_min", 256)      # (by default the fast path only runs where it pays: from 700 .. 1000 rows)
     yield
     if exact:
         ctx.set_option("eigh_fast", 1)
+    if fast:
+        ctx.set_option("eigh_fast_min", 0)
 
 
 # ---- Gram -------------------------------------------------------------------------------------

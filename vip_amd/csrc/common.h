@@ -163,6 +163,7 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
                  double* evals, double* evecs, bool all_evals = false);
 // verified fast path for the leading pairs of ONE positive semi-definite matrix (eigh_chfsi.hip); G is not modified
 bool eigh_chfsi_supported(int64_t n, int64_t k);
+int64_t eigh_chfsi_pays_from(int64_t k);      // smallest n at which the fast path beats the exact solvers (measured, by block width)
 int eigh_chfsi_f64(vipmi_ctx* ctx, const double* G, int64_t n, int64_t k, double* evals, double* evecs, int* converged,
                    int* info);
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,

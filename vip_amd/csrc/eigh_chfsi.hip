@@ -552,6 +552,15 @@ bool eigh_chfsi_supported(int64_t n, int64_t k) {
   return want <= BMAX && 4 * k <= n;
 }
 
+// Smallest matrix on which the fast path is faster than the exact solvers, by block width (tools/eigh_fast_threshold.py, one
+// MI355X, wall time incl. the host round trips of the Rayleigh-Ritz rounds): b = 32: 5.5 against 6.2 ms at n = 700 (5.2 / 5.1 at
+// 620); b = 48: 7.2 / 7.9 ms at n = 800; b = 64: 10.0 / 6.0 ms at n = 600, 15.7 / 31.9 ms at n = 2000 -- a round costs ~0.3 / 0.45 /
+// 0.7 ms at b = 32 / 48 / 64 whatever n is, the exact path grows like n^2 .. n^3.
+int64_t eigh_chfsi_pays_from(int64_t k) {
+  const int64_t want = k + std::max<int64_t>(12, k / 4);
+  return want <= 32 ? 700 : want <= 48 ? 800 : 1000;
+}
+
 // Leading k eigenpairs of the symmetric positive semi-definite G (n x n, float64, NOT modified).  *converged = 1: evals[0..k)
 // (descending) and evecs (row c = eigenvector c, the sign convention of the exact solvers) are set and every pair satisfies
 // ||G q - theta q|| <= tol * theta_1;  *converged = 0: nothing was written, the caller runs the exact path.

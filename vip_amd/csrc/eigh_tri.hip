@@ -1395,7 +1395,8 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
   // verified Chebyshev-filtered subspace iteration first (eigh_chfsi.hip); it leaves G untouched, so when the spectrum does
   // not allow it within its budget the exact path below runs as if nothing had happened.
   if (batch == 1 && !nact && !all_evals && ctx->opt("eigh_fast", 1) != 0 && ctx->opt("eigh_check", 1) != 0 &&
-      ctx->opt("eigh_method", 0) != 1 && n >= ctx->opt("eigh_fast_min", 600) && eigh_chfsi_supported(n, k)) {
+      ctx->opt("eigh_method", 0) != 1 &&
+      n >= (ctx->opt("eigh_fast_min", 0) > 0 ? ctx->opt("eigh_fast_min", 0) : eigh_chfsi_pays_from(k)) && eigh_chfsi_supported(n, k)) {
     int conv = 0, info[4];
     {
       StageScope sc(ctx, "eigh");
