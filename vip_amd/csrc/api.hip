@@ -216,7 +216,7 @@ __global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const do
 
 extern "C" {
 
-int vipmi_version(void) { return 102; }
+int vipmi_version(void) { return 103; }
 
 const char* vipmi_last_error(void) { return g_err; }
 
