@@ -885,7 +885,11 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
     // line at Le = 2048 with 12 or 16 waves per workgroup (3 waves per SIMD, but workgroup barriers and 1.5x the
     // instructions per line: 6.2 against 3.8 ms at C2); four waves per line at Le = 4096.
     case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
-    case 2048: return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
+    case 2048:
+      // rot_2048_half=1: four-wave workgroups (one wave per SIMD), so that the MFMA-bound Gram of another call in flight can
+      // share the SIMDs with the VALU-bound shears (experiment)
+      if (ctx->opt("rot_2048_half", 0)) return run_plan2<Plan2048w1h>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
+      return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
     case 4096:
       // one wave per line and per SIMD (512-VGPR budget), column shear software-pipelined: 200 frames of 1024 px
       // 10.85 -> 9.4 ms against the two-wave plan (kept behind rot_4096_w1=0)
