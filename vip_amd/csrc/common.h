@@ -137,6 +137,8 @@ struct StageScope {
 // ---- internal entry points implemented per .hip file (all enqueue on ctx->stream) ----
 int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t nb, int64_t P,
              int64_t ld, double* G);
+// symmetric Gram matrices on the int8 matrix cores (gram_i8.hip): mode 1 = 5 digits (7e-12), 2 = 6 digits (2e-15)
+int gram_i8_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double* G, int64_t batch, int mode);
 int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs);
 // leading k eigenpairs only (eigh_tri.hip); falls back to eigh_f64 when the sizes are outside its range or
 // option "eigh_method" == 1.  nact: optional device array with the active size of each (zero padded) problem.

@@ -416,6 +416,10 @@ int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t
   StageScope sc(ctx, "gram");
   const bool symmetric = (A == B) && (na == nb);
   const bool f32acc = ctx->opt("gram_f32", 0) != 0;
+  {
+    const int i8 = (int)ctx->opt("gram_i8", 0);
+    if (i8 > 0 && symmetric && !f32acc && na >= 32 && P >= 1024) return gram_i8_f32(ctx, A, na, P, ld, G, 1, i8);
+  }
   const int64_t nmax = na > nb ? na : nb;
   int tb = (int)ctx->opt("gram_tb", 0);
   if (tb <= 0) tb = nmax <= 16 ? 1 : (nmax <= 32 ? 2 : 4);

@@ -1,0 +1,376 @@
+// gram_i8.hip -- the Gram matrix G = M M^T of a float32 matrix on the INT8 matrix cores (v_mfma_i32_16x16x64_i8, ~4 POPS on
+// MI355X: 50x the float64 MFMA rate), to float64 accuracy: the "Ozaki scheme" with integer slices.
+//
+// psfsub/svd.py:449 forms the covariance in float64 because it squares the condition number; gram.hip does so on
+// v_mfma_f64_16x16x4_f64 (78.6 TF/s peak, 66 % reached: 1.08 ms at C2, 77 ms at C5 -- 19 % / 37 % of those calls).  Here:
+//   1. split (gram_split_kernel): every row is cut into K-slices (the split-K slices of the product); per (row, slice) the
+//      samples become fixed-point numbers with T = 7 S bits below 2^e, e = exponent of the slice's largest |a|,
+//      written as S signed (balanced, |d| <= 64) base-128 digits d_0 (least significant) .. d_{S-1} in S int8 planes.  A local exponent per slice
+//      keeps faint regions of a frame as accurate as bright ones.
+//   2. product (gram_i8_kernel): a wave owns a 32 x 32 tile of G and a slice; digit planes j (rows) and j' (columns) are
+//      multiplied on the int8 MFMA with EXACT int32 accumulation over the slice (|d| <= 64, top digit <= 127: no overflow up to
+//      16384 samples), one accumulator set per significance level L = j + j'; levels below S - 1 - KEEP are dropped (their
+//      terms are < 2^-7(S+1-KEEP) of the largest).  At the end of the slice the levels are combined in float64,
+//      sum_L 128^L acc_L, scaled by the two rows' 2^(e+2-T), and written as a float64 partial tile;
+//   3. the slices are summed in float64 in a fixed order (deterministic).
+// Accuracy against an exact float64 product (numpy prototype and tools/gram_parity.py): S = 5, KEEP = 1 (19 digit products):
+// max |dG| = 7e-12 max|G|;  S = 6, KEEP = 1 (26): 2e-15.  The exact float32 products of gram.hip give 1e-16: see DESIGN 3.4 for
+// what 7e-12 means for the leading subspace (a rotation of 3e-7 between pairs 20 and 21 of C2).
+// Non-finite samples make their row's scale NaN: the row and column of G are NaN, as with the float64 kernel.
+#include "common.h"
+#include <algorithm>
+#include <vector>
+
+namespace vipmi {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// ---- 1. split: M[n][ld] float32 -> D[S][npad][Ppad] int8, sc[npad][nslices] float64 ------------------------------------------
+// One workgroup per (row, slice): the slice is read ONCE into registers (16 consecutive samples per thread and pass), its largest
+// magnitude found through LDS, and the digits are peeled off in float32 -- y = a 2^(6-ex) (|y| < 64); d = rint(y); y = 128 (y - d);
+// ... : every subtraction is exact (the remainder is a multiple of the sample's ulp and at most half a unit), the digits come out
+// balanced in [-64, 64], and the last one carries the rounding.  a = sum_j d_j 128^j 2^(ex - 6 - 7 (S-1)) to 2^-(7S-1) of 2^ex.
+template <int S, int NP>                           // NP = passes of 256 x 16 samples (slice length <= 4096 NP)
+__global__ __launch_bounds__(256) void gram_split_kernel(const float* __restrict__ M, int n, int64_t P, int64_t ld,
+                                                         int klen, int nslices, int64_t Ppad, int64_t plane,
+                                                         int8_t* __restrict__ D, double* __restrict__ sc,
+                                                         int64_t bstride_in) {
+  __shared__ float red[256];
+  const int slice = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  M += (int64_t)blockIdx.z * bstride_in;
+  const int npad = gridDim.y;
+  D += (int64_t)blockIdx.z * S * plane;
+  sc += (int64_t)blockIdx.z * npad * nslices;
+  const int64_t k0 = (int64_t)slice * klen;
+  int8_t* drow = D + (int64_t)row * Ppad + k0;
+  if (row >= n) {                                   // padding rows: zero digits
+    for (int e = tid * 16; e < klen; e += 256 * 16)
+#pragma unroll
+      for (int j = 0; j < S; ++j) *reinterpret_cast<v4i*>(drow + j * plane + e) = v4i{0, 0, 0, 0};
+    if (tid == 0) sc[(int64_t)row * nslices + slice] = 0.0;
+    return;
+  }
+  const float* src = M + (int64_t)row * ld + k0;
+  const int64_t valid = (P - k0) < klen ? (P - k0) : klen;       // samples of this slice inside the row
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
+  float av[NP][16];
+  float amax = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int e = (ps * 256 + tid) * 16;
+    if (vec && e + 16 <= valid) {
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        const float4 f = *reinterpret_cast<const float4*>(src + e + 4 * u4);
+        av[ps][4 * u4] = f.x; av[ps][4 * u4 + 1] = f.y; av[ps][4 * u4 + 2] = f.z; av[ps][4 * u4 + 3] = f.w;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) av[ps][u] = (e + u < valid) ? src[e + u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float a = fabsf(av[ps][u]);
+      if (!(a <= 3.0e38f)) bad = true;              // NaN / Inf poison the slice
+      amax = fmaxf(amax, a);
+    }
+  }
+  red[tid] = bad ? __int_as_float(0x7fc00000) : amax;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const float x = red[tid], y = red[tid + s];
+      red[tid] = (x != x || y != y) ? __int_as_float(0x7fc00000) : fmaxf(x, y);
+    }
+    __syncthreads();
+  }
+  amax = red[0];
+  const bool poisoned = amax != amax;
+  int ex = -100;
+  if (!poisoned && amax > 0.f) (void)frexpf(amax, &ex);          // amax = m 2^ex, 0.5 <= m < 1  ->  |a| < 2^ex
+  if (ex < -100) ex = -100;                                        // (denormal slices: keep the scale factors finite in float32)
+  const float up = ldexpf(1.f, 6 - ex);
+  if (tid == 0)
+    sc[(int64_t)row * nslices + slice] = poisoned ? __longlong_as_double(0x7ff8000000000000ll) : ldexp(1.0, ex - 6 - 7 * (S - 1));
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int e = (ps * 256 + tid) * 16;
+    if (e >= klen) break;
+    unsigned w[S][4];
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w[j][c] = 0u;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      float y = poisoned ? 0.f : av[ps][u] * up;
+#pragma unroll
+      for (int j = S - 1; j >= 0; --j) {              // most significant digit first
+        const float d = rintf(y);
+        w[j][u >> 2] |= ((unsigned)(int)d & 255u) << (8 * (u & 3));
+        y = (y - d) * 128.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+      *reinterpret_cast<v4i*>(drow + j * plane + e) = v4i{(int)w[j][0], (int)w[j][1], (int)w[j][2], (int)w[j][3]};
+  }
+}
+
+// ---- 2. product: a workgroup of four waves = one 64 x 64 tile of G over one slice, every wave a 32 x 32 quarter ---------------
+// Operands go through LDS: per 64-sample step the workgroup loads the S digit planes of its 64 rows and 64 columns ONCE
+// (one 16-byte load per thread, plane and side; the loads of step i+1 are in flight in registers while the MFMAs of step i
+// issue, then stored into the other half of the double buffer), every wave reads its two row blocks and two column blocks from
+// there in MFMA fragment layout (lane (r, kq): 16 bytes of row r at sample offset 16 kq -- a 16 x 64-byte block is 1 KB
+// contiguous: conflict-free ds_read_b128).  Straight from global memory (first version) the same product was bound by L1 / L2
+// round trips: 1.38 ms at C2 against 0.25 ms of int8 MFMA time.
+// the step loop of one workgroup, specialised at compile time: DIAG = the tile lies on the diagonal (its columns are its rows:
+// one side is loaded), ROLE = 0 full quarter (four blocks), 1 quarter on the diagonal (block (1, 0) skipped), 2 idle quarter
+// (below the diagonal: the wave only helps loading).  With these as run-time flags every MFMA sat in a basic block of its own
+// behind a branch and a just-in-time s_waitcnt (the lesson of gram.hip's guarded tile loop, again).
+template <int S, int KEEP, bool DIAG, int ROLE>
+__device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, const int8_t* gb, int64_t plane, int nsteps, int nbuf,
+                                              int loff, int fa, int fb, v4i (&acc)[2 * S - 1 - (S - 1 - KEEP)][2][2]) {
+  constexpr int LMIN = S - 1 - KEEP;
+  constexpr int PL = 64 * 64;                       // one plane of one side: 64 rows of 64 bytes (an 80-byte row stride removes the
+                                                    // bank conflicts of the fragment reads -- a third of the LDS cycles -- but changes
+                                                    // nothing: 0.78 against 0.75 ms, and two buffers no longer fit twice per CU)
+  constexpr int SIDE = S * PL, BUF = 2 * SIDE;
+  v4i la[S], lb[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    la[j] = *reinterpret_cast<const v4i*>(ga + j * plane);
+    if (!DIAG) lb[j] = *reinterpret_cast<const v4i*>(gb + j * plane);
+  }
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    *reinterpret_cast<v4i*>(smem + j * PL + loff) = la[j];
+    if (!DIAG) *reinterpret_cast<v4i*>(smem + SIDE + j * PL + loff) = lb[j];
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int8_t* cur = smem + (nbuf == 2 ? (step & 1) * BUF : 0);
+    int8_t* nxt = smem + (nbuf == 2 ? ((step + 1) & 1) * BUF : 0);
+    const bool more = step + 1 < nsteps;
+    if (more) {
+      const int64_t o = (int64_t)(step + 1) * 64;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        la[j] = *reinterpret_cast<const v4i*>(ga + j * plane + o);
+        if (!DIAG) lb[j] = *reinterpret_cast<const v4i*>(gb + j * plane + o);
+      }
+    }
+    if (ROLE != 2) {
+      // the column digits stay in registers for the step, the row digits are read plane by plane as they are used (the full
+      // set of both sides made 312 VGPRs: one workgroup per CU, every LDS / global wait exposed)
+      v4i b[2][S];
+      const int8_t* cb = DIAG ? cur - SIDE : cur;       // a diagonal tile's columns are its rows: the A side serves both
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) b[i][j] = *reinterpret_cast<const v4i*>(cb + fb + i * 1024 + j * PL);
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        v4i a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const v4i*>(cur + fa + i * 1024 + j * PL);
+#pragma unroll
+        for (int jp = 0; jp < S; ++jp) {
+          const int l = j + jp - LMIN;
+          if (l < 0) continue;
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj) {
+              if (ROLE == 1 && bj < bi) continue;
+              acc[l][bi][bj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[bi], b[bj][jp], acc[l][bi][bj], 0, 0, 0);
+            }
+        }
+      }
+    }
+    if (nbuf == 1) __syncthreads();                   // single buffer: everybody has read this step before it is overwritten
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        *reinterpret_cast<v4i*>(nxt + j * PL + loff) = la[j];
+        if (!DIAG) *reinterpret_cast<v4i*>(nxt + SIDE + j * PL + loff) = lb[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int S, int KEEP>
+__global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ D, const double* __restrict__ sc, int npad,
+                                                      int klen, int nslices, int64_t Ppad, int64_t plane,
+                                                      const int2* __restrict__ wgtiles, int nwg,
+                                                      double* __restrict__ partial, int gram_i8_nbuf) {
+  constexpr int LMIN = S - 1 - KEEP, NL = 2 * S - 2 - LMIN + 1;
+  extern __shared__ __attribute__((aligned(16))) int8_t smem[];          // [1 or 2 buffers][2 sides][S planes][64 rows][64 bytes]
+  constexpr int SIDE = S * 64 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // blockIdx.x = (slice % 8) + 8 * tile, blockIdx.y = slice / 8: workgroup ids go round-robin over the 8 XCDs, so every tile of
+  // a slice runs on ONE XCD at the same time and the slice's digit rows are fetched once into that L2 (each row block is an
+  // operand of n / 64 tiles; with the slices fastest the same product moved 3.7 GB from HBM: 0.99 ms)
+  const int slice = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7), wg = (int)blockIdx.x >> 3;
+  if (slice >= nslices) return;                      // (uniform for the workgroup: before any barrier)
+  D += (int64_t)blockIdx.z * S * plane;
+  sc += (int64_t)blockIdx.z * npad * nslices;
+  const int2 t = wgtiles[wg];
+  const bool diag = __builtin_amdgcn_readfirstlane((int)(t.x == t.y)) != 0;
+  const int wi = wave >> 1, wj = wave & 1;
+  // global -> LDS: thread -> (row = tid / 4, 16-byte segment = tid % 4) of every plane and side
+  const int lrow = tid >> 2, lseg = tid & 3;
+  const int64_t kbase = (int64_t)slice * klen + 16 * lseg;
+  const int8_t* ga = D + (int64_t)(t.x * 64 + lrow) * Ppad + kbase;
+  const int8_t* gb = D + (int64_t)(t.y * 64 + lrow) * Ppad + kbase;
+  const int loff = lrow * 64 + 16 * lseg;
+  const int r = lane & 15, kq = lane >> 4;
+  const int fa = (wi * 32 + r) * 64 + 16 * kq, fb = SIDE + (wj * 32 + r) * 64 + 16 * kq;      // fragment offsets of block 0
+  v4i acc[NL][2][2];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[l][i][j] = v4i{0, 0, 0, 0};
+  const int nsteps = klen >> 6, nbuf = gram_i8_nbuf;
+  int role = 0;
+  if (!diag) {
+    gram_i8_steps<S, KEEP, false, 0>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
+  } else {
+    role = wi > wj ? 2 : (wi == wj ? 1 : 0);          // (wave-uniform)
+    if (role == 0) gram_i8_steps<S, KEEP, true, 0>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
+    else if (role == 1) gram_i8_steps<S, KEEP, true, 1>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
+    else gram_i8_steps<S, KEEP, true, 2>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
+  }
+  if (role == 2) return;
+  const bool qdiag = role == 1;
+  // combine the levels in float64, scale, write the quarter's partial tile: block (bi, bj) at (bi * 2 + bj) * 256, element
+  // row * 16 + col (int8 / float32 MFMA output layout: row = 4 (lane >> 4) + g, column = lane & 15)
+  double* out = partial + ((((int64_t)blockIdx.z * nslices + slice) * nwg + wg) * 4 + wave) * 1024;
+  const double lm = (double)(1ll << (7 * LMIN));
+  const int row0 = t.x * 64 + wi * 32, col0 = t.y * 64 + wj * 32;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      if (qdiag && bj < bi) continue;
+      const double sb = sc[(int64_t)(col0 + bj * 16 + r) * nslices + slice] * lm;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 4 * kq + g;
+        const double sa = sc[(int64_t)(row0 + bi * 16 + row) * nslices + slice];
+        double v = 0.0;
+#pragma unroll
+        for (int l = NL - 1; l >= 0; --l) v = v * 128.0 + (double)acc[l][bi][bj][g];     // Horner: sum_l 128^l acc_l
+        out[(bi * 2 + bj) * 256 + row * 16 + r] = v * sa * sb;
+      }
+    }
+}
+
+// ---- 3. slices summed in a fixed order, upper triangle mirrored -------------------------------------------------------------
+__global__ void gram_i8_reduce_kernel(const double* __restrict__ partial, const int2* __restrict__ wgtiles, int nwg,
+                                      int nslices, int n, double* __restrict__ G) {
+  const int64_t total = (int64_t)nwg * 4096;
+  partial += (int64_t)blockIdx.y * nslices * total;
+  G += (int64_t)blockIdx.y * n * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int wg = (int)(e >> 12), wave = (int)(e >> 10) & 3, rem = (int)(e & 1023);
+    const int blk = rem >> 8, idx = rem & 255;
+    const int bi = blk >> 1, bj = blk & 1, wi = wave >> 1, wj = wave & 1;
+    const int2 t = wgtiles[wg];
+    if (t.x == t.y && (wi > wj || (wi == wj && bj < bi))) continue;          // never written: lower part of a diagonal tile
+    const int gi = t.x * 64 + wi * 32 + bi * 16 + (idx >> 4), gj = t.y * 64 + wj * 32 + bj * 16 + (idx & 15);
+    if (gi >= n || gj >= n) continue;
+    double s = 0.0;
+    for (int sl = 0; sl < nslices; ++sl) s += partial[(int64_t)sl * total + e];
+    G[(int64_t)gi * n + gj] = s;
+    G[(int64_t)gj * n + gi] = s;
+  }
+}
+
+template <int S, int KEEP>
+int run(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double* G, int64_t batch) {
+  const int npad = (int)cdiv(n, 64) * 64, nt = npad / 64;
+  std::vector<int2> tiles;
+  // Tile order = dispatch order on every XCD (ids go round-robin over the XCDs, the slice is the id's low bits): ~64 consecutive
+  // tiles of a slice are resident on an XCD at the same time and walk through the slice in step, so tiles listed together
+  // should share operands -- 8 x 8 super-blocks (8 + 8 row blocks feed 64 tiles; row-major order re-fetched every column block
+  // for every tile row: 351 GB through the L2s at C5).  Small problems (<= 8 tile rows): off-diagonal tiles first, the lighter
+  // diagonal ones fill the tail.
+  if (nt <= 8) {
+    for (int i = 0; i < nt; ++i)
+      for (int j = i + 1; j < nt; ++j) tiles.push_back(int2{i, j});
+    for (int i = 0; i < nt; ++i) tiles.push_back(int2{i, i});
+  } else {
+    for (int I = 0; I < nt; I += 8)
+      for (int J = I; J < nt; J += 8)
+        for (int i = I; i < std::min(I + 8, nt); ++i)
+          for (int j = std::max(J, i); j < std::min(J + 8, nt); ++j) tiles.push_back(int2{i, j});
+  }
+  const int nwg = (int)tiles.size();
+  // slices: ~6 workgroups per CU in total (two are resident at a time: 80 KB of LDS each); a multiple of 64 samples, at most
+  // 8192 (int32 head room: 5 x 8192 x 65 x 64 < 2^31)
+  int64_t want = cdiv((int64_t)6 * ctx->num_cu, (int64_t)nwg * batch);
+  if (ctx->opt("gram_i8_slices", 0) > 0) want = ctx->opt("gram_i8_slices", 0);
+  if (want < 1) want = 1;
+  int64_t klen = cdiv(cdiv(P, want), 64) * 64;
+  if (klen < 256) klen = 256;
+  if (klen > 8192) klen = 8192;
+  const int nslices = (int)cdiv(P, klen);
+  const int64_t Ppad = (int64_t)nslices * klen, plane = (int64_t)npad * Ppad;
+  int8_t* D = nullptr;
+  double *sc = nullptr, *partial = nullptr;
+  VIPMI_TRY(ws(ctx, "gram_i8_digits", (size_t)batch * S * plane, &D));
+  VIPMI_TRY(ws(ctx, "gram_i8_scale", (size_t)batch * npad * nslices, &sc));
+  VIPMI_TRY(ws(ctx, "gram_i8_partial", (size_t)batch * nslices * nwg * 4096, &partial));
+  int2* d_tiles = nullptr;
+  {
+    char key[64];
+    snprintf(key, sizeof key, "i8/%d", nt);
+    void* p = nullptr;
+    VIPMI_TRY(ctx->upload_cached("gram_i8_tiles", key, tiles.data(), sizeof(int2) * nwg, &p));
+    d_tiles = reinterpret_cast<int2*>(p);
+  }
+  VIPMI_REQUIRE(batch <= 65535, "gram: batch too large");
+  {
+    const dim3 sg((unsigned)nslices, (unsigned)npad, (unsigned)batch);
+    if (klen <= 4096)
+      hipLaunchKernelGGL((gram_split_kernel<S, 1>), sg, dim3(256), 0, ctx->stream, M, (int)n, P, ld, (int)klen, nslices, Ppad, plane,
+                         D, sc, (int64_t)n * ld);
+    else
+      hipLaunchKernelGGL((gram_split_kernel<S, 2>), sg, dim3(256), 0, ctx->stream, M, (int)n, P, ld, (int)klen, nslices, Ppad, plane,
+                         D, sc, (int64_t)n * ld);
+  }
+  VIPMI_CHECK_HIP(hipGetLastError());
+  const int nbuf = (int)ctx->opt("gram_i8_nbuf", S <= 5 ? 2 : 1);          // LDS buffers per workgroup (5 digits: 2 x 40 KB, two workgroups per CU)
+  const size_t lds = (size_t)(nbuf == 2 ? 2 : 1) * 2 * S * 64 * 64;
+  auto kern = gram_i8_kernel<S, KEEP>;
+  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * nwg), (unsigned)cdiv(nslices, 8), (unsigned)batch), dim3(256), lds, ctx->stream, D, sc, npad,
+                     (int)klen, nslices, Ppad, plane, d_tiles, nwg, partial, nbuf == 2 ? 2 : 1);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  int rb = (int)cdiv((int64_t)nwg * 4096, 256);
+  if (rb > 4096) rb = 4096;
+  if (batch > 1 && rb > 64) rb = 64;
+  hipLaunchKernelGGL(gram_i8_reduce_kernel, dim3((unsigned)rb, (unsigned)batch), dim3(256), 0, ctx->stream, partial, d_tiles, nwg,
+                     nslices, (int)n, G);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+}  // namespace
+
+// G[batch][n][n] = M M^T for `batch` float32 matrices [n][P] (row length ld; problems n * ld apart) on the int8 matrix cores.
+// mode 1: 5 digits, 19 products (7e-12 max|G|); mode 2: 6 digits, 26 products (2e-15).
+int gram_i8_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double* G, int64_t batch, int mode) {
+  VIPMI_REQUIRE((reinterpret_cast<uintptr_t>(M) & 3) == 0, "gram_i8: unaligned input");
+  if (mode >= 2) return run<6, 1>(ctx, M, n, P, ld, G, batch);
+  return run<5, 1>(ctx, M, n, P, ld, G, batch);
+}
+
+}  // namespace vipmi
