@@ -902,3 +902,64 @@ def test_pca_with_and_without_the_fast_eigensolver(B):
     ctx.set_option("eigh_fast", 1)
     ok = torch.isfinite(f0)
     assert torch.equal(ok, torch.isfinite(f1)) and float((f1[ok] - f0[ok]).abs().max()) < 2e-6
+
+
+# ---- Gram matrix on the int8 matrix cores (gram_i8.hip) ------------------------------------------------------------
+
+@pytest.mark.parametrize("n,P,batch", [(64, 4096, 1), (100, 10201, 1), (400, 70001, 1), (257, 131072, 1), (39, 8192, 5)])
+def test_gram_on_the_int8_matrix_cores(B, n, P, batch):
+    """Integer-slice (Ozaki) Gram: 5 digits -> 1e-10 of sqrt(G_ii G_jj) entry by entry (3e-12 of max|G| on image data), 6 digits
+    -> float64 round-off; rows of very different magnitude, a zero row, negative data, ragged sizes; deterministic."""
+    import torch
+    rng = np.random.default_rng(n + P)
+    M = rng.standard_normal((batch, n, P)).astype(np.float32) * np.logspace(-2, 2, P, dtype=np.float32)
+    M[:, 1] = 0.0
+    M[:, 2] *= np.float32(1e18)
+    M[:, 3] *= np.float32(1e-18)
+    M[:, 4, ::7] = 0.0
+    ref = np.einsum("bip,bjp->bij", M.astype(np.float64), M.astype(np.float64))
+    dg = np.sqrt(np.abs(np.einsum("bii->bi", ref)))
+    scale = dg[:, :, None] * dg[:, None, :] + 1e-300
+    Mt = torch.from_numpy(M).cuda()
+    ctx = B.get_context()
+    try:
+        for mode, tol in ((1, 1e-10), (2, 2e-13)):
+            ctx.set_option("gram_i8", mode)
+            ctx.set_option("gram_i8_min_n", 16)
+            G = (B.gram_batched(Mt) if batch > 1 else B.gram(Mt[0])[None])
+            G2 = (B.gram_batched(Mt) if batch > 1 else B.gram(Mt[0])[None])
+            assert torch.equal(G, G2)
+            G = G.cpu().numpy()
+            assert np.array_equal(G, np.swapaxes(G, 1, 2))
+            assert np.all(G[:, 1] == 0.0)
+            assert np.abs(G - ref).max() <= 1e-300 or (np.abs(G - ref) / scale).max() < tol, (mode, (np.abs(G - ref) / scale).max())
+    finally:
+        ctx.set_option("gram_i8", -1)
+        ctx.set_option("gram_i8_min_n", 32)
+
+
+def test_gram_int8_non_finite_rows_and_the_default_rule(B):
+    """A NaN / Inf sample poisons its row and column of G (as with the float64 kernel) and nothing else; by default the int8
+    path serves large single problems only (>= 256 rows x 131072 samples) -- its result is within 1e-11 of the float64 kernel's."""
+    import torch
+    rng = np.random.default_rng(3)
+    M = rng.standard_normal((300, 131072)).astype(np.float32)
+    Mt = torch.from_numpy(M).cuda()
+    ctx = B.get_context()
+    try:
+        ctx.set_option("gram_i8", 0)
+        G0 = B.gram(Mt).cpu().numpy()
+        ctx.set_option("gram_i8", -1)
+        G1 = B.gram(Mt).cpu().numpy()
+        assert not np.array_equal(G0, G1)                                   # the int8 path ran ...
+        assert np.abs(G1 - G0).max() < 1e-11 * np.abs(G0).max()             # ... and agrees
+        M[5, 77] = np.nan
+        M[9, 100000] = np.inf
+        ctx.set_option("gram_i8", 1)
+        G = B.gram(torch.from_numpy(M).cuda()).cpu().numpy()
+        bad = np.zeros(300, bool)
+        bad[[5, 9]] = True
+        assert np.all(~np.isfinite(G[bad])) and np.all(~np.isfinite(G[:, bad]))
+        assert np.all(np.isfinite(G[~bad][:, ~bad]))
+    finally:
+        ctx.set_option("gram_i8", -1)

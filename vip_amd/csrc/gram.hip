@@ -417,8 +417,12 @@ int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t
   const bool symmetric = (A == B) && (na == nb);
   const bool f32acc = ctx->opt("gram_f32", 0) != 0;
   {
-    const int i8 = (int)ctx->opt("gram_i8", 0);
-    if (i8 > 0 && symmetric && !f32acc && na >= 32 && P >= 1024) return gram_i8_f32(ctx, A, na, P, ld, G, 1, i8);
+    // int8 matrix cores (gram_i8.hip): option gram_i8 = 0 off, 1 / 2 forced (5 / 6 digits), unset = where it is measured to
+    // pay (tools/gram_i8_sizes.py: 1.3-1.5x from 256 rows x 131072 samples; slower than this kernel on small or skinny problems)
+    const int64_t i8 = ctx->opt("gram_i8", -1);
+    const bool forced = i8 > 0 && na >= ctx->opt("gram_i8_min_n", 32) && P >= 1024;
+    const bool pays = i8 < 0 && na >= 256 && P >= 131072;
+    if (symmetric && !f32acc && (forced || pays)) return gram_i8_f32(ctx, A, na, P, ld, G, 1, i8 == 2 ? 2 : 1);
   }
   const int64_t nmax = na > nb ? na : nb;
   int tb = (int)ctx->opt("gram_tb", 0);
@@ -447,6 +451,13 @@ int gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, i
   VIPMI_REQUIRE(batch > 0 && n > 0 && P > 0 && n < (1 << 20), "gram_batched: bad sizes batch=%ld n=%ld P=%ld", (long)batch,
                 (long)n, (long)P);
   StageScope sc(ctx, "gram");
+  {
+    // (batches of small problems: the float64-MFMA kernel is the faster one -- 39 x (200 x 65536): 3.0 against 3.3 ms -- so the
+    // int8 path only runs when forced)
+    const int64_t i8 = ctx->opt("gram_i8", -1);
+    if (i8 > 0 && ctx->opt("gram_f32", 0) == 0 && n >= ctx->opt("gram_i8_min_n", 32) && P >= 1024 && batch <= 65535)
+      return gram_i8_f32(ctx, M, n, P, P, G, batch, i8 == 2 ? 2 : 1);
+  }
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb_ = (batch - b0) < 65535 ? (batch - b0) : 65535;
     const float* Mb = M + (size_t)b0 * n * P;
