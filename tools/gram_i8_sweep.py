@@ -3,6 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from vip_amd import backend as B
 from vip_amd.synth import synth_adi_device
 n, N = (int(a) for a in sys.argv[1:3]) if len(sys.argv) > 2 else (400, 512)
+SL = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0, 24, 32, 48, 64, 96]
 ct, ang = synth_adi_device(n, N, seed=0)
 M = ct.reshape(n, -1)
 ctx = B.get_context()
@@ -15,6 +16,6 @@ def t(fn, reps=5):
 ctx.set_option("gram_i8", 0); print("f64 mfma      %.3f ms" % t(lambda: B.gram(M)))
 ctx.set_option("gram_i8", 1)
 for nbuf in (1, 2):
-    for sl in (0, 24, 32, 48, 64, 96):
+    for sl in SL:
         ctx.set_option("gram_i8_nbuf", nbuf); ctx.set_option("gram_i8_slices", sl)
         print("i8 nbuf=%d slices=%d  %.3f ms" % (nbuf, sl, t(lambda: B.gram(M))))

@@ -418,10 +418,11 @@ int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t
   const bool f32acc = ctx->opt("gram_f32", 0) != 0;
   {
     // int8 matrix cores (gram_i8.hip): option gram_i8 = 0 off, 1 / 2 forced (5 / 6 digits), unset = where it is measured to
-    // pay (tools/gram_i8_sizes.py: 1.3-1.5x from 256 rows x 131072 samples; slower than this kernel on small or skinny problems)
+    // pay (tools/gram_i8_sizes.py: 1.3-1.5x from 256 rows and 2^25 elements, 1.9x at 2000 x 1024^2; slower than this kernel on
+    // small or skinny problems)
     const int64_t i8 = ctx->opt("gram_i8", -1);
     const bool forced = i8 > 0 && na >= ctx->opt("gram_i8_min_n", 32) && P >= 1024;
-    const bool pays = i8 < 0 && na >= 256 && P >= 131072;
+    const bool pays = i8 < 0 && na >= 256 && P >= 32768 && na * P >= ((int64_t)1 << 25);
     if (symmetric && !f32acc && (forced || pays)) return gram_i8_f32(ctx, A, na, P, ld, G, 1, i8 == 2 ? 2 : 1);
   }
   const int64_t nmax = na > nb ? na : nb;

@@ -27,7 +27,11 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-// ---- 1. split: M[n][ld] float32 -> D[S][npad][Ppad] int8, sc[npad][nslices] float64 ------------------------------------------
+// ---- 1. split: M[n][ld] float32 -> D[slice][row block][step][S][64 rows][64 samples] int8, sc[npad][nslices] float64 ----------
+// The digits are stored in the order the product reads them: what a 64-row block needs for one 64-sample step -- S planes of
+// 64 x 64 bytes -- is ONE contiguous 4 S KB piece, so every wave-wide load of the product covers 1 KB of whole cache lines.
+// (Row-major planes [S][row][sample], the first layout, made each such load touch 16 rows at 64 of their line's 128 bytes: the
+// product then asked its L2 for twice the bytes it used and sat at 43 % of the MFMA rate waiting for them.)
 // One workgroup per (row, slice): the slice is read ONCE into registers (16 consecutive samples per thread and pass), its largest
 // magnitude found through LDS, and the digits are peeled off in float32 -- y = a 2^(6-ex) (|y| < 64); d = rint(y); y = 128 (y - d);
 // ... : every subtraction is exact (the remainder is a multiple of the sample's ulp and at most half a unit), the digits come out
@@ -44,11 +48,13 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const float* __restrict
   D += (int64_t)blockIdx.z * S * plane;
   sc += (int64_t)blockIdx.z * npad * nslices;
   const int64_t k0 = (int64_t)slice * klen;
-  int8_t* drow = D + (int64_t)row * Ppad + k0;
+  const int nstep = klen >> 6;
+  int8_t* drow = D + ((int64_t)slice * (npad >> 6) + (row >> 6)) * nstep * (S * 4096) + (row & 63) * 64;   // + tiled(e, j)
+#define VIPMI_DIGIT_AT(e, j) (drow + ((int64_t)((e) >> 6) * S + (j)) * 4096 + ((e) & 63))
   if (row >= n) {                                   // padding rows: zero digits
     for (int e = tid * 16; e < klen; e += 256 * 16)
 #pragma unroll
-      for (int j = 0; j < S; ++j) *reinterpret_cast<v4i*>(drow + j * plane + e) = v4i{0, 0, 0, 0};
+      for (int j = 0; j < S; ++j) *reinterpret_cast<v4i*>(VIPMI_DIGIT_AT(e, j)) = v4i{0, 0, 0, 0};
     if (tid == 0) sc[(int64_t)row * nslices + slice] = 0.0;
     return;
   }
@@ -116,8 +122,9 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const float* __restrict
     }
 #pragma unroll
     for (int j = 0; j < S; ++j)
-      *reinterpret_cast<v4i*>(drow + j * plane + e) = v4i{(int)w[j][0], (int)w[j][1], (int)w[j][2], (int)w[j][3]};
+      *reinterpret_cast<v4i*>(VIPMI_DIGIT_AT(e, j)) = v4i{(int)w[j][0], (int)w[j][1], (int)w[j][2], (int)w[j][3]};
   }
+#undef VIPMI_DIGIT_AT
 }
 
 // ---- 2. product: a workgroup of four waves = one 64 x 64 tile of G over one slice, every wave a 32 x 32 quarter ---------------
@@ -132,13 +139,14 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const float* __restrict
 // (below the diagonal: the wave only helps loading).  With these as run-time flags every MFMA sat in a basic block of its own
 // behind a branch and a just-in-time s_waitcnt (the lesson of gram.hip's guarded tile loop, again).
 template <int S, int KEEP, bool DIAG, int ROLE>
-__device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, const int8_t* gb, int64_t plane, int nsteps, int nbuf,
+__device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, const int8_t* gb, int nsteps, int nbuf,
                                               int loff, int fa, int fb, v4i (&acc)[2 * S - 1 - (S - 1 - KEEP)][2][2]) {
   constexpr int LMIN = S - 1 - KEEP;
   constexpr int PL = 64 * 64;                       // one plane of one side: 64 rows of 64 bytes (an 80-byte row stride removes the
                                                     // bank conflicts of the fragment reads -- a third of the LDS cycles -- but changes
                                                     // nothing: 0.78 against 0.75 ms, and two buffers no longer fit twice per CU)
   constexpr int SIDE = S * PL, BUF = 2 * SIDE;
+  constexpr int plane = PL;                         // (global layout = LDS layout: [step][plane][row][64 bytes])
   v4i la[S], lb[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
@@ -156,7 +164,7 @@ __device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, co
     int8_t* nxt = smem + (nbuf == 2 ? ((step + 1) & 1) * BUF : 0);
     const bool more = step + 1 < nsteps;
     if (more) {
-      const int64_t o = (int64_t)(step + 1) * 64;
+      const int64_t o = (int64_t)(step + 1) * SIDE;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         la[j] = *reinterpret_cast<const v4i*>(ga + j * plane + o);
@@ -224,9 +232,9 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   const int wi = wave >> 1, wj = wave & 1;
   // global -> LDS: thread -> (row = tid / 4, 16-byte segment = tid % 4) of every plane and side
   const int lrow = tid >> 2, lseg = tid & 3;
-  const int64_t kbase = (int64_t)slice * klen + 16 * lseg;
-  const int8_t* ga = D + (int64_t)(t.x * 64 + lrow) * Ppad + kbase;
-  const int8_t* gb = D + (int64_t)(t.y * 64 + lrow) * Ppad + kbase;
+  const int64_t tile = (int64_t)(klen >> 6) * (S * 4096);          // bytes of one (slice, row block)
+  const int8_t* ga = D + ((int64_t)slice * (npad >> 6) + t.x) * tile + 16 * tid;
+  const int8_t* gb = D + ((int64_t)slice * (npad >> 6) + t.y) * tile + 16 * tid;
   const int loff = lrow * 64 + 16 * lseg;
   const int r = lane & 15, kq = lane >> 4;
   const int fa = (wi * 32 + r) * 64 + 16 * kq, fb = SIDE + (wj * 32 + r) * 64 + 16 * kq;      // fragment offsets of block 0
@@ -240,12 +248,12 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   const int nsteps = klen >> 6, nbuf = gram_i8_nbuf;
   int role = 0;
   if (!diag) {
-    gram_i8_steps<S, KEEP, false, 0>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
+    gram_i8_steps<S, KEEP, false, 0>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
   } else {
     role = wi > wj ? 2 : (wi == wj ? 1 : 0);          // (wave-uniform)
-    if (role == 0) gram_i8_steps<S, KEEP, true, 0>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
-    else if (role == 1) gram_i8_steps<S, KEEP, true, 1>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
-    else gram_i8_steps<S, KEEP, true, 2>(smem, ga, gb, plane, nsteps, nbuf, loff, fa, fb, acc);
+    if (role == 0) gram_i8_steps<S, KEEP, true, 0>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
+    else if (role == 1) gram_i8_steps<S, KEEP, true, 1>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
+    else gram_i8_steps<S, KEEP, true, 2>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
   }
   if (role == 2) return;
   const bool qdiag = role == 1;
