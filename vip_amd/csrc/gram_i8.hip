@@ -138,9 +138,18 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const float* __restrict
 // one side is loaded), ROLE = 0 full quarter (four blocks), 1 quarter on the diagonal (block (1, 0) skipped), 2 idle quarter
 // (below the diagonal: the wave only helps loading).  With these as run-time flags every MFMA sat in a basic block of its own
 // behind a branch and a just-in-time s_waitcnt (the lesson of gram.hip's guarded tile loop, again).
-template <int S, int KEEP, bool DIAG, int ROLE>
+// 16 bytes per lane straight from global memory into LDS (global_load_lds_dwordx4: destination = M0 + 16 * lane, wave-uniform
+// base; no staging registers, no ds_write pass).  hipcc does not count this load: the caller waits with glds_wait().
+__device__ __forceinline__ void glds16(const int8_t* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int S, int KEEP, bool DIAG, int ROLE, bool DMA>
 __device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, const int8_t* gb, int nsteps, int nbuf,
-                                              int loff, int fa, int fb, v4i (&acc)[2 * S - 1 - (S - 1 - KEEP)][2][2]) {
+                                              int loff, int fa, int fb, v4i (&acc)[2 * S - 1 - (S - 1 - KEEP)][2][2], int wave) {
   constexpr int LMIN = S - 1 - KEEP;
   constexpr int PL = 64 * 64;                       // one plane of one side: 64 rows of 64 bytes (an 80-byte row stride removes the
                                                     // bank conflicts of the fragment reads -- a third of the LDS cycles -- but changes
@@ -148,15 +157,30 @@ __device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, co
   constexpr int SIDE = S * PL, BUF = 2 * SIDE;
   constexpr int plane = PL;                         // (global layout = LDS layout: [step][plane][row][64 bytes])
   v4i la[S], lb[S];
+  // DMA (two buffers only): wave w moves rows 16 w .. 16 w + 15 of every plane, 1 KB per instruction, into the same place the
+  // register-staged path stores them
+  const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
+  auto dma = [&](unsigned buf, int64_t o) {
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    la[j] = *reinterpret_cast<const v4i*>(ga + j * plane);
-    if (!DIAG) lb[j] = *reinterpret_cast<const v4i*>(gb + j * plane);
-  }
+    for (int j = 0; j < S; ++j) {
+      glds16(ga + j * plane + o, lds0 + buf + j * PL);
+      if (!DIAG) glds16(gb + j * plane + o, lds0 + buf + SIDE + j * PL);
+    }
+  };
+  if (DMA) {
+    dma(0u, 0);
+    glds_wait();
+  } else {
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    *reinterpret_cast<v4i*>(smem + j * PL + loff) = la[j];
-    if (!DIAG) *reinterpret_cast<v4i*>(smem + SIDE + j * PL + loff) = lb[j];
+    for (int j = 0; j < S; ++j) {
+      la[j] = *reinterpret_cast<const v4i*>(ga + j * plane);
+      if (!DIAG) lb[j] = *reinterpret_cast<const v4i*>(gb + j * plane);
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      *reinterpret_cast<v4i*>(smem + j * PL + loff) = la[j];
+      if (!DIAG) *reinterpret_cast<v4i*>(smem + SIDE + j * PL + loff) = lb[j];
+    }
   }
   __syncthreads();
   for (int step = 0; step < nsteps; ++step) {
@@ -165,10 +189,14 @@ __device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, co
     const bool more = step + 1 < nsteps;
     if (more) {
       const int64_t o = (int64_t)(step + 1) * SIDE;
+      if (DMA) {
+        dma(((step + 1) & 1) * BUF, o);
+      } else {
 #pragma unroll
-      for (int j = 0; j < S; ++j) {
-        la[j] = *reinterpret_cast<const v4i*>(ga + j * plane + o);
-        if (!DIAG) lb[j] = *reinterpret_cast<const v4i*>(gb + j * plane + o);
+        for (int j = 0; j < S; ++j) {
+          la[j] = *reinterpret_cast<const v4i*>(ga + j * plane + o);
+          if (!DIAG) lb[j] = *reinterpret_cast<const v4i*>(gb + j * plane + o);
+        }
       }
     }
     if (ROLE != 2) {
@@ -200,7 +228,9 @@ __device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, co
       }
     }
     if (nbuf == 1) __syncthreads();                   // single buffer: everybody has read this step before it is overwritten
-    if (more) {
+    if (DMA) {
+      glds_wait();
+    } else if (more) {
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         *reinterpret_cast<v4i*>(nxt + j * PL + loff) = la[j];
@@ -211,7 +241,7 @@ __device__ __forceinline__ void gram_i8_steps(int8_t* smem, const int8_t* ga, co
   }
 }
 
-template <int S, int KEEP>
+template <int S, int KEEP, bool DMA>
 __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ D, const double* __restrict__ sc, int npad,
                                                       int klen, int nslices, int64_t Ppad, int64_t plane,
                                                       const int2* __restrict__ wgtiles, int nwg,
@@ -248,12 +278,12 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   const int nsteps = klen >> 6, nbuf = gram_i8_nbuf;
   int role = 0;
   if (!diag) {
-    gram_i8_steps<S, KEEP, false, 0>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
+    gram_i8_steps<S, KEEP, false, 0, DMA>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc, wave);
   } else {
     role = wi > wj ? 2 : (wi == wj ? 1 : 0);          // (wave-uniform)
-    if (role == 0) gram_i8_steps<S, KEEP, true, 0>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
-    else if (role == 1) gram_i8_steps<S, KEEP, true, 1>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
-    else gram_i8_steps<S, KEEP, true, 2>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc);
+    if (role == 0) gram_i8_steps<S, KEEP, true, 0, DMA>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc, wave);
+    else if (role == 1) gram_i8_steps<S, KEEP, true, 1, DMA>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc, wave);
+    else gram_i8_steps<S, KEEP, true, 2, DMA>(smem, ga, gb, nsteps, nbuf, loff, fa, fb, acc, wave);
   }
   if (role == 2) return;
   const bool qdiag = role == 1;
@@ -357,7 +387,9 @@ int run(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double
   VIPMI_CHECK_HIP(hipGetLastError());
   const int nbuf = (int)ctx->opt("gram_i8_nbuf", S <= 5 ? 2 : 1);          // LDS buffers per workgroup (5 digits: 2 x 40 KB, two workgroups per CU)
   const size_t lds = (size_t)(nbuf == 2 ? 2 : 1) * 2 * S * 64 * 64;
-  auto kern = gram_i8_kernel<S, KEEP>;
+  // global -> LDS by DMA (two buffers) unless gram_i8_dma = 0
+  const bool dma = nbuf == 2 && ctx->opt("gram_i8_dma", 1) != 0;
+  auto kern = dma ? gram_i8_kernel<S, KEEP, true> : gram_i8_kernel<S, KEEP, false>;
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * nwg), (unsigned)cdiv(nslices, 8), (unsigned)batch), dim3(256), lds, ctx->stream, D, sc, npad,
                      (int)klen, nslices, Ppad, plane, d_tiles, nwg, partial, nbuf == 2 ? 2 : 1);
