@@ -6,6 +6,9 @@ import numpy as np, torch
 from vip_amd import backend as B
 rng = np.random.default_rng(0)
 ctx = B.get_context()
+ctx.set_option("eigh_fast", 0)
+for o in sys.argv[1:]:
+    a, b = o.split("="); ctx.set_option(a, int(b))
 for n, k in ((256, 20), (400, 20), (512, 20)):
     X = rng.standard_normal((n, 3 * n)); X[:, :5] *= 10
     G = torch.from_numpy(X @ X.T).cuda()[None]

@@ -17,6 +17,8 @@
 // as eigh.hip for the leading k rows: evals descending, evecs[c*n + i] unit norm with the largest-magnitude
 // component positive.  Zero-padded problems (annular PCA: library sizes differ per frame) pass their active size.
 #include "common.h"
+#include <atomic>
+#include <unistd.h>
 #include "wave_util.h"
 #include "tri_common.h"
 
@@ -42,6 +44,7 @@ using tri::sturm_count;
 // per step of the batched solver were (annular PCA: 24 of C3's 35 ms).  The whole (symmetric) square is kept, so A v
 // needs only column sums -- per lane, in registers, no wave reduction -- combined across the waves through LDS.
 // workgroup barrier that orders LDS traffic only (no wait for outstanding global stores)
+constexpr int TRI_BAR_WORDS = 136;            // per problem: counter (8 words), 64 flags, 64 XCC ids (tri_multi_kernel)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // (256 threads: capped at 80 VGPRs so that six workgroups share a CU -- that variant runs the latency-bound second half of
@@ -824,9 +827,14 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double
 template <int RPL>
 __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aall, int n, int k, int RW, int VW, int rows_d, int all_evals,
                                                         double* __restrict__ evals_all, double* __restrict__ evecs_all,
-                                                        double* __restrict__ gbuf_all, unsigned* __restrict__ bars) {
+                                                        double* __restrict__ gbuf_all, unsigned* __restrict__ bars, int one_xcd) {
   extern __shared__ double sm[];
-  const int W = gridDim.x, wg = blockIdx.x, prob = blockIdx.y;
+  const int prob = blockIdx.y;
+  // one_xcd = 1 + base: the grid is 8 x wider and only the ids that land on XCD (base + problem) % 8 stay (ids go round-robin
+  // over the XCDs):
+  // the W workgroups of a problem then share one L2 and exchange through it (wave_util.h, checked below)
+  if (one_xcd && (int)(blockIdx.x & 7) != ((one_xcd - 1 + prob) & 7)) return;
+  const int W = one_xcd ? gridDim.x >> 3 : gridDim.x, wg = one_xcd ? blockIdx.x >> 3 : blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* rows = sm;                         // [RW][n]  row lr <-> global row lr*W + wg ; reused after phase 1
   double* vbuf0 = rows + rows_d;             // Householder vector, double buffered (rows_d >= RW*n, 6*n*VW)
@@ -847,8 +855,10 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   double* Pb = gb;                           // [2][n]
   double* Cb = gb + 2 * n;                   // [2][n]
   double* Db = gb + 4 * n;                   // [n] diagonal, last step only
-  unsigned* bar = bars + prob;
-  unsigned bar_target = 0;
+  unsigned* bar = bars + (size_t)prob * TRI_BAR_WORDS;       // [0] counter, [8 ..] flags, [72 ..] XCC ids
+  unsigned* xflags = bar + 8;
+  unsigned* xids = bar + 72;
+  unsigned bar_target = 0, xepoch = 0;
   const int na = n;
   const int kk = k < na ? k : na;
 
@@ -864,8 +874,27 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
     pfull[c] = 0.0;
   }
   // every workgroup has read row 0 (and its own rows) before any reflector is written over the input matrix
+  if (one_xcd && tid == 0) __hip_atomic_store(xids + wg, 1u + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bar_target += W;
   grid_barrier(bar, bar_target, W);
+  bool fast = one_xcd != 0;                  // all workgroups really on one XCD?  (uniform: everybody reads the same ids)
+  if (fast) {
+    const unsigned mine = 1u + xcc_id();
+    for (int j = 0; j < W; ++j) fast = fast && __hip_atomic_load(xids + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine;
+  }
+  auto put = [&](double* p, double v) {
+    if (fast) st_xcd(p, v);
+    else st_shared(p, v);
+  };
+  auto sync_all = [&]() {
+    if (fast) {
+      xepoch += 1;
+      xcd_barrier(xflags, xepoch, W, wg);
+    } else {
+      bar_target += W;
+      grid_barrier(bar, bar_target, W);
+    }
+  };
   double* vcur = vbuf0;
   double* vnext = vbuf1;
   // derive (v_{s+1}, beta, alpha, diagonal) from x = updated row s+1 held in cfull[c], c >= s+1 ; every wave
@@ -907,7 +936,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
     const double beta = tau[s];
     // the owner of row s keeps the reflector for the back-transformation
     if (s % W == wg)
-      for (int c = s + 1 + tid; c < na; c += TNT) st_shared(&A[(size_t)s * n + c], vcur[c]);
+      for (int c = s + 1 + tid; c < na; c += TNT) put(&A[(size_t)s * n + c], vcur[c]);
     const int lr0 = (s + 1 - wg + W - 1) / W;            // first local row with r >= s+1
     for (int lr = (lr0 > 0 ? lr0 : 0) + wave; lr < RW; lr += TNW) {
       const int r = lr * W + wg;
@@ -928,17 +957,16 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
       }
       acc = wave_sum(acc);
       if (lane == 0) {
-        st_shared(&Pb[par * n + r], beta * acc);
-        st_shared(&Cb[par * n + r], cval);
+        put(&Pb[par * n + r], beta * acc);
+        put(&Cb[par * n + r], cval);
       }
       if (s + 3 == na) {
         const int dl = r - s - 1;
-        if (lane == (dl & 63)) st_shared(&Db[r], dval);
+        if (lane == (dl & 63)) put(&Db[r], dval);
       }
     }
     MSEG(0);
-    bar_target += W;
-    grid_barrier(bar, bar_target, W);
+    sync_all();
     MSEG(1);
     for (int c = s + 1 + tid; c < na; c += TNT) {
       pfull[c] = ld_shared(&Pb[par * n + c]);
@@ -1150,12 +1178,11 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
 #pragma unroll
     for (int rr = 0; rr < RPL; ++rr) {
       const int i = lane + 64 * rr;
-      if (i < n) st_shared(&evecs[(size_t)c * n + i], z[rr]);
+      if (i < n) put(&evecs[(size_t)c * n + i], z[rr]);
     }
-    if (lane == 0) st_shared(&evals[c], lam[wave] * scale);
+    if (lane == 0) put(&evals[c], lam[wave] * scale);
   }
-  bar_target += W;
-  grid_barrier(bar, bar_target, W);
+  sync_all();
   if (wg != 0) return;
 
   // ---------------- 5. workgroup 0: modified Gram-Schmidt over the k vectors, sign convention, output ----------------
@@ -1251,13 +1278,14 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
 template <int RPL>
 int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, double* evals, double* evecs,
                      int all_evals) {
-  const int W = n <= 256 ? 8 : (n <= 448 ? 16 : 32);
+  int W = n <= 256 ? 8 : (n <= 448 ? 16 : 32);
+  if (ctx->opt("eigh_w", 0) >= 2 && ctx->opt("eigh_w", 0) <= 64) W = (int)ctx->opt("eigh_w", 0);       // (experiments)
   const int RW = (int)cdiv(n, W);
   double* gbuf = nullptr;
   unsigned* bars = nullptr;
   VIPMI_TRY(ws(ctx, "eigh_tri_gbuf", (size_t)batch * 5 * n, &gbuf));
-  VIPMI_TRY(ws(ctx, "eigh_tri_bars", (size_t)batch, &bars));
-  VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch, ctx->stream));
+  VIPMI_TRY(ws(ctx, "eigh_tri_bars", (size_t)batch * TRI_BAR_WORDS, &bars));
+  VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch * TRI_BAR_WORDS, ctx->stream));
   size_t rows_d = (size_t)RW * n;
   const int VW = (int)cdiv(k, W);
   const size_t inv_d = (size_t)6 * n * VW;             // phase-3 scratch aliases the rows region
@@ -1268,11 +1296,22 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
   // all W workgroups of a problem must be co-resident (counter barrier): one per CU, launch at most num_cu/W problems
+  // one_xcd (wave_util.h): problem p on XCD (base + p) % 8, num_cu / 8 CUs each -- the same count.  The base rotates from
+  // launch to launch (and starts at a per-process value): concurrent launches from several streams or processes then sit on
+  // different XCDs and stay co-resident exactly as the spread layout does (two or four workgroups per XCD each).  Automatic
+  // choice: synchronous mode only -- that is where the latency shows and where every pair is verified by its residual
+  // afterwards; the pipelined (asynchronous) mode keeps the spread layout, whose CUs the shear kernels of the other calls
+  // lose evenly over the XCD task queues.
+  static std::atomic<unsigned> xcd_base{(unsigned)getpid() * 2654435761u >> 16};
+  const int64_t want_xcd = ctx->opt("eigh_one_xcd", -1);
+  const bool xcd_ok = W <= 64 && W <= ctx->num_cu / 8 && ctx->num_cu % 8 == 0;
+  const int one_xcd = xcd_ok && (want_xcd > 0 || (want_xcd < 0 && ctx->opt("eigh_check", 1) != 0)) ? 1 : 0;
   const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
   for (int64_t p0 = 0; p0 < batch; p0 += per_launch) {
     const int64_t nb = batch - p0 < per_launch ? batch - p0 : per_launch;
-    hipLaunchKernelGGL(kern, dim3(W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW, (int)rows_d, all_evals,
-                       evals + (size_t)p0 * n, evecs + (size_t)p0 * n * n, gbuf + (size_t)p0 * 5 * n, bars + p0);
+    hipLaunchKernelGGL(kern, dim3(one_xcd ? 8 * W : W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW,
+                       (int)rows_d, all_evals, evals + (size_t)p0 * n, evecs + (size_t)p0 * n * n, gbuf + (size_t)p0 * 5 * n,
+                       bars + (size_t)p0 * TRI_BAR_WORDS, one_xcd ? (int)(1 + ((xcd_base.fetch_add((unsigned)nb) + (unsigned)p0) & 7u)) : 0);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   return VIPMI_OK;

@@ -69,4 +69,36 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target,
   __syncthreads();
 }
 
+// ---- the same exchange between workgroups of ONE XCD ------------------------------------------------------------------------
+// An agent-scope (sc1) store leaves the XCD's L2 for memory, and every reader pays a fabric round trip (~1 us) whichever XCD
+// it sits on.  Workgroups that share an XCD share its L2: a workgroup-scope store (sc0: written through the CU's L1, KEPT in
+// the L2) is visible to an sc1 load (L1 bypassed, L2-served) of any CU of that XCD at L2 latency.  There is no "XCD" scope in
+// the memory model, so the kernel that uses this (a) places its workgroups itself -- workgroup ids go round-robin over the 8
+// XCDs --, (b) VERIFIES the placement at run time with HW_REG_XCC_ID behind one agent-scope barrier, and (c) falls back to the
+// agent-scope exchange when the check fails.  The barrier is a flag per workgroup (plain epoch numbers, no atomic: an atomic
+// is executed beyond the L2), polled by one lane per flag.
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(6164) & 15u; }   // hwreg(HW_REG_XCC_ID, 0, 4)
+__device__ __forceinline__ void st_xcd(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void xcd_barrier(unsigned* flags, unsigned epoch, int nwg, int wg) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores are in the L2
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(flags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const int l = threadIdx.x;
+    unsigned spins = 0;
+    bool ok = l >= nwg;
+    while (true) {
+      if (!ok) ok = (int)(__hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0;
+      if (__all(ok)) break;
+      if (++spins > (1u << 28)) break;               // bounded spin: a lost workgroup must not hang the GPU
+    }
+  }
+  __syncthreads();
+}
+
 }  // namespace vipmi
