@@ -677,6 +677,59 @@ def test_eigh_topk_repeatable_under_load():
                 first[n] = (ev, ec)
 
 
+def test_eigh_topk_one_xcd_exchange_matches_the_spread_layout(B):
+    """eigh_one_xcd: the cooperating workgroups of a problem on one XCD, exchanging through its L2 (placement verified
+    with HW_REG_XCC_ID in the kernel) -- bit-identical to the agent-scope exchange of the spread layout, for one problem and
+    for a batch (problems on different XCDs), and under concurrent launches from several threads (the XCD rotates per launch)."""
+    import threading
+    import torch
+    rng = np.random.default_rng(5)
+    ctx = B.get_context()
+    mats = {}
+    for n in (130, 256, 300, 400, 448, 512):
+        M = rng.standard_normal((n, 2 * n))
+        mats[n] = M @ M.T
+    try:
+        res = {}
+        for mode in (0, 1):
+            ctx.set_option("eigh_one_xcd", mode)
+            for n, G in mats.items():
+                res[mode, n] = B_eigh(G, 15)
+            Gb = torch.from_numpy(np.stack([mats[300] * (1.0 + 0.1 * i) for i in range(5)])).cuda()
+            ev, ec = B.eigh_topk(Gb, 9)
+            res[mode, "batch"] = (ev.cpu().numpy(), ec.cpu().numpy())
+        for key in [k for k in res if k[0] == 0]:
+            a, b = res[key], res[1, key[1]]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), key
+        w = np.linalg.eigvalsh(mats[400])[::-1][:15]
+        np.testing.assert_allclose(res[1, 400][0], w, atol=1e-12 * w[0])
+        # four threads, each on its own stream / context, all in the one-XCD mode at the same time
+        out, errs = {}, []
+
+        def work(i):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    c = B.get_context()
+                    c.set_option("eigh_one_xcd", 1)
+                    c.set_option("eigh_fast", 0)
+                    for rep in range(8):
+                        ev_, ec_ = B.eigh_topk(torch.from_numpy(mats[400].copy()).cuda(), 15)
+                        out[i, rep] = (ev_.cpu().numpy(), ec_.cpu().numpy())
+                    c.set_option("eigh_one_xcd", -1)
+                    c.set_option("eigh_fast", 1)
+            except Exception as e:           # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        for v in out.values():
+            assert np.array_equal(v[0], res[1, 400][0]) and np.array_equal(v[1], res[1, 400][1])
+    finally:
+        ctx.set_option("eigh_one_xcd", -1)
+
+
 def B_eigh(G, k):
     import torch
     from vip_amd import backend
