@@ -737,9 +737,10 @@ def B_eigh(G, k):
     return ev.cpu().numpy(), ec.cpu().numpy()
 
 
-@pytest.mark.parametrize("n,k", [(513, 5), (700, 30), (1000, 50), (1536, 64)])
+@pytest.mark.parametrize("n,k", [(513, 5), (640, 64), (641, 7), (700, 30), (1000, 50), (1536, 64)])
 def test_eigh_topk_large(B, n, k):
-    """512 < n <= 2048: the matrix stays in global memory, 64 cooperating workgroups (eigh_tri_large.hip); graded
+    """640 < n <= 2048: the matrix stays in global memory, 64 cooperating workgroups (eigh_tri_large.hip; 513 .. 640 rows:
+    the LDS-resident kernel on 32 workgroups); graded
     spectrum (dynamic range 2^-n/20), on which a Jacobi sweep count would explode."""
     import torch
     rng = np.random.default_rng(n + k)

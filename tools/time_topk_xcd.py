@@ -7,13 +7,15 @@ from vip_amd import backend as B
 rng = np.random.default_rng(0)
 ctx = B.get_context()
 ctx.set_option("eigh_fast", 0)
-for n, k in ((300, 20), (400, 20), (400, 50), (640, 30)):
+import sys
+SIZES = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]] or [(300, 20), (400, 20), (400, 50), (640, 30)]
+for n, k in SIZES:
     X = rng.standard_normal((n, 3 * n)); X[:, :5] *= 10
     Gh = X @ X.T
     G = torch.from_numpy(Gh).cuda()[None]
     w = np.linalg.eigvalsh(Gh)[::-1][:k]
     ref = None
-    for xcd, W in ((0, 0), (1, 0), (1, 8), (1, 12), (1, 16), (1, 20), (1, 24), (1, 32)):
+    for xcd, W in ((0, 0), (1, 0)) + (((1, 8), (1, 12), (1, 16), (1, 20), (1, 24), (1, 32)) if len(sys.argv) == 1 else ()):
         ctx.set_option("eigh_one_xcd", xcd); ctx.set_option("eigh_w", W)
         evals = torch.zeros((1, n), dtype=torch.float64, device="cuda"); evecs = torch.zeros((1, n, n), dtype=torch.float64, device="cuda")
         best = 1e9

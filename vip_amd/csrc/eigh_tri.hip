@@ -1449,6 +1449,13 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
   }
   if (ctx->opt("eigh_method", 0) != 1 && eigh_topk_supported(n, k))
     return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs, all_evals);
+  // 513 .. 640 rows, a few problems: still LDS-resident on 32 workgroups (20 rows of 640 doubles + ten vectors = 154 KB each) --
+  // 3.1 ms at n = 640 (one XCD; 3.7 ms spread) against 5.7 ms for the matrix-in-L2 kernel below
+  if (ctx->opt("eigh_method", 0) != 1 && !nact && batch <= 8 && n > 512 && n <= 640 && k >= 1 && k <= 64 &&
+      ctx->opt("eigh_multi", 1) != 0 && ctx->num_cu >= 32) {
+    StageScope sc(ctx, "eigh");
+    return launch_tri_multi<10>(ctx, G, batch, (int)n, (int)k, evals, evecs, all_evals);
+  }
   if (ctx->opt("eigh_method", 0) != 1 && !nact && batch <= 4 && eigh_large_supported(n, k))
     return eigh_large_f64(ctx, G, batch, n, k, evals, evecs, all_evals);
   return eigh_f64(ctx, G, batch, n, evals, evecs);
