@@ -131,6 +131,8 @@ struct Aux {          // per-batch auxiliary arrays (device)
   // and subtracts 1e-30 of them -- the instruction and memory stream a fused project-subtract would add, at no visible change
   int probe_k;
   const float* probe_T;
+  // blocked A2r with the 2 x 2 blocks of row groups G and G + 1 side by side (option rot_pair_store, see rs_shear2_direct)
+  int pair;
 };
 
 #define VIPMI_SLOT_PROLOGUE()                                                     \
@@ -651,13 +653,21 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear2_direct(const float* __r
     const float bfl = (dr & 1) ? -bf0 : bf0;
     const float k1c = sn1 * ((X1 & 1) ? -bfl : bfl);
     const float k2c = sn2 * ((X2 & 1) ? -bfl : bfl);
-    float4* dst = reinterpret_cast<float4*>(A2r) + (int64_t)fl * B::NB * B::NBC + u;
+    // A lane's 16-byte block shares its 32-byte sector with the block of the NEXT column pair, which another wave writes
+    // some time later: two thirds of the sectors go to HBM twice (2.6 GB written for a 1.68 GB intermediate).  Paired layout
+    // (option rot_pair_store = 1, even NG): the blocks of row groups G and G + 1 of one column pair lie side by side -- the
+    // lane writes 32 contiguous bytes back to back, shear 3 reads them in two consecutive sub-tasks of one wave.  Measured
+    // (C2, round 3): WRITE_SIZE of this kernel 2.60 -> 2.02 GB, but FETCH_SIZE of shear 3 1.04 -> 1.85 GB (the second
+    // sub-task finds its half of the lines evicted: 16 MB per XCD are in flight between the two), times unchanged (3.82 /
+    // 3.81 ms; 1024 px: 13.5 / 13.8 ms): neither kernel is bound by memory.  Off by default.
+    float4* dst = reinterpret_cast<float4*>(A2r) + (int64_t)fl * B::NB * B::NBC;
 #pragma unroll
     for (int G = 0; G < B::NG; ++G) {
       const cf a = v[B::reg(B::OFF + 128 * G)], b = v[B::reg(B::OFF + 128 * G + 64)];
       const float sg = ((B::OFF + lane) & 1) ? -1.f : 1.f;           // rows Y and Y + 64 (+128 G): same parity
-      dst[(int64_t)(64 * G + lane) * B::NBC] =
-          make_float4(a.x - sg * k1c, b.x - sg * k1c, a.y - sg * k2c, b.y - sg * k2c);
+      const int64_t at = aux.pair ? ((int64_t)(64 * (G >> 1) + lane) * B::NBC + u) * 2 + (G & 1)
+                                  : (int64_t)(64 * G + lane) * B::NBC + u;
+      dst[at] = make_float4(a.x - sg * k1c, b.x - sg * k1c, a.y - sg * k2c, b.y - sg * k2c);
     }
     if (lane == 0) {
       aux.gam[fl * P::L + X1] = ((X1 & 1) ? -sn1 : sn1) * alt1;
@@ -709,17 +719,22 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
     const bool live = pr < npairs;
     if (PW && !live) break;
     if (!live) pr = npairs - 1;
-    const int fl = pr / half, tb = pr % half, f = f0 + fl;
+    const int fl = pr / half, f = f0 + fl;
+    int tb = pr % half;
+    if (BLK && aux.pair) tb = 64 * (2 * (tb >> 7) + (tb & 1)) + ((tb >> 1) & 63);     // (consecutive pairs: the two halves of a 32-byte block pair)
     const int m = BLK ? 128 * (tb / 64) + (tb % 64) : 2 * tb, dm = BLK ? 64 : 1;     // output rows m, m + dm
     const RotFrame p = fr[f];
     const int Y1 = g.off + m, Y2 = Y1 + dm;
     cf v[P::VL];
     if constexpr (BLK) {
       using B = Blk<P>;
-      const float4* ib = reinterpret_cast<const float4*>(A2r) + ((int64_t)fl * B::NB + tb) * B::NBC + lane;
+      const int Gt = tb >> 6, lt = tb & 63;
+      const float4* ib = aux.pair ? reinterpret_cast<const float4*>(A2r) + (((int64_t)fl * (B::NB / 2) + 64 * (Gt >> 1) + lt) * B::NBC + lane) * 2 + (Gt & 1)
+                                  : reinterpret_cast<const float4*>(A2r) + ((int64_t)fl * B::NB + tb) * B::NBC + lane;
+      const int gstep = aux.pair ? 128 : 64;
 #pragma unroll
       for (int gq = 0; gq < P::L / 128; ++gq) {
-        const float4 blk = ib[64 * gq];
+        const float4 blk = ib[gstep * gq];
         v[B::reg(128 * gq)] = mkcf(blk.x, blk.y);
         v[B::reg(128 * gq + 64)] = mkcf(blk.z, blk.w);
       }
@@ -787,6 +802,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   VIPMI_TRY(ws(ctx, "rot_gam", (size_t)(chunk * P::L), &aux.gam));
   VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
   VIPMI_TRY(ws(ctx, "rot_dph", (size_t)chunk * 2 * DPH_STRIDE, &aux.dph));
+  aux.pair = (BLK && (Blk<P>::NG % 2 == 0) && ctx->opt("rot_pair_store", 0) != 0) ? 1 : 0;
   aux.probe_k = (int)std::min<int64_t>(ctx->opt("rot_fuse_probe", 0), n);
   aux.probe_T = in;
   int* counters = nullptr;                       // 3 kernels x 8 task queues, one 128-byte line each
