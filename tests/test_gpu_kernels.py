@@ -574,6 +574,26 @@ def test_derotate_batching_is_bit_identical(B, N):
         ctx.set_option("rot_batch", 0)
 
 
+@pytest.mark.parametrize("N", [128, 256, 512])
+def test_derotate_paired_store_layout_is_bit_identical(B, N):
+    """rot_pair_store: another layout of the intermediate between the column shear and the last row shear (32-byte stores);
+    the arithmetic is the same, so are the bits (N = 128 has an odd number of row groups: the option is ignored there)."""
+    import torch
+    rng = np.random.default_rng(N + 1)
+    ang = np.array([3.0, -47.5, 95.0, 200.1, 333.3, 135.0, 44.999, 270.0, 181.0])
+    cube = rng.standard_normal((len(ang), N, N)).astype(np.float32)
+    cube[2, :5, :7] = np.nan
+    ct = torch.from_numpy(cube).cuda()
+    ctx = B.get_context()
+    ref = B.derotate(ct, ang).cpu().numpy()
+    try:
+        ctx.set_option("rot_pair_store", 1)
+        got = B.derotate(ct, ang).cpu().numpy()
+    finally:
+        ctx.set_option("rot_pair_store", 0)
+    assert np.array_equal(got, ref, equal_nan=True)
+
+
 def test_derotate_fft_edge_cases(B):
     """Few frames (fewer tasks than workgroups in the dynamic queues), a single frame, an all-NaN frame, a constant
     frame and angles that are exact multiples of 90 / 360 degrees."""
@@ -990,6 +1010,30 @@ def test_gram_on_the_int8_matrix_cores(B, n, P, batch):
     finally:
         ctx.set_option("gram_i8", -1)
         ctx.set_option("gram_i8_min_n", 32)
+
+
+def test_gram_int8_staging_variants_are_bit_identical(B):
+    """Operands global -> LDS by DMA (default) or through registers, one or two LDS buffers, any slice count: the integer
+    accumulation is exact, so every variant gives the same bits."""
+    import torch
+    rng = np.random.default_rng(11)
+    M = torch.from_numpy(rng.standard_normal((200, 50000)).astype(np.float32) * 3.0).cuda()
+    ctx = B.get_context()
+    try:
+        ctx.set_option("gram_i8", 1)
+        ref = B.gram(M).clone()
+        for dma, nbuf, slices in ((0, 2, 0), (0, 1, 0), (1, 2, 7), (0, 2, 7), (1, 2, 40)):
+            ctx.set_option("gram_i8_dma", dma)
+            ctx.set_option("gram_i8_nbuf", nbuf)
+            ctx.set_option("gram_i8_slices", slices)
+            G = B.gram(M)
+            if slices == 0:
+                assert torch.equal(G, ref), (dma, nbuf, slices)
+            else:                       # other slices: other per-slice exponents and another summation order -- round-off only
+                assert float((G - ref).abs().max()) < 1e-11 * float(ref.abs().max())
+    finally:
+        for o, v in (("gram_i8", -1), ("gram_i8_dma", 1), ("gram_i8_nbuf", 0), ("gram_i8_slices", 0)):
+            ctx.set_option(o, v)
 
 
 def test_gram_int8_non_finite_rows_and_the_default_rule(B):

@@ -385,7 +385,8 @@ int run(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double
                          D, sc, (int64_t)n * ld);
   }
   VIPMI_CHECK_HIP(hipGetLastError());
-  const int nbuf = (int)ctx->opt("gram_i8_nbuf", S <= 5 ? 2 : 1);          // LDS buffers per workgroup (5 digits: 2 x 40 KB, two workgroups per CU)
+  int nbuf = (int)ctx->opt("gram_i8_nbuf", 0);                            // LDS buffers per workgroup (0 = default: 5 digits 2 x 40 KB,
+  if (nbuf != 1 && nbuf != 2) nbuf = S <= 5 ? 2 : 1;                        // two workgroups per CU; 6 digits one buffer)
   const size_t lds = (size_t)(nbuf == 2 ? 2 : 1) * 2 * S * 64 * 64;
   // global -> LDS by DMA (two buffers) unless gram_i8_dma = 0
   const bool dma = nbuf == 2 && ctx->opt("gram_i8_dma", 1) != 0;
