@@ -281,6 +281,32 @@ def test_rowspace_and_subtract_gemm(B, n, k, P):
     assert np.array_equal(R.cpu().numpy(), R2.cpu().numpy())
 
 
+@pytest.mark.parametrize("n,P,k", [(70, 1000, 33), (120, 4099, 50), (200, 2048, 64), (150, 777, 100), (140, 1536, 128), (140, 1536, 129)])
+def test_subtract_with_more_than_32_components_lds_tile(B, n, P, k):
+    """More than 32 components: the subtraction stages the tile of T in LDS, shared by the four waves of a workgroup, which
+    split the frame blocks (same accumulation order: bit-identical to the register kernel); residuals + reconstruction = input
+    rows, residuals orthogonal to the PCs."""
+    import torch
+    rng = np.random.default_rng(n + k)
+    M = torch.from_numpy(rng.standard_normal((n, P)).astype(np.float32)).cuda()
+    ctx = B.get_context()
+    out = {}
+    try:
+        for mode in (0, 1):
+            ctx.set_option("subtract_lds", mode)
+            res, recon, pcs, _ = B.pca_project(M, k, want_recon=True, want_pcs=True)
+            out[mode] = (res.clone(), recon.clone(), pcs.clone())
+            res_only = B.pca_project(M, k)[0]
+            assert torch.equal(res_only, res)
+    finally:
+        ctx.set_option("subtract_lds", 1)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    res, recon, pcs = out[1]
+    assert float((res + recon - M).abs().max()) < 1e-5
+    assert float((res.double() @ pcs.double().T).abs().max()) < 2e-3 * float(M.abs().max()) * np.sqrt(P) / 30
+
+
 def test_pca_project_matches_golden(B):
     g = load_golden("g2_project_subtract")
     cube = g["cube"]

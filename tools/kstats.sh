@@ -8,6 +8,6 @@ python - <<P
 import csv, glob
 f = glob.glob("/tmp/kstats/**/*kernel_stats.csv", recursive=True)
 if not f: print(open("/tmp/kstats.log").read()[-2000:]); raise SystemExit(1)
-for r in list(csv.DictReader(open(f[0])))[:10]:
+for r in list(csv.DictReader(open(f[0])))[:14]:
     print("%-72s calls %5s  avg %9.1f us  min %9.1f us" % (r["Name"].replace("void vipmi::(anonymous namespace)::", "")[:72], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
 P

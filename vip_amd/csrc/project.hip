@@ -55,7 +55,7 @@ __device__ __forceinline__ void strow4(float* __restrict__ base, int64_t row, in
 // NG groups of 32 output rows per wave: with more than 32 components (C5: k = 50) one pass over M serves 64 of them
 // (the streamed operand is the expensive one: 8.4 GB at C5; same accumulation order per output element as NG = 1).
 template <bool VEC, int NG>
-__global__ __launch_bounds__(256) void rowspace_kernel(const float* __restrict__ Wt, int kld,
+__global__ __launch_bounds__(256, 2) void rowspace_kernel(const float* __restrict__ Wt, int kld,
                                                        const float* __restrict__ M, int k, int n,
                                                        int64_t P, const float* __restrict__ rowscale,
                                                        float* __restrict__ T, int64_t sWt, int64_t sM, int64_t sT) {
@@ -176,6 +176,66 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
   }
 }
 
+// More than 32 components (C5: 50): the wave's tile of T no longer fits in registers, and re-read per block of 32 frames it
+// came 63 times through the L2 (13 GB at C5 beside the 16.8 GB of M and R).  Here the FOUR waves of a workgroup share one
+// 128-pixel tile, staged once in LDS ([component][128 pixels], <= 64 KB), and split the frame blocks between them.
+template <bool VEC, bool RECON>
+__global__ __launch_bounds__(256) void subtract_lds_kernel(const float* __restrict__ M, const float* __restrict__ Ct, int nld,
+                                                           const float* __restrict__ T, int n, int k, int64_t P,
+                                                           float* __restrict__ R, float* __restrict__ recon) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];          // [kp][128], kp = k rounded up to even
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t px0 = (int64_t)blockIdx.x * 128;
+  const int jl = lane & 31, kh = lane >> 5;
+  const int64_t px = px0 + 4 * jl;
+  const int kp = (k + 1) & ~1;
+  for (int e = threadIdx.x; e < kp * 32; e += 256) {
+    const int comp = e >> 5, q = e & 31;
+    const f32x4 v = ldrow4<VEC>(T, comp, k, P, px0 + 4 * q);
+    *reinterpret_cast<f32x4*>(tsm + comp * 128 + 4 * q) = v;
+  }
+  __syncthreads();
+  for (int fb = 32 * wave; fb < n; fb += 128) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    f32x4 m[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      m[r] = ldrow4<VEC>(M, f, n, P, px);
+    }
+    constexpr int KS = 8;
+    for (int c0 = 0; c0 < kp; c0 += 2 * KS) {
+      f32x4 b[KS];
+      float a[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int comp = c0 + 2 * s + kh;
+        b[s] = comp < kp ? *reinterpret_cast<const f32x4*>(tsm + comp * 128 + 4 * jl) : f32x4{0.f, 0.f, 0.f, 0.f};
+        a[s] = (comp < k) ? Ct[(int64_t)comp * nld + fb + jl] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (c0 + 2 * s < kp) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s][c], acc[c], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      f32x4 rec = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      f32x4 res = m[r] - rec;
+      strow4<VEC>(R, f, n, P, px, res);
+      if (RECON) strow4<VEC>(recon, f, n, P, px, rec);
+    }
+  }
+}
+
 // dst[cols, ldd] = src[rows, cols]^T, zero padded to ldd (blockIdx.y = matrix of a contiguous batch)
 __global__ void transpose_pad_kernel(const float* __restrict__ src, int rows, int cols,
                                      float* __restrict__ dst, int ldd) {
@@ -228,6 +288,24 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
   const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(T) && aligned16(R) &&
                    (!recon || aligned16(recon));
   dim3 grid((unsigned)cdiv(cdiv(P, 128), 4)), block(256);
+  if (k > 32 && k <= 128 && ctx->opt("subtract_lds", 1) != 0) {          // (see subtract_lds_kernel)
+    const size_t lds = (size_t)((k + 1) & ~(int64_t)1) * 128 * sizeof(float);
+    dim3 g1((unsigned)cdiv(P, 128));
+#define LAUNCHL(V, RC)                                                                                              \
+  do {                                                                                                               \
+    auto kern = subtract_lds_kernel<V, RC>;                                                                          \
+    VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, g1, block, lds, ctx->stream, M, Ct, nld, T, (int)n, (int)k, P, R, recon);              \
+  } while (0)
+    if (vec) {
+      if (recon) LAUNCHL(true, true); else LAUNCHL(true, false);
+    } else {
+      if (recon) LAUNCHL(false, true); else LAUNCHL(false, false);
+    }
+#undef LAUNCHL
+    VIPMI_CHECK_HIP(hipGetLastError());
+    return VIPMI_OK;
+  }
 #define LAUNCH(V, RC)                                                                             \
   hipLaunchKernelGGL((subtract_kernel<V, RC>), grid, block, 0, ctx->stream, M, Ct, nld, T, (int)n, \
                      (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0)
