@@ -826,9 +826,12 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   }
   // (the one-line-per-frame K kernel of the one-wave Le = 4096 plan would spill: it runs on the two-wave plan of the same
   // radices -- same twiddle table, same LDS footprint, same number of lines per workgroup)
-  using PA = typename std::conditional<std::is_same<P, Plan4096w1>::value, Plan4096w2, P>::type;
-  static_assert(PA::LPB == P::LPB && PA::LDS_ELEMS == P::LDS_ELEMS && Twiddles<PA>::LDS_ELEMS == Twiddles<P>::LDS_ELEMS,
-                "rs_aux_k: substitute plan must share the launch geometry");
+  // (Le = 2048: with eight lines per workgroup the float64 phase factors of the kernel spilled 105 registers under the 256
+  // budget; it runs on the four-line plan of the same radices -- one wave per SIMD, 512 registers: 49 -> 24 us)
+  using PA = typename std::conditional<std::is_same<P, Plan4096w1>::value, Plan4096w2,
+                                       typename std::conditional<std::is_same<P, Plan2048w1>::value, Plan2048w1h, P>::type>::type;
+  static_assert(PA::LDS_ELEMS == P::LDS_ELEMS && Twiddles<PA>::LDS_ELEMS == Twiddles<P>::LDS_ELEMS && PA::LPB <= P::LPB,
+                "rs_aux_k: substitute plan must fit the launch geometry");
   auto k1 = rs_shear1<P>;
   auto ka = rs_aux_k<PA>;
   auto k2 = rs_shear2<P>;
@@ -854,7 +857,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     // numbers of them
     if (gc < 8) gc = 8;
     gc = gc / 8 * 8;
-    int ga = (int)cdiv(nf, P::LPB);
+    int ga = (int)cdiv(nf, PA::LPB);
     if (ga > maxwg) ga = maxwg;
     VIPMI_CHECK_HIP(hipMemsetAsync(counters, 0, 3 * 256 * sizeof(int), ctx->stream));
     if constexpr (BLK)
