@@ -281,11 +281,12 @@ def test_rowspace_and_subtract_gemm(B, n, k, P):
     assert np.array_equal(R.cpu().numpy(), R2.cpu().numpy())
 
 
-@pytest.mark.parametrize("n,P,k", [(70, 1000, 33), (120, 4099, 50), (200, 2048, 64), (150, 777, 100), (140, 1536, 128), (140, 1536, 129)])
-def test_subtract_with_more_than_32_components_lds_tile(B, n, P, k):
-    """More than 32 components: the subtraction stages the tile of T in LDS, shared by the four waves of a workgroup, which
-    split the frame blocks (same accumulation order: bit-identical to the register kernel); residuals + reconstruction = input
-    rows, residuals orthogonal to the PCs."""
+@pytest.mark.parametrize("n,P,k", [(40, 1000, 3), (100, 16384, 20), (33, 515, 32), (70, 1000, 33), (120, 4099, 50), (200, 2048, 64), (150, 777, 100),
+                                   (140, 1536, 128), (140, 1536, 129)])
+def test_subtract_lds_tile_is_bit_identical_to_the_register_kernel(B, n, P, k):
+    """The subtraction stages the tile of T in LDS, shared by the four waves of a workgroup, which split the frame blocks
+    (same accumulation order: bit-identical to the register kernel, option subtract_lds = 0; more than 128 components: the
+    register kernel); residuals + reconstruction = input rows, residuals orthogonal to the PCs."""
     import torch
     rng = np.random.default_rng(n + k)
     M = torch.from_numpy(rng.standard_normal((n, P)).astype(np.float32)).cuda()

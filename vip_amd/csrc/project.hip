@@ -176,14 +176,22 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
   }
 }
 
-// More than 32 components (C5: 50): the wave's tile of T no longer fits in registers, and re-read per block of 32 frames it
-// came 63 times through the L2 (13 GB at C5 beside the 16.8 GB of M and R).  Here the FOUR waves of a workgroup share one
-// 128-pixel tile, staged once in LDS ([component][128 pixels], <= 64 KB), and split the frame blocks between them.
+// The default subtraction (up to 128 components).  The FOUR waves of a workgroup share one 128-pixel tile of T, staged once in
+// LDS ([component][128 pixels], <= 64 KB), and split the blocks of 32 frames between them.  subtract_kernel above keeps the
+// tile in registers (up to 32 components) or re-reads it through the L2 per frame block (more: 13 GB at C5 beside the 16.8 GB
+// of M and R), and with both operand sets needs 426 registers -- ONE wave per SIMD, whose load / MFMA / store phases nothing
+// overlaps.  This one takes 228: two waves per SIMD.  C2 (k = 20) 213 -> 177 us, C5 (k = 50) 6.1 -> 4.6 ms; same accumulation
+// order per element, bit-identical.
 template <bool VEC, bool RECON>
-__global__ __launch_bounds__(256) void subtract_lds_kernel(const float* __restrict__ M, const float* __restrict__ Ct, int nld,
+__global__ __launch_bounds__(256, 2) void subtract_lds_kernel(const float* __restrict__ M, const float* __restrict__ Ct, int nld,
                                                            const float* __restrict__ T, int n, int k, int64_t P,
-                                                           float* __restrict__ R, float* __restrict__ recon) {
+                                                           float* __restrict__ R, float* __restrict__ recon,
+                                                           int64_t sM, int64_t sCt, int64_t sT) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];          // [kp][128], kp = k rounded up to even
+  M += blockIdx.y * sM;                      // blockIdx.y = problem of the batch (strides 0 for a single one)
+  R += blockIdx.y * sM;
+  Ct += blockIdx.y * sCt;
+  T += blockIdx.y * sT;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t px0 = (int64_t)blockIdx.x * 128;
   const int jl = lane & 31, kh = lane >> 5;
@@ -288,14 +296,14 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
   const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(T) && aligned16(R) &&
                    (!recon || aligned16(recon));
   dim3 grid((unsigned)cdiv(cdiv(P, 128), 4)), block(256);
-  if (k > 32 && k <= 128 && ctx->opt("subtract_lds", 1) != 0) {          // (see subtract_lds_kernel)
+  if (k <= 128 && ctx->opt("subtract_lds", 1) != 0) {      // (see subtract_lds_kernel)
     const size_t lds = (size_t)((k + 1) & ~(int64_t)1) * 128 * sizeof(float);
     dim3 g1((unsigned)cdiv(P, 128));
 #define LAUNCHL(V, RC)                                                                                              \
   do {                                                                                                               \
     auto kern = subtract_lds_kernel<V, RC>;                                                                          \
     VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(kern, g1, block, lds, ctx->stream, M, Ct, nld, T, (int)n, (int)k, P, R, recon);              \
+    hipLaunchKernelGGL(kern, g1, block, lds, ctx->stream, M, Ct, nld, T, (int)n, (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0); \
   } while (0)
     if (vec) {
       if (recon) LAUNCHL(true, true); else LAUNCHL(true, false);
@@ -363,6 +371,12 @@ int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t 
   VIPMI_TRY(ws(ctx, "projb_ct", (size_t)chunk * k * nld, &Ct));
   VIPMI_TRY(ws(ctx, "projb_t", (size_t)chunk * k * P, &T));
   const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(R) && aligned16(T);
+  const bool use_lds = k <= 128 && ctx->opt("subtract_lds", 1) != 0;
+  const size_t lds_t = (size_t)((k + 1) & ~(int64_t)1) * 128 * sizeof(float);
+  if (use_lds) {
+    VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subtract_lds_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subtract_lds_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+  }
   for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
     const int64_t cb = std::min(chunk, nb - b0);
     const float* Mb = M + b0 * n * P;
@@ -370,17 +384,25 @@ int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t 
     float* Rb = R + b0 * n * P;
     hipLaunchKernelGGL(transpose_pad_kernel, dim3(8, (unsigned)cb), dim3(256), 0, ctx->stream, Eb, (int)k, (int)n, Wt, kld);
     hipLaunchKernelGGL(pad_cols_kernel, dim3(8, (unsigned)cb), dim3(256), 0, ctx->stream, Eb, (int)k, (int)n, Ct, nld);
-    dim3 g1((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(k, 32), (unsigned)cb), g2((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cb);
+    dim3 g1((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(k, 32), (unsigned)cb), g2((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cb), g3((unsigned)cdiv(P, 128), (unsigned)cb);
     if (vec) {
       hipLaunchKernelGGL((rowspace_kernel<true, 1>), g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
                          (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
-      hipLaunchKernelGGL((subtract_kernel<true, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
-                         (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+      if (use_lds)
+        hipLaunchKernelGGL((subtract_lds_kernel<true, false>), g3, dim3(256), lds_t, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+      else
+        hipLaunchKernelGGL((subtract_kernel<true, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
     } else {
       hipLaunchKernelGGL((rowspace_kernel<false, 1>), g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
                          (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
-      hipLaunchKernelGGL((subtract_kernel<false, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
-                         (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+      if (use_lds)
+        hipLaunchKernelGGL((subtract_lds_kernel<false, false>), g3, dim3(256), lds_t, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+      else
+        hipLaunchKernelGGL((subtract_kernel<false, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
     }
     VIPMI_CHECK_HIP(hipGetLastError());
   }
