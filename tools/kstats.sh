@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/kstats.sh <python script and args ...>   -> rocprofv3 kernel stats (top 10) of that command, on the GPU box
 R=${GRAFT_REPO_ROOT:-/root/repo}
+export PYTHONPATH=$R:$PYTHONPATH
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kstats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -o k -- python "$@" > /tmp/kstats.log 2>&1

@@ -453,11 +453,13 @@ int gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, i
                 (long)n, (long)P);
   StageScope sc(ctx, "gram");
   {
-    // (batches of small problems: the float64-MFMA kernel is the faster one -- 39 x (200 x 65536): 3.0 against 3.3 ms -- so the
-    // int8 path only runs when forced)
+    // batches: the int8 path from 128 rows and 2^25 elements in all (tools/gram_i8_sizes.py: 39 x (200 x 65536) 3.0 -> 2.6 ms,
+    // 8 x (196 x 30000) 0.43 -> 0.29 ms; 200 x (39 x 65536) and 16 x (100 x 16384) are faster on the float64 MFMA)
     const int64_t i8 = ctx->opt("gram_i8", -1);
-    if (i8 > 0 && ctx->opt("gram_f32", 0) == 0 && n >= ctx->opt("gram_i8_min_n", 32) && P >= 1024 && batch <= 65535)
-      return gram_i8_f32(ctx, M, n, P, P, G, batch, i8 == 2 ? 2 : 1);
+    const bool fits = ctx->opt("gram_f32", 0) == 0 && P >= 1024 && batch <= 65535;
+    const bool forced = i8 > 0 && n >= ctx->opt("gram_i8_min_n", 32);
+    const bool pays = i8 < 0 && n >= 128 && P >= 16384 && batch * n * P >= ((int64_t)1 << 25);
+    if (fits && (forced || pays)) return gram_i8_f32(ctx, M, n, P, P, G, batch, i8 == 2 ? 2 : 1);
   }
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb_ = (batch - b0) < 65535 ? (batch - b0) : 65535;
