@@ -255,6 +255,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle in this GPU-free process and print its JSON object")
     ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
+    ap.add_argument("--setup-burst", type=int, default=20,
+                    help="untimed pipelined calls issued in one burst before the W warm-up steps (0 = none; see the comment at its use)")
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the strong-scaling legs (C5 single cube / C3 annular / C4 4-D sharded over the ranks)")
     ap.add_argument("--no-stage-timing", action="store_true",
@@ -332,6 +334,7 @@ def main():
         B.set_async(True)       # (VIPMI_RESERVE_CUS=<n> keeps n CUs free of the shear kernels; measured best: 0)
 
     last = [None]
+    step_events = None            # VIPMI_BENCH_TRACE=1: an event after every timed step (printed to stderr)
 
     def run(nsteps):
         if depth == 1:
@@ -341,7 +344,11 @@ def main():
         for i in range(nsteps):
             with torch.cuda.stream(streams[i % depth]):
                 frame = pca(cubes_t[i % depth], angles, ncomp=k, scaling=args.scaling, verbose=False, check_memory=False)
-                pinned[i].copy_(frame, non_blocking=True)
+                pinned[i % len(pinned)].copy_(frame, non_blocking=True)
+                if step_events is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    step_events.append(ev)
 
     STAGES = ("scale", "gram", "eigh", "project", "derotate", "collapse", "k_rot_s1", "k_rot_s2", "k_rot_s3",
               "k_rot_aux")
@@ -356,6 +363,14 @@ def main():
     torch.cuda.synchronize()
     run(depth)                                  # creates the per-stream contexts
     torch.cuda.synchronize()
+    # One deep burst before the warm-up steps (untimed, once per process).  The first time the host runs many calls ahead of
+    # the GPU -- ~200 launches queued on two streams -- steps 2..10 of that burst take 6.2 ms instead of 5.0
+    # (tools/pipe_history.py: bursts of 7 calls before the measured pass, however many: 110 ms per 20 steps; ONE burst of 20
+    # at any earlier time: 100 ms ever after; every stage ~9 % slower, so it is not one kernel but the runtime growing its
+    # per-queue pools under a deep queue).  A survey loop pays that once in its first ten cubes; it is not part of a step.
+    if depth > 1 and args.setup_burst > 0:
+        run(args.setup_burst)
+        torch.cuda.synchronize()
     if timing:
         set_timing(True)                        # hipEvent pairs around every stage / shear kernel, on the
     run(args.warmup)                            # stream the kernels are launched on (events are created here)
@@ -364,10 +379,17 @@ def main():
         c.reset_timers()
     # timed region
     barrier()
+    if os.environ.get("VIPMI_BENCH_TRACE") and depth > 1:
+        step_events = []
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if step_events is not None:
+        print("GPU end of each timed step (ms):", " ".join("%.1f" % ev0.elapsed_time(e) for e in step_events), file=sys.stderr)
+        step_events = None
     if depth > 1:
         B.check_deferred()
     out = pinned[args.steps - 1] if depth > 1 else last[0]
@@ -473,7 +495,7 @@ def main():
                                    "vip-fft derotation, median collapse" % (n, N, N, k) +
                                    (", scaling=%s" % args.scaling if args.scaling else ""),
                        "cubes_per_step": world, "parallelism": "one cube per GPU (no data-path collective)",
-                       "pipeline_depth": depth},
+                       "pipeline_depth": depth, "untimed_setup_burst": (args.setup_burst if depth > 1 else 0)},
             "ms_per_svd": ms_svd,
             "stages": stages,
             "stages_serial_ms": stages_serial,

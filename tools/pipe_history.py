@@ -1,0 +1,29 @@
+"""Does the speed of a 20-step pipelined pass depend on the TOTAL number of calls before it or on the length of the last burst?"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vip_amd import backend as B
+from vip_amd.psfsub import pca
+from vip_amd.synth import synth_adi_device
+pattern = [int(x) for x in sys.argv[1].split(",")]          # bursts before the measured pass, e.g. 7  or 7,7,7 or 20
+n, N, k, depth, K = 400, 512, 20, 2, 20
+cubes = [synth_adi_device(n, N, seed=s)[0] for s in range(depth)]
+ang = np.linspace(0, 90, n)
+streams = [torch.cuda.Stream() for _ in range(depth)]
+pinned = [torch.empty((N, N), dtype=torch.float32).pin_memory() for _ in range(K)]
+B.set_async(True)
+def run(m, rec=None):
+    for i in range(m):
+        with torch.cuda.stream(streams[i % depth]):
+            fr = pca(cubes[i % depth], ang, ncomp=k, verbose=False, check_memory=False)
+            pinned[i % K].copy_(fr, non_blocking=True)
+            if rec is not None:
+                e = torch.cuda.Event(enable_timing=True); e.record(); rec.append(e)
+for b in pattern:
+    run(b); torch.cuda.synchronize()
+rec = []
+e0 = torch.cuda.Event(enable_timing=True); e0.record()
+run(K, rec); torch.cuda.synchronize()
+ends = [e0.elapsed_time(e) for e in rec]
+print("bursts %s -> %.1f ms; periods: %s" % (pattern, ends[-1], " ".join("%.1f" % (b - a) for a, b in zip(ends, ends[1:]))))
+B.check_deferred(); B.set_async(False)
