@@ -5,7 +5,8 @@ import numpy as np, torch
 from vip_amd import backend as B
 from vip_amd.psfsub import pca
 from vip_amd.synth import synth_adi_device
-pattern = [int(x) for x in sys.argv[1].split(",")]          # bursts before the measured pass, e.g. 7  or 7,7,7 or 20
+pattern = sys.argv[1].split(",")          # bursts before the measured pass, e.g. 7  or 7,7,7 or 20; mNNN = NNN ms of torch matmuls
+# on one stream (GPU load without our library), qNNN = NNN tiny kernels queued on each of the two streams (queue depth without load)
 n, N, k, depth, K = 400, 512, 20, 2, 20
 cubes = [synth_adi_device(n, N, seed=s)[0] for s in range(depth)]
 ang = np.linspace(0, 90, n)
@@ -19,8 +20,22 @@ def run(m, rec=None):
             pinned[i % K].copy_(fr, non_blocking=True)
             if rec is not None:
                 e = torch.cuda.Event(enable_timing=True); e.record(); rec.append(e)
+A_ = torch.randn(4096, 4096, device="cuda")
 for b in pattern:
-    run(b); torch.cuda.synchronize()
+    if b[0] == "m":
+        t_ = time.perf_counter()
+        while time.perf_counter() - t_ < float(b[1:]) * 1e-3:
+            for _ in range(8): A_ @ A_
+            if torch.cuda.current_stream().query(): pass
+        torch.cuda.synchronize()
+    elif b[0] == "q":
+        z_ = torch.zeros(64, device="cuda")
+        for st in streams:
+            with torch.cuda.stream(st):
+                for _ in range(int(b[1:])): z_.add_(1.0)
+        torch.cuda.synchronize()
+    else:
+        run(int(b)); torch.cuda.synchronize()
 rec = []
 e0 = torch.cuda.Event(enable_timing=True); e0.record()
 run(K, rec); torch.cuda.synchronize()
