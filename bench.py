@@ -255,8 +255,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle in this GPU-free process and print its JSON object")
     ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
-    ap.add_argument("--setup-burst", type=int, default=20,
-                    help="untimed pipelined calls issued in one burst before the W warm-up steps (0 = none; see the comment at its use)")
+    ap.add_argument("--setup-burst", type=int, default=0,
+                    help="untimed pipelined calls issued in one burst before the W warm-up steps (experiments; see the comment at its use)")
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the strong-scaling legs (C5 single cube / C3 annular / C4 4-D sharded over the ranks)")
     ap.add_argument("--no-stage-timing", action="store_true",
@@ -363,11 +363,11 @@ def main():
     torch.cuda.synchronize()
     run(depth)                                  # creates the per-stream contexts
     torch.cuda.synchronize()
-    # One deep burst before the warm-up steps (untimed, once per process).  The first time the host runs many calls ahead of
-    # the GPU -- ~200 launches queued on two streams -- steps 2..10 of that burst take 6.2 ms instead of 5.0
-    # (tools/pipe_history.py: bursts of 7 calls before the measured pass, however many: 110 ms per 20 steps; ONE burst of 20
-    # at any earlier time: 100 ms ever after; every stage ~9 % slower, so it is not one kernel but the runtime growing its
-    # per-queue pools under a deep queue).  A survey loop pays that once in its first ten cubes; it is not part of a step.
+    # (experiments) one deep burst before the warm-up steps.  With FOUR staging slots per upload the host ran eight calls ahead
+    # of the two streams, and the first time it did so in a process calls 2..10 took 6.2 ms instead of 4.9 (the HIP runtime
+    # growing its per-queue pools: tools/pipe_history.py) -- 20 timed steps after 5 warm-up steps measured that transient
+    # (108-111 ms) unless a burst of 20 had gone before (100 ms).  The library now keeps ONE slot (option upload_ring): the
+    # host stays about one call ahead, the transient is gone (100.4 ms without any burst) and small cubes gained 30 %.
     if depth > 1 and args.setup_burst > 0:
         run(args.setup_burst)
         torch.cuda.synchronize()

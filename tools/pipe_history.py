@@ -13,9 +13,16 @@ ang = np.linspace(0, 90, n)
 streams = [torch.cuda.Stream() for _ in range(depth)]
 pinned = [torch.empty((N, N), dtype=torch.float32).pin_memory() for _ in range(K)]
 B.set_async(True)
+for o in sys.argv[2:]:
+    a_, b_ = o.split('=')
+    os.environ['VIPMI_OPT_' + a_] = b_
+OPTS = {o.split('=')[0]: int(o.split('=')[1]) for o in sys.argv[2:]}
 def run(m, rec=None):
     for i in range(m):
         with torch.cuda.stream(streams[i % depth]):
+            if OPTS:
+                c_ = B.get_context()
+                for a_, b_ in OPTS.items(): c_.set_option(a_, b_)
             fr = pca(cubes[i % depth], ang, ncomp=k, verbose=False, check_memory=False)
             pinned[i % K].copy_(fr, non_blocking=True)
             if rec is not None:
@@ -27,6 +34,14 @@ for b in pattern:
         while time.perf_counter() - t_ < float(b[1:]) * 1e-3:
             for _ in range(8): A_ @ A_
             if torch.cuda.current_stream().query(): pass
+        torch.cuda.synchronize()
+    elif b[0] == "t":                                    # tNN: NN pipelined pca() calls on TINY cubes (50 x 128 x 128)
+        if "tiny" not in globals():
+            tiny = [synth_adi_device(50, 128, seed=9 + s_)[0] for s_ in range(depth)]; tang = np.linspace(0, 90, 50)
+        for i in range(int(b[1:])):
+            with torch.cuda.stream(streams[i % depth]):
+                fr = pca(tiny[i % depth], tang, ncomp=5, verbose=False, check_memory=False)
+                pinned[i % K][:128, :128].copy_(fr, non_blocking=True)
         torch.cuda.synchronize()
     elif b[0] == "q":
         z_ = torch.zeros(64, device="cuda")

@@ -104,7 +104,12 @@ int vipmi_ctx::upload_cached(const char* name, const std::string& key, const voi
 
 int vipmi_ctx::upload_async(const char* name, const void* host, size_t bytes, void* dst) {
   auto& ring = pinned[name];
-  if (ring.empty()) ring.resize(4);
+  // ONE staging slot by default (option upload_ring): before it is refilled the host waits for the previous upload of this
+  // name to have executed, i.e. it runs at most about one call ahead of each stream.  Four slots let it run eight calls ahead
+  // of two streams -- no gain (the GPU only needs the next call queued) and a cost: the HIP runtime grows its per-queue pools
+  // under the deep queue, and the first ten calls of every process took 6.2 ms instead of 4.9 (tools/pipe_history.py); small
+  // cubes: 236 -> 164 us per pipelined call at 50 x 128 x 128 (tools/pipe_small.py).
+  if (ring.empty()) ring.resize((size_t)std::min<int64_t>(std::max<int64_t>(opt("upload_ring", 1), 1), 16));
   PinnedSlot& sl = ring[pinned_next[name]++ % ring.size()];
   if (sl.ev) {
     hipError_t e = hipEventSynchronize(sl.ev);
@@ -287,7 +292,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "rot_fuse_probe", "rot_2048_half", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "rot_pair_store", "subtract_lds", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "rot_fuse_probe", "rot_2048_half", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "rot_pair_store", "subtract_lds", "upload_ring", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
