@@ -577,8 +577,7 @@ int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64
   while (TP > 1 && (size_t)n * (TP + 1) * 4 + hist_bytes > 150 * 1024) TP >>= 1;
   const size_t lds = (size_t)n * (TP + 1) * 4 + hist_bytes;
   auto kern = median_kernel<RPL, TRIM>;
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
   const int64_t ntiles = cdiv(P, TP);
   hipLaunchKernelGGL(kern, dim3((unsigned)(cdiv(ntiles, 8) * 8), (unsigned)batch), dim3(512), lds, ctx->stream, cube, n, P, TP, out,
                      t0, tn, (int)ntiles, lds <= 80 * 1024 ? 1 : 0);

@@ -127,6 +127,27 @@ inline int ws(vipmi_ctx* ctx, const char* name, size_t count, T** out) {
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), remembered per (device, kernel): the attribute only
+// ever has to grow, and the call costs ~3 us -- eight of them were a tenth of the host time of a pca() call on a small cube.
+inline hipError_t set_dyn_lds(const void* f, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> seen;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find({dev, f});
+    if (it != seen.end() && it->second >= bytes) return hipSuccess;
+  }
+  const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(mu);
+    int& v = seen[{dev, f}];
+    if (v < bytes) v = bytes;
+  }
+  return e;
+}
+
 struct StageScope {
   vipmi_ctx* c;
   const char* s;

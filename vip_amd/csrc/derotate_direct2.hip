@@ -503,17 +503,15 @@ int derotate_direct2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, 
   const size_t lds3 = (size_t)(2 * Lpad + 8 + tsw(Lpad + Npad) + (t3 / lg3) * Npad) * sizeof(float);
   VIPMI_REQUIRE(lds1 <= 160 * 1024 && ldsk <= 160 * 1024 && lds2 <= 160 * 1024 && lds3 <= 160 * 1024,
                 "derotate(direct): frame size %d too large for the LDS-resident tables", g.N);
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ds_shear1), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds1));
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ds_aux_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)ldsk));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(ds_shear1), (int)lds1));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(ds_aux_k), (int)ldsk));
   const void* k2 = CT == 16  ? reinterpret_cast<const void*>(ds_shear2<16>)
                    : CT == 8 ? reinterpret_cast<const void*>(ds_shear2<8>)
                    : CT == 4 ? reinterpret_cast<const void*>(ds_shear2<4>)
                              : reinterpret_cast<const void*>(ds_shear2<2>);
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  VIPMI_CHECK_HIP(set_dyn_lds(k2, (int)lds2));
   const void* k3 = na3 == 8 ? reinterpret_cast<const void*>(ds_shear3<8>) : reinterpret_cast<const void*>(ds_shear3<4>);
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+  VIPMI_CHECK_HIP(set_dyn_lds(k3, (int)lds3));
   // threads: one lane per TNA outputs
   auto threads_for = [](int nout, int cap) {
     int t = (int)cdiv(cdiv(nout, TNA), 64) * 64;

@@ -838,7 +838,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   auto k3 = rs_shear3<P>;
   for (const void* f : {reinterpret_cast<const void*>(k1), reinterpret_cast<const void*>(ka),
                         reinterpret_cast<const void*>(k2), reinterpret_cast<const void*>(k3)})
-    VIPMI_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VIPMI_CHECK_HIP(set_dyn_lds(f, (int)lds));
   const int wgs_per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   int usable_cu = ctx->num_cu - (int)ctx->opt("reserve_cus", 0);
   if (usable_cu < 1) usable_cu = 1;
@@ -872,8 +872,7 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
     ctx->tic("k_rot_s2");
     if constexpr (P::WPL == 1) {
       auto k2d = rs_shear2_direct<P>;
-      VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2d),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(k2d), (int)lds));
       hipLaunchKernelGGL(k2d, dim3(gr), blk, lds, ctx->stream, A1r, d_frames, g, A2r, aux, (int)f0, nf, twtab,
                          counters + 256);
     } else {

@@ -279,8 +279,7 @@ int launch_jacobi(vipmi_ctx* ctx, double* G, int64_t batch, int n, double* evals
   const double tol = 1e-12;
   const size_t lds_bytes = (size_t)B * RPL * 64 * sizeof(double);
   auto kern = jacobi_kernel<B, RPL>;
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds_bytes));
   // co-residency: workgroups per CU limited by LDS and by 2048 threads/CU
   int per_cu_lds = (int)((160 * 1024) / (lds_bytes + 256));
   int per_cu_thr = 2048 / (64 * B);

@@ -1293,8 +1293,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   const size_t lds = (rows_d + (size_t)10 * n + 64) * sizeof(double);
   VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(multi): LDS budget exceeded (%zu)", lds);
   auto kern = tri_multi_kernel<RPL>;
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
   // all W workgroups of a problem must be co-resident (counter barrier): one per CU, launch at most num_cu/W problems
   // one_xcd (wave_util.h): problem p on XCD (base + p) % 8, num_cu / 8 CUs each -- the same count.  The base rotates from
   // launch to launch (and starts at a per-process value): concurrent launches from several streams or processes then sit on
@@ -1351,8 +1350,7 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   const bool reg = ctx->opt("eigh_reg", 1) != 0 && (RPL == 2 || RPL == 4) && reg_variant_fits(n, k);
   if (reg) {
     auto launch_reg = [&](auto kern) -> int {
-      VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds_r));
+      VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds_r));
       // big batches: tridiagonalisation and the rest as two launches (see the kernel); option eigh_split = 0 / 1 forces
       const int64_t split_opt = ctx->opt("eigh_split", -1);
       // (measured, 200 x 200, k = 10: 400 problems 1.47 ms in one launch / 1.57 split, 1600: 4.33 / 3.70, 3200: 8.33 / 6.83)
@@ -1370,8 +1368,7 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
       VIPMI_CHECK_HIP(hipGetLastError());
       const size_t lds2 = ((size_t)(9 + 256 / 64) * n + 64 + 8) * sizeof(double);
       auto kern2 = tri_eig_kernel<RPL, 256>;
-      VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds2));
+      VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern2), (int)lds2));
       hipLaunchKernelGGL(kern2, dim3((unsigned)batch), dim3(256), lds2, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
                          all_evals, k < n ? k : n, 2, det);
       VIPMI_CHECK_HIP(hipGetLastError());
@@ -1388,7 +1385,7 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
   const void* kern = nt == 256   ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 256>)
                      : nt == 512 ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 512>)
                                  : reinterpret_cast<const void*>(tri_eig_kernel<RPL, 1024>);
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  VIPMI_CHECK_HIP(set_dyn_lds(kern, (int)lds));
   if (nt == 256)
     hipLaunchKernelGGL((tri_eig_kernel<RPL, 256>), dim3((unsigned)batch), dim3(256), lds, ctx->stream, A, n, k, nact,
                        evals, evecs, scratch, kp, all_evals, k < n ? k : n);

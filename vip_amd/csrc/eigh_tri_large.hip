@@ -914,8 +914,7 @@ int launch_xl(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double* ev
   VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned), ctx->stream));
   const size_t lds = ((size_t)3 * n + 6 * LNW + 8 + 16) * sizeof(double);
   VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(xl): LDS budget exceeded (%zu)", lds);
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tri_xl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(tri_xl_kernel), (int)lds));
   hipLaunchKernelGGL(tri_xl_kernel, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, scr, bars, all_evals);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
@@ -935,8 +934,7 @@ int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double*
   const size_t lds = ((size_t)9 * n + 8 + 2 * LNW + 16) * sizeof(double);
   VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(large): LDS budget exceeded (%zu)", lds);
   auto kern = tri_large_kernel<RPL>;
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, bars, all_evals);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;

@@ -391,7 +391,7 @@ int run(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double
   // global -> LDS by DMA (two buffers) unless gram_i8_dma = 0
   const bool dma = nbuf == 2 && ctx->opt("gram_i8_dma", 1) != 0;
   auto kern = dma ? gram_i8_kernel<S, KEEP, true> : gram_i8_kernel<S, KEEP, false>;
-  VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * nwg), (unsigned)cdiv(nslices, 8), (unsigned)batch), dim3(256), lds, ctx->stream, D, sc, npad,
                      (int)klen, nslices, Ppad, plane, d_tiles, nwg, partial, nbuf == 2 ? 2 : 1);
   VIPMI_CHECK_HIP(hipGetLastError());

@@ -302,7 +302,7 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
 #define LAUNCHL(V, RC)                                                                                              \
   do {                                                                                                               \
     auto kern = subtract_lds_kernel<V, RC>;                                                                          \
-    VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)); \
     hipLaunchKernelGGL(kern, g1, block, lds, ctx->stream, M, Ct, nld, T, (int)n, (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0); \
   } while (0)
     if (vec) {
@@ -374,8 +374,8 @@ int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t 
   const bool use_lds = k <= 128 && ctx->opt("subtract_lds", 1) != 0;
   const size_t lds_t = (size_t)((k + 1) & ~(int64_t)1) * 128 * sizeof(float);
   if (use_lds) {
-    VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subtract_lds_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-    VIPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subtract_lds_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(subtract_lds_kernel<true, false>), (int)lds_t));
+    VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(subtract_lds_kernel<false, false>), (int)lds_t));
   }
   for (int64_t b0 = 0; b0 < nb; b0 += chunk) {
     const int64_t cb = std::min(chunk, nb - b0);
