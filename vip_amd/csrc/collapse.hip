@@ -246,7 +246,7 @@ constexpr int HIST_WORDS = 384;                  // 256 bins + dump bin + 64 dum
 // TRIM = false: nanmedian.  TRIM = true: mean of sorted[t0 : t0+tn] (np.sort order, NaN last, then nanmean):
 // the reference's 'trimmean' (subsampling.py:87-96).
 template <int RPL, bool TRIM>
-__global__ __launch_bounds__(512) void median_kernel(const float* __restrict__ cube0, int n, int64_t P,
+__global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_kernel(const float* __restrict__ cube0, int n, int64_t P,
                                                      int TP, float* __restrict__ out0, int t0, int tn, int ntiles, int xcd_ranges) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 256 histogram words per wave, then the n x (TP+1) tile
   const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;       // blockIdx.y = cube of the batch

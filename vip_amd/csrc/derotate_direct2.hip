@@ -120,6 +120,11 @@ __device__ __forceinline__ void fill_table(float* __restrict__ T, int OFF, int n
 // table entries; the others are the previous steps').  X: x (p = 1) or xo (p = 0), nin_pad floats, zero padded (at least one
 // zero after the last input), 16-byte aligned; T: OFF == nin_pad, entries up to OFF + M + 2 TNA - 1 valid.
 typedef float f2 __attribute__((ext_vector_type(2)));
+// acc + (w.y x.x, w.x x.y): one packed FMA, the swapped operand in src0
+__device__ __forceinline__ f2 fma_swz(f2 w, f2 x, f2 acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(x));
+  return acc;
+}
 constexpr int TNA = 8;                   // outputs per lane: 4 inputs x 8 outputs = 16 packed FMAs per 2 LDS reads (with 4
                                          // outputs per lane the passes were bound by LDS bandwidth, not by the FMAs)
 template <int NA>
@@ -137,17 +142,18 @@ __device__ __forceinline__ void toeplitz_par(const float* __restrict__ X, int ni
     const float4 wm = *reinterpret_cast<const float4*>(T + tsw(b - 4));
     const float4 xv = *reinterpret_cast<const float4*>(X + k);
     const f2 x0 = f2{xv.x, xv.y}, x1 = f2{xv.z, xv.w};
-    // swapped table pairs P(j) = (T[b + 2 j + 1], T[b + 2 j]), j = -1 .. NA - 1
-    f2 P[NA + 1];
-    P[0] = f2{wm.w, wm.z};
+    // table pairs W(j) = (T[b + 2 j], T[b + 2 j + 1]), j = -1 .. NA - 1, multiplied in SWAPPED order: the swizzle sits on src0
+    // (fma_swz) -- left to the compiler it lands on src1 (`op_sel:[0,1,0]`), the operand form gfx950 gets wrong beside
+    // another wave's 16x16x64-i8 / 16x16x32-bf16 MFMA (common.h, VIPMI_NO_PK32)
+    f2 W[NA + 1];
+    W[0] = f2{wm.z, wm.w};
 #pragma unroll
     for (int i = 0; i < NA / 2; ++i) {
-      P[1 + 2 * i] = f2{w[i].y, w[i].x};
-      P[2 + 2 * i] = f2{w[i].w, w[i].z};
+      W[1 + 2 * i] = f2{w[i].x, w[i].y};
+      W[2 + 2 * i] = f2{w[i].z, w[i].w};
     }
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
-      acc[a] = __builtin_elementwise_fma(x1, P[a], __builtin_elementwise_fma(x0, P[a + 1], acc[a]));
+    for (int a = 0; a < NA; ++a) acc[a] = fma_swz(W[a], x1, fma_swz(W[a + 1], x0, acc[a]));
 #pragma unroll
     for (int i = NA / 2 - 1; i > 0; --i) w[i] = w[i - 1];
     w[0] = wm;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void ds_bf(const RotFrame* __restrict__ fr, Ro
 // Two launches over a grid (frames, S): phase 1 writes the spectrum H of a frame in S slices to global memory, phase 2
 // computes S slices of K from the whole H.  (One workgroup per frame did both: 0.6 ms for a 2048-pixel frame, a third of
 // the derotation of a handful of such frames.)
-__global__ __launch_bounds__(1024) void ds_aux_k(const RotFrame* __restrict__ fr, RotGeom g, AuxD aux, int f0, int phase,
+__global__ VIPMI_NO_PK32 __launch_bounds__(1024) void ds_aux_k(const RotFrame* __restrict__ fr, RotGeom g, AuxD aux, int f0, int phase,
                                                  float2* __restrict__ Hg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float2* root = reinterpret_cast<float2*>(smem);          // [Le] e^{+2 pi i t/Le}

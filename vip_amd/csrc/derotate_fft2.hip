@@ -465,6 +465,10 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_aux_k(const RotFrame* __restri
         }
         v[ul * P::R1 + n1] = mkcf(x, 0.f);
       }
+    // the zero imaginary parts stay opaque: folded into the first butterflies they made hipcc emit packed adds of a register pair
+    // with its own swapped self in the src1-high operand form (common.h, VIPMI_NO_PK32; tools/isa_lint.py)
+#pragma unroll
+    for (int i = 0; i < P::VL; ++i) asm volatile("" : "+v"(v[i]));
     fft_forward<P>(v, tw, lds, lane, sub);
     // g(k) = sum_{X=0}^{L-1} exp(-2 pi i ks b (X - c)/L) = exp(-2 pi i ks b ((L-1)/2 - c)/L) sin(pi ks b)/sin(pi ks b/L)
     const int u0 = sub * P::U3L;
@@ -481,8 +485,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_aux_k(const RotFrame* __restri
         sincospi(-2.0 * kbv * (0.5 * (double)(P::L - 1) - (double)g.c) / (double)P::L, &sn, &cs);
         float gre = (float)(ratio * cs / (double)P::L), gim = (float)(ratio * sn / (double)P::L);
         if (kb == R3 / 2 && wq == 0) gim = 0.f;          // Nyquist: sum of cos(pi s_X) (real part)
-        const cf z = v[ul * R3 + kb];
-        v[ul * R3 + kb] = mkcf(z.x * gre - z.y * gim, z.x * gim + z.y * gre);
+        v[ul * R3 + kb] = cmul(v[ul * R3 + kb], mkcf(gre, gim));   // (the hand-written form: hipcc's own packed lowering of
+                                                                   // the scalar formula used the src1-high operand form, common.h)
       }
     }
     fft_inverse<P>(v, tw, lds, lane, sub);
