@@ -13,7 +13,11 @@
  *   - array arguments are CALLER-OWNED DEVICE pointers (e.g. torch.Tensor.data_ptr()), C-order,
  *     contiguous, unless the name ends in _host.  Sizes are explicit int64.
  *   - a vipmi_ctx owns a device id, a stream and a growable scratch workspace; one ctx per
- *     (device, stream); a ctx is not thread-safe, distinct ctxs are independent.
+ *     (device, stream); a ctx is not thread-safe, distinct ctxs are independent: calls on different
+ *     ctxs may be issued from different host threads at the same time and return the results of
+ *     the single-threaded call bit for bit (tests/test_gpu_threads.py; the kernels of two ctxs do
+ *     share compute units -- see csrc/common.h VIPMI_NO_PK32 for the one hardware interaction that
+ *     this needed care for).
  *   - all work is enqueued on the ctx stream; nothing synchronises unless stated.
  */
 #ifndef VIPMI_H
