@@ -99,6 +99,7 @@ struct vipmi_ctx {
   std::map<std::string, int> pinned_next;
   void* host_pinned = nullptr;     // grow-only pinned scratch for small read-backs (host_scratch)
   size_t host_pinned_bytes = 0;
+  int sticky_fail[2] = {0, 0};    // deferred failures latched on the host when their device words are freed (vipmi_trim)
   int num_cu = 256;
   int timing = 0;                 // 0 off, 1 every stage / kernel, 2 only the roofline kernel (k_rot_s2)
 
@@ -144,6 +145,16 @@ inline int ws(vipmi_ctx* ctx, const char* name, size_t count, T** out) {
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// The context's deferred-failure words on the device: [0] eigenproblems that did not converge, [1] inter-workgroup barriers that
+// timed out (a co-resident partner never arrived: results of that launch are invalid).  Read and cleared by vipmi_check_deferred;
+// vipmi_trim latches them on the host before it frees the buffer.
+inline int deferred_fail_words(vipmi_ctx* ctx, int** out) {
+  const bool fresh = ctx->buffers.find("deferred_fail") == ctx->buffers.end();
+  VIPMI_TRY(ws(ctx, "deferred_fail", 4, out));
+  if (fresh) VIPMI_CHECK_HIP(hipMemsetAsync(*out, 0, 4 * sizeof(int), ctx->stream));
+  return VIPMI_OK;
+}
 
 // hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), remembered per (device, kernel): the attribute only
 // ever has to grow, and the call costs ~3 us -- eight of them were a tenth of the host time of a pca() call on a small cube.

@@ -127,10 +127,6 @@ struct Aux {          // per-batch auxiliary arrays (device)
   float* gam;         // [nf][L]   (-1)^X gamma_X
   float* gsum;        // [nf]      Gam
   cf* dph;            // [nf][2][DPH_STRIDE] phase factors of the 64-line increments (rs_phase_delta), blocked plans only
-  // measurement probe (option "rot_fuse_probe" = k): shear 1 additionally gathers k "component images" per sample
-  // and subtracts 1e-30 of them -- the instruction and memory stream a fused project-subtract would add, at no visible change
-  int probe_k;
-  const float* probe_T;
   // blocked A2r with the 2 x 2 blocks of row groups G and G + 1 side by side (option rot_pair_store, see rs_shear2_direct)
   int pair;
 };
@@ -351,17 +347,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
 #pragma unroll
         for (int n1 = P::NLO; n1 < P::NLO + P::NCNT; ++n1) {
           const int X = P::M1 * n1 + lane + 64 * ul + dc;           // canvas column of canonical position M1 n1 + ...
-          float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
-          if (aux.probe_k > 0) {
-            float q1 = 0.f, q2 = 0.f;
-            for (int c = 0; c < aux.probe_k; ++c) {
-              const float* Tc = aux.probe_T + (int64_t)c * g.N * g.N;
-              q1 = fmaf(1e-30f, Tc[b1 + X * st1], q1);
-              q2 = fmaf(1e-30f, Tc[b2 + X * st2], q2);
-            }
-            t1 -= q1;
-            t2 -= q2;
-          }
+          const float t1 = frame[b1 + X * st1], t2 = frame[b2 + X * st2];
           v[ul * P::R1 + n1] = mkcf((t1 == t1) ? t1 : 0.f, (t2 == t2) ? t2 : 0.f);
         }
       const double s1 = p.a * (double)(Y1 - g.c) + (double)dc, s2 = p.a * (double)(Y2 - g.c) + (double)dc;
@@ -807,8 +793,6 @@ int run_plan2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, const R
   VIPMI_TRY(ws(ctx, "rot_gsum", (size_t)chunk, &aux.gsum));
   VIPMI_TRY(ws(ctx, "rot_dph", (size_t)chunk * 2 * DPH_STRIDE, &aux.dph));
   aux.pair = (BLK && (Blk<P>::NG % 2 == 0) && ctx->opt("rot_pair_store", 0) != 0) ? 1 : 0;
-  aux.probe_k = (int)std::min<int64_t>(ctx->opt("rot_fuse_probe", 0), n);
-  aux.probe_T = in;
   int* counters = nullptr;                       // 3 kernels x 8 task queues, one 128-byte line each
   VIPMI_TRY(ws(ctx, "rot_counters", (size_t)3 * 256, &counters));
   size_t lds = (size_t)P::LPB * P::LDS_ELEMS * sizeof(cf);
@@ -908,9 +892,8 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
     // instructions per line: 6.2 against 3.8 ms at C2); four waves per line at Le = 4096.
     case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
     case 2048:
-      // rot_2048_half=1: four-wave workgroups (one wave per SIMD), so that the MFMA-bound Gram of another call in flight can
-      // share the SIMDs with the VALU-bound shears (experiment)
-      if (ctx->opt("rot_2048_half", 0)) return run_plan2<Plan2048w1h>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
+      // (four-wave workgroups, one wave per SIMD, so that the MFMA-bound Gram of another call could share the SIMDs: measured in
+      // round 3, 3.90 -> 4.55 ms alone and 5.60 -> 6.20 ms pipelined, removed from the build -- DESIGN 7.1)
       return run_plan2<Plan2048w1>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
     case 4096:
       // one wave per line and per SIMD (512-VGPR budget), column shear software-pipelined: 200 frames of 1024 px

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
       __syncthreads();
     }
     ++phase;
-    grid_barrier(bar, phase * nwg, nwg);
+    grid_barrier(bar, phase * nwg, nwg, fail);
     // ---- block-pair rounds ----
     for (int r = 0; r < nblk - 1; ++r) {
       int I, J;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
         }
       }
       ++phase;
-      grid_barrier(bar, phase * nwg, nwg);
+      grid_barrier(bar, phase * nwg, nwg, fail);
     }
     const float smax = __uint_as_float(__hip_atomic_load(&cv[sweep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (smax <= (float)tol) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
     if (lane == 0) st_shared(&norms[col], (col < n) ? s : -1.0);
   }
   ++phase;
-  grid_barrier(bar, phase * nwg, nwg);
+  grid_barrier(bar, phase * nwg, nwg, fail);
   double* evals = evals_all + (size_t)prob * n;
   double* evecs = evecs_all + (size_t)prob * n * n;
   for (int hb = 0; hb < 2; ++hb) {
@@ -301,11 +301,7 @@ int launch_jacobi(vipmi_ctx* ctx, double* G, int64_t batch, int n, double* evals
   VIPMI_TRY(ws(ctx, "eigh_info", (size_t)batch, &info));
   VIPMI_TRY(ws(ctx, "eigh_norms", (size_t)batch * nblk * B, &norms));
   int* fail = nullptr;
-  {
-    const bool fresh = ctx->buffers.find("deferred_fail") == ctx->buffers.end();
-    VIPMI_TRY(ws(ctx, "deferred_fail", 4, &fail));
-    if (fresh) VIPMI_CHECK_HIP(hipMemsetAsync(fail, 0, 4 * sizeof(int), ctx->stream));
-  }
+  VIPMI_TRY(deferred_fail_words(ctx, &fail));
   VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch, ctx->stream));
   VIPMI_CHECK_HIP(hipMemsetAsync(conv, 0, sizeof(unsigned) * batch * max_sweeps, ctx->stream));
   VIPMI_CHECK_HIP(hipMemsetAsync(info, 0xff, sizeof(int) * batch, ctx->stream));

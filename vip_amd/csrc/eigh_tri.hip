@@ -827,7 +827,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double
 template <int RPL>
 __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aall, int n, int k, int RW, int VW, int rows_d, int all_evals,
                                                         double* __restrict__ evals_all, double* __restrict__ evecs_all,
-                                                        double* __restrict__ gbuf_all, unsigned* __restrict__ bars, int one_xcd) {
+                                                        double* __restrict__ gbuf_all, unsigned* __restrict__ bars, int one_xcd,
+                                                        int* __restrict__ fail) {
   extern __shared__ double sm[];
   const int prob = blockIdx.y;
   // one_xcd = 1 + base: the grid is 8 x wider and only the ids that land on XCD (base + problem) % 8 stay (ids go round-robin
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   // every workgroup has read row 0 (and its own rows) before any reflector is written over the input matrix
   if (one_xcd && tid == 0) __hip_atomic_store(xids + wg, 1u + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bar_target += W;
-  grid_barrier(bar, bar_target, W);
+  grid_barrier(bar, bar_target, W, fail);
   bool fast = one_xcd != 0;                  // all workgroups really on one XCD?  (uniform: everybody reads the same ids)
   if (fast) {
     const unsigned mine = 1u + xcc_id();
@@ -889,10 +890,10 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   auto sync_all = [&]() {
     if (fast) {
       xepoch += 1;
-      xcd_barrier(xflags, xepoch, W, wg);
+      xcd_barrier(xflags, xepoch, W, wg, fail);
     } else {
       bar_target += W;
-      grid_barrier(bar, bar_target, W);
+      grid_barrier(bar, bar_target, W, fail);
     }
   };
   double* vcur = vbuf0;
@@ -1306,11 +1307,13 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   const bool xcd_ok = W <= 64 && W <= ctx->num_cu / 8 && ctx->num_cu % 8 == 0;
   const int one_xcd = xcd_ok && (want_xcd > 0 || (want_xcd < 0 && ctx->opt("eigh_check", 1) != 0)) ? 1 : 0;
   const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
+  int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
+  VIPMI_TRY(deferred_fail_words(ctx, &fail));
   for (int64_t p0 = 0; p0 < batch; p0 += per_launch) {
     const int64_t nb = batch - p0 < per_launch ? batch - p0 : per_launch;
     hipLaunchKernelGGL(kern, dim3(one_xcd ? 8 * W : W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW,
                        (int)rows_d, all_evals, evals + (size_t)p0 * n, evecs + (size_t)p0 * n * n, gbuf + (size_t)p0 * 5 * n,
-                       bars + (size_t)p0 * TRI_BAR_WORDS, one_xcd ? (int)(1 + ((xcd_base.fetch_add((unsigned)nb) + (unsigned)p0) & 7u)) : 0);
+                       bars + (size_t)p0 * TRI_BAR_WORDS, one_xcd ? (int)(1 + ((xcd_base.fetch_add((unsigned)nb) + (unsigned)p0) & 7u)) : 0, fail);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   return VIPMI_OK;

@@ -25,7 +25,7 @@ constexpr double LEPS = tri::EPS;
 template <int RPL>
 __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, int n, int k, double* __restrict__ evals,
                                                         double* __restrict__ evecs, double* __restrict__ gb,
-                                                        unsigned* __restrict__ bar, int all_evals) {
+                                                        unsigned* __restrict__ bar, int all_evals, int* __restrict__ fail) {
   extern __shared__ double sm[];
   const int W = gridDim.x, wg = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
   }
   __syncthreads();
   bar_target += W;
-  grid_barrier(bar, bar_target, W);            // everybody has row 0 before reflectors overwrite the matrix
+  grid_barrier(bar, bar_target, W, fail);            // everybody has row 0 before reflectors overwrite the matrix
   double* vcur = vbuf0;
   double* vnext = vbuf1;
   double beta_cur = 0.0;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
       }
     }
     bar_target += W;
-    grid_barrier(bar, bar_target, W);
+    grid_barrier(bar, bar_target, W, fail);
     for (int c = s + 1 + tid; c < na; c += LNT) {
       pfull[c] = ld_shared(&Pb[par * n + c]);
       cfull[c] = ld_shared(&Cb[par * n + c]);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
     st_shared(&ge[b], 0.0);
   }
   bar_target += W;
-  grid_barrier(bar, bar_target, W);
+  grid_barrier(bar, bar_target, W, fail);
 
   // ---------------- 2. T into LDS (scaled), eigenvalue of this workgroup's vector ----------------
   double* dd = sm;                 // [n]
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
   }
   }   // vectors of this workgroup
   bar_target += W;
-  grid_barrier(bar, bar_target, W);
+  grid_barrier(bar, bar_target, W, fail);
   if (wg != 0) return;
 
   // ---------------- 5. workgroup 0: modified Gram-Schmidt in place (vectors in global / L2), sign convention ---------
@@ -455,7 +455,7 @@ __device__ __forceinline__ double xl_block_sum(double x, double* __restrict__ re
 __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int n, int k, double* __restrict__ evals,
                                                      double* __restrict__ evecs, double* __restrict__ gb,
                                                      double* __restrict__ scr_all, unsigned* __restrict__ bar,
-                                                     int all_evals) {
+                                                     int all_evals, int* __restrict__ fail) {
   extern __shared__ double sm[];
   const int W = gridDim.x, wg = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
   }
   __syncthreads();
   bar_target += W;
-  grid_barrier(bar, bar_target, W);                // everybody has row 0 before reflectors overwrite the matrix
+  grid_barrier(bar, bar_target, W, fail);                // everybody has row 0 before reflectors overwrite the matrix
   double* vprev = vb0;                             // v_{s-1} (zeros before the first step)
   double* vcur = vb1;
   int rs = 0;                                      // reduction slot, cycles 0..5
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
       }
     }
     bar_target += W;
-    grid_barrier(bar, bar_target, W);
+    grid_barrier(bar, bar_target, W, fail);
     double kd = 0.0;
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
     }
   }
   bar_target += W;
-  grid_barrier(bar, bar_target, W);
+  grid_barrier(bar, bar_target, W, fail);
 
   // ---------------- 2. T into LDS (scaled) ----------------
   double* dd = sm;                 // [n]
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
     }
   }   // vectors of this workgroup
   bar_target += W;
-  grid_barrier(bar, bar_target, W);
+  grid_barrier(bar, bar_target, W, fail);
   if (wg != 0) return;
 
   // ---------------- 5. workgroup 0: modified Gram-Schmidt in place (vectors in global / L2), sign convention ---------
@@ -912,10 +912,12 @@ int launch_xl(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double* ev
   VIPMI_TRY(ws(ctx, "eigh_xl_factors", (size_t)W * 5 * n, &scr));
   VIPMI_TRY(ws(ctx, "eigh_large_bar", (size_t)1, &bars));
   VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned), ctx->stream));
+  int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
+  VIPMI_TRY(deferred_fail_words(ctx, &fail));
   const size_t lds = ((size_t)3 * n + 6 * LNW + 8 + 16) * sizeof(double);
   VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(xl): LDS budget exceeded (%zu)", lds);
   VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(tri_xl_kernel), (int)lds));
-  hipLaunchKernelGGL(tri_xl_kernel, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, scr, bars, all_evals);
+  hipLaunchKernelGGL(tri_xl_kernel, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, scr, bars, all_evals, fail);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -931,11 +933,13 @@ int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double*
   VIPMI_TRY(ws(ctx, "eigh_large_gbuf", (size_t)8 * n, &gbuf));
   VIPMI_TRY(ws(ctx, "eigh_large_bar", (size_t)1, &bars));
   VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned), ctx->stream));
+  int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
+  VIPMI_TRY(deferred_fail_words(ctx, &fail));
   const size_t lds = ((size_t)9 * n + 8 + 2 * LNW + 16) * sizeof(double);
   VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(large): LDS budget exceeded (%zu)", lds);
   auto kern = tri_large_kernel<RPL>;
   VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
-  hipLaunchKernelGGL(kern, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, bars, all_evals);
+  hipLaunchKernelGGL(kern, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, bars, all_evals, fail);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }

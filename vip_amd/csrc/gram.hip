@@ -423,7 +423,13 @@ int gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float* B, int64_t
     const int64_t i8 = ctx->opt("gram_i8", -1);
     const bool forced = i8 > 0 && na >= ctx->opt("gram_i8_min_n", 32) && P >= 1024;
     const bool pays = i8 < 0 && na >= 256 && P >= 32768 && na * P >= ((int64_t)1 << 25);
-    if (symmetric && !f32acc && (forced || pays)) return gram_i8_f32(ctx, A, na, P, ld, G, 1, i8 == 2 ? 2 : 1);
+    if (symmetric && !f32acc && (forced || pays)) {
+      // the digit planes need batch * S * npad * Ppad bytes (10.7 GB at 2000 x 1024^2) PER CONTEXT: when that allocation fails the
+      // float64-MFMA kernel below, which needs none of it, serves the call as it did before the int8 path existed
+      const int st = gram_i8_f32(ctx, A, na, P, ld, G, 1, i8 == 2 ? 2 : 1);
+      if (st != VIPMI_ERR_NOMEM) return st;
+      (void)hipGetLastError();                       // (the failed hipMalloc must not surface at the next launch check)
+    }
   }
   const int64_t nmax = na > nb ? na : nb;
   int tb = (int)ctx->opt("gram_tb", 0);
@@ -459,7 +465,11 @@ int gram_batched_f32(vipmi_ctx* ctx, const float* M, int64_t batch, int64_t n, i
     const bool fits = ctx->opt("gram_f32", 0) == 0 && P >= 1024 && batch <= 65535;
     const bool forced = i8 > 0 && n >= ctx->opt("gram_i8_min_n", 32);
     const bool pays = i8 < 0 && n >= 128 && P >= 16384 && batch * n * P >= ((int64_t)1 << 25);
-    if (fits && (forced || pays)) return gram_i8_f32(ctx, M, n, P, P, G, batch, i8 == 2 ? 2 : 1);
+    if (fits && (forced || pays)) {
+      const int st = gram_i8_f32(ctx, M, n, P, P, G, batch, i8 == 2 ? 2 : 1);
+      if (st != VIPMI_ERR_NOMEM) return st;          // (no room for the digit planes: the float64-MFMA kernel below)
+      (void)hipGetLastError();
+    }
   }
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
     const int64_t nb_ = (batch - b0) < 65535 ? (batch - b0) : 65535;

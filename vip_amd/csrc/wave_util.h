@@ -51,7 +51,7 @@ __device__ __forceinline__ void st_shared(double* p, double v) {
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, int nwg) {
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, int nwg, int* fail = nullptr) {
   if (nwg == 1) {
     __syncthreads();
     return;
@@ -63,7 +63,10 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target,
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 28)) break;   // bounded spin: a lost workgroup must not hang the GPU
+      if (++spins > (1u << 28)) {        // bounded spin: a lost workgroup must not hang the GPU -- but the caller must hear of
+        if (fail) atomicAdd(fail + 1, 1);   // it: latched in the context's deferred-failure words (vipmi_check_deferred)
+        break;
+      }
     }
   }
   __syncthreads();
@@ -82,7 +85,7 @@ __device__ __forceinline__ void st_xcd(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void xcd_barrier(unsigned* flags, unsigned epoch, int nwg, int wg) {
+__device__ __forceinline__ void xcd_barrier(unsigned* flags, unsigned epoch, int nwg, int wg, int* fail = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores are in the L2
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -95,7 +98,10 @@ __device__ __forceinline__ void xcd_barrier(unsigned* flags, unsigned epoch, int
     while (true) {
       if (!ok) ok = (int)(__hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0;
       if (__all(ok)) break;
-      if (++spins > (1u << 28)) break;               // bounded spin: a lost workgroup must not hang the GPU
+      if (++spins > (1u << 28)) {                    // bounded spin: a lost workgroup must not hang the GPU (and is reported)
+        if (fail && threadIdx.x == 0) atomicAdd(fail + 1, 1);
+        break;
+      }
     }
   }
   __syncthreads();

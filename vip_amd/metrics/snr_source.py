@@ -58,49 +58,64 @@ def aperture_sums_exact(array, xx, yy, r):
     return out
 
 
-def indep_ap_centers(array, source_xy, fwhm, exclude_negative_lobes=False, exclude_theta_range=None, no_gap=False):
-    """Centres of the non-overlapping apertures at the separation of ``source_xy`` (snr_source.py:226-318); first entry =
-    the test aperture.  Returns (yy, xx)."""
-    sourcex, sourcey = source_xy
-    centery, centerx = frame_center(array)
-    sep = np.sqrt((centery - float(sourcey)) ** 2 + (centerx - float(sourcex)) ** 2)
-    theta_0 = np.rad2deg(np.arctan2(sourcey - centery, sourcex - centerx))
-    if exclude_theta_range is not None:
-        exc = list(exclude_theta_range)
-    if not sep > (fwhm / 2):
+def _ring_geometry(array, source_xy, fwhm):
+    """(cy, cx, separation, polar angle [rad], angular pitch [rad], number of apertures that fit) of the ring of 1-FWHM
+    apertures through ``source_xy``: neighbours touch, i.e. the chord between their centres is one FWHM."""
+    cy, cx = frame_center(array)
+    dx, dy = float(source_xy[0]) - cx, float(source_xy[1]) - cy
+    sep = np.hypot(dy, dx)
+    if not sep > fwhm / 2:
         raise RuntimeError("`source_xy` is too close to the frame center")
-    sign = -1                                               # clockwise, as the reference
-    if exclude_theta_range is not None:
-        if exc[0] < theta_0 < exc[1]:
-            exc[0] += 360
-        while theta_0 < exc[1]:
-            theta_0 += 360
-    theta = theta_0
-    angle = np.arcsin(fwhm / 2.0 / sep) * 2
-    number_apertures = int(np.floor(2 * np.pi / angle))
+    pitch = 2.0 * np.arcsin(0.5 * fwhm / sep)
+    return cy, cx, sep, np.arctan2(dy, dx), pitch, int(np.floor(2 * np.pi / pitch))
+
+
+def indep_ap_centers(array, source_xy, fwhm, exclude_negative_lobes=False, exclude_theta_range=None, no_gap=False):
+    """Centres of the non-overlapping apertures at the separation of ``source_xy`` (reference snr_source.py:226-318); first
+    entry = the test aperture.  Returns (yy, xx).
+
+    Aperture m sits at polar angle phi0 - m * pitch (clockwise from the source, as the reference walks the ring), written
+    here in closed form, sep * (cos, sin)(phi0 - m pitch), instead of the reference's chained rotations.  Dropped from the
+    list: the two neighbours of the test aperture when ``exclude_negative_lobes``; every aperture whose angle in degrees
+    falls inside ``exclude_theta_range`` -- compared, as the reference does, after the source angle has been lifted by
+    whole turns above the range's upper end (and the lower end by one turn when the source itself lies inside)."""
+    cy, cx, sep, phi0, pitch, count = _ring_geometry(array, source_xy, fwhm)
     if no_gap:
-        number_apertures += 1
-    yy, xx = [sourcey - centery], [sourcex - centerx]
-    yy_all = np.zeros(number_apertures)
-    xx_all = np.zeros(number_apertures)
-    cosangle, sinangle = np.cos(angle), np.sin(angle)
-    xx_all[0], yy_all[0] = sourcex - centerx, sourcey - centery
-    for i in range(number_apertures - 1):
-        xx_all[i + 1] = cosangle * xx_all[i] - sign * sinangle * yy_all[i]
-        yy_all[i + 1] = cosangle * yy_all[i] + sign * sinangle * xx_all[i]
-        theta += sign * np.rad2deg(angle)
-        if exclude_negative_lobes and (i == 0 or i == number_apertures - 2):
-            continue
-        if exclude_theta_range is None or theta < exc[0] or theta > exc[1]:
-            xx.append(cosangle * xx_all[i] - sign * sinangle * yy_all[i])
-            yy.append(cosangle * yy_all[i] + sign * sinangle * xx_all[i])
-    return np.array(yy) + centery, np.array(xx) + centerx
+        count += 1
+    m = np.arange(1, count)                                  # ring positions after the test aperture
+    keep = np.ones(m.shape, dtype=bool)
+    if exclude_negative_lobes:
+        keep &= (m != 1) & (m != count - 1)
+    if exclude_theta_range is not None:
+        lo, hi = (float(v) for v in exclude_theta_range)
+        deg0 = np.rad2deg(phi0)
+        if lo < deg0 < hi:
+            lo += 360.0
+        if deg0 < hi:
+            deg0 += 360.0 * np.ceil((hi - deg0) / 360.0)
+            if deg0 < hi:                                    # (the reference adds turns WHILE below the upper end)
+                deg0 += 360.0
+        deg = deg0 - m * np.rad2deg(pitch)
+        keep &= (deg < lo) | (deg > hi)
+    phi = phi0 - m[keep] * pitch
+    xs = np.concatenate(([float(source_xy[0]) - cx], sep * np.cos(phi))) + cx
+    ys = np.concatenate(([float(source_xy[1]) - cy], sep * np.sin(phi))) + cy
+    return ys, xs
+
+
+def _small_sample_snr(test_flux, ring_fluxes):
+    """[MAW14] eq. 9: (x1 - mean(x2)) / (s2 sqrt(1 + 1/n2)), s2 the sample standard deviation of the n2 ring apertures."""
+    n2 = ring_fluxes.size
+    spread = ring_fluxes.std(ddof=1)
+    return (test_flux - ring_fluxes.mean()) / (spread * np.sqrt(1.0 + 1.0 / n2)), spread
 
 
 def snr(array, source_xy, fwhm, full_output=False, array2=None, use2alone=False, exclude_negative_lobes=False,
         exclude_theta_range=None, plot=False, verbose=False):
-    """Student-t S/N of [MAW14] (snr_source.py:321-456): flux of the test aperture against the mean / sample standard
-    deviation of the other apertures at the same separation, with the small-sample factor sqrt(1 + 1/n2)."""
+    """Student-t S/N of [MAW14] (reference snr_source.py:321-456): flux of the 1-FWHM test aperture against the other
+    apertures of its ring, with the small-sample penalty.  ``array2`` adds (or, with ``use2alone``, replaces) the noise
+    apertures by those of a second frame at the same positions -- all of them, its test position included, as the
+    reference does."""
     array = np.asarray(array)
     if array.ndim != 2:
         raise TypeError("Input array is not a frame or 2d array")
@@ -108,26 +123,19 @@ def snr(array, source_xy, fwhm, full_output=False, array2=None, use2alone=False,
         raise TypeError("`source_xy` must be a tuple of floats")
     if array2 is not None and np.asarray(array2).shape != array.shape:
         raise TypeError("`array2` has not the same shape as input array")
-    sourcex, sourcey = source_xy
-    yy, xx = indep_ap_centers(array, source_xy, fwhm, exclude_negative_lobes, exclude_theta_range)
-    rad = fwhm / 2.0
-    fluxes = aperture_sums_exact(array, xx, yy, rad)
+    ys, xs = indep_ap_centers(array, source_xy, fwhm, exclude_negative_lobes, exclude_theta_range)
+    sums = aperture_sums_exact(array, xs, ys, 0.5 * fwhm)
+    test_flux, ring = float(sums[0]), sums[1:]
     if array2 is not None:
-        fluxes2 = aperture_sums_exact(array2, xx, yy, rad)
-        fluxes = np.concatenate(([fluxes[0]], fluxes2)) if use2alone else np.concatenate((fluxes, fluxes2))
-    f_source = fluxes[0].copy()
-    fluxes = fluxes[1:]
-    n2 = fluxes.shape[0]
-    backgr_apertures_std = fluxes.std(ddof=1)
-    snr_vale = (f_source - fluxes.mean()) / (backgr_apertures_std * np.sqrt(1 + (1 / n2)))
+        other = aperture_sums_exact(array2, xs, ys, 0.5 * fwhm)
+        ring = other if use2alone else np.concatenate((ring, other))
+    value, spread = _small_sample_snr(test_flux, ring)
     if verbose:
-        print("S/N for the given pixel = {:.3f}".format(snr_vale))
-        print("Integrated flux in FWHM test aperture = {:.3f}".format(f_source))
-        print("Mean of background apertures integrated fluxes = {:.3f}".format(fluxes.mean()))
-        print("Std-dev of background apertures integrated fluxes = {:.3f}".format(backgr_apertures_std))
+        print("S/N at (x, y) = ({:.1f}, {:.1f}): {:.3f}   [test aperture {:.3f}; {} ring apertures: mean {:.3f}, std {:.3f}]".format(
+            float(source_xy[0]), float(source_xy[1]), value, test_flux, ring.size, ring.mean(), spread))
     if full_output:
-        return sourcey, sourcex, f_source, fluxes, snr_vale
-    return snr_vale
+        return source_xy[1], source_xy[0], test_flux, ring, value
+    return value
 
 
 def disk_pixels(y, x, radius, shape=None):
@@ -144,38 +152,28 @@ def disk_pixels(y, x, radius, shape=None):
 
 
 def frame_report(array, fwhm, source_xy=None, verbose=True, **snr_arguments):
-    """Flux in a centred 1xFWHM aperture, S/N of the central pixel and mean S/N over the aperture's pixels for the given
-    position(s) (snr_source.py:515-590).  The automatic detection branch (``source_xy=None`` -> ``snrmap``) is outside
-    the accelerated path."""
+    """Per position: flux in the centred 1-FWHM aperture, S/N of the position itself, mean S/N over the pixels of that
+    aperture (reference snr_source.py:515-590; returns (positions, fluxes, central S/N, mean S/N) as lists).  The automatic
+    detection branch (``source_xy=None`` -> ``snrmap``) is outside the accelerated path."""
     array = np.asarray(array)
     if array.ndim != 2:
         raise TypeError("Array is not 2d.")
     if source_xy is None:
         raise NotImplementedError("frame_report without source_xy needs snrmap (outside the accelerated path)")
-    if isinstance(source_xy, (list, tuple)):
-        if not isinstance(source_xy[0], tuple):
-            source_xy = [source_xy]
-    else:
+    if not isinstance(source_xy, (list, tuple)):
         raise TypeError("`source_xy` must be a tuple of floats or tuple of tuples")
-    obj_flux, meansnr_pixels, snr_centpx = [], [], []
-    for x, y in source_xy:
-        obj_flux_i = float(aperture_sums_exact(array, [x], [y], fwhm / 2.0)[0])
-        yy, xx = disk_pixels(y, x, fwhm / 2)
-        snr_pixels_i = [snr(array, (x_, y_), fwhm) for y_, x_ in zip(yy, xx)]
-        meansnr_i = np.mean(snr_pixels_i)
-        pxsnr_i = snr(array, (x, y), fwhm)
-        obj_flux.append(obj_flux_i)
-        meansnr_pixels.append(meansnr_i)
-        snr_centpx.append(pxsnr_i)
-        if verbose:
-            print("Coords of chosen px (X,Y) = {:.1f}, {:.1f}".format(x, y))
-            print("Flux in a centered 1xFWHM circular aperture = {:.3f}".format(obj_flux_i))
-            print("Central pixel S/N = {:.3f}".format(pxsnr_i))
-            print("Inside a centered 1xFWHM circular aperture:")
-            print("Mean S/N (shifting the aperture center) = {:.3f}".format(meansnr_i))
-            print("Max S/N (shifting the aperture center) = {:.3f}".format(np.max(snr_pixels_i)))
-            print("stddev S/N (shifting the aperture center) = {:.3f}".format(np.std(snr_pixels_i, ddof=1)))
-    return source_xy, obj_flux, snr_centpx, meansnr_pixels
+    positions = source_xy if isinstance(source_xy[0], tuple) else [source_xy]
+    table = []
+    for px, py in positions:
+        rows, cols = disk_pixels(py, px, 0.5 * fwhm)
+        inside = np.array([snr(array, (float(c), float(r)), fwhm) for r, c in zip(rows, cols)])
+        table.append((float(aperture_sums_exact(array, [px], [py], 0.5 * fwhm)[0]), snr(array, (px, py), fwhm), inside))
+    if verbose:
+        for (px, py), (flux, central, inside) in zip(positions, table):
+            print("(x, y) = ({:.1f}, {:.1f}): flux in the 1xFWHM aperture {:.3f}, S/N of the position {:.3f}; over the {} "
+                  "pixels of the aperture: mean S/N {:.3f}, max {:.3f}, std {:.3f}".format(
+                      px, py, flux, central, inside.size, inside.mean(), inside.max(), inside.std(ddof=1)))
+    return positions, [t[0] for t in table], [t[1] for t in table], [float(np.mean(t[2])) for t in table]
 
 
 __all__ = ["snr", "indep_ap_centers", "frame_report", "aperture_sums_exact", "circle_pixel_overlap", "disk_pixels",
