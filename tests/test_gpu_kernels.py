@@ -374,6 +374,7 @@ def test_collapse_golden(B, n):
 
 
 @pytest.mark.parametrize("n,P", [(1, 100), (2, 100), (63, 1000), (64, 1000), (65, 333), (129, 257), (400, 4096), (1000, 70),
+                                 (1025, 130), (1500, 70), (2048, 33), (2000, 4096),       # (1025 .. 2048: keys in registers, chunked staging)
                                  (4097, 300), (6001, 130), (5000, 64)])      # (more than 4096 frames: the streaming kernel)
 def test_median_sizes_bitexact(B, n, P):
     rng = np.random.default_rng(n + P)
@@ -423,7 +424,7 @@ def test_median_bucket_selection_hard_cases(B, n):
 
 
 @pytest.mark.parametrize("n,P,tn", [(7, 50, 3), (8, 50, 3), (8, 64, 4), (7, 33, 9), (7, 33, 50), (65, 333, 20),
-                                    (400, 1024, 100), (129, 100, 129), (10, 40, 1),
+                                    (400, 1024, 100), (129, 100, 129), (10, 40, 1), (1500, 40, 700), (2048, 64, 50),
                                     (4100, 70, 50), (5001, 40, 1001)])      # (more than 4096 frames: the streaming kernel)
 def test_trimmean_sizes(B, n, P, tn):
     rng = np.random.default_rng(n * 7 + P + tn)

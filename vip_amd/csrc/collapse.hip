@@ -243,6 +243,52 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
 
 constexpr int HIST_WORDS = 384;                  // 256 bins + dump bin + 64 dump slots, padded to a multiple of 64 words
 
+// Result for ONE pixel from the keys a wave holds (RPL per lane, invalid / NaN = 0xffffffff, nvalid_lane valid ones in this lane):
+// nanmedian (TRIM = false) or the reference's trimmed mean of sorted[t0 : t0 + tn] (TRIM = true).
+template <int RPL, bool TRIM>
+__device__ __forceinline__ float pixel_result(const unsigned (&key)[RPL], int nvalid_lane, int n, int t0, int tn, unsigned* hist, int lane) {
+  const int m = wave_count<RPL>(nvalid_lane);
+  float res;
+  if (TRIM) {
+    int hi_end = t0 + tn;                    // slice [t0, hi_end) of the sorted samples, NaNs (rank >= m) dropped
+    if (hi_end > n) hi_end = n;
+    if (hi_end > m) hi_end = m;
+    if (t0 >= hi_end) {
+      res = __uint_as_float(0x7fc00000u);
+    } else {
+      const unsigned klo = select_rank<RPL>(key, t0), khi = select_rank<RPL>(key, hi_end - 1);
+      int clt_lo = 0, cle_lo = 0, clt_hi = 0;
+      double mid = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        clt_lo += __popcll(__ballot(key[r] < klo));
+        cle_lo += __popcll(__ballot(key[r] <= klo));
+        clt_hi += __popcll(__ballot(key[r] < khi));
+        if (key[r] > klo && key[r] < khi) mid += (double)key2f(key[r]);
+      }
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) mid += __shfl_xor(mid, s, 64);
+      double tot;
+      if (klo == khi) {
+        tot = (double)key2f(klo) * (double)(hi_end - t0);
+      } else {
+        const int nlo = (cle_lo < hi_end ? cle_lo : hi_end) - t0;      // copies of the low value inside the slice
+        const int nhi = hi_end - clt_hi;                                 // copies of the high value inside the slice
+        tot = mid + (double)key2f(klo) * nlo + (double)key2f(khi) * nhi;
+      }
+      (void)clt_lo;
+      res = (float)(tot / (double)(hi_end - t0));
+    }
+  } else if (m == 0) {
+    res = __uint_as_float(0x7fc00000u);
+  } else {
+    unsigned klow, khigh;
+    median_keys<RPL>(key, m, hist, lane, klow, khigh);
+    res = (m & 1) ? key2f(klow) : (key2f(klow) + key2f(khigh)) * 0.5f;    // even: (a+b)*0.5 in float32, as numpy
+  }
+  return res;
+}
+
 // TRIM = false: nanmedian.  TRIM = true: mean of sorted[t0 : t0+tn] (np.sort order, NaN last, then nanmean):
 // the reference's 'trimmean' (subsampling.py:87-96).
 template <int RPL, bool TRIM>
@@ -319,46 +365,116 @@ __global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_kernel(const float* 
       }
       key[r] = kk;
     }
-    const int m = wave_count<RPL>(nvalid_lane);
-    float res;
-    if (TRIM) {
-      int hi_end = t0 + tn;                    // slice [t0, hi_end) of the sorted samples, NaNs (rank >= m) dropped
-      if (hi_end > n) hi_end = n;
-      if (hi_end > m) hi_end = m;
-      if (t0 >= hi_end) {
-        res = __uint_as_float(0x7fc00000u);
-      } else {
-        const unsigned klo = select_rank<RPL>(key, t0), khi = select_rank<RPL>(key, hi_end - 1);
-        int clt_lo = 0, cle_lo = 0, clt_hi = 0;
-        double mid = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          clt_lo += __popcll(__ballot(key[r] < klo));
-          cle_lo += __popcll(__ballot(key[r] <= klo));
-          clt_hi += __popcll(__ballot(key[r] < khi));
-          if (key[r] > klo && key[r] < khi) mid += (double)key2f(key[r]);
-        }
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) mid += __shfl_xor(mid, s, 64);
-        double tot;
-        if (klo == khi) {
-          tot = (double)key2f(klo) * (double)(hi_end - t0);
-        } else {
-          const int nlo = (cle_lo < hi_end ? cle_lo : hi_end) - t0;      // copies of the low value inside the slice
-          const int nhi = hi_end - clt_hi;                                 // copies of the high value inside the slice
-          tot = mid + (double)key2f(klo) * nlo + (double)key2f(khi) * nhi;
-        }
-        (void)clt_lo;
-        res = (float)(tot / (double)(hi_end - t0));
-      }
-    } else if (m == 0) {
-      res = __uint_as_float(0x7fc00000u);
-    } else {
-      unsigned klow, khigh;
-      median_keys<RPL>(key, m, hist, lane, klow, khigh);
-      res = (m & 1) ? key2f(klow) : (key2f(klow) + key2f(khigh)) * 0.5f;    // even: (a+b)*0.5 in float32, as numpy
-    }
+    const float res = pixel_result<RPL, TRIM>(key, nvalid_lane, n, t0, tn, hist, lane);
     if (lane == 0) out[p] = res;
+  }
+}
+
+// ---- the same selection with the keys kept in REGISTERS across a chunked staging (1025 .. 2048 frames) ----------------------
+// median_kernel stages a whole [n][TP] tile in LDS before the first selection: at n = 2000 that is 136 KB for 16 pixels -- ONE
+// workgroup per CU (nothing overlaps its load phase), 64-byte row segments (half of every line fetched is for the neighbour
+// tile), 9.6 ms for the 8.4 GB of C5 in the pipeline (0.87 TB/s; 7.3 ms on a cube of normal deviates).  Here a tile is 32 pixels (whole 128-byte lines) and passes through
+// LDS in CHUNKS of 64 CH frames (double buffered, 17 / 34 KB each): after every chunk a wave moves the samples of ITS FOUR pixels
+// (wave w: pixels w, w + 8, w + 16, w + 24 of the tile) into registers as keys -- 4 x RPL per lane, the full tile never exists
+// in LDS.  Workgroups are persistent and walk a flat list of (tile, chunk) items: the global loads of item i + 1 are issued
+// before item i is consumed and sit in registers across the selection of a finished tile, so loading and selecting overlap even
+// with one workgroup per CU.  Which sample lands in which lane is irrelevant to an order statistic; frames beyond n are staged as
+// NaN (key 0xffffffff, sorts last like any NaN).
+// (plain functions, not capturing lambdas: a closure that holds the register array by reference is materialised in scratch memory)
+// global loads of one (tile, chunk) item of this workgroup: CH rows of 16 bytes per thread
+template <int CH, int NCHUNK>
+__device__ __forceinline__ void mreg_issue(float4 (&pre)[CH], int item, const float* __restrict__ cube, int n, int64_t P, int seg, int r0,
+                                           int vec_ok) {
+  const float nanv = __uint_as_float(0x7fc00000u);
+  const int64_t tile = (int64_t)blockIdx.x + (int64_t)(item / NCHUNK) * gridDim.x;
+  const int f0 = (item % NCHUNK) * (64 * CH);
+  const int64_t pc = tile * 32 + 4 * seg;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int f = f0 + r0 + 64 * i;
+    float4 v = make_float4(nanv, nanv, nanv, nanv);
+    if (f < n) {
+      const float* src = cube + (int64_t)f * P + pc;
+      if (vec_ok && pc + 3 < P) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = pc < P ? src[0] : 0.f;
+        v.y = pc + 1 < P ? src[1] : 0.f;
+        v.z = pc + 2 < P ? src[2] : 0.f;
+        v.w = pc + 3 < P ? src[3] : 0.f;
+      }
+    }
+    pre[i] = v;
+  }
+}
+template <int CH>
+__device__ __forceinline__ void mreg_deposit(const float4 (&pre)[CH], float* __restrict__ buf, int seg, int r0) {
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    float* t = buf + (r0 + 64 * i) * 33 + 4 * seg;
+    t[0] = pre[i].x;
+    t[1] = pre[i].y;
+    t[2] = pre[i].z;
+    t[3] = pre[i].w;
+  }
+}
+
+template <int RPL, int CH, bool TRIM>
+__global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_reg_kernel(const float* __restrict__ cube0, int n, int64_t P,
+                                                                       float* __restrict__ out0, int t0, int tn, int ntiles, int vec_ok) {
+  constexpr int TP = 32, LDT = TP + 1, CF = 64 * CH, NCHUNK = RPL / CH, PPW = 4;
+  static_assert(RPL % CH == 0, "keys per lane = chunks x 64-frame groups per chunk");
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 8 x HIST_WORDS histogram words, then 2 x [CF][LDT] staging buffers
+  const float* __restrict__ cube = cube0 + (size_t)blockIdx.y * n * P;
+  float* __restrict__ out = out0 + (size_t)blockIdx.y * P;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned* hist = reinterpret_cast<unsigned*>(smem) + HIST_WORDS * wave;
+  float* stage = smem + HIST_WORDS * 8;
+  const int seg = threadIdx.x & 7, r0 = threadIdx.x >> 3;         // loader: 8 threads x 16 bytes per row segment, 64 rows per pass
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles blockIdx.x + j gridDim.x
+  const int items = my_tiles * NCHUNK;
+  float4 pre[CH];
+  unsigned key[PPW][RPL];
+  int nvalid[PPW];
+  if (items > 0) {
+    mreg_issue<CH, NCHUNK>(pre, 0, cube, n, P, seg, r0, vec_ok);
+    mreg_deposit<CH>(pre, stage, seg, r0);
+  }
+  for (int item = 0; item < items; ++item) {
+    const int chunk = item % NCHUNK;
+    if (item + 1 < items) mreg_issue<CH, NCHUNK>(pre, item + 1, cube, n, P, seg, r0, vec_ok);
+    __syncthreads();                                // the buffer of this item is complete; the other one is free again
+    const float* b = stage + (item & 1) * (CF * LDT);
+    if (chunk == 0) {
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) nvalid[q] = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {              // (compile-time register indices: the chunk number selects the slot)
+      if (c == chunk) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q)
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const float v = b[(lane + 64 * i) * LDT + wave + 8 * q];
+            const bool ok = v == v;
+            key[q][c * CH + i] = ok ? f2key(v) : 0xffffffffu;
+            nvalid[q] += ok ? 1 : 0;
+          }
+      }
+    }
+    if (chunk == NCHUNK - 1) {                      // the tile is complete in registers: select
+      const int64_t p0 = ((int64_t)blockIdx.x + (int64_t)(item / NCHUNK) * gridDim.x) * TP;
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) {
+        const int64_t p = p0 + wave + 8 * q;
+        if (p < P) {                                // (wave-uniform)
+          const float res = pixel_result<RPL, TRIM>(key[q], nvalid[q], n, t0, tn, hist, lane);
+          if (lane == 0) out[p] = res;
+        }
+      }
+    }
+    if (item + 1 < items) mreg_deposit<CH>(pre, stage + ((item + 1) & 1) * (CF * LDT), seg, r0);
   }
 }
 
@@ -562,6 +678,26 @@ __global__ __launch_bounds__(256) void median_stream_kernel(const float* __restr
   out[p] = res;
 }
 
+template <int RPL, int CH, bool TRIM>
+int launch_median_reg(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64_t P, float* out, int t0, int tn) {
+  constexpr int TP = 32, CF = 64 * CH;
+  const size_t lds = (size_t)8 * HIST_WORDS * 4 + (size_t)2 * CF * (TP + 1) * 4;
+  auto kern = median_reg_kernel<RPL, CH, TRIM>;
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+  const int64_t ntiles = cdiv(P, TP);
+  // persistent workgroups: as many as are resident (registers allow two per CU up to 8 keys per lane and pixel, the 32-key
+  // instance holds 128 key registers: one), a few tiles each
+  const int per_cu = RPL <= 8 ? 2 : 1;
+  int64_t grid = (int64_t)ctx->num_cu * per_cu;
+  if (batch > 1) grid = cdiv(grid, batch);
+  if (grid > ntiles) grid = ntiles;
+  if (grid < 1) grid = 1;
+  const int vec_ok = ((P & 3) == 0 && (reinterpret_cast<uintptr_t>(cube) & 15) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)batch), dim3(512), lds, ctx->stream, cube, n, P, out, t0, tn, (int)ntiles, vec_ok);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
 template <int RPL, bool TRIM>
 int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64_t P, float* out, int t0, int tn) {
   // pixels per tile: 32 (128-byte row segments) unless 16 lets more workgroups share a CU -- after the bucket-selection
@@ -619,6 +755,15 @@ int collapse_batched_f32(vipmi_ctx* ctx, const float* cube, int64_t batch, int64
         tn = (int)(e > k ? e - k : 0);
       }
       const int rpl = (int)cdiv(n, 64);
+      // 1025 .. 2048 frames: keys in registers, chunked staging (median_reg_kernel) -- where the tile kernel is down to one workgroup
+      // per CU and 64-byte row segments.  Measured (tools/time_median.py, normal deviates + 1 % NaN), tile kernel / register kernel:
+      // 2000 x 1024^2 7.26 / 5.87 ms; 1000 x 512^2 0.43 / 0.68, 400 x 512^2 0.18 / 0.29, 200 x 512^2 0.13 / 0.17: with two or more
+      // workgroups per CU the tile kernel's 32 waves hide the selection's LDS round trips better than 16 waves with four pixels
+      // each, so the smaller instances were dropped again.  Option median_reg = 0 keeps the tile kernel everywhere.
+      if (n > 1024 && n <= 2048 && ctx->opt("median_reg", 1) != 0) {
+        return trim ? launch_median_reg<32, 4, true>(ctx, cube, batch, (int)n, P, out, t0, tn)
+                    : launch_median_reg<32, 4, false>(ctx, cube, batch, (int)n, P, out, 0, 0);
+      }
 #define VIPMI_MED(R)                                                                              \
   return trim ? launch_median<R, true>(ctx, cube, batch, (int)n, P, out, t0, tn)                 \
               : launch_median<R, false>(ctx, cube, batch, (int)n, P, out, 0, 0)

@@ -1280,6 +1280,11 @@ template <int RPL>
 int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, double* evals, double* evecs,
                      int all_evals) {
   int W = n <= 256 ? 8 : (n <= 448 ? 16 : 32);
+  // a lone synchronous call owns the chip: with the workgroups of a problem on ONE XCD (below) twice as many of them halve the
+  // row pass at no extra exchange cost (n = 400: 16 / 24 / 32 workgroups 1.74 / 1.66 / 1.63 ms, round 3); the pipelined mode keeps
+  // 16 -- its eigensolver runs beside the other call's shears and every CU it takes is one they lose
+  const bool lone = batch == 1 && ctx->opt("eigh_check", 1) != 0 && ctx->opt("eigh_one_xcd", -1) != 0 && ctx->num_cu % 8 == 0;
+  if (lone && n > 320 && n <= 448 && ctx->num_cu / 8 >= 32) W = 32;
   if (ctx->opt("eigh_w", 0) >= 2 && ctx->opt("eigh_w", 0) <= 64) W = (int)ctx->opt("eigh_w", 0);       // (experiments)
   const int RW = (int)cdiv(n, W);
   double* gbuf = nullptr;
