@@ -112,7 +112,7 @@ def pmc_traffic(frames_per_launch, N, kernel="rs_shear2"):
     return None
 
 
-def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512, ncomp=20):
+def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512, ncomp=20, spectrum=None):
     """One problem sharded over all ranks (strong scaling): every rank holds the same synthetic input in HBM; a step is
     one complete sharded call ending with the final frame on every rank.  Returns the record (every rank).
     (VIPMI_BENCH_BACKEND=gloo + VIPMI_BENCH_DEVICE=0 run the multi-rank code path on a single-GPU box.)"""
@@ -138,8 +138,10 @@ def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512,
             return D.pca_annular(cube_t, angles, ncomp=10, asize=32, fwhm=4, delta_rot=(0.1, 1), n_segments=1)
         units = n
     elif mode == "single-cube":
-        cube_t, angles = synth_adi_device(n, N, seed=0)
+        cube_t, angles = synth_adi_device(n, N, seed=0, **(dict(nmodes=spectrum[0], halving=spectrum[1]) if spectrum else {}))
         what = "%dx%dx%d ADI cube, full-frame PCA ncomp=%d, ONE cube sharded (Gram all-reduce + 2 all-to-all)" % (n, N, N, k)
+        if spectrum:
+            what += "; decaying speckle spectrum (%d modes, amplitude halves every %g modes) instead of the generator's 30 / 3" % spectrum
 
         def step():
             return D.pca_single_cube(cube_t, angles, k)
@@ -166,6 +168,16 @@ def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512,
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # one more step with the phase clock on (every phase boundary synchronises: not part of the timed region): where the step's
+    # time goes -- compute phases against the collectives -- MAX over the ranks per phase
+    D.phase_timing(True)
+    step()
+    phases = D.phase_timing(False)
+    if world > 1 and phases:
+        names = sorted(phases)
+        t = torch.tensor([phases[k_] for k_ in names], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases = dict(zip(names, [float(v) for v in t.tolist()]))
     # the frame's corners are NaN by design (mask_val of the vip-fft rotation): check the disk the rotation keeps
     out = np.asarray(out)
     c = out.shape[-1] // 2
@@ -173,9 +185,14 @@ def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512,
         raise SystemExit("bench.py --mode %s: the final frame is not finite around its centre" % mode)
     del cube_t
     torch.cuda.empty_cache()
+    from vip_amd import backend as _B
+    ctx = _B.get_context()
+    solver = {k_: int(ctx.get_option("eigh_fast_last_" + k_)) for k_ in ("reason", "products", "rounds", "locked")} if mode == "single-cube" else None
     return {"metric": "frames/sec, %s" % mode, "value": units * steps / elapsed, "unit": "frames/s",
+            "eigh_fast_last": solver,          # the verified fast path's last run on this rank: reason 0 = converged
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "phases_ms": {k_: round(v_, 3) for k_, v_ in (phases or {}).items()},
             "config": {"workload": what, "parallelism": "one problem over %d GPU(s), collectives of SURVEY 8(e)" % world}}
 
 
@@ -215,11 +232,14 @@ def strong_scaling_legs(world, rank, backend):
         raise RuntimeError("sharded results deviate from the single-GPU path: %r" % chk)
     del cube_t
     for key, mode, kw, st in (("single_cube_c5", "single-cube", dict(frames=2000, size=1024, ncomp=50), 3),
+                              ("single_cube_c5_decaying_spectrum", "single-cube",
+                               dict(frames=2000, size=1024, ncomp=50, spectrum=(150, 10.0)), 3),
                               ("annular_c3", "annular", dict(frames=400, size=512, ncomp=10), 10),
                               ("ifs_4d_c4", "4d", dict(frames=200, size=256, ncomp=20), 10)):
         r = sharded_leg(mode, world, rank, backend, st, 1, **kw)
         out[key] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": st,
-                    "workload": r["config"]["workload"]}
+                    "workload": r["config"]["workload"], "eigh_fast_last": r["eigh_fast_last"],
+                    "phases_ms": r["phases_ms"]}      # (one extra step, synchronised at every phase boundary; MAX over ranks)
     return out
 
 

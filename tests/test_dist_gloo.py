@@ -89,6 +89,11 @@ def _worker(rank, world, port, q):
                 return torch.from_numpy(O.cube_collapse(cube.numpy(), mode)).reshape(-1)
         cs, as_ = O.synth_adi(11, 23, seed=21)
         res["single"] = D.pca_single_cube(cs, as_, 3, ops=NumpyOps()).numpy()
+        # the phase clock bench.py's strong-scaling legs report (one extra step, synchronised at the phase boundaries)
+        D.phase_timing(True)
+        again = D.pca_single_cube(cs, as_, 3, ops=NumpyOps()).numpy()
+        res["phases"] = D.phase_timing(False)
+        res["phases_same"] = bool(np.array_equal(again, res["single"], equal_nan=True))
         # --- annular PCA with the SURVEY 8(e) partition: residual columns -> all_to_all to frame shards -> sharded
         #     derotation -> all_to_all back -> sharded collapse -> gather (ragged: 12 frames / 32 rows / 3 segments)
         res["ann_frame"] = D.pca_annular_frame(cube, angc, plan, resid, collapse="median", ops=NumpyOps()).numpy()
@@ -132,6 +137,11 @@ def test_world_gloo(world):
         assert r["single"].shape == (23, 23)
         assert np.nanmax(np.abs(r["single"] - ref_single)) < 2e-5
     assert np.array_equal(r0["single"], r1["single"], equal_nan=True)
+    for r in (r0, r1):
+        assert r["phases_same"]
+        assert {"all_reduce (n x n float64 Gram)", "all_to_all 1 (pixel slabs -> whole frames)", "derotation (own frames)",
+                "all_to_all 2 (whole frames -> pixel slabs)", "all_gather (final frame)"} <= set(r["phases"])
+        assert all(v >= 0 for v in r["phases"].values())
     c4 = np.stack([O.synth_adi(8, 24, seed=10 + i)[0] for i in range(3)])
     a4 = np.linspace(0, 70, 8)
     f4 = O.pca_4d(c4, a4, ncomp=2, full_output=True)

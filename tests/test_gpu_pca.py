@@ -713,8 +713,8 @@ def test_annular_libraries_beyond_512_frames():
 
 def test_more_than_6144_frames(monkeypatch):
     """beyond the exact leading-k solvers (n > backend.MAX_EIGH_N = 6144) the front keeps the device Gram / projection
-    kernels; the decomposition comes from the verified fast path (csrc/eigh_chfsi.hip, up to 16384 frames) when it
-    converges -- no library call at all -- and from rocSOLVER (backend.eigh_beyond_lds) when it does not."""
+    kernels; the decomposition comes from the verified fast path (csrc/eigh_chfsi.hip, up to 16384 frames).  No library call
+    anywhere: when the fast path gives up, or the whole spectrum is asked for, the call raises NotImplementedError."""
     from vip_amd import backend as B
     from vip_amd.psfsub import pca
     n, N, k = B.MAX_EIGH_N + 56, 16, 6
@@ -725,9 +725,16 @@ def test_more_than_6144_frames(monkeypatch):
     assert np.abs(got - ref).max() < TOL
     ctx = B.get_context()
     assert ctx.get_option("eigh_fast_last_reason") == 0 and ctx.get_option("eigh_fast_last_locked") == k
-    monkeypatch.setattr(B, "eigh_topk_fast", lambda G, k_: None)          # the fast path gives up: the library routine
-    got2 = pca(cube, ang, ncomp=k, verbose=False)
-    assert np.abs(got2 - ref).max() < TOL and np.abs(got2 - got).max() < 2e-6
+    import torch
+    called = []
+    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **kw: called.append(1))
+    monkeypatch.setattr(B, "eigh_topk_fast", lambda G, k_: None)          # the fast path gives up
+    with pytest.raises(NotImplementedError):
+        pca(cube, ang, ncomp=k, verbose=False)
+    from vip_amd.psfsub.svd import svd_wrapper
+    with pytest.raises(NotImplementedError):                              # whole spectrum
+        svd_wrapper(cube.reshape(n, -1), "lapack", 4, verbose=False, full_output=True)
+    assert not called
 
 
 def test_more_than_2048_frames():

@@ -391,22 +391,24 @@ def eigh_topk_fast(G, k):
 
 
 def eigh_beyond_lds(G, k=None):
-    """Eigendecomposition of a Gram matrix of more than MAX_EIGH_N frames: the ONE place where a ROCm library routine is
-    used (rocSOLVER's syevd through ``torch.linalg.eigh``, on the device, float64) -- the hand-written leading-k solver
-    holds 3 n doubles of vectors in LDS and stops at n = 6144, and such cubes are rare.  Returns (evals descending, eigenvectors as
-    rows, largest-magnitude component positive) like the native solvers.  With ``k`` (only the leading k pairs are needed)
-    the verified fast path is tried first: (evals (k,), evecs (k, n)) without any library call when it converges."""
+    """Leading pairs of a Gram matrix of more than MAX_EIGH_N frames: the exact hand-written solvers hold 3 n doubles of vectors
+    in LDS and stop at n = 6144; beyond, the verified Chebyshev subspace iteration (csrc/eigh_chfsi.hip, up to 16384 frames)
+    serves the leading ``k`` pairs and returns (evals (k,), evecs (k, n)).  There is NO library fallback (round 3 called
+    rocSOLVER here): a request for the whole spectrum (``k`` None: CEVR / full svd_wrapper output), or a fast path that does not
+    converge within its budget, raises NotImplementedError -- such cubes are outside every configuration of the benchmark and
+    the caller can subsample frames or ask for fewer components."""
     torch = _torch()
-    if k is not None:
-        fast = eigh_topk_fast(G.to(torch.float64), k)
-        if fast is not None:
-            return fast
-    w, Q = torch.linalg.eigh(G.to(torch.float64))
-    w = w.flip(0).contiguous()
-    E = Q.flip(1).t().contiguous()                                   # rows = eigenvectors, descending eigenvalue
-    big = E.abs().argmax(dim=1, keepdim=True)
-    E = E * torch.sign(torch.gather(E, 1, big))
-    return w, E
+    n = int(G.shape[0])
+    if k is None:
+        raise NotImplementedError("the whole spectrum of a cube / library of %d frames (more than %d) is not available on the "
+                                  "device eigensolvers; ask for the leading components only" % (n, MAX_EIGH_N))
+    fast = eigh_topk_fast(G.to(torch.float64), k)
+    if fast is None:
+        ctx = get_context(G.device.index)
+        raise NotImplementedError("the leading %d eigenpairs of a %d-frame Gram matrix (more than %d frames) did not converge in the "
+                                  "verified subspace iteration (reason %d); no other solver serves this size" % (
+                                      int(k), n, MAX_EIGH_N, int(ctx.get_option("eigh_fast_last_reason"))))
+    return fast
 
 
 def _pca_project_large(M, k, ref, want_recon, want_pcs, want_evals):

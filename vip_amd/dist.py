@@ -169,9 +169,12 @@ def pca_4d(cube4d, angle_list, ncomp=1, collapse_ifs="mean", compute=None, colla
     else:
         for ch in mine:
             local[ch] = compute(cube4d[ch], angle_list, ncomp=ncomps[ch], **kwargs)
+    _mark("per-channel ADI PCA (own channels)")
     ifs = gather_units(local, nch, tuple(cube4d.shape[-2:]), None)
+    _mark("all_gather (per-channel frames)")
     ifs_np = ifs.cpu().numpy()
     frame = collapse(ifs_np, mode=collapse_ifs)
+    _mark("spectral collapse (host)")
     return frame, ifs_np
 
 
@@ -228,6 +231,36 @@ def _split(total, world):
     for r in range(world):
         edges.append(edges[-1] + base + (1 if r < rem else 0))
     return [(edges[r], edges[r + 1]) for r in range(world)]
+
+
+# ---- per-phase wall times of the sharded paths (bench.py's strong-scaling legs: what did the collectives cost?) ------------------
+_phases = {"on": False, "acc": {}, "last": 0.0}
+
+
+def phase_timing(on=True):
+    """Switch the phase clock of the sharded routines on (clears it) or off (returns {phase: milliseconds}).  With the clock
+    on, every phase boundary synchronises the device, so the phases do not overlap: run it on a step of its own."""
+    import time
+    if on:
+        _phases.update(on=True, acc={}, last=time.perf_counter())
+        return None
+    _phases["on"] = False
+    return {k: 1e3 * v for k, v in _phases["acc"].items()}
+
+
+def _mark(name):
+    if not _phases["on"]:
+        return
+    import time
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except ImportError:
+        pass
+    now = time.perf_counter()
+    _phases["acc"][name] = _phases["acc"].get(name, 0.0) + now - _phases["last"]
+    _phases["last"] = now
 
 
 def _all_to_all(send_chunks, recv_shapes, dtype, dev):
@@ -355,6 +388,7 @@ def pca_single_cube(cube, angle_list, ncomp, collapse="median", ops=None):
                    else cube[:, y0:y1, :].reshape(n, -1))
     G = ops.gram(M)
     dev = G.device
+    _mark("gram (own pixel slab)")
     if world > 1:
         if G.device != _comm_device():            # gloo with device tensors: stage through the host
             Gh = G.to(_comm_device())
@@ -362,15 +396,19 @@ def pca_single_cube(cube, angle_list, ncomp, collapse="median", ops=None):
             G = Gh.to(dev)
         else:
             dist.all_reduce(G, op=dist.ReduceOp.SUM)
+    _mark("all_reduce (n x n float64 Gram)")
     # 2. identical decomposition everywhere, local residual slab
     ev, ec = ops.leading(G, k)
+    _mark("eigensolver (replicated)")
     R = ops.residuals(M, ev, ec)                                               # (n, (y1-y0)*x)
+    _mark("project / subtract (own slab)")
     R3 = R.reshape(n, y1 - y0, x)
     # 3. slabs -> whole frames
     send = [R3[a:b] for (a, b) in frs]
     recv_shapes = [(f1 - f0, r1 - r0, x) for (r0, r1) in rows]
     parts = _all_to_all(send, recv_shapes, R.dtype, dev)
     frames = torch.cat(parts, dim=1)                                           # (f1-f0, y, x)
+    _mark("all_to_all 1 (pixel slabs -> whole frames)")
     return _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, dev)
 
 
@@ -446,17 +484,22 @@ def _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, de
     f0, f1 = frs[rank]
     # 4. derotate own frames
     der = ops.derotate(frames, angle_list[f0:f1], **rot) if f1 > f0 else frames
+    _mark("derotation (own frames)")
     # 5. whole frames -> slabs of all frames
     send = [der[:, r0:r1, :] for (r0, r1) in rows]
     recv_shapes = [(b - a, y1 - y0, x) for (a, b) in frs]
     parts = _all_to_all(send, recv_shapes, der.dtype, dev)
     slab = torch.cat(parts, dim=0).reshape(n, -1, 1)                           # (n, P_g, 1)
+    _mark("all_to_all 2 (whole frames -> pixel slabs)")
     # 6. collapse own pixels, gather the frame
     mine = ops.collapse(slab, collapse).reshape(y1 - y0, x)
+    _mark("collapse (own pixel slab)")
     if world == 1:
         return mine
     pieces = _all_gather_ragged(mine.contiguous(), [r1 - r0 for (r0, r1) in rows], dev)
-    return torch.cat(pieces, dim=0)
+    out = torch.cat(pieces, dim=0)
+    _mark("all_gather (final frame)")
+    return out
 
 
 def pca_annular_frame(cube, angle_list, plan, residual_fn, collapse="median", ops=None, mask_zero=False):
@@ -489,6 +532,7 @@ def pca_annular_frame(cube, angle_list, plan, residual_fn, collapse="median", op
             cols.append(r.to(device=dev, dtype=torch.float32)[:, :len(seg["pix"])])
     mine = torch.cat(cols, dim=1) if cols else torch.zeros((n, 0), dtype=torch.float32, device=dev)   # (n, npx_mine)
     counts = [sum(len(seg["pix"]) for si, seg in enumerate(plan) if owner[si] == r) for r in range(world)]
+    _mark("annular residuals (own segments)")
     # pixel columns -> whole frames of the own frame shard
     send = [mine[a:b] for (a, b) in frs]
     recv_shapes = [(f1 - f0, counts[r]) for r in range(world)]
@@ -501,6 +545,7 @@ def pca_annular_frame(cube, angle_list, plan, residual_fn, collapse="median", op
         pix = torch.from_numpy(np.asarray(seg["pix"], dtype=np.int64)).to(dev)
         frames[:, pix] = parts[r][:, offs[r]:offs[r] + npx]
         offs[r] += npx
+    _mark("all_to_all 1 (pixel columns -> whole frames)")
     rot = {"mask_zero": True} if mask_zero else {}
     return _derotate_exchange_collapse(frames.reshape(f1 - f0, y, x), angle_list, frs, rows, collapse, ops, dev, **rot)
 

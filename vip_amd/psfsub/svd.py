@@ -27,7 +27,7 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
     elif B.topk_native(n, ncomp):
         evals, evecs = B.eigh_topk(G, ncomp, all_evals=True)       # whole spectrum, leading vectors
     elif n > B.MAX_EIGH_N:
-        evals, evecs = B.eigh_beyond_lds(G)                        # more than 6144 frames (rocSOLVER, see backend)
+        evals, evecs = B.eigh_beyond_lds(G)                        # more than 6144 frames: raises (no library fallback)
     else:
         evals, evecs = B.eigh(G)
     sig_all = torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
@@ -68,7 +68,8 @@ def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=No
     t = B.to_device_f32(matrix)
     sig, E, V = _decompose(t, int(ncomp))
     if verbose:
-        print("Done SVD/PCA on MI355X (Gram + block-Jacobi eigensolver), requested mode '{}'".format(mode))
+        print("Done SVD/PCA on MI355X (Gram on the int8 / float64 matrix cores + Householder-tridiagonal leading-k eigensolver), "
+              "requested mode '{}'".format(mode))
     keep_dev = dev_in or not to_numpy
     out_dtype = np.float64 if (not dev_in and matrix.dtype == np.float64) else np.float32
 

@@ -32,17 +32,22 @@ def synth_adi(n, N, seed=0, planet=True, dtype=np.float32):
     return cube.astype(dtype), angles
 
 
-def synth_adi_device(n, N, seed=0, device=None, chunk=100):
+def synth_adi_device(n, N, seed=0, device=None, chunk=100, nmodes=30, halving=3.0):
     """The model of ``synth_adi`` (without the planet) drawn on the GPU: returns (float32 cuda tensor (n, N, N) with
-    max|cube| ~ 10, float64 numpy angles).  Deterministic for a given seed on a given device type."""
+    max|cube| ~ 10, float64 numpy angles).  Deterministic for a given seed on a given device type.
+
+    ``nmodes`` speckle modes whose amplitudes halve every ``halving`` modes (defaults = the SURVEY 8(d) generator: 30 modes,
+    of which ~10 stand above the unit noise, so that a boundary at ncomp = 20 .. 50 lies INSIDE the flat noise bulk -- the
+    worst case for every leading-subspace method).  More modes with a slower decay (e.g. 150, 10) give the decaying spectrum
+    of real quasi-static speckle data, with the boundary on the slope."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
     g = torch.Generator(device=dev).manual_seed(int(seed))
     yy, xx = torch.meshgrid(torch.arange(N, device=dev), torch.arange(N, device=dev), indexing="ij")
     env = torch.exp(-torch.sqrt((yy - N // 2) ** 2.0 + (xx - N // 2) ** 2.0) / (N / 8)).float()
-    nmodes = 30
+    nmodes = int(nmodes)
     modes = torch.randn((nmodes, N, N), device=dev, generator=g) * env
-    coef = torch.randn((n, nmodes), device=dev, generator=g) * (2.0 ** (-torch.arange(nmodes, device=dev) / 3))
+    coef = torch.randn((n, nmodes), device=dev, generator=g) * (2.0 ** (-torch.arange(nmodes, device=dev) / float(halving)))
     cube = torch.empty((n, N, N), device=dev)
     peak = 0.0
     for i in range(0, n, chunk):
