@@ -739,6 +739,7 @@ def test_eigh_topk_one_xcd_exchange_matches_the_spread_layout(B):
         mats[n] = M @ M.T
     try:
         res = {}
+        ctx.set_option("eigh_wave", 0)        # the LDS-resident kernel in both layouts (the register-resident one: next test)
         for mode in (0, 1):
             ctx.set_option("eigh_one_xcd", mode)
             for n, G in mats.items():
@@ -759,11 +760,13 @@ def test_eigh_topk_one_xcd_exchange_matches_the_spread_layout(B):
                 with torch.cuda.stream(torch.cuda.Stream()):
                     c = B.get_context()
                     c.set_option("eigh_one_xcd", 1)
+                    c.set_option("eigh_wave", 0)
                     c.set_option("eigh_fast", 0)
                     for rep in range(8):
                         ev_, ec_ = B.eigh_topk(torch.from_numpy(mats[400].copy()).cuda(), 15)
                         out[i, rep] = (ev_.cpu().numpy(), ec_.cpu().numpy())
                     c.set_option("eigh_one_xcd", -1)
+                    c.set_option("eigh_wave", 1)
                     c.set_option("eigh_fast", 1)
             except Exception as e:           # noqa: BLE001
                 errs.append(e)
@@ -776,6 +779,59 @@ def test_eigh_topk_one_xcd_exchange_matches_the_spread_layout(B):
             assert np.array_equal(v[0], res[1, 400][0]) and np.array_equal(v[1], res[1, 400][1])
     finally:
         ctx.set_option("eigh_one_xcd", -1)
+        ctx.set_option("eigh_wave", 1)
+
+
+def test_eigh_topk_wave_resident_tridiagonalisation(B):
+    """A lone synchronous problem of 129 .. 448 rows: Householder reduction on 64 cooperating single-wave workgroups with the
+    matrix in registers (eigh_wave.hip), stages 2-5 of the LDS kernel as a second launch.  Against numpy float64 (eigenvalues,
+    residuals, the invariant subspace), against the LDS-resident reduction, deterministic from call to call, and from four
+    threads at once (each launch on its own XCD)."""
+    import threading
+    import torch
+    rng = np.random.default_rng(11)
+    ctx = B.get_context()
+    try:
+        ref400 = None
+        for n, k in ((129, 3), (192, 64), (200, 10), (257, 7), (320, 40), (385, 5), (400, 20), (448, 20)):
+            M = rng.standard_normal((n, n + 40)) * (2.0 ** (-np.arange(n + 40) / 60.0))
+            G = M @ M.T
+            ctx.set_option("eigh_wave", 1)
+            ev, ec = B_eigh(G, k)
+            ev2, ec2 = B_eigh(G, k)
+            assert np.array_equal(ev, ev2) and np.array_equal(ec, ec2), n
+            _topk_check(G, ev, ec, k)
+            ctx.set_option("eigh_wave", 0)
+            ev0, ec0 = B_eigh(G, k)
+            np.testing.assert_allclose(ev, ev0, atol=1e-12 * ev0[0])
+            assert np.abs(ec.T @ ec - ec0.T @ ec0).max() < 1e-8, n      # same invariant subspace
+            if n == 400:
+                ref400 = (G, ev, ec)
+        ctx.set_option("eigh_wave", 1)
+        G, ev, ec = ref400
+        out, errs = {}, []
+
+        def work(i):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    c = B.get_context()
+                    c.set_option("eigh_fast", 0)
+                    for rep in range(8):
+                        ev_, ec_ = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), 20)
+                        out[i, rep] = (ev_.cpu().numpy(), ec_.cpu().numpy())
+                    c.set_option("eigh_fast", 1)
+                    B.check_deferred()
+            except Exception as e:           # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        for v in out.values():
+            assert np.array_equal(v[0], ev) and np.array_equal(v[1], ec)
+    finally:
+        ctx.set_option("eigh_wave", 1)
 
 
 def B_eigh(G, k):

@@ -202,6 +202,11 @@ int lincomb_f32(vipmi_ctx* ctx, const float* x, const float* y, float a, float b
 int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float* A1, const float* B1,
                   const int32_t* ia, const int32_t* ib, int64_t nbatch, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc, float* C);
+// Householder tridiagonalisation of one matrix of 129 .. 448 rows on 64 cooperating single-wave workgroups, matrix in registers
+// (eigh_wave.hip): d, e, tau -> det[3][n], reflectors in the rows of A.  bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8
+// doubles; xcd_slot = 1 + XCD the waves sit on (0 = spread over the chip, agent-scope exchange); fail: deferred-failure words.
+bool tri_wave_supported(int64_t n);
+int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf, unsigned* bars, int xcd_slot, int* fail);
 // one larger problem (512 < n <= 2048): eigh_tri_large.hip
 bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,

@@ -828,7 +828,7 @@ template <int RPL>
 __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aall, int n, int k, int RW, int VW, int rows_d, int all_evals,
                                                         double* __restrict__ evals_all, double* __restrict__ evecs_all,
                                                         double* __restrict__ gbuf_all, unsigned* __restrict__ bars, int one_xcd,
-                                                        int* __restrict__ fail) {
+                                                        int* __restrict__ fail, const double* __restrict__ det = nullptr) {
   extern __shared__ double sm[];
   const int prob = blockIdx.y;
   // one_xcd = 1 + base: the grid is 8 x wider and only the ids that land on XCD (base + problem) % 8 stay (ids go round-robin
@@ -863,22 +863,32 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   const int na = n;
   const int kk = k < na ? k : na;
 
+  // det != nullptr: the tridiagonalisation was done by tri_wave_reduce (eigh_wave.hip): d, e, tau come from det[3][n], the
+  // reflectors are in A; this launch only runs stages 2-5 (agent-scope exchange: one barrier, nothing to gain from the XCD path)
+  const bool pre = det != nullptr;
   // own rows into LDS; row 0 (input data, no synchronisation needed) gives v_0 in every workgroup
-  for (int e = tid; e < RW * n; e += TNT) {
+  for (int e = tid; e < (pre ? 0 : RW * n); e += TNT) {
     const int lr = e / n, c = e - lr * n, r = lr * W + wg;
     rows[e] = (r < n) ? A[(size_t)r * n + c] : 0.0;
   }
   for (int c = tid; c < n; c += TNT) {
-    cfull[c] = A[c];
+    cfull[c] = pre ? 0.0 : A[c];
     vprev[c] = 0.0;
     wprev[c] = 0.0;
     pfull[c] = 0.0;
+    if (pre) {
+      dd[c] = det[c];
+      ee[c] = det[n + c];
+      tau[c] = det[2 * n + c];
+    }
   }
   // every workgroup has read row 0 (and its own rows) before any reflector is written over the input matrix
-  if (one_xcd && tid == 0) __hip_atomic_store(xids + wg, 1u + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  bar_target += W;
-  grid_barrier(bar, bar_target, W, fail);
-  bool fast = one_xcd != 0;                  // all workgroups really on one XCD?  (uniform: everybody reads the same ids)
+  if (!pre) {
+    if (one_xcd && tid == 0) __hip_atomic_store(xids + wg, 1u + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bar_target += W;
+    grid_barrier(bar, bar_target, W, fail);
+  }
+  bool fast = one_xcd != 0 && !pre;          // all workgroups really on one XCD?  (uniform: everybody reads the same ids)
   if (fast) {
     const unsigned mine = 1u + xcc_id();
     for (int j = 0; j < W; ++j) fast = fast && __hip_atomic_load(xids + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine;
@@ -922,17 +932,23 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
       tau[s1] = beta;
     }
   };
-  form_reflector(0, vcur);
+  if (!pre) form_reflector(0, vcur);
   __syncthreads();
 
   // ---------------- 1. tridiagonalisation ----------------
+#ifdef VIPMI_TRI_PROFILE      // stage stamps of workgroup 0 (s_memtime; tools/multi_profile.py): evals[n-16 ..] at the end
+  unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PSTAMP(i) pst[i] = __builtin_amdgcn_s_memtime()
+#else
+#define PSTAMP(i)
+#endif
 #ifdef VIPMI_TRI_PROFILE      // s_memtime segments of wave 0 of workgroup 0 (tools/multi_profile.py)
   unsigned long long seg_t[6] = {0, 0, 0, 0, 0, 0}, seg_c = __builtin_amdgcn_s_memtime();
 #define MSEG(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_t[i] += t_ - seg_c; seg_c = t_; } while (0)
 #else
 #define MSEG(i)
 #endif
-  for (int s = 0; s + 2 < na; ++s) {
+  for (int s = 0; s + 2 < (pre ? 0 : na); ++s) {
     const int par = s & 1;
     const double beta = tau[s];
     // the owner of row s keeps the reflector for the back-transformation
@@ -1001,7 +1017,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   if (wg == 0 && tid == 0 && prob == 0)
     for (int i = 0; i < 5; ++i) evals[n - 8 + i] = (double)seg_t[i];
 #endif
-  if (tid == 0) {
+  if (tid == 0 && !pre) {
     // trailing 2 x 2 block: cfull holds row na-2 (fully updated) ; the last diagonal entry came through Db
     const int a = na - 2, b = na - 1;
     dd[a] = cfull[a];
@@ -1012,6 +1028,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   __syncthreads();
 
   // ---------------- 2. eigenvalues of the vectors of this workgroup ----------------
+  PSTAMP(0);
   double scale = 0.0, glo = 0.0, ghi = 0.0;
   {
     double mx = 0.0;
@@ -1058,6 +1075,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
 
   // ---------------- 3. inverse iteration, vectors of this workgroup, everything in LDS (rows region) ----------------
   // VW = vectors per workgroup (ceil(k / W)) = row stride of the per-vector arrays
+  PSTAMP(1);
   double* U0 = rows;                                      // [n][VW]
   double* U1 = U0 + (size_t)n * VW;
   double* U2 = U1 + (size_t)n * VW;
@@ -1135,6 +1153,7 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
   __syncthreads();
 
   // ---------------- 4. back-transformation of this workgroup's vectors: wave j <-> vector j ----------------
+  PSTAMP(2);
   double z[RPL];
   const bool have = wave < nmine;
   {
@@ -1183,7 +1202,9 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
     }
     if (lane == 0) put(&evals[c], lam[wave] * scale);
   }
+  PSTAMP(3);
   sync_all();
+  PSTAMP(4);
   if (wg != 0) return;
 
   // ---------------- 5. workgroup 0: modified Gram-Schmidt over the k vectors, sign convention, output ----------------
@@ -1274,6 +1295,11 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
       if (lane == 0 && c >= kk) evals[c] = 0.0;
     }
   }
+#ifdef VIPMI_TRI_PROFILE
+  PSTAMP(5);
+  if (tid == 0 && prob == 0)
+    for (int i = 0; i < 6; ++i) evals[n - 16 + i] = (double)(pst[i] - pst[0]);
+#endif
 }
 
 template <int RPL>
@@ -1314,11 +1340,27 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
   int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
   VIPMI_TRY(deferred_fail_words(ctx, &fail));
+  // A lone synchronous problem of 129 .. 448 rows: the tridiagonalisation on 64 single-wave workgroups of one XCD with the
+  // matrix in registers (eigh_wave.hip), then stages 2-5 of this kernel as a second launch (option eigh_wave = 0: off)
+  if (lone && one_xcd && tri_wave_supported(n) && ctx->opt("eigh_wave", 1) != 0) {
+    double *det = nullptr, *gw = nullptr;
+    unsigned* bars2 = nullptr;
+    VIPMI_TRY(ws(ctx, "eigh_wave_det", (size_t)3 * n, &det));
+    VIPMI_TRY(ws(ctx, "eigh_wave_gbuf", (size_t)4 * 64 * cdiv(n, 64) + 8, &gw));
+    VIPMI_TRY(ws(ctx, "eigh_wave_bars", (size_t)TRI_BAR_WORDS, &bars2));
+    VIPMI_CHECK_HIP(hipMemsetAsync(bars2, 0, sizeof(unsigned) * TRI_BAR_WORDS, ctx->stream));
+    VIPMI_TRY(tri_wave_reduce(ctx, A, n, det, gw, bars2, (int)(1 + (xcd_base.fetch_add(1u) & 7u)), fail));
+    hipLaunchKernelGGL(kern, dim3(W, 1), dim3(TNT), lds, ctx->stream, A, n, k, RW, VW, (int)rows_d, all_evals, evals, evecs, gbuf,
+                       bars, 0, fail, (const double*)det);
+    VIPMI_CHECK_HIP(hipGetLastError());
+    return VIPMI_OK;
+  }
   for (int64_t p0 = 0; p0 < batch; p0 += per_launch) {
     const int64_t nb = batch - p0 < per_launch ? batch - p0 : per_launch;
     hipLaunchKernelGGL(kern, dim3(one_xcd ? 8 * W : W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW,
                        (int)rows_d, all_evals, evals + (size_t)p0 * n, evecs + (size_t)p0 * n * n, gbuf + (size_t)p0 * 5 * n,
-                       bars + (size_t)p0 * TRI_BAR_WORDS, one_xcd ? (int)(1 + ((xcd_base.fetch_add((unsigned)nb) + (unsigned)p0) & 7u)) : 0, fail);
+                       bars + (size_t)p0 * TRI_BAR_WORDS, one_xcd ? (int)(1 + ((xcd_base.fetch_add((unsigned)nb) + (unsigned)p0) & 7u)) : 0, fail,
+                       (const double*)nullptr);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   return VIPMI_OK;

@@ -29,6 +29,45 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// Eight full-wave sums at once, "transposed": lane l returns the sum over the 64 lanes of x[l & 7].  Each of the first three
+// stages halves the number of values a lane carries (the lane keeps the values whose index bit equals its lane bit and sends
+// the others to its partner: quad_perm xor 1, xor 2, then a rotation by 4 inside the row of 16 -- the sender of a rotation has
+// the opposite bit 2, which is all the scheme needs); the last three stages (rotation by 8, v_permlane16_swap,
+// v_permlane32_swap -- gfx950) run on ONE value.  ~67 instructions against 8 x 23 for eight wave_sum()s, one dependent chain of
+// six exchanges instead of eight; no SGPR traffic.  The summation order differs from wave_sum (not bit-identical to it).
+__device__ __forceinline__ double swap_add16_f64(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double swap_add32_f64(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double wave_sum8_scatter(const double (&x)[8]) {
+  const int lane = threadIdx.x & 63;
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  double y[4], z[2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double keep = b0 ? x[2 * m + 1] : x[2 * m], send = b0 ? x[2 * m] : x[2 * m + 1];
+    y[m] = keep + dpp_f64<0xB1>(send);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const double keep = b1 ? y[2 * m + 1] : y[2 * m], send = b1 ? y[2 * m] : y[2 * m + 1];
+    z[m] = keep + dpp_f64<0x4E>(send);
+  }
+  const double keep = b2 ? z[1] : z[0], send = b2 ? z[0] : z[1];
+  double w = keep + dpp_f64<0x124>(send);     // row_ror:4
+  w += dpp_f64<0x128>(w);                     // row_ror:8
+  w = swap_add16_f64(w);
+  return swap_add32_f64(w);
+}
+
 __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_f64<0xB1>(v));
   v = fmax(v, dpp_f64<0x4E>(v));
