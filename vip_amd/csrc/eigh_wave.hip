@@ -29,6 +29,28 @@ namespace vipmi {
 namespace {
 
 constexpr int WW = 64;   // participating waves
+constexpr int VG = 4;    // reflectors per group of the back-transformation
+constexpr int GW = 8;    // doubles per group in the table of products (VG (VG - 1) / 2 = 6 used)
+// position of the product v_a . v_b (a < b < VG) in a group's block
+__host__ __device__ constexpr int gram_idx(int a, int b) { return a * (2 * VG - 1 - a) / 2 + (b - a - 1); }
+
+// four full-wave sums, transposed like wave_sum8_scatter (wave_util.h): lane l returns the sum over the wave of x[l & 3]
+__device__ __forceinline__ double wave_sum4_scatter(const double (&x)[4]) {
+  const int lane = threadIdx.x & 63;
+  const bool b0 = lane & 1, b1 = lane & 2;
+  double y[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const double keep = b0 ? x[2 * m + 1] : x[2 * m], send = b0 ? x[2 * m] : x[2 * m + 1];
+    y[m] = keep + dpp_f64<0xB1>(send);
+  }
+  const double keep = b1 ? y[1] : y[0], send = b1 ? y[0] : y[1];
+  double w = keep + dpp_f64<0x4E>(send);
+  w += dpp_f64<0x124>(w);     // row_ror:4
+  w += dpp_f64<0x128>(w);     // row_ror:8
+  w = swap_add16_f64(w);
+  return swap_add32_f64(w);
+}
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -66,7 +88,7 @@ struct IC {
 template <int NCH>
 __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, int n, double* __restrict__ det,
                                                       double* __restrict__ gb, unsigned* __restrict__ bar, int one_xcd,
-                                                      int* __restrict__ fail) {
+                                                      int* __restrict__ fail, double* __restrict__ gram) {
   static_assert(NCH >= 1 && NCH <= 7, "tri_wave_kernel: up to 448 rows");
   if (one_xcd && (int)(blockIdx.x & 7) != ((one_xcd - 1) & 7)) return;
   const int wg = __builtin_amdgcn_readfirstlane(one_xcd ? blockIdx.x >> 3 : blockIdx.x);
@@ -166,11 +188,12 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
     const int s = 64 * C0 + ls - 1;
     const int par = s & 1;
     // the owner of row s keeps the reflector for the back-transformation
+    // (the WHOLE row: zeros up to column s, so that the back-transformation reads its rows without masks)
     if ((s & 63) == wg) {
 #pragma unroll
-      for (int ch = C0; ch < NCH; ++ch) {
+      for (int ch = 0; ch < NCH; ++ch) {
         const int c = 64 * ch + lane;
-        if (c > s && c < n) put(&A[(size_t)s * n + c], vcur[ch]);
+        if (c < n) put(&A[(size_t)s * n + c], ch >= C0 ? vcur[ch] : 0.0);
       }
     }
     // own rows r > s (local rows C0 .., the first one only when wg >= ls), columns from chunk C0 on: pending rank-2 update
@@ -272,24 +295,447 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
   chunk_steps(IC<4>{});
   chunk_steps(IC<5>{});
   chunk_steps(IC<6>{});
+
+  // Epilogue: the back-transformation (tri_vec_kernel) applies the reflectors in groups of VG with the compact-WY recurrence and
+  // needs the products v_a . v_b inside every group -- 64 waves are here with nothing left to do: wave w takes the groups w and
+  // w + 64 (group g = reflectors j = n-3 - VG g - q, q = 0 .. VG-1): six products, one transposed wave reduction.  gram[g][GW].
+  epoch += 1;
+  wave_exchange(xflags, epoch, wg, fast, fail);            // every reflector is in memory / the L2
+  const int ngroups = (n - 2 + VG - 1) / VG;
+  for (int g = wg; g < ngroups; g += WW) {
+    double v[VG][NCH];
+#pragma unroll
+    for (int q = 0; q < VG; ++q) {
+      const int j = n - 3 - VG * g - q;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c = 64 * ch + lane;
+        v[q][ch] = (j >= 0 && c < n) ? ld_shared(&A[(size_t)j * n + c]) : 0.0;
+      }
+    }
+    double part[4] = {0.0, 0.0, 0.0, 0.0}, part2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int a = 0; a < VG; ++a)
+#pragma unroll
+      for (int b = a + 1; b < VG; ++b) {
+        double t = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) t += v[a][ch] * v[b][ch];
+        if (gram_idx(a, b) < 4) part[gram_idx(a, b)] = t;
+        else part2[gram_idx(a, b) - 4] = t;
+      }
+    const double t0 = wave_sum4_scatter(part), t1 = wave_sum4_scatter(part2);
+    if (lane < 4) {
+      gram[(size_t)g * GW + lane] = t0;
+      gram[(size_t)g * GW + 4 + lane] = t1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stages 2-4 for ONE eigenvector per workgroup (4 waves, one per SIMD), from d, e, tau (det), the reflectors (rows of A) and
+// the group products (gram):
+//   2. its eigenvalue by multisection: 256 Sturm counts per sweep (bracket / 257: 7 sweeps), the count loop with the zero test
+//      off the dependent chain (sturm_count_fast);
+//   3. inverse iteration (dlagtf-style pivoted LU, two solves) by one lane, the factors in LDS, operands fetched in blocks;
+//   4. back-transformation by wave 0: z <- H_0 .. H_{n-3} z, reflectors streamed from L2 one group ahead (registers), applied
+//      VG = 4 at a time (two groups of registers, no AGPR traffic) -- the VG products v_q . z come out of ONE transposed wave reduction, the sequential coefficients follow
+//      from the group products:  s_q = beta_q (v_q . z - sum_{a<q} s_a v_a . v_q),  z -= sum_q s_q v_q.
+// tri_multi_kernel ran these stages on one wave / one lane of a 16-wave workgroup capped at 128 VGPRs: 85 + 155 + 245 us at
+// n = 400 (s_memtime, tools/tri_stage_profile.py) -- more than the tridiagonalisation once that ran on eigh_wave's step loop.
+// Output: evecs[c][n] not yet orthonormalised against its neighbours (tri_mgs_kernel), evals[c].
+template <int NCH>
+__global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__ A, int n, const double* __restrict__ det,
+                                                      const double* __restrict__ gram, double* __restrict__ evals,
+                                                      double* __restrict__ evecs) {
+  constexpr int NP = 64 * NCH;
+  __shared__ double dd[NP], ee[NP], e2[NP], U0[NP], U1[NP], U2[NP], Lm[NP], Ls[NP], Zl[NP];
+  __shared__ double red[2][4];
+  __shared__ double redv[4][3];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr double TEPS = tri::EPS;
+#ifdef VIPMI_TRI_PROFILE     // stage stamps of workgroup 0 (tools/tri_stage_profile.py): evals[n-16 ..]
+  unsigned long long pst[6] = {0, 0, 0, 0, 0, 0};
+#define VSTAMP(i) pst[i] = __builtin_amdgcn_s_memtime()
+#else
+#define VSTAMP(i)
+#endif
+  VSTAMP(0);
+  // ---- 2. scaling, Gershgorin bounds, multisection ----
+  double mx = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double d = det[i], e = det[n + i];
+    dd[i] = d;
+    ee[i] = e;
+    mx = fmax(mx, fmax(fabs(d), fabs(e)));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) redv[wave][0] = mx;
+  __syncthreads();
+  const double scale = fmax(fmax(redv[0][0], redv[1][0]), fmax(redv[2][0], redv[3][0]));
+  const double iscale = scale > 0.0 ? 1.0 / scale : 0.0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const double e = ee[i] * iscale;
+    dd[i] *= iscale;
+    ee[i] = e;
+    e2[i] = e * e;
+  }
+  __syncthreads();
+  double glo, ghi;
+  {
+    double lo = 1e300, hi = -1e300;
+    for (int i = tid; i < n; i += 256) {
+      const double rad = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i + 1 < n ? fabs(ee[i]) : 0.0);
+      lo = fmin(lo, dd[i] - rad);
+      hi = fmax(hi, dd[i] + rad);
+    }
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    if (lane == 0) {
+      redv[wave][1] = lo;
+      redv[wave][2] = hi;
+    }
+    __syncthreads();
+    glo = fmin(fmin(redv[0][1], redv[1][1]), fmin(redv[2][1], redv[3][1]));
+    ghi = fmax(fmax(redv[0][2], redv[1][2]), fmax(redv[2][2], redv[3][2]));
+    const double margin = 4.0 * TEPS * (double)n + 1e-290;
+    glo -= margin;
+    ghi += margin;
+  }
+  double lam_c;
+  {
+    const int target = n - 1 - c;
+    double a = glo, b = ghi;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+      const double h = (b - a) * (1.0 / 257.0);
+      const int cnt = tri::sturm_count_fast(dd, e2, n, a + h * (double)(tid + 1));
+      const int Lw = __popcll(__ballot(cnt <= target));      // sigma <= lambda_target for a prefix of the 256 points
+      if (lane == 0) red[sweep & 1][wave] = (double)Lw;
+      __syncthreads();
+      const int L = (int)(red[sweep & 1][0] + red[sweep & 1][1] + red[sweep & 1][2] + red[sweep & 1][3]);
+      const double na_ = (L == 0) ? a : a + h * (double)L;
+      const double nb_ = (L == 256) ? b : a + h * (double)(L + 1);
+      a = na_;
+      b = nb_;
+      if (b - a <= 2.0 * TEPS * fmax(fabs(a), fabs(b)) + 1e-290) break;
+    }
+    lam_c = 0.5 * (a + b);
+  }
+  VSTAMP(1);
+  // ---- 3. inverse iteration (one lane; the start vector is tabulated by everybody first) ----
+  for (int i = tid; i < n; i += 256) Zl[i] = tri::hash_unit((unsigned)i, (unsigned)c);
+  __syncthreads();
+  if (tid == 0) {
+    const double lc = lam_c - (double)(c + 1) * 4.0 * TEPS;
+    const double ptiny = 1e-3 * TEPS;
+    double p = dd[0] - lc, q = (n > 1) ? ee[0] : 0.0, r = 0.0;
+    double yc = Zl[0];
+    constexpr int BL = 8;
+    for (int i0 = 0; i0 + 1 < n; i0 += BL) {
+      double sb[BL], db[BL], ub[BL], yb[BL];
+#pragma unroll
+      for (int u = 0; u < BL; ++u) {                        // operands of BL steps up front (LDS round trips off the chain)
+        const int i = i0 + u;
+        sb[u] = ee[min(i, n - 1)];
+        db[u] = dd[min(i + 1, n - 1)];
+        ub[u] = (i + 2 < n) ? ee[min(i + 1, n - 1)] : 0.0;
+        yb[u] = Zl[min(i + 1, n - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < BL; ++u) {
+        const int i = i0 + u;
+        if (i + 1 < n) {
+          const double sub = sb[u], nd = db[u] - lc, nu = ub[u], yn = yb[u];
+          const bool sw = fabs(sub) > fabs(p) && fabs(sub) >= ptiny;
+          double pp = p;
+          if (!sw && fabs(pp) < ptiny) pp = (pp < 0.0) ? -ptiny : ptiny;
+          const double inv = tri::fast_rcp(sw ? sub : pp);
+          const double m = (sw ? pp : sub) * inv;
+          const double u1 = sw ? nd : q, u2 = sw ? nu : r;
+          const double yi = sw ? yn : yc;
+          yc = sw ? (yc - m * yn) : (yn - m * yc);
+          p = sw ? (q - m * nd) : (nd - m * q);
+          q = sw ? (r - m * nu) : (nu - m * r);
+          r = 0.0;
+          U0[i] = inv;
+          U1[i] = u1;
+          U2[i] = u2;
+          Lm[i] = m;
+          Ls[i] = sw ? 1.0 : 0.0;
+          Zl[i] = yi;
+        }
+      }
+    }
+    if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+    const double invlast = tri::fast_rcp(p);
+    double rs = 1.0;
+    for (int it = 0; it < 2; ++it) {
+      if (it > 0) {
+        yc = Zl[0] * rs;
+        for (int i0 = 0; i0 + 1 < n; i0 += BL) {
+          double zb[BL], mb[BL], lb[BL];
+#pragma unroll
+          for (int u = 0; u < BL; ++u) {
+            const int i = min(i0 + u, n - 2);
+            zb[u] = Zl[i + 1];
+            mb[u] = Lm[i];
+            lb[u] = Ls[i];
+          }
+#pragma unroll
+          for (int u = 0; u < BL; ++u) {
+            const int i = i0 + u;
+            if (i + 1 < n) {
+              const double yn = zb[u] * rs, m = mb[u];
+              const bool sw = lb[u] != 0.0;
+              const double yi = sw ? yn : yc;
+              yc = sw ? (yc - m * yn) : (yn - m * yc);
+              Zl[i] = yi;
+            }
+          }
+        }
+      }
+      double x1 = yc * invlast, x2 = 0.0;
+      Zl[n - 1] = x1;
+      double acc = x1 * x1;
+      for (int i0 = n - 2; i0 >= 0; i0 -= BL) {
+        double zb[BL], a0[BL], a1[BL], a2[BL];
+#pragma unroll
+        for (int u = 0; u < BL; ++u) {
+          const int i = max(i0 - u, 0);
+          zb[u] = Zl[i];
+          a0[u] = U0[i];
+          a1[u] = U1[i];
+          a2[u] = U2[i];
+        }
+#pragma unroll
+        for (int u = 0; u < BL; ++u) {
+          const int i = i0 - u;
+          if (i >= 0) {
+            const double x = (zb[u] - a1[u] * x1 - a2[u] * x2) * a0[u];
+            Zl[i] = x;
+            acc += x * x;
+            x2 = x1;
+            x1 = x;
+          }
+        }
+      }
+      rs = acc > 0.0 ? 1.0 / sqrt(acc) : 1.0;
+    }
+    red[0][0] = rs;                                         // normalisation of the final solution
+  }
+  __syncthreads();
+  VSTAMP(2);
+  if (wave != 0) return;
+  // ---- 4. back-transformation (wave 0) ----
+  const double rs = red[0][0];
+  double z[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int i = 64 * ch + lane;
+    z[ch] = (i < n) ? Zl[i] * rs : 0.0;
+  }
+  const int ngroups = (n - 2 + VG - 1) / VG;
+  const double* tau = det + 2 * n;
+  // rows are clean (zeros up to the diagonal: tri_wave_kernel) -- no masks; the last chunk is read clamped into the row, what
+  // the lanes beyond n pick up there meets z = 0 in the products and is removed from z after the update
+  const int last = min(64 * (NCH - 1) + lane, n - 1);
+  const bool tail = 64 * (NCH - 1) + lane < n;
+  auto fetch = [&](int g, double (&v)[VG][NCH]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < VG; ++q) {
+      const double* row = A + (size_t)max(n - 3 - VG * g - q, 0) * n;
+#pragma unroll
+      for (int ch = 0; ch + 1 < NCH; ++ch) v[q][ch] = row[64 * ch + lane];
+      v[q][NCH - 1] = row[last];
+    }
+  };
+  auto apply = [&](int g, const double (&v)[VG][NCH]) __attribute__((always_inline)) {
+    const int j0 = n - 3 - VG * g;
+    double y[4], sc[VG];
+#pragma unroll
+    for (int q = 0; q < VG; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) t += v[q][ch] * z[ch];
+      y[q] = t;
+    }
+    const double tot = wave_sum4_scatter(y);                  // lane l: v_(l & 3) . z
+    const double* G = gram + (size_t)g * GW;
+#pragma unroll
+    for (int q = 0; q < VG; ++q) {
+      double d = readlane_f64(tot, q);
+#pragma unroll
+      for (int a = 0; a < q; ++a) d -= sc[a] * G[gram_idx(a, q)];
+      sc[q] = (j0 - q >= 0) ? tau[max(j0 - q, 0)] * d : 0.0;
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      double t = z[ch];
+#pragma unroll
+      for (int q = 0; q < VG; ++q) t -= sc[q] * v[q][ch];
+      z[ch] = t;
+    }
+    z[NCH - 1] = tail ? z[NCH - 1] : 0.0;
+  };
+  double va[VG][NCH], vb[VG][NCH];
+  fetch(0, va);
+  for (int g = 0; g < ngroups; g += 2) {
+    if (g + 1 < ngroups) fetch(g + 1, vb);
+    apply(g, va);
+    if (g + 2 < ngroups) fetch(g + 2, va);
+    if (g + 1 < ngroups) apply(g + 1, vb);
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int i = 64 * ch + lane;
+    if (i < n) evecs[(size_t)c * n + i] = z[ch];
+  }
+  if (lane == 0) evals[c] = lam_c * scale;
+#ifdef VIPMI_TRI_PROFILE
+  VSTAMP(3);
+  if (c == 0 && lane == 0)
+    for (int i = 0; i < 4; ++i) evals[n - 16 + i] = (double)(pst[i] - pst[0]);
+#endif
+}
+
+// 5. modified Gram-Schmidt over the k vectors in eigenvalue order (inverse iteration leaves the vectors of close eigenvalues
+// nearly parallel), sign convention (largest-magnitude component positive).  One workgroup: vector c in wave c mod 16, slot
+// c div 16 (registers), the current vector broadcast through LDS.
+template <int NCH>
+__global__ __launch_bounds__(1024) void tri_mgs_kernel(int n, int k, double* __restrict__ evals, double* __restrict__ evecs) {
+  constexpr int NP = 64 * NCH, NW = 16, VPW = 4;
+  __shared__ double qv[NP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kk = k < n ? k : n;
+  double zz[VPW][NCH];
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = wave + NW * v;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int i = 64 * ch + lane;
+      zz[v][ch] = (c < kk && i < n) ? evecs[(size_t)c * n + i] : 0.0;
+    }
+  }
+  for (int c = 0; c < kk; ++c) {
+    const int ow = c % NW, ov = c / NW;
+    if (wave == ow) {
+#pragma unroll
+      for (int v = 0; v < VPW; ++v)
+        if (v == ov) {
+          double sq = 0.0;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) sq += zz[v][ch] * zz[v][ch];
+          sq = wave_sum(sq);
+          const double inv = sq > 0.0 ? 1.0 / sqrt(sq) : 0.0;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            zz[v][ch] *= inv;
+            qv[64 * ch + lane] = zz[v][ch];
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c2 = wave + NW * v;
+      if (c2 > c && c2 < kk) {
+        double sq = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) sq += zz[v][ch] * qv[64 * ch + lane];
+        sq = wave_sum(sq);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) zz[v][ch] -= sq * qv[64 * ch + lane];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = wave + NW * v;
+    if (c < k) {
+      double best = -1.0, bval = 0.0;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int i = 64 * ch + lane;
+        const double a = fabs(zz[v][ch]);
+        if (i < n && a > best) {
+          best = a;
+          bval = zz[v][ch];
+          bidx = i;
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(best, m, 64), ovv = __shfl_xor(bval, m, 64);
+        const int oi = __shfl_xor(bidx, m, 64);
+        if (ob > best || (ob == best && oi < bidx)) {
+          best = ob;
+          bval = ovv;
+          bidx = oi;
+        }
+      }
+      const double sg = (c < kk) ? (bval < 0.0 ? -1.0 : 1.0) : 0.0;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int i = 64 * ch + lane;
+        if (i < n) evecs[(size_t)c * n + i] = zz[v][ch] * sg;
+      }
+      if (lane == 0 && c >= kk) evals[c] = 0.0;
+    }
+  }
 }
 
 }  // namespace
 
 bool tri_wave_supported(int64_t n) { return n >= 129 && n <= 448; }
 
-// Tridiagonalise A (n x n, symmetric, float64, destroyed): d, e, tau -> det[3][n], reflector s in A[s][s+1 ..].
-// bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8 doubles.  xcd_slot = 1 + XCD to sit on (0: spread, agent scope).
-int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf, unsigned* bars, int xcd_slot, int* fail) {
+// Tridiagonalise A (n x n, symmetric, float64, destroyed): d, e, tau -> det[3][n], reflector s in A[s][s+1 ..], the products of the
+// reflector groups of four -> gram[ceil((n-2)/4)][8].  bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8 doubles.
+// xcd_slot = 1 + XCD to sit on (0: spread, agent scope).
+int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf, unsigned* bars, int xcd_slot, int* fail, double* gram) {
   VIPMI_REQUIRE(tri_wave_supported(n), "tri_wave_reduce: unsupported size %d", n);
   const int nch = (int)cdiv(n, 64);
   const dim3 grid(xcd_slot ? 8 * WW : WW), block(64);
   switch (nch) {
-    case 3: hipLaunchKernelGGL(tri_wave_kernel<3>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail); break;
-    case 4: hipLaunchKernelGGL(tri_wave_kernel<4>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail); break;
-    case 5: hipLaunchKernelGGL(tri_wave_kernel<5>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail); break;
-    case 6: hipLaunchKernelGGL(tri_wave_kernel<6>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail); break;
-    default: hipLaunchKernelGGL(tri_wave_kernel<7>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail); break;
+    case 3: hipLaunchKernelGGL(tri_wave_kernel<3>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
+    case 4: hipLaunchKernelGGL(tri_wave_kernel<4>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
+    case 5: hipLaunchKernelGGL(tri_wave_kernel<5>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
+    case 6: hipLaunchKernelGGL(tri_wave_kernel<6>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
+    default: hipLaunchKernelGGL(tri_wave_kernel<7>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
+  }
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+// Stages 2-5 after tri_wave_reduce: the leading k eigenpairs (k <= 64), one workgroup per vector, then the Gram-Schmidt pass.
+int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double* det, const double* gram, double* evals,
+                     double* evecs) {
+  VIPMI_REQUIRE(tri_wave_supported(n) && k >= 1 && k <= 64, "tri_wave_vectors: unsupported sizes n=%d k=%d", n, k);
+  const int nch = (int)cdiv(n, 64), kk = k < n ? k : n;
+  switch (nch) {
+    case 3:
+      hipLaunchKernelGGL(tri_vec_kernel<3>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<3>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      break;
+    case 4:
+      hipLaunchKernelGGL(tri_vec_kernel<4>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<4>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      break;
+    case 5:
+      hipLaunchKernelGGL(tri_vec_kernel<5>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<5>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      break;
+    case 6:
+      hipLaunchKernelGGL(tri_vec_kernel<6>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<6>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      break;
+    default:
+      hipLaunchKernelGGL(tri_vec_kernel<7>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<7>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      break;
   }
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
