@@ -207,11 +207,12 @@ int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float*
 // doubles; xcd_slot = 1 + XCD the waves sit on (0 = spread over the chip, agent-scope exchange); fail: deferred-failure words.
 bool tri_wave_supported(int64_t n);
 int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf, unsigned* bars, int xcd_slot, int* fail,
-                    double* gram);      // gram[ceil((n-2)/4)][8]: products of the reflectors inside each group of four
+                    double* gram,       // gram[ceil((n-2)/4)][8]: products of the reflectors inside each group of four
+                    double* det2);      // det2[3 n + 3]: d, e, e^2 scaled to max-norm 1, then scale and the Gershgorin interval
 // stages 2-5 from those arrays: eigenvalue (multisection), inverse iteration and back-transformation with one workgroup per
 // vector, then Gram-Schmidt + sign convention; leading k <= 64 pairs -> evals[k], evecs[k][n]
-int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double* det, const double* gram, double* evals,
-                     double* evecs);
+int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double* det, const double* det2, const double* gram,
+                     double* evals, double* evecs);
 // one larger problem (512 < n <= 2048): eigh_tri_large.hip
 bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,

@@ -88,7 +88,8 @@ struct IC {
 template <int NCH>
 __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, int n, double* __restrict__ det,
                                                       double* __restrict__ gb, unsigned* __restrict__ bar, int one_xcd,
-                                                      int* __restrict__ fail, double* __restrict__ gram) {
+                                                      int* __restrict__ fail, double* __restrict__ gram,
+                                                      double* __restrict__ det2) {
   static_assert(NCH >= 1 && NCH <= 7, "tri_wave_kernel: up to 448 rows");
   if (one_xcd && (int)(blockIdx.x & 7) != ((one_xcd - 1) & 7)) return;
   const int wg = __builtin_amdgcn_readfirstlane(one_xcd ? blockIdx.x >> 3 : blockIdx.x);
@@ -330,13 +331,52 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
       gram[(size_t)g * GW + 4 + lane] = t1;
     }
   }
+  // ... and wave 0 leaves the tridiagonal matrix the way the multisection wants it: scaled to max-norm 1, the squares of the
+  // off-diagonals, the Gershgorin interval:  det2 = { d / scale [n], e / scale [n], (e / scale)^2 [n], scale, lo, hi }
+  if (wg == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double dl[NCH], el[NCH], ep[NCH];
+    double mx = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = 64 * ch + lane;
+      dl[ch] = (c < n) ? ld_shared(&det[c]) : 0.0;
+      el[ch] = (c < n) ? ld_shared(&det[n + c]) : 0.0;
+      ep[ch] = (c >= 1 && c < n) ? ld_shared(&det[n + c - 1]) : 0.0;
+      mx = fmax(mx, fmax(fabs(dl[ch]), fabs(el[ch])));
+    }
+    const double scale = wave_max(mx);
+    const double iscale = scale > 0.0 ? 1.0 / scale : 0.0;
+    double lo = 1e300, hi = -1e300;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = 64 * ch + lane;
+      const double d = dl[ch] * iscale, e = el[ch] * iscale, em = ep[ch] * iscale;
+      if (c < n) {
+        det2[c] = d;
+        det2[n + c] = e;
+        det2[2 * n + c] = e * e;
+        const double rad = fabs(em) + (c + 1 < n ? fabs(e) : 0.0);
+        lo = fmin(lo, d - rad);
+        hi = fmax(hi, d + rad);
+      }
+    }
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    const double margin = 4.0 * tri::EPS * (double)n + 1e-290;
+    if (lane == 0) {
+      det2[3 * n] = scale;
+      det2[3 * n + 1] = lo - margin;
+      det2[3 * n + 2] = hi + margin;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Stages 2-4 for ONE eigenvector per workgroup (4 waves, one per SIMD), from d, e, tau (det), the reflectors (rows of A) and
 // the group products (gram):
 //   2. its eigenvalue by multisection: 256 Sturm counts per sweep (bracket / 257: 7 sweeps), the count loop with the zero test
-//      off the dependent chain (sturm_count_fast);
+//      off the dependent chain (sturm_count_fast) and the matrix entries as scalar operands (scaled once by tri_wave_kernel);
 //   3. inverse iteration (dlagtf-style pivoted LU, two solves) by one lane, the factors in LDS, operands fetched in blocks;
 //   4. back-transformation by wave 0: z <- H_0 .. H_{n-3} z, reflectors streamed from L2 one group ahead (registers), applied
 //      VG = 4 at a time (two groups of registers, no AGPR traffic) -- the VG products v_q . z come out of ONE transposed wave reduction, the sequential coefficients follow
@@ -346,14 +386,19 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
 // Output: evecs[c][n] not yet orthonormalised against its neighbours (tri_mgs_kernel), evals[c].
 template <int NCH>
 __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__ A, int n, const double* __restrict__ det,
-                                                      const double* __restrict__ gram, double* __restrict__ evals,
-                                                      double* __restrict__ evecs) {
+                                                      const double* __restrict__ det2, const double* __restrict__ gram,
+                                                      double* __restrict__ evals, double* __restrict__ evecs) {
   constexpr int NP = 64 * NCH;
-  __shared__ double dd[NP], ee[NP], e2[NP], U0[NP], U1[NP], U2[NP], Lm[NP], Ls[NP], Zl[NP];
+  __shared__ double U0[NP], U1[NP], U2[NP], Lm[NP], Ls[NP], Zl[NP];
   __shared__ double red[2][4];
-  __shared__ double redv[4][3];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr double TEPS = tri::EPS;
+  // the scaled tridiagonal matrix stays in global memory: its entries are wave-uniform operands (scalar loads, SGPR operands
+  // of the recurrences) -- from LDS every step of a Sturm count paid two broadcast reads and their wait
+  const double* __restrict__ dd = det2;
+  const double* __restrict__ ee = det2 + n;
+  const double* __restrict__ e2 = det2 + 2 * n;
+  const double scale = det2[3 * n], glo = det2[3 * n + 1], ghi = det2[3 * n + 2];
 #ifdef VIPMI_TRI_PROFILE     // stage stamps of workgroup 0 (tools/tri_stage_profile.py): evals[n-16 ..]
   unsigned long long pst[6] = {0, 0, 0, 0, 0, 0};
 #define VSTAMP(i) pst[i] = __builtin_amdgcn_s_memtime()
@@ -361,48 +406,7 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
 #define VSTAMP(i)
 #endif
   VSTAMP(0);
-  // ---- 2. scaling, Gershgorin bounds, multisection ----
-  double mx = 0.0;
-  for (int i = tid; i < n; i += 256) {
-    const double d = det[i], e = det[n + i];
-    dd[i] = d;
-    ee[i] = e;
-    mx = fmax(mx, fmax(fabs(d), fabs(e)));
-  }
-  mx = wave_max(mx);
-  if (lane == 0) redv[wave][0] = mx;
-  __syncthreads();
-  const double scale = fmax(fmax(redv[0][0], redv[1][0]), fmax(redv[2][0], redv[3][0]));
-  const double iscale = scale > 0.0 ? 1.0 / scale : 0.0;
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) {
-    const double e = ee[i] * iscale;
-    dd[i] *= iscale;
-    ee[i] = e;
-    e2[i] = e * e;
-  }
-  __syncthreads();
-  double glo, ghi;
-  {
-    double lo = 1e300, hi = -1e300;
-    for (int i = tid; i < n; i += 256) {
-      const double rad = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i + 1 < n ? fabs(ee[i]) : 0.0);
-      lo = fmin(lo, dd[i] - rad);
-      hi = fmax(hi, dd[i] + rad);
-    }
-    lo = -wave_max(-lo);
-    hi = wave_max(hi);
-    if (lane == 0) {
-      redv[wave][1] = lo;
-      redv[wave][2] = hi;
-    }
-    __syncthreads();
-    glo = fmin(fmin(redv[0][1], redv[1][1]), fmin(redv[2][1], redv[3][1]));
-    ghi = fmax(fmax(redv[0][2], redv[1][2]), fmax(redv[2][2], redv[3][2]));
-    const double margin = 4.0 * TEPS * (double)n + 1e-290;
-    glo -= margin;
-    ghi += margin;
-  }
+  // ---- 2. multisection ----
   double lam_c;
   {
     const int target = n - 1 - c;
@@ -693,47 +697,48 @@ __global__ __launch_bounds__(1024) void tri_mgs_kernel(int n, int k, double* __r
 bool tri_wave_supported(int64_t n) { return n >= 129 && n <= 448; }
 
 // Tridiagonalise A (n x n, symmetric, float64, destroyed): d, e, tau -> det[3][n], reflector s in A[s][s+1 ..], the products of the
-// reflector groups of four -> gram[ceil((n-2)/4)][8].  bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8 doubles.
+// reflector groups of four -> gram[ceil((n-2)/4)][8], the scaled tridiagonal matrix and its Gershgorin interval -> det2[3 n + 3].  bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8 doubles.
 // xcd_slot = 1 + XCD to sit on (0: spread, agent scope).
-int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf, unsigned* bars, int xcd_slot, int* fail, double* gram) {
+int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf, unsigned* bars, int xcd_slot, int* fail, double* gram,
+                    double* det2) {
   VIPMI_REQUIRE(tri_wave_supported(n), "tri_wave_reduce: unsupported size %d", n);
   const int nch = (int)cdiv(n, 64);
   const dim3 grid(xcd_slot ? 8 * WW : WW), block(64);
   switch (nch) {
-    case 3: hipLaunchKernelGGL(tri_wave_kernel<3>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
-    case 4: hipLaunchKernelGGL(tri_wave_kernel<4>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
-    case 5: hipLaunchKernelGGL(tri_wave_kernel<5>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
-    case 6: hipLaunchKernelGGL(tri_wave_kernel<6>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
-    default: hipLaunchKernelGGL(tri_wave_kernel<7>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram); break;
+    case 3: hipLaunchKernelGGL(tri_wave_kernel<3>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
+    case 4: hipLaunchKernelGGL(tri_wave_kernel<4>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
+    case 5: hipLaunchKernelGGL(tri_wave_kernel<5>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
+    case 6: hipLaunchKernelGGL(tri_wave_kernel<6>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
+    default: hipLaunchKernelGGL(tri_wave_kernel<7>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
   }
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
 
 // Stages 2-5 after tri_wave_reduce: the leading k eigenpairs (k <= 64), one workgroup per vector, then the Gram-Schmidt pass.
-int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double* det, const double* gram, double* evals,
-                     double* evecs) {
+int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double* det, const double* det2, const double* gram,
+                     double* evals, double* evecs) {
   VIPMI_REQUIRE(tri_wave_supported(n) && k >= 1 && k <= 64, "tri_wave_vectors: unsupported sizes n=%d k=%d", n, k);
   const int nch = (int)cdiv(n, 64), kk = k < n ? k : n;
   switch (nch) {
     case 3:
-      hipLaunchKernelGGL(tri_vec_kernel<3>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_vec_kernel<3>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
       hipLaunchKernelGGL(tri_mgs_kernel<3>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
       break;
     case 4:
-      hipLaunchKernelGGL(tri_vec_kernel<4>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_vec_kernel<4>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
       hipLaunchKernelGGL(tri_mgs_kernel<4>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
       break;
     case 5:
-      hipLaunchKernelGGL(tri_vec_kernel<5>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_vec_kernel<5>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
       hipLaunchKernelGGL(tri_mgs_kernel<5>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
       break;
     case 6:
-      hipLaunchKernelGGL(tri_vec_kernel<6>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_vec_kernel<6>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
       hipLaunchKernelGGL(tri_mgs_kernel<6>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
       break;
     default:
-      hipLaunchKernelGGL(tri_vec_kernel<7>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, gram, evals, evecs);
+      hipLaunchKernelGGL(tri_vec_kernel<7>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
       hipLaunchKernelGGL(tri_mgs_kernel<7>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
       break;
   }
