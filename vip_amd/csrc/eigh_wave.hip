@@ -21,6 +21,9 @@
 // Output: d, e, tau in det[3][n] and the reflectors in the rows of A (row s, columns > s) -- exactly what stages 2-5 of
 // tri_multi_kernel (multisection, inverse iteration, back-transformation, Gram-Schmidt) start from.
 #include "common.h"
+#include <mutex>
+#include <map>
+#include <vector>
 #include "wave_util.h"
 #include "tri_common.h"
 
@@ -56,8 +59,10 @@ __device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// all stores of this wave have landed, publish the epoch, wait for everybody's
-__device__ __forceinline__ void wave_exchange(unsigned* flags, unsigned epoch, int wg, bool fast, int* fail) {
+// all stores of this wave have landed, publish the epoch, wait for everybody's.  Returns false when a partner did not arrive
+// within ~1 s (it never became resident: another kernel holds its CU): the failure is latched for vipmi_check_deferred and the
+// caller leaves the kernel -- every wave runs into the same time-out at the same epoch, nobody waits for a wave that left.
+__device__ __forceinline__ bool wave_exchange(unsigned* flags, unsigned epoch, int wg, bool fast, int* fail) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0) {
     if (fast) __hip_atomic_store(flags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -68,11 +73,12 @@ __device__ __forceinline__ void wave_exchange(unsigned* flags, unsigned epoch, i
   while (true) {
     if (!ok) ok = (int)(ld_flag(flags + threadIdx.x) - epoch) >= 0;
     if (__all(ok)) break;
-    if (++spins > (1u << 24)) {          // a partner that never became resident must not hang the GPU -- and is reported
+    if (++spins > (1u << 20)) {
       if (fail && threadIdx.x == 0) atomicAdd(fail + 1, 1);
-      break;
+      return false;
     }
   }
+  return true;
 }
 
 template <int V>
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
   // everybody has read row 0 and its own rows before a reflector overwrites a row of the input; placement check
   if (lane == 0) __hip_atomic_store(xids + wg, 1u + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   epoch += 1;
-  wave_exchange(xflags, epoch, wg, false, fail);
+  if (!wave_exchange(xflags, epoch, wg, false, fail)) return;
   const bool fast = one_xcd != 0 && __all(ld_flag(xids + lane) == 1u + xcc_id());
   auto put = [&](double* p, double v) __attribute__((always_inline)) {
     if (fast) st_xcd(p, v);
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) vprev[ch] = wprev[ch] = vcur[ch] = 0.0;
   double beta = 0.0, v0 = 0.0, e2 = 0.0;
+  bool dead = false;                 // an exchange timed out (wave-uniform): leave
   // Reflector of the row held in cc = row s1 = 64 C0 + ls (chunks C0 ..): x = cc[c > s1]; x0 = x[s1 + 1] and diag = cc[s1] come
   // as scalars.  v = x with v[s1 + 1] = x0 - alpha -> vcur (zero up to column s1), beta = 2 / v.v, and e2 = x[s1 + 2] as a
   // scalar for the next step.
@@ -234,7 +241,10 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
       if (lane < NCH && r > s && r < n) put(&Pb[par * NP + r], beta * tot);
     }
     epoch += 1;
-    wave_exchange(xflags, epoch, wg, fast, fail);
+    if (!wave_exchange(xflags, epoch, wg, fast, fail)) {
+      dead = true;
+      return;
+    }
     // gather beta A v and row s + 1 (left of column s + 1 they are stale: masked), and the entries s + 1, s + 2 of both once
     // more as wave-uniform scalars (vector loads of one address: the scalar cache is not coherent)
     double p[NCH];
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
       const int lo = C0 == 0 ? 1 : 0;                       // s = 64 C0 + ls - 1 >= 0
       int hi = n - 2 - 64 * C0;                             // s <= n - 3
       if (hi > 63) hi = 63;
-      for (int ls = lo; ls <= hi; ++ls) step(C0c, ls);
+      for (int ls = lo; ls <= hi && !dead; ++ls) step(C0c, ls);
     }
   };
   chunk_steps(IC<0>{});
@@ -300,8 +310,9 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
   // Epilogue: the back-transformation (tri_vec_kernel) applies the reflectors in groups of VG with the compact-WY recurrence and
   // needs the products v_a . v_b inside every group -- 64 waves are here with nothing left to do: wave w takes the groups w and
   // w + 64 (group g = reflectors j = n-3 - VG g - q, q = 0 .. VG-1): six products, one transposed wave reduction.  gram[g][GW].
+  if (dead) return;
   epoch += 1;
-  wave_exchange(xflags, epoch, wg, fast, fail);            // every reflector is in memory / the L2
+  if (!wave_exchange(xflags, epoch, wg, fast, fail)) return;       // every reflector is in memory / the L2
   const int ngroups = (n - 2 + VG - 1) / VG;
   for (int g = wg; g < ngroups; g += WW) {
     double v[VG][NCH];
@@ -704,6 +715,19 @@ int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf,
   VIPMI_REQUIRE(tri_wave_supported(n), "tri_wave_reduce: unsupported size %d", n);
   const int nch = (int)cdiv(n, 64);
   const dim3 grid(xcd_slot ? 8 * WW : WW), block(64);
+  // One wave kernel at a time per device (process-wide): its 64 waves spin on each other, and two launches that became resident
+  // only in part at the same moment (several host threads, each on its own stream) could fill an XCD and wait for waves that no
+  // longer fit -- until the time-out.  Every launch waits for the event the previous one recorded; a lone caller never waits.
+  static std::mutex order_mu;
+  static std::map<int, std::pair<std::vector<hipEvent_t>, int>> order_ring;
+  std::lock_guard<std::mutex> order_lock(order_mu);
+  auto& ring = order_ring[ctx->device];
+  if (ring.first.empty()) {
+    ring.first.resize(8);
+    for (auto& e : ring.first) VIPMI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ring.second = -1;
+  }
+  if (ring.second >= 0) VIPMI_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ring.first[ring.second], 0));
   switch (nch) {
     case 3: hipLaunchKernelGGL(tri_wave_kernel<3>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
     case 4: hipLaunchKernelGGL(tri_wave_kernel<4>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
@@ -712,6 +736,8 @@ int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf,
     default: hipLaunchKernelGGL(tri_wave_kernel<7>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
   }
   VIPMI_CHECK_HIP(hipGetLastError());
+  ring.second = (ring.second + 1) % (int)ring.first.size();
+  VIPMI_CHECK_HIP(hipEventRecord(ring.first[ring.second], ctx->stream));
   return VIPMI_OK;
 }
 
