@@ -1470,7 +1470,11 @@ int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k
   // (up to 200 rows the register-resident single-workgroup variant is the faster one even for a lone problem:
   // 0.31 / 0.82 ms against 0.42 / 0.93 ms at n = 100 / 200)
   const bool reg1 = ctx->opt("eigh_reg", 1) != 0 && reg_variant_fits((int)n, (int)k);
-  const bool multi = !nact && n >= 96 && batch <= 8 && !reg1 && ctx->opt("eigh_multi", 1) != 0;
+  // (a lone synchronous problem of 129 .. 200 rows: the wave-resident path of launch_tri_multi beats the register-resident
+  //  single-workgroup kernel as well -- n = 200, k = 10: 0.82 -> see tools/eigh_wave_check.py)
+  const bool wave1 = batch == 1 && !nact && tri_wave_supported(n) && ctx->opt("eigh_wave", 1) != 0 && ctx->opt("eigh_check", 1) != 0 &&
+                     ctx->opt("eigh_one_xcd", -1) != 0 && ctx->num_cu % 8 == 0 && ctx->num_cu >= 64;
+  const bool multi = !nact && n >= 96 && batch <= 8 && (!reg1 || wave1) && ctx->opt("eigh_multi", 1) != 0;
   if (multi) {
     if (n <= 128) return launch_tri_multi<2>(ctx, A, batch, (int)n, (int)k, evals, evecs, all_evals);
     if (n <= 256) return launch_tri_multi<4>(ctx, A, batch, (int)n, (int)k, evals, evecs, all_evals);
