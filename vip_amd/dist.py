@@ -263,21 +263,27 @@ def _mark(name):
     _phases["last"] = now
 
 
-def _all_to_all(send_chunks, recv_shapes, dtype, dev):
+def _all_to_all(send_chunks, recv_shapes, dtype, dev, out=None):
     """send_chunks[r] goes to rank r; returns the list of chunks received (recv_shapes[r] from rank r).
-    RCCL: one all_to_all over the xGMI links; gloo (CPU tests) has no all_to_all, so pairwise isend/irecv."""
+    RCCL: one all_to_all over the xGMI links; gloo (CPU tests) has no all_to_all, so pairwise isend/irecv.
+    out: optional list of preallocated CONTIGUOUS receive buffers (views of the tensor the caller assembles the chunks in:
+    saves the concatenation pass).  World 1: nothing moves -- the chunk itself is returned (a view; round 3 copied it and the
+    caller concatenated it again: 2 x 7 ms of the 174 ms of a C5 call on one GPU)."""
     import torch
     dist = _dist()
     rank, world = world_info()
-    cdev = _comm_device() if world > 1 else dev
+    if world == 1:
+        return [send_chunks[0]]
+    cdev = _comm_device()
     if torch.device(dev) != cdev:                 # gloo with device tensors: stage through the host
         got = _all_to_all([c.to(cdev) for c in send_chunks], recv_shapes, dtype, cdev)
+        if out is not None:
+            for o, g in zip(out, got):
+                o.copy_(g)
+            return out
         return [g.to(dev) for g in got]
-    recv = [torch.empty(s, dtype=dtype, device=dev) for s in recv_shapes]
+    recv = out if out is not None else [torch.empty(s, dtype=dtype, device=dev) for s in recv_shapes]
     send = [c.contiguous() for c in send_chunks]
-    if world == 1:
-        recv[0].copy_(send[0])
-        return recv
     if dist.get_backend() == "nccl":
         dist.all_to_all(recv, send)
         return recv
@@ -407,7 +413,7 @@ def pca_single_cube(cube, angle_list, ncomp, collapse="median", ops=None):
     send = [R3[a:b] for (a, b) in frs]
     recv_shapes = [(f1 - f0, r1 - r0, x) for (r0, r1) in rows]
     parts = _all_to_all(send, recv_shapes, R.dtype, dev)
-    frames = torch.cat(parts, dim=1)                                           # (f1-f0, y, x)
+    frames = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)          # (f1-f0, y, x)
     _mark("all_to_all 1 (pixel slabs -> whole frames)")
     return _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, dev)
 
@@ -488,8 +494,13 @@ def _derotate_exchange_collapse(frames, angle_list, frs, rows, collapse, ops, de
     # 5. whole frames -> slabs of all frames
     send = [der[:, r0:r1, :] for (r0, r1) in rows]
     recv_shapes = [(b - a, y1 - y0, x) for (a, b) in frs]
-    parts = _all_to_all(send, recv_shapes, der.dtype, dev)
-    slab = torch.cat(parts, dim=0).reshape(n, -1, 1)                           # (n, P_g, 1)
+    # (the chunk of rank r holds its frames [a, b) of this rank's rows: contiguous pieces of the slab -- received in place)
+    if world == 1:
+        slab = der.reshape(n, -1, 1)
+    else:
+        slab3 = torch.empty((n, y1 - y0, x), dtype=der.dtype, device=der.device)
+        _all_to_all(send, recv_shapes, der.dtype, dev, out=[slab3[a:b] for (a, b) in frs])
+        slab = slab3.reshape(n, -1, 1)                                         # (n, P_g, 1)
     _mark("all_to_all 2 (whole frames -> pixel slabs)")
     # 6. collapse own pixels, gather the frame
     mine = ops.collapse(slab, collapse).reshape(y1 - y0, x)
