@@ -834,6 +834,30 @@ def test_eigh_topk_wave_resident_tridiagonalisation(B):
         ctx.set_option("eigh_wave", 1)
 
 
+def test_eigh_wave_time_out_is_loud(B):
+    """The 64 waves of the wave-resident reduction spin on each other; when one of them never becomes resident (here: the test
+    hook eigh_wave_drop launches one short) every wave runs into the time-out (~1 s) and leaves.  The caller must not get
+    plausible numbers: NaN eigenpairs, vipmi_check_deferred reports the barrier time-out, and the next call is unaffected."""
+    import torch
+    from vip_amd import _lib
+    rng = np.random.default_rng(3)
+    M = rng.standard_normal((300, 700))
+    G = M @ M.T
+    ctx = B.get_context()
+    good = B_eigh(G, 8)
+    try:
+        ctx.set_option("eigh_wave_drop", 1)
+        ev, ec = B_eigh(G, 8)
+        assert np.isnan(ev).all() and np.isnan(ec).all()
+        st = ctx.lib.vipmi_check_deferred(ctx.handle)
+        assert st != 0
+    finally:
+        ctx.set_option("eigh_wave_drop", 0)
+    assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0
+    again = B_eigh(G, 8)
+    assert np.array_equal(good[0], again[0]) and np.array_equal(good[1], again[1])
+
+
 def B_eigh(G, k):
     import torch
     from vip_amd import backend

@@ -212,7 +212,7 @@ int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf,
 // stages 2-5 from those arrays: eigenvalue (multisection), inverse iteration and back-transformation with one workgroup per
 // vector, then Gram-Schmidt + sign convention; leading k <= 64 pairs -> evals[k], evecs[k][n]
 int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double* det, const double* det2, const double* gram,
-                     double* evals, double* evecs);
+                     double* evals, double* evecs, const unsigned* bars);   // bars[4] != 0 (tri_wave_reduce timed out): NaN results
 // one larger problem (512 < n <= 2048): eigh_tri_large.hip
 bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,

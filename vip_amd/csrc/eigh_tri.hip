@@ -1355,7 +1355,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
     VIPMI_TRY(ws(ctx, "eigh_wave_det2", (size_t)3 * n + 8, &det2));
     VIPMI_TRY(tri_wave_reduce(ctx, A, n, det, gw, bars2, (int)(1 + (xcd_base.fetch_add(1u) & 7u)), fail, gram, det2));
     // the leading pairs alone: one workgroup per vector (eigh_wave.hip); with the rest of the spectrum: stages 2-5 of this kernel
-    if (!all_evals && k <= 64) return tri_wave_vectors(ctx, A, n, k, det, det2, gram, evals, evecs);
+    if (!all_evals && k <= 64) return tri_wave_vectors(ctx, A, n, k, det, det2, gram, evals, evecs, bars2);
     hipLaunchKernelGGL(kern, dim3(W, 1), dim3(TNT), lds, ctx->stream, A, n, k, RW, VW, (int)rows_d, all_evals, evals, evecs, gbuf,
                        bars, 0, fail, (const double*)det);
     VIPMI_CHECK_HIP(hipGetLastError());

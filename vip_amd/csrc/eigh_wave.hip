@@ -74,7 +74,10 @@ __device__ __forceinline__ bool wave_exchange(unsigned* flags, unsigned epoch, i
     if (!ok) ok = (int)(ld_flag(flags + threadIdx.x) - epoch) >= 0;
     if (__all(ok)) break;
     if (++spins > (1u << 20)) {
-      if (fail && threadIdx.x == 0) atomicAdd(fail + 1, 1);
+      if (threadIdx.x == 0) {
+        if (fail) atomicAdd(fail + 1, 1);
+        __hip_atomic_store(flags - 8 + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bar[4]: this call is void
+      }
       return false;
     }
   }
@@ -485,6 +488,7 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
     if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
     const double invlast = tri::fast_rcp(p);
     double rs = 1.0;
+    VSTAMP(4);
     for (int it = 0; it < 2; ++it) {
       if (it > 0) {
         yc = Zl[0] * rs;
@@ -510,6 +514,7 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
           }
         }
       }
+      if (it > 0) VSTAMP(5);
       double x1 = yc * invlast, x2 = 0.0;
       Zl[n - 1] = x1;
       double acc = x1 * x1;
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
 #ifdef VIPMI_TRI_PROFILE
   VSTAMP(3);
   if (c == 0 && lane == 0)
-    for (int i = 0; i < 4; ++i) evals[n - 16 + i] = (double)(pst[i] - pst[0]);
+    for (int i = 0; i < 6; ++i) evals[n - 16 + i] = (double)(pst[i] - pst[0]);
 #endif
 }
 
@@ -618,11 +623,20 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
 // nearly parallel), sign convention (largest-magnitude component positive).  One workgroup: vector c in wave c mod 16, slot
 // c div 16 (registers), the current vector broadcast through LDS.
 template <int NCH>
-__global__ __launch_bounds__(1024) void tri_mgs_kernel(int n, int k, double* __restrict__ evals, double* __restrict__ evecs) {
+__global__ __launch_bounds__(1024) void tri_mgs_kernel(int n, int k, double* __restrict__ evals, double* __restrict__ evecs,
+                                                       const unsigned* __restrict__ bar) {
   constexpr int NP = 64 * NCH, NW = 16, VPW = 4;
   __shared__ double qv[NP];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = k < n ? k : n;
+  if (bar[4] != 0u) {
+    // the reduction timed out (its 64 waves were not co-resident: another kernel held their CUs for a second): the failure is
+    // latched for vipmi_check_deferred, and a synchronous caller that never asks must not get plausible numbers -- NaN
+    const double bad = __longlong_as_double(0x7ff8000000000000ll);
+    for (int e = tid; e < k * n; e += 1024) evecs[e] = bad;
+    for (int e = tid; e < k; e += 1024) evals[e] = bad;
+    return;
+  }
   double zz[VPW][NCH];
 #pragma unroll
   for (int v = 0; v < VPW; ++v) {
@@ -714,7 +728,10 @@ int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf,
                     double* det2) {
   VIPMI_REQUIRE(tri_wave_supported(n), "tri_wave_reduce: unsupported size %d", n);
   const int nch = (int)cdiv(n, 64);
-  const dim3 grid(xcd_slot ? 8 * WW : WW), block(64);
+  // (test hook, option eigh_wave_drop = 1: launch one participant short -- every exchange then runs into its time-out, which is
+  //  how tests/test_gpu_kernels.py exercises the failure path: NaN results, latched error, the next call unaffected)
+  const int drop = ctx->opt("eigh_wave_drop", 0) != 0 ? 1 : 0;
+  const dim3 grid(xcd_slot ? 8 * (WW - drop) : WW - drop), block(64);
   // One wave kernel at a time per device (process-wide): its 64 waves spin on each other, and two launches that became resident
   // only in part at the same moment (several host threads, each on its own stream) could fill an XCD and wait for waves that no
   // longer fit -- until the time-out.  Every launch waits for the event the previous one recorded; a lone caller never waits.
@@ -743,29 +760,29 @@ int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf,
 
 // Stages 2-5 after tri_wave_reduce: the leading k eigenpairs (k <= 64), one workgroup per vector, then the Gram-Schmidt pass.
 int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double* det, const double* det2, const double* gram,
-                     double* evals, double* evecs) {
+                     double* evals, double* evecs, const unsigned* bars) {
   VIPMI_REQUIRE(tri_wave_supported(n) && k >= 1 && k <= 64, "tri_wave_vectors: unsupported sizes n=%d k=%d", n, k);
   const int nch = (int)cdiv(n, 64), kk = k < n ? k : n;
   switch (nch) {
     case 3:
       hipLaunchKernelGGL(tri_vec_kernel<3>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
-      hipLaunchKernelGGL(tri_mgs_kernel<3>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<3>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs, bars);
       break;
     case 4:
       hipLaunchKernelGGL(tri_vec_kernel<4>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
-      hipLaunchKernelGGL(tri_mgs_kernel<4>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<4>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs, bars);
       break;
     case 5:
       hipLaunchKernelGGL(tri_vec_kernel<5>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
-      hipLaunchKernelGGL(tri_mgs_kernel<5>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<5>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs, bars);
       break;
     case 6:
       hipLaunchKernelGGL(tri_vec_kernel<6>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
-      hipLaunchKernelGGL(tri_mgs_kernel<6>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<6>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs, bars);
       break;
     default:
       hipLaunchKernelGGL(tri_vec_kernel<7>, dim3(kk), dim3(256), 0, ctx->stream, A, n, det, det2, gram, evals, evecs);
-      hipLaunchKernelGGL(tri_mgs_kernel<7>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs);
+      hipLaunchKernelGGL(tri_mgs_kernel<7>, dim3(1), dim3(1024), 0, ctx->stream, n, k, evals, evecs, bars);
       break;
   }
   VIPMI_CHECK_HIP(hipGetLastError());
