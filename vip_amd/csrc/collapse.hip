@@ -119,7 +119,7 @@ __device__ __forceinline__ int lane_rank_in(unsigned long long mask) {   // set 
 template <int RPL>
 __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, unsigned* __restrict__ hist, int lane,
                                             unsigned& klow, unsigned& khigh) {
-  // hist: HIST_WORDS words of LDS private to the wave: 256 bins, one dump bin for the keys outside the current range
+  // hist: HIST_WORDS words of LDS private to the wave: 256 bins, then (from word 257) one dump word per lane for the keys outside the current range
   // (keeps the loops free of divergent branches), then 64 dump slots for the lanes that have no candidate to store
   const int k = (m - 1) >> 1;
   const bool even = (m & 1) == 0;
@@ -154,16 +154,18 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
     const float scale = 256.0f / (fhi - flo);
     if (!(scale > 0.f && scale < 3.0e38f)) break;          // range overflows / underflows: bisection
     reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
-    if (lane == 0) hist[256] = 0u;
     wave_lds_sync();
-    // bin of every key (256 = outside the range) and, from the returning atomic, its ordinal inside the bin
+    // bin of every key (>= 257: outside the range) and, from the returning atomic, its ordinal inside the bin
     int bin[RPL];
     unsigned ord[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
       int b = (int)((key2f(key[r]) - flo) * scale);
       b = b > 255 ? 255 : b;
-      bin[r] = (key[r] >= lo && key[r] <= hi) ? b : 256;
+      // outside the range: a dump word of the lane's own (257 + lane).  ONE shared dump bin made every atomic of a second level
+      // a 64-way same-address collision (at level >= 1 nearly all keys are outside the range): real residual cubes, where a fifth
+      // of the pixels need a second level, paid for it -- C5 10.5 ms against 5.8 on Gaussian noise (tools/time_median_c5.py)
+      bin[r] = (key[r] >= lo && key[r] <= hi) ? b : 257 + lane;
     }
 #pragma unroll
     for (int r = 0; r < RPL; ++r) ord[r] = atomicAdd(&hist[bin[r]], 1u);
