@@ -147,12 +147,13 @@ inline int ws(vipmi_ctx* ctx, const char* name, size_t count, T** out) {
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // The context's deferred-failure words on the device: [0] eigenproblems that did not converge, [1] inter-workgroup barriers that
-// timed out (a co-resident partner never arrived: results of that launch are invalid).  Read and cleared by vipmi_check_deferred;
+// timed out ([2]: scratch of the barriers themselves, wave_util.h barrier_gave_up) (a co-resident partner never arrived: results of that launch are invalid).  Read and cleared by vipmi_check_deferred;
 // vipmi_trim latches them on the host before it frees the buffer.
 inline int deferred_fail_words(vipmi_ctx* ctx, int** out) {
   const bool fresh = ctx->buffers.find("deferred_fail") == ctx->buffers.end();
   VIPMI_TRY(ws(ctx, "deferred_fail", 4, out));
   if (fresh) VIPMI_CHECK_HIP(hipMemsetAsync(*out, 0, 4 * sizeof(int), ctx->stream));
+  else VIPMI_CHECK_HIP(hipMemsetAsync(*out + 2, 0, sizeof(int), ctx->stream));    // [2]: "the current launch gave up a barrier"
   return VIPMI_OK;
 }
 
@@ -202,6 +203,20 @@ int lincomb_f32(vipmi_ctx* ctx, const float* x, const float* y, float a, float b
 int bgemm_abt_f32(vipmi_ctx* ctx, const float* A0, const float* B0, const float* A1, const float* B1,
                   const int32_t* ia, const int32_t* ib, int64_t nbatch, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc, float* C);
+// Launches whose workgroups WAIT FOR EACH OTHER inside one XCD (the one-XCD layout of tri_multi_kernel: up to 32 whole-CU
+// workgroups = the whole XCD; tri_wave_kernel: 64 spinning waves) must not overlap with another such launch on the same XCD: two of
+// them, each resident in part, wait for workgroups that no longer fit -- until the barrier time-out.  Several host threads on
+// their own streams can produce exactly that (the XCD rotates per launch, but two of four concurrent launches share one more
+// often than not).  CoopOrder chains such launches per device: the constructor makes the context's stream wait for the event the
+// previous one recorded, done() records this one's.  A lone caller never waits; the lock is held only while enqueuing.
+struct CoopOrder {
+  vipmi_ctx* ctx;
+  int status;
+  bool locked;
+  explicit CoopOrder(vipmi_ctx* c);
+  int done();
+  ~CoopOrder();
+};
 // Householder tridiagonalisation of one matrix of 129 .. 448 rows on 64 cooperating single-wave workgroups, matrix in registers
 // (eigh_wave.hip): d, e, tau -> det[3][n], reflectors in the rows of A.  bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8
 // doubles; xcd_slot = 1 + XCD the waves sit on (0 = spread over the chip, agent-scope exchange); fail: deferred-failure words.

@@ -18,6 +18,7 @@
 // component positive.  Zero-padded problems (annular PCA: library sizes differ per frame) pass their active size.
 #include "common.h"
 #include <atomic>
+#include <memory>
 #include <unistd.h>
 #include "wave_util.h"
 #include "tri_common.h"
@@ -1361,6 +1362,12 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
     VIPMI_CHECK_HIP(hipGetLastError());
     return VIPMI_OK;
   }
+  // one-XCD layout: ordered against every other cooperating one-XCD launch of the device (common.h: CoopOrder)
+  std::unique_ptr<CoopOrder> order;
+  if (one_xcd) {
+    order.reset(new CoopOrder(ctx));
+    VIPMI_TRY(order->status);
+  }
   for (int64_t p0 = 0; p0 < batch; p0 += per_launch) {
     const int64_t nb = batch - p0 < per_launch ? batch - p0 : per_launch;
     hipLaunchKernelGGL(kern, dim3(one_xcd ? 8 * W : W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW,
@@ -1369,6 +1376,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
                        (const double*)nullptr);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
+  if (order) return order->done();
   return VIPMI_OK;
 }
 

@@ -75,7 +75,10 @@ __device__ __forceinline__ bool wave_exchange(unsigned* flags, unsigned epoch, i
     if (__all(ok)) break;
     if (++spins > (1u << 20)) {
       if (threadIdx.x == 0) {
-        if (fail) atomicAdd(fail + 1, 1);
+        if (fail) {
+          atomicAdd(fail + 1, 1);
+          __hip_atomic_store(fail + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __hip_atomic_store(flags - 8 + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bar[4]: this call is void
       }
       return false;
@@ -719,6 +722,40 @@ __global__ __launch_bounds__(1024) void tri_mgs_kernel(int n, int k, double* __r
 
 }  // namespace
 
+// ---- launches whose workgroups wait for each other, ordered per device (common.h: CoopOrder) ----
+namespace {
+std::mutex coop_mu;
+std::map<int, std::pair<std::vector<hipEvent_t>, int>> coop_ring;
+}  // namespace
+
+CoopOrder::CoopOrder(vipmi_ctx* c) : ctx(c), status(VIPMI_OK), locked(false) {
+  coop_mu.lock();
+  locked = true;
+  auto& ring = coop_ring[ctx->device];
+  if (ring.first.empty()) {
+    ring.first.resize(8);
+    for (auto& e : ring.first)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) status = VIPMI_ERR_HIP;
+    ring.second = -1;
+  }
+  if (status == VIPMI_OK && ring.second >= 0 && hipStreamWaitEvent(ctx->stream, ring.first[ring.second], 0) != hipSuccess)
+    status = VIPMI_ERR_HIP;
+}
+int CoopOrder::done() {
+  auto& ring = coop_ring[ctx->device];
+  int st = status;
+  if (st == VIPMI_OK) {
+    ring.second = (ring.second + 1) % (int)ring.first.size();
+    if (hipEventRecord(ring.first[ring.second], ctx->stream) != hipSuccess) st = VIPMI_ERR_HIP;
+  }
+  if (locked) coop_mu.unlock();
+  locked = false;
+  return st;
+}
+CoopOrder::~CoopOrder() {
+  if (locked) coop_mu.unlock();
+}
+
 bool tri_wave_supported(int64_t n) { return n >= 129 && n <= 448; }
 
 // Tridiagonalise A (n x n, symmetric, float64, destroyed): d, e, tau -> det[3][n], reflector s in A[s][s+1 ..], the products of the
@@ -735,16 +772,8 @@ int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf,
   // One wave kernel at a time per device (process-wide): its 64 waves spin on each other, and two launches that became resident
   // only in part at the same moment (several host threads, each on its own stream) could fill an XCD and wait for waves that no
   // longer fit -- until the time-out.  Every launch waits for the event the previous one recorded; a lone caller never waits.
-  static std::mutex order_mu;
-  static std::map<int, std::pair<std::vector<hipEvent_t>, int>> order_ring;
-  std::lock_guard<std::mutex> order_lock(order_mu);
-  auto& ring = order_ring[ctx->device];
-  if (ring.first.empty()) {
-    ring.first.resize(8);
-    for (auto& e : ring.first) VIPMI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ring.second = -1;
-  }
-  if (ring.second >= 0) VIPMI_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ring.first[ring.second], 0));
+  CoopOrder order(ctx);
+  VIPMI_TRY(order.status);
   switch (nch) {
     case 3: hipLaunchKernelGGL(tri_wave_kernel<3>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
     case 4: hipLaunchKernelGGL(tri_wave_kernel<4>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
@@ -753,9 +782,7 @@ int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf,
     default: hipLaunchKernelGGL(tri_wave_kernel<7>, grid, block, 0, ctx->stream, A, n, det, gbuf, bars, xcd_slot, fail, gram, det2); break;
   }
   VIPMI_CHECK_HIP(hipGetLastError());
-  ring.second = (ring.second + 1) % (int)ring.first.size();
-  VIPMI_CHECK_HIP(hipEventRecord(ring.first[ring.second], ctx->stream));
-  return VIPMI_OK;
+  return order.done();
 }
 
 // Stages 2-5 after tri_wave_reduce: the leading k eigenpairs (k <= 64), one workgroup per vector, then the Gram-Schmidt pass.

@@ -90,6 +90,25 @@ __device__ __forceinline__ void st_shared(double* p, double v) {
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Bounded spinning.  A partner that never became resident must not hang the GPU: after 2^22 polls (seconds) the wait is given up,
+// which is latched in the context's deferred-failure words (fail[1]: vipmi_check_deferred) -- and in fail[2], "this launch is
+// dead" (cleared by deferred_fail_words() before every launch): every later barrier of the launch looks at that word once per 1024
+// polls and gives up at once, so a dead launch drains in milliseconds instead of timing out again at each of its ~n steps
+// (round 4: one such launch held the GPU for the rest of a test run).
+__device__ __forceinline__ bool barrier_gave_up(unsigned spins, int* report, int* fail = nullptr) {
+  int* f = fail ? fail : report;
+  if (!f) return spins > (1u << 22);
+  if ((spins & 1023u) == 0u && __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+  if (spins > (1u << 22)) {
+    if (report) {
+      atomicAdd(report + 1, 1);
+      __hip_atomic_store(report + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+  }
+  return false;
+}
+
 __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, int nwg, int* fail = nullptr) {
   if (nwg == 1) {
     __syncthreads();
@@ -102,10 +121,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target,
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 28)) {        // bounded spin: a lost workgroup must not hang the GPU -- but the caller must hear of
-        if (fail) atomicAdd(fail + 1, 1);   // it: latched in the context's deferred-failure words (vipmi_check_deferred)
-        break;
-      }
+      if (barrier_gave_up(++spins, fail)) break;
     }
   }
   __syncthreads();
@@ -137,10 +153,7 @@ __device__ __forceinline__ void xcd_barrier(unsigned* flags, unsigned epoch, int
     while (true) {
       if (!ok) ok = (int)(__hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0;
       if (__all(ok)) break;
-      if (++spins > (1u << 28)) {                    // bounded spin: a lost workgroup must not hang the GPU (and is reported)
-        if (fail && threadIdx.x == 0) atomicAdd(fail + 1, 1);
-        break;
-      }
+      if (__any(barrier_gave_up(++spins, threadIdx.x == 0 ? fail : nullptr, fail))) break;
     }
   }
   __syncthreads();
