@@ -149,11 +149,11 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // The context's deferred-failure words on the device: [0] eigenproblems that did not converge, [1] inter-workgroup barriers that
 // timed out ([2]: scratch of the barriers themselves, wave_util.h barrier_gave_up) (a co-resident partner never arrived: results of that launch are invalid).  Read and cleared by vipmi_check_deferred;
 // vipmi_trim latches them on the host before it frees the buffer.
-inline int deferred_fail_words(vipmi_ctx* ctx, int** out) {
+inline int deferred_fail_words(vipmi_ctx* ctx, int** out, bool clear_gave_up = true) {
   const bool fresh = ctx->buffers.find("deferred_fail") == ctx->buffers.end();
   VIPMI_TRY(ws(ctx, "deferred_fail", 4, out));
   if (fresh) VIPMI_CHECK_HIP(hipMemsetAsync(*out, 0, 4 * sizeof(int), ctx->stream));
-  else VIPMI_CHECK_HIP(hipMemsetAsync(*out + 2, 0, sizeof(int), ctx->stream));    // [2]: "the current launch gave up a barrier"
+  else if (clear_gave_up) VIPMI_CHECK_HIP(hipMemsetAsync(*out + 2, 0, sizeof(int), ctx->stream));    // [2]: "the current launch gave up a barrier"
   return VIPMI_OK;
 }
 

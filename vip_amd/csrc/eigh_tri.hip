@@ -1318,7 +1318,11 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   unsigned* bars = nullptr;
   VIPMI_TRY(ws(ctx, "eigh_tri_gbuf", (size_t)batch * 5 * n, &gbuf));
   VIPMI_TRY(ws(ctx, "eigh_tri_bars", (size_t)batch * TRI_BAR_WORDS, &bars));
-  VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch * TRI_BAR_WORDS, ctx->stream));
+  // (the wave-resident path below needs neither this buffer nor the barriers' give-up word unless the whole spectrum is asked for:
+  //  two fills less in front of a 1 ms solve)
+  const bool wave_only = lone && tri_wave_supported(n) && ctx->opt("eigh_wave", 1) != 0 && !all_evals && k <= 64 &&
+                         W <= 64 && W <= ctx->num_cu / 8 && ctx->opt("eigh_one_xcd", -1) != 0;
+  if (!wave_only) VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch * TRI_BAR_WORDS, ctx->stream));
   size_t rows_d = (size_t)RW * n;
   const int VW = (int)cdiv(k, W);
   const size_t inv_d = (size_t)6 * n * VW;             // phase-3 scratch aliases the rows region
@@ -1340,7 +1344,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   const int one_xcd = xcd_ok && (want_xcd > 0 || (want_xcd < 0 && ctx->opt("eigh_check", 1) != 0)) ? 1 : 0;
   const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
   int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
-  VIPMI_TRY(deferred_fail_words(ctx, &fail));
+  VIPMI_TRY(deferred_fail_words(ctx, &fail, !wave_only));
   // A lone synchronous problem of 129 .. 448 rows: the tridiagonalisation on 64 single-wave workgroups of one XCD with the
   // matrix in registers (eigh_wave.hip), then stages 2-5 of this kernel as a second launch (option eigh_wave = 0: off)
   if (lone && one_xcd && tri_wave_supported(n) && ctx->opt("eigh_wave", 1) != 0) {

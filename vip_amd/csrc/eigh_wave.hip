@@ -75,10 +75,7 @@ __device__ __forceinline__ bool wave_exchange(unsigned* flags, unsigned epoch, i
     if (__all(ok)) break;
     if (++spins > (1u << 20)) {
       if (threadIdx.x == 0) {
-        if (fail) {
-          atomicAdd(fail + 1, 1);
-          __hip_atomic_store(fail + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (fail) atomicAdd(fail + 1, 1);
         __hip_atomic_store(flags - 8 + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bar[4]: this call is void
       }
       return false;
