@@ -441,50 +441,69 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
     lam_c = 0.5 * (a + b);
   }
   VSTAMP(1);
-  // ---- 3. inverse iteration (one lane; the start vector is tabulated by everybody first) ----
-  for (int i = tid; i < n; i += 256) Zl[i] = tri::hash_unit((unsigned)i, (unsigned)c);
+  // ---- 3. inverse iteration (one lane; the start vector and 1 / e are tabulated by everybody first) ----
+  // The pass is a chain of n dependent rows on ONE lane, and every instruction costs its 4+ cycles whether 1 or 64 lanes are
+  // active: what counts is the instruction count per row.  Rows come in blocks of eight with their operands fetched up front; the
+  // pivoting is a (wave-uniform) branch with a handful of instructions on each side -- as selects it was ~75 instructions and ~500
+  // cycles per row; the swap branch divides by the sub-diagonal, whose reciprocal is tabulated (IE): no reciprocal on its chain.
+  __shared__ double IEs[NP];
+  for (int i = tid; i < n; i += 256) {
+    Zl[i] = tri::hash_unit((unsigned)i, (unsigned)c);
+    IEs[i] = tri::fast_rcp(ee[i]);
+  }
   __syncthreads();
   if (tid == 0) {
     const double lc = lam_c - (double)(c + 1) * 4.0 * TEPS;
     const double ptiny = 1e-3 * TEPS;
-    double p = dd[0] - lc, q = (n > 1) ? ee[0] : 0.0, r = 0.0;
+    double p = dd[0] - lc, q = (n > 1) ? ee[0] : 0.0;
     double yc = Zl[0];
     constexpr int BL = 8;
-    for (int i0 = 0; i0 + 1 < n; i0 += BL) {
-      double sb[BL], db[BL], ub[BL], yb[BL];
+    auto lu_row = [&](int i, double sub, double nd, double nu, double yn, double isub) __attribute__((always_inline)) {
+      double inv, m, u1, u2, yi, sw;
+      if (fabs(sub) > fabs(p) && fabs(sub) >= ptiny) {      // interchange: the pivot is the sub-diagonal entry
+        inv = isub;
+        m = p * inv;
+        u1 = nd;
+        u2 = nu;
+        yi = yn;
+        yc = yc - m * yn;
+        p = q - m * nd;
+        q = -(m * nu);
+        sw = 1.0;
+      } else {
+        if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
+        inv = tri::fast_rcp(p);
+        m = sub * inv;
+        u1 = q;
+        u2 = 0.0;
+        yi = yc;
+        yc = yn - m * yc;
+        p = nd - m * q;
+        q = nu;
+        sw = 0.0;
+      }
+      U0[i] = inv;
+      U1[i] = u1;
+      U2[i] = u2;
+      Lm[i] = m;
+      Ls[i] = sw;
+      Zl[i] = yi;
+    };
+    const int nrow = n - 1, nfull = nrow / BL * BL;         // rows 0 .. n-2
+    for (int i0 = 0; i0 < nfull; i0 += BL) {
+      double sb[BL], db[BL], ub[BL], yb[BL], ib[BL];
 #pragma unroll
-      for (int u = 0; u < BL; ++u) {                        // operands of BL steps up front (LDS round trips off the chain)
-        const int i = i0 + u;
-        sb[u] = ee[min(i, n - 1)];
-        db[u] = dd[min(i + 1, n - 1)];
-        ub[u] = (i + 2 < n) ? ee[min(i + 1, n - 1)] : 0.0;
-        yb[u] = Zl[min(i + 1, n - 1)];
+      for (int u = 0; u < BL; ++u) {                        // (i0 + u + 1 <= n - 1: in range; e[n-1] = 0 is the missing super-diagonal)
+        sb[u] = ee[i0 + u];
+        db[u] = dd[i0 + u + 1];
+        ub[u] = ee[i0 + u + 1];
+        yb[u] = Zl[i0 + u + 1];
+        ib[u] = IEs[i0 + u];
       }
 #pragma unroll
-      for (int u = 0; u < BL; ++u) {
-        const int i = i0 + u;
-        if (i + 1 < n) {
-          const double sub = sb[u], nd = db[u] - lc, nu = ub[u], yn = yb[u];
-          const bool sw = fabs(sub) > fabs(p) && fabs(sub) >= ptiny;
-          double pp = p;
-          if (!sw && fabs(pp) < ptiny) pp = (pp < 0.0) ? -ptiny : ptiny;
-          const double inv = tri::fast_rcp(sw ? sub : pp);
-          const double m = (sw ? pp : sub) * inv;
-          const double u1 = sw ? nd : q, u2 = sw ? nu : r;
-          const double yi = sw ? yn : yc;
-          yc = sw ? (yc - m * yn) : (yn - m * yc);
-          p = sw ? (q - m * nd) : (nd - m * q);
-          q = sw ? (r - m * nu) : (nu - m * r);
-          r = 0.0;
-          U0[i] = inv;
-          U1[i] = u1;
-          U2[i] = u2;
-          Lm[i] = m;
-          Ls[i] = sw ? 1.0 : 0.0;
-          Zl[i] = yi;
-        }
-      }
+      for (int u = 0; u < BL; ++u) lu_row(i0 + u, sb[u], db[u] - lc, ub[u], yb[u], ib[u]);
     }
+    for (int i = nfull; i < nrow; ++i) lu_row(i, ee[i], dd[i + 1] - lc, ee[i + 1], Zl[i + 1], IEs[i]);
     if (fabs(p) < ptiny) p = (p < 0.0) ? -ptiny : ptiny;
     const double invlast = tri::fast_rcp(p);
     double rs = 1.0;
@@ -492,54 +511,56 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
     for (int it = 0; it < 2; ++it) {
       if (it > 0) {
         yc = Zl[0] * rs;
-        for (int i0 = 0; i0 + 1 < n; i0 += BL) {
+        auto fw_row = [&](int i, double zn, double m, double sw) __attribute__((always_inline)) {
+          const double yn = zn * rs;
+          double yi;
+          if (sw != 0.0) {
+            yi = yn;
+            yc = yc - m * yn;
+          } else {
+            yi = yc;
+            yc = yn - m * yc;
+          }
+          Zl[i] = yi;
+        };
+        for (int i0 = 0; i0 < nfull; i0 += BL) {
           double zb[BL], mb[BL], lb[BL];
 #pragma unroll
           for (int u = 0; u < BL; ++u) {
-            const int i = min(i0 + u, n - 2);
-            zb[u] = Zl[i + 1];
-            mb[u] = Lm[i];
-            lb[u] = Ls[i];
+            zb[u] = Zl[i0 + u + 1];
+            mb[u] = Lm[i0 + u];
+            lb[u] = Ls[i0 + u];
           }
 #pragma unroll
-          for (int u = 0; u < BL; ++u) {
-            const int i = i0 + u;
-            if (i + 1 < n) {
-              const double yn = zb[u] * rs, m = mb[u];
-              const bool sw = lb[u] != 0.0;
-              const double yi = sw ? yn : yc;
-              yc = sw ? (yc - m * yn) : (yn - m * yc);
-              Zl[i] = yi;
-            }
-          }
+          for (int u = 0; u < BL; ++u) fw_row(i0 + u, zb[u], mb[u], lb[u]);
         }
+        for (int i = nfull; i < nrow; ++i) fw_row(i, Zl[i + 1], Lm[i], Ls[i]);
+        VSTAMP(5);
       }
-      if (it > 0) VSTAMP(5);
       double x1 = yc * invlast, x2 = 0.0;
       Zl[n - 1] = x1;
       double acc = x1 * x1;
-      for (int i0 = n - 2; i0 >= 0; i0 -= BL) {
+      auto bw_row = [&](int i, double z, double a0, double a1, double a2) __attribute__((always_inline)) {
+        const double x = (z - a1 * x1 - a2 * x2) * a0;
+        Zl[i] = x;
+        acc += x * x;
+        x2 = x1;
+        x1 = x;
+      };
+      int i = n - 2;
+      for (; i >= BL - 1; i -= BL) {
         double zb[BL], a0[BL], a1[BL], a2[BL];
 #pragma unroll
         for (int u = 0; u < BL; ++u) {
-          const int i = max(i0 - u, 0);
-          zb[u] = Zl[i];
-          a0[u] = U0[i];
-          a1[u] = U1[i];
-          a2[u] = U2[i];
+          zb[u] = Zl[i - u];
+          a0[u] = U0[i - u];
+          a1[u] = U1[i - u];
+          a2[u] = U2[i - u];
         }
 #pragma unroll
-        for (int u = 0; u < BL; ++u) {
-          const int i = i0 - u;
-          if (i >= 0) {
-            const double x = (zb[u] - a1[u] * x1 - a2[u] * x2) * a0[u];
-            Zl[i] = x;
-            acc += x * x;
-            x2 = x1;
-            x1 = x;
-          }
-        }
+        for (int u = 0; u < BL; ++u) bw_row(i - u, zb[u], a0[u], a1[u], a2[u]);
       }
+      for (; i >= 0; --i) bw_row(i, Zl[i], U0[i], U1[i], U2[i]);
       rs = acc > 0.0 ? 1.0 / sqrt(acc) : 1.0;
     }
     red[0][0] = rs;                                         // normalisation of the final solution
