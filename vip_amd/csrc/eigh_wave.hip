@@ -602,13 +602,30 @@ __global__ __launch_bounds__(256) void tri_vec_kernel(const double* __restrict__
       y[q] = t;
     }
     const double tot = wave_sum4_scatter(y);                  // lane l: v_(l & 3) . z
-    const double* G = gram + (size_t)g * GW;
+    // the group's six products and four betas: two contiguous scalar loads, issued with the row loads (fetched one at a time
+    // where they are used, their latency sat four times in the recurrence's chain)
+    double Gv[6], tv[VG];
+    {
+      const double* G = gram + (size_t)g * GW;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Gv[i] = G[i];
+      const int jb = max(j0 - (VG - 1), 0);                   // betas of reflectors jb .. jb + 3 (the last group may start at 0)
+#pragma unroll
+      for (int i = 0; i < VG; ++i) tv[i] = tau[jb + i];
+#pragma unroll
+      for (int q = 0; q < VG; ++q) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < VG; ++i) t = (j0 - q - jb == i) ? tv[i] : t;
+        sc[q] = (j0 - q >= 0) ? t : 0.0;                     // (sc[q] holds beta_q until the recurrence overwrites it)
+      }
+    }
 #pragma unroll
     for (int q = 0; q < VG; ++q) {
       double d = readlane_f64(tot, q);
 #pragma unroll
-      for (int a = 0; a < q; ++a) d -= sc[a] * G[gram_idx(a, q)];
-      sc[q] = (j0 - q >= 0) ? tau[max(j0 - q, 0)] * d : 0.0;
+      for (int a = 0; a < q; ++a) d -= sc[a] * Gv[gram_idx(a, q)];
+      sc[q] = sc[q] * d;
     }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
