@@ -102,34 +102,13 @@ __device__ __forceinline__ int sturm_count_fast(const double* __restrict__ d, co
   unsigned sg = hi_word(p) >> 31;
   int cnt = (int)sg;
   int i0 = 1;
-  // The operands of the NEXT block are requested as soon as this block's have arrived: d and e2 are wave-uniform (scalar loads
-  // when they point to global memory), scalar loads return out of order and can only be waited for all at once -- requested at the
-  // top of their own block, their latency (~200 cycles) stood in front of every 16 steps.
-  double dn[16], en[16];
-  if (i0 + 16 <= n) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      dn[u] = d[i0 + u];
-      en[u] = e2[i0 + u - 1];
-    }
-  }
   for (; i0 + 16 <= n; i0 += 16) {
-    double db[16], eb[16], dr[16];
+    double db[16], eb[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      dr[u] = dn[u];
-      db[u] = dn[u] - sigma;
-      eb[u] = en[u];
+      db[u] = d[i0 + u] - sigma;
+      eb[u] = e2[i0 + u - 1];
     }
-    asm volatile("" ::: "memory");
-    if (i0 + 32 <= n) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        dn[u] = d[i0 + 16 + u];
-        en[u] = e2[i0 + 16 + u - 1];
-      }
-    }
-    asm volatile("" ::: "memory");
     double fp = p, fpm = pm;
     unsigned fsg = sg;
     bool zero = false;
@@ -143,7 +122,7 @@ __device__ __forceinline__ int sturm_count_fast(const double* __restrict__ d, co
     }
     if (__builtin_expect(__any(zero), 0)) {                 // redo the block with the careful step (wave-uniform branch)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) p = sturm_step(dr[u], eb[u], sigma, pm, p, sg);
+      for (int u = 0; u < 16; ++u) p = sturm_step(d[i0 + u], eb[u], sigma, pm, p, sg);
     } else {
       p = fp;
       pm = fpm;
