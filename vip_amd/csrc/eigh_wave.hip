@@ -18,8 +18,10 @@
 // Placement and visibility follow tri_multi_kernel's one-XCD path (wave_util.h): ids x (mod 8) of an 8 x wider grid, verified
 // with HW_REG_XCC_ID behind an agent-scope barrier; agent-scope stores when the check fails.  All 64 waves must be resident
 // at once (spin barrier): the launcher uses the kernel for lone synchronous calls only, spins are bounded and latched.
-// Output: d, e, tau in det[3][n] and the reflectors in the rows of A (row s, columns > s) -- exactly what stages 2-5 of
-// tri_multi_kernel (multisection, inverse iteration, back-transformation, Gram-Schmidt) start from.
+// Output: d, e, tau in det[3][n] and the reflectors in the rows of A (row s, zeros up to the diagonal) -- what stages 2-5 of
+// tri_multi_kernel start from --, plus, from the epilogue, the products of the reflectors inside every group of four and the
+// tridiagonal matrix scaled for the multisection.  The file also holds the rest of the lone solve: tri_vec_kernel (eigenvalue,
+// inverse iteration and back-transformation of ONE vector per workgroup) and tri_mgs_kernel (Gram-Schmidt, signs); DESIGN 3.2a.
 #include "common.h"
 #include <mutex>
 #include <map>
