@@ -315,6 +315,82 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
     }
   };
   if constexpr (!BLK) tasks.request();
+  // One wave per line (blocked intermediates): software pipeline over the tasks of a wave -- the 16 source loads and the frame
+  // record of task i + 1 are requested before the transforms of task i.  Without it the gather stands at the head of every task
+  // (column-wise for half the quadrants) and, vmcnt counting loads and stores in order, the wait for it also waits for the
+  // previous task's 16 KB of stores.  Measured on one box, A / B (400 frames of 512 px): 0.821 -> 0.789 ms, parity unchanged.
+  if constexpr (BLK && P::CAN_PRUNE && P::WPB == 8) {
+    using B = Blk<P>;
+    constexpr int NIN = P::U1L * P::NCNT;
+    float t1n[NIN], t2n[NIN];
+    RotFrame pn;
+    int prn = 0;
+    auto fetch = [&](int task_) {
+      prn = task_ * P::LPB + slot;
+      if (task_ < ntask && prn < npairs) {
+        const int fl = prn / half, f = f0 + fl, tb = prn % half;
+        pn = fr[f];
+        const int r0 = (pn.q == 1 || pn.q == 2) ? g.alt0 : g.off;
+        const int c0 = (pn.q == 2 || pn.q == 3) ? g.alt0 : g.off;
+        const float* frame = in + (int64_t)f * g.N * g.N;
+        const int yrel = 128 * (tb / 64) + (tb % 64);
+        const int Y1 = r0 + yrel, Y2 = Y1 + 64, dc = c0 - g.off;
+        int b1, st1, b2, st2;
+        src_map(pn.q, Y1, g, b1, st1);
+        src_map(pn.q, Y2, g, b2, st2);
+#pragma unroll
+        for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+          for (int n1 = 0; n1 < P::NCNT; ++n1) {
+            const int X = P::M1 * (P::NLO + n1) + lane + 64 * ul + dc;
+            t1n[ul * P::NCNT + n1] = frame[b1 + X * st1];
+            t2n[ul * P::NCNT + n1] = frame[b2 + X * st2];
+          }
+      }
+    };
+    int task = next_task();
+    fetch(task);
+    while (task < ntask) {
+      const int pr = prn;
+      const bool live = pr < npairs;
+      const RotFrame p = pn;
+      cf v[P::VL];
+      if (live) {
+#pragma unroll
+        for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+          for (int n1 = 0; n1 < P::NCNT; ++n1) {
+            const float a = t1n[ul * P::NCNT + n1], b = t2n[ul * P::NCNT + n1];
+            v[ul * P::R1 + P::NLO + n1] = mkcf((a == a) ? a : 0.f, (b == b) ? b : 0.f);
+          }
+      }
+      const int nxt = next_task();
+      fetch(nxt);
+      if (live) {
+        const int fl = pr / half, tb = pr % half;
+        const int r0 = (p.q == 1 || p.q == 2) ? g.alt0 : g.off;
+        const int c0 = (p.q == 2 || p.q == 3) ? g.alt0 : g.off;
+        const int yrel = 128 * (tb / 64) + (tb % 64);
+        const int Y1 = r0 + yrel, Y2 = Y1 + 64, dc = c0 - g.off;
+        const double s1 = p.a * (double)(Y1 - g.c) + (double)dc, s2 = p.a * (double)(Y2 - g.c) + (double)dc;
+        float alt1, alt2, sn1, sn2;
+        pair_shift<P, true, false, true>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2,
+                                         aux.dph + ((int64_t)fl * 2 + 0) * DPH_STRIDE);
+        float4* o = reinterpret_cast<float4*>(A1r) + ((int64_t)fl * B::NB + tb) * B::NBC + lane;
+#pragma unroll
+        for (int gq = 0; gq < P::L / 128; ++gq) {
+          const cf a = v[B::reg(128 * gq)], b = v[B::reg(128 * gq + 64)];
+          o[64 * gq] = make_float4(a.x, a.y, b.x, b.y);
+        }
+        if (lane == 0) {
+          aux.beta[fl * g.N + yrel] = sn1 * alt1;
+          aux.beta[fl * g.N + yrel + 64] = sn2 * alt2;
+        }
+      }
+      task = nxt;
+    }
+    return;
+  }
   for (int task = next_task(); task < ntask; task = next_task()) {
    for (int sub_task = 0; sub_task < (PW ? PPT : 1); ++sub_task) {
     int pr = PW ? task * PPT + sub_task : task * P::LPB + slot;
