@@ -221,7 +221,7 @@ __global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const do
 
 extern "C" {
 
-int vipmi_version(void) { return 103; }
+int vipmi_version(void) { return 104; }
 
 const char* vipmi_last_error(void) { return g_err; }
 
