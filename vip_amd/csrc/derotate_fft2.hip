@@ -816,6 +816,21 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
         }
     }
     const double s1 = p.a * (double)(Y1 - g.c), s2 = p.a * (double)(Y2 - g.c);
+    // the source pixels that restore the mask at the end are requested NOW (16 registers): asked for after the transforms, their
+    // round trip stood at the tail of every task
+    const int64_t ob1 = ((int64_t)f * g.N + m) * g.N, ob2 = ob1 + (int64_t)dm * g.N;
+    constexpr bool EARLY = BLK && P::L <= 2048;            // (the Le = 4096 plans have no registers to spare)
+    float srcA[P::U1L * P::NCNT], srcB[P::U1L * P::NCNT];
+    if constexpr (EARLY) {
+#pragma unroll
+      for (int ul = 0; ul < P::U1L; ++ul)
+#pragma unroll
+        for (int n1 = 0; n1 < P::NCNT; ++n1) {
+          const int j = P::M1 * n1 + lane + 64 * (sub * P::U1L + ul);
+          srcA[ul * P::NCNT + n1] = in[ob1 + j];
+          srcB[ul * P::NCNT + n1] = in[ob2 + j];
+        }
+    }
     float alt1, alt2, sn1, sn2;
     pair_shift<P, false, P::CAN_PRUNE, BLK>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2,
                                                    aux.dph + ((int64_t)fl * 2 + 0) * DPH_STRIDE);
@@ -823,7 +838,6 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
       const float gs = aux.gsum[fl];
       const float c1 = sn1 * (aux.kv[fl * g.N + m] + ((Y1 & 1) ? -gs : gs));
       const float c2 = sn2 * (aux.kv[fl * g.N + m + dm] + ((Y2 & 1) ? -gs : gs));
-      const int64_t ob1 = ((int64_t)f * g.N + m) * g.N, ob2 = ob1 + (int64_t)dm * g.N;
 #pragma unroll
       for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
@@ -832,7 +846,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
           const float sg = ((g.off + j) & 1) ? -1.f : 1.f;
           float re1 = v[ul * P::R1 + n1].x - sg * c1;
           float re2 = v[ul * P::R1 + n1].y - sg * c2;
-          const float src1 = in[ob1 + j], src2 = in[ob2 + j];
+          const float src1 = EARLY ? srcA[ul * P::NCNT + (n1 - P::NLO)] : in[ob1 + j];
+          const float src2 = EARLY ? srcB[ul * P::NCNT + (n1 - P::NLO)] : in[ob2 + j];
           if (mask_nan && !(src1 == src1)) re1 = __uint_as_float(0x7fc00000u);
           if (mask_nan && !(src2 == src2)) re2 = __uint_as_float(0x7fc00000u);
           if (mask_zero && src1 == mask_v) re1 = mask_v;
