@@ -819,6 +819,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
     // the source pixels that restore the mask at the end are requested NOW (16 registers): asked for after the transforms, their
     // round trip stood at the tail of every task
     const int64_t ob1 = ((int64_t)f * g.N + m) * g.N, ob2 = ob1 + (int64_t)dm * g.N;
+    const float gs = aux.gsum[fl], kv1 = aux.kv[fl * g.N + m], kv2 = aux.kv[fl * g.N + m + dm];     // (likewise)
     constexpr bool EARLY = BLK && P::L <= 2048;            // (the Le = 4096 plans have no registers to spare)
     float srcA[P::U1L * P::NCNT], srcB[P::U1L * P::NCNT];
     if constexpr (EARLY) {
@@ -835,9 +836,8 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear3(const float* __restrict
     pair_shift<P, false, P::CAN_PRUNE, BLK>(v, tw, lds, s1, s2, lane, sub, alt1, alt2, sn1, sn2,
                                                    aux.dph + ((int64_t)fl * 2 + 0) * DPH_STRIDE);
     if (live) {
-      const float gs = aux.gsum[fl];
-      const float c1 = sn1 * (aux.kv[fl * g.N + m] + ((Y1 & 1) ? -gs : gs));
-      const float c2 = sn2 * (aux.kv[fl * g.N + m + dm] + ((Y2 & 1) ? -gs : gs));
+      const float c1 = sn1 * (kv1 + ((Y1 & 1) ? -gs : gs));
+      const float c2 = sn2 * (kv2 + ((Y2 & 1) ? -gs : gs));
 #pragma unroll
       for (int ul = 0; ul < P::U1L; ++ul)
 #pragma unroll
