@@ -152,9 +152,9 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
     else st_shared(p, v);
   };
 
-  double vcur[NCH], vprev[NCH], wprev[NCH];
+  double vcur[NCH];
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) vprev[ch] = wprev[ch] = vcur[ch] = 0.0;
+  for (int ch = 0; ch < NCH; ++ch) vcur[ch] = 0.0;
   double beta = 0.0, v0 = 0.0, e2 = 0.0;
   bool dead = false;                 // an exchange timed out (wave-uniform): leave
   // Reflector of the row held in cc = row s1 = 64 C0 + ls (chunks C0 ..): x = cc[c > s1]; x0 = x[s1 + 1] and diag = cc[s1] come
@@ -209,22 +209,17 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
         if (c < n) put(&A[(size_t)s * n + c], ch >= C0 ? vcur[ch] : 0.0);
       }
     }
-    // own rows r > s (local rows C0 .., the first one only when wg >= ls), columns from chunk C0 on: pending rank-2 update
-    // of step s - 1, then row . v_s
+    // own rows r > s (local rows C0 .., the first one only when wg >= ls), columns from chunk C0 on: row . v_s  (the rows
+    // already carry the rank-2 update of step s - 1: it is applied at the END of that step, see below)
     double acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int lr = C0; lr < NCH; ++lr) {
       if (lr > C0 || wg >= ls) {
-        const double vr = readlane_f64(vprev[lr], wg), wr = readlane_f64(wprev[lr], wg);
         double a = 0.0;
 #pragma unroll
-        for (int ch = C0; ch < NCH; ++ch) {
-          const double t = rows[lr][ch] - vr * wprev[ch] - wr * vprev[ch];
-          rows[lr][ch] = t;
-          a += t * vcur[ch];
-        }
+        for (int ch = C0; ch < NCH; ++ch) a += rows[lr][ch] * vcur[ch];
         acc[lr] = a;
       }
     }
@@ -270,13 +265,23 @@ __global__ __launch_bounds__(64) void tri_wave_kernel(double* __restrict__ A, in
     const double w2 = p2 - K * e2;                          // w[s + 2]  (v[s + 2] = e2)
     const double diag = c1 - 2.0 * v0 * ws1;                // row s + 1 after this step's own update: entries s + 1, s + 2
     const double x0 = cx - v0 * w2 - ws1 * e2;
+    double w[NCH];
 #pragma unroll
     for (int ch = C0; ch < NCH; ++ch) {
       const double v = vcur[ch];
-      const double w = p[ch] - K * v;
-      wprev[ch] = w;
-      vprev[ch] = v;
-      cc[ch] = cc[ch] - v0 * w - ws1 * v;
+      w[ch] = p[ch] - K * v;
+      cc[ch] = cc[ch] - v0 * w[ch] - ws1 * v;
+    }
+    // rank-2 update A <- A - v w^T - w v^T of the own rows r >= s + 2 (row s + 1 lives on as cc), HERE rather than fused into the
+    // next step's row pass: these 2/3 of a step's multiply-adds are independent of the reflector's scalar chain below (wave sum,
+    // square root, reciprocal) and fill its latency instead of standing between the reflector and the publication of A v
+#pragma unroll
+    for (int lr = C0; lr < NCH; ++lr) {
+      if (lr > C0 || wg > ls) {
+        const double vr = readlane_f64(vcur[lr], wg), wr = readlane_f64(w[lr], wg);
+#pragma unroll
+        for (int ch = C0; ch < NCH; ++ch) rows[lr][ch] = rows[lr][ch] - vr * w[ch] - wr * vcur[ch];
+      }
     }
     if (s + 3 < n) {
       reflect(C0c, ls, x0, diag);
