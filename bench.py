@@ -112,6 +112,119 @@ def pmc_traffic(frames_per_launch, N, kernel="rs_shear2"):
     return None
 
 
+class PowerSampler:
+    """Socket power and shader clock of THIS rank's GPU from sysfs hwmon (power1_input / power1_average in uW, freq1_input in Hz),
+    sampled by a host thread every 20 ms while a leg runs.  The card is matched by PCI address; the chip-filling kernels of the
+    path run AT the board's power cap (1381 of 1400 W under the shears, shader clock 1.96 of 2.4 GHz), which is what
+    bounds them -- the roofline fractions below are to be read with that in mind."""
+
+    def __init__(self, device):
+        import glob
+        self.dir = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device)
+            want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            want = None
+        cands = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
+        for d in cands:
+            try:
+                real = os.path.realpath(os.path.join(d, "..", ".."))
+            except Exception:
+                continue
+            if want and want in real:
+                self.dir = d
+        self.cands = cands if self.dir is None else [self.dir]
+        self.samples, self._stop, self._th = [], False, None
+
+    def _read(self, d):
+        out = {}
+        for name in ("power1_input", "power1_average", "freq1_input", "power1_cap"):
+            try:
+                out[name] = int(open(os.path.join(d, name)).read())
+            except Exception:
+                pass
+        return out
+
+    def _loop(self):
+        while not self._stop:
+            self.samples.append([self._read(d) for d in self.cands])
+            time.sleep(0.02)
+
+    def start(self):
+        import threading
+        if not self.cands:
+            return self
+        self.samples, self._stop = [], False
+        self._th = threading.Thread(target=self._loop, daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self, what):
+        if self._th is None:
+            return None
+        self._stop = True
+        self._th.join()
+        self._th = None
+        smp = self.samples[2:-1] if len(self.samples) > 6 else self.samples        # (drop the ramp at both ends)
+        if not smp:
+            return None
+        best = None
+        for i in range(len(self.cands)):                 # unmatched card: the one that draws the most (ours is the busy one)
+            pw = [s[i].get("power1_input", s[i].get("power1_average")) for s in smp]
+            pw = [v for v in pw if v is not None]
+            if not pw:
+                continue
+            fr = [s[i]["freq1_input"] for s in smp if "freq1_input" in s[i]]
+            rec = {"mean_w": float(np.mean(pw)) / 1e6, "max_w": float(np.max(pw)) / 1e6,
+                   "cap_w": (smp[-1][i].get("power1_cap") or 0) / 1e6 or None,
+                   "sclk_mhz_mean": (float(np.mean(fr)) / 1e6 if fr else None), "samples": len(pw), "during": what,
+                   "card_matched_by_pci": self.dir is not None}
+            if best is None or rec["mean_w"] > best["mean_w"]:
+                best = rec
+        return best
+
+
+def numpy_in_legs(n, N, k, angles, seed0, pca, B, torch):
+    """The reference's callers pass numpy arrays (metrics/contrcurve.py:768-790, psfsub/pca_fullfr.py:137): the drop-in
+    signature pays the PCIe upload that `value` excludes ("H2D ... reported separately").  Measured here:
+    the raw host->device copy of one cube (pageable memory, as a caller's array is), one synchronous pca(numpy cube) ->
+    numpy frame, and pca_many() over distinct numpy cubes (the upload of cube i+1 overlaps the kernels of cube i)."""
+    from vip_amd.psfsub.pca_fullfr import pca_many
+    from vip_amd.synth import synth_adi
+    hosts = [synth_adi(n, N, seed=seed0 + 100 + d)[0] for d in range(3)]
+    torch.cuda.synchronize()
+    t = B.to_device_f32(hosts[0]); torch.cuda.synchronize(); del t
+    t0 = time.perf_counter()
+    for h in hosts:
+        t = B.to_device_f32(h)
+        torch.cuda.synchronize()
+        del t
+    h2d_ms = (time.perf_counter() - t0) / len(hosts) * 1e3
+    pca(hosts[0], angles, ncomp=k, verbose=False, check_memory=False)
+    t0 = time.perf_counter()
+    reps = 6
+    for i in range(reps):
+        fr = pca(hosts[i % len(hosts)], angles, ncomp=k, verbose=False, check_memory=False)
+    lat_ms = (time.perf_counter() - t0) / reps * 1e3
+    assert isinstance(fr, np.ndarray) and np.isfinite(fr[N // 2 - 4:N // 2 + 4, N // 2 - 4:N // 2 + 4]).all()
+    many = [hosts[i % len(hosts)] for i in range(12)]
+    pca_many(many[:3], [angles] * 3, ncomp=k, check_memory=False)
+    t0 = time.perf_counter()
+    outs = pca_many(many, [angles] * len(many), ncomp=k, check_memory=False)
+    many_ms = (time.perf_counter() - t0) / len(many) * 1e3
+    assert len(outs) == len(many) and isinstance(outs[0], np.ndarray)
+    gb = hosts[0].nbytes / 1e9
+    return {"h2d_ms": h2d_ms, "h2d_gbs": gb / (h2d_ms * 1e-3), "host_memory": "pageable (a caller's numpy array)",
+            "latency_ms_per_call": lat_ms, "value": n / (lat_ms * 1e-3), "unit": "frames/s",
+            "pipelined": {"value": n / (many_ms * 1e-3), "ms_per_cube": many_ms, "cubes": len(many),
+                          "note": "pca_many: the (synchronous, pageable) upload of cube i+1 runs beside the kernels of cube i; "
+                                  "bounded by PCIe: %.1f ms per %.0f MB cube" % (h2d_ms, hosts[0].nbytes / 1e6)},
+            "note": "one synchronous call = upload + the serial call (the Gram needs every frame, and everything after it needs "
+                    "the Gram: only its 0.2 ms digit split could overlap the copy, DESIGN 7.8)"}
+
+
 def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512, ncomp=20, spectrum=None):
     """One problem sharded over all ranks (strong scaling): every rank holds the same synthetic input in HBM; a step is
     one complete sharded call ending with the final frame on every rank.  Returns the record (every rank).
@@ -275,6 +388,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle in this GPU-free process and print its JSON object")
     ap.add_argument("--no-latency", action="store_true", help="skip the un-pipelined latency measurement")
+    ap.add_argument("--no-numpy-in", action="store_true", help="skip the numpy-in (PCIe-inclusive) legs")
     ap.add_argument("--setup-burst", type=int, default=0,
                     help="untimed pipelined calls issued in one burst before the W warm-up steps (experiments; see the comment at its use)")
     ap.add_argument("--no-strong", action="store_true",
@@ -482,20 +596,31 @@ def main():
             iso_ms = stages_serial["k_rot_s2"] / roof_launches
             roof["isolated_avg_launch_ms"] = iso_ms
             roof["isolated_frac"] = roof_alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if roof is not None and "derotate" in stages_serial:
+            # the same bytes charged to the WHOLE derotation stage (its three shears + auxiliaries), and the call's
+            # algorithmic bytes (Gram n P 4 + project 2 n P 4 + derotation 2 n P 4 + median n P 4) over a serial
+            # call and over the pipelined step
+            roof["stage_frac"] = 2.0 * n * P * 4 / (stages_serial["derotate"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["call_bytes"] = 6.0 * n * P * 4
+            roof["call_frac"] = roof["call_bytes"] / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["call_frac_pipelined"] = roof["call_bytes"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
 
     # steady state over >= ~1.5 s of pipelined calls (the K timed steps above include the pipeline's fill and drain, and
     # K = 20 lasts 0.1 s): reported beside `value`, never instead of it
     sustained = None
+    power = None
     if depth > 1 and not args.no_latency:
         B.set_async(True)
         ns = min(len(pinned), max(args.steps, 1))
         reps = max(1, int(np.ceil(1.5 / max(elapsed * ns / args.steps, 1e-3))))
         barrier()
+        sampler = PowerSampler(torch.cuda.current_device()).start()
         t1 = time.perf_counter()
         for _ in range(reps):
             run(ns)
         barrier()
         ts = time.perf_counter() - t1
+        power = sampler.stop("sustained leg (pipelined calls, %.1f s)" % ts)
         B.check_deferred()
         B.set_async(False)
         if world > 1:
@@ -504,6 +629,12 @@ def main():
             ts = float(t.item())
         sustained = {"value": world * n * ns * reps / ts, "unit": "frames/s", "steps": ns * reps, "seconds": ts}
 
+    numpy_in = None
+    if rank == 0 and not args.no_latency and not args.no_numpy_in:
+        try:
+            numpy_in = numpy_in_legs(n, N, k, angles, rank * depth, pca, B, torch)
+        except Exception as e:                  # (never costs the headline line)
+            sys.stderr.write("numpy-in legs failed: %r\n" % (e,))
     del cubes_t, cube_t
     torch.cuda.empty_cache()
     rec = None
@@ -526,6 +657,10 @@ def main():
             "stages_serial_ms": stages_serial,
             "roofline": roof,
             "sustained": sustained,
+            "power": power,
+            "h2d_ms": (numpy_in or {}).get("h2d_ms"),
+            "value_numpy_in": (numpy_in or {}).get("value"),
+            "numpy_in": numpy_in,
             "strong": None,
         }
         if not args.no_cpu_baseline:

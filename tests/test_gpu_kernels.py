@@ -834,28 +834,87 @@ def test_eigh_topk_wave_resident_tridiagonalisation(B):
         ctx.set_option("eigh_wave", 1)
 
 
-def test_eigh_wave_time_out_is_loud(B):
+def _recovered(ctx):
+    return max(0, ctx.get_option("eigh_recovered"))
+
+
+def test_eigh_wave_time_out_recovers(B):
     """The 64 waves of the wave-resident reduction spin on each other; when one of them never becomes resident (here: the test
-    hook eigh_wave_drop launches one short) every wave runs into the time-out (~1 s) and leaves.  The caller must not get
-    plausible numbers: NaN eigenpairs, vipmi_check_deferred reports the barrier time-out, and the next call is unaffected."""
+    hook eigh_wave_drop launches one short; in the field: a chip-filling kernel of ANOTHER process holds its CU) every wave runs
+    into the time-out (~1 s) and leaves.  The recovery launch that follows every cooperating solve then solves the problem again
+    on the single-workgroup kernel: right eigenpairs, no error, a counter (`eigh_recovered`).  With eigh_recover = 0 the
+    round-4 behaviour: NaN eigenpairs, vipmi_check_deferred reports the time-out.  The next call is unaffected either way."""
     import torch
-    from vip_amd import _lib
+    from vip_amd import backend
     rng = np.random.default_rng(3)
     M = rng.standard_normal((300, 700))
     G = M @ M.T
     ctx = B.get_context()
+    assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0
     good = B_eigh(G, 8)
+    rec0 = _recovered(ctx)
     try:
         ctx.set_option("eigh_wave_drop", 1)
         ev, ec = B_eigh(G, 8)
+        _topk_check(G, ev, ec, 8)
+        np.testing.assert_allclose(ev, good[0], rtol=1e-11)
+        assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0
+        assert _recovered(ctx) == rec0 + 1
+        # whole spectrum + leading vectors: stages 2-5 run as a second cooperating launch, which must not consume the void reduction
+        evs, ecs = backend.eigh_topk(torch.from_numpy(G.copy()).cuda(), 8, all_evals=True)
+        evs, ecs = evs.cpu().numpy(), ecs.cpu().numpy()
+        w = np.linalg.eigvalsh(G)[::-1]
+        np.testing.assert_allclose(evs, w, atol=1e-12 * w[0])
+        _topk_check(G, evs[:8], ecs, 8)
+        assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0
+        assert _recovered(ctx) == rec0 + 2
+        ctx.set_option("eigh_recover", 0)
+        ev, ec = B_eigh(G, 8)
         assert np.isnan(ev).all() and np.isnan(ec).all()
-        st = ctx.lib.vipmi_check_deferred(ctx.handle)
-        assert st != 0
+        assert ctx.lib.vipmi_check_deferred(ctx.handle) != 0
     finally:
         ctx.set_option("eigh_wave_drop", 0)
+        ctx.set_option("eigh_recover", 1)
     assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0
     again = B_eigh(G, 8)
     assert np.array_equal(good[0], again[0]) and np.array_equal(good[1], again[1])
+    assert _recovered(ctx) == rec0 + 2
+
+
+@pytest.mark.parametrize("batch,n,k", [(1, 400, 20), (3, 300, 12), (2, 120, 5)])
+def test_eigh_multi_time_out_recovers(B, batch, n, k):
+    """The same for the multi-workgroup kernel (8-32 workgroups per problem behind counter barriers; the pipelined mode's solver and
+    the one for a few problems at a time): a participant that never arrives (hook eigh_multi_drop) -> every barrier gives up, the
+    recovery launch solves all problems of the launch again."""
+    import torch
+    from vip_amd import backend
+    rng = np.random.default_rng(100 * batch + n)
+    Gs = []
+    for _ in range(batch):
+        M = rng.standard_normal((n, n + 150)) * (2.0 ** (-np.arange(n + 150) / 60.0))
+        Gs.append(M @ M.T)
+    Gs = np.stack(Gs)
+    ctx = B.get_context()
+    assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0
+    rec0 = _recovered(ctx)
+    try:
+        ctx.set_option("eigh_wave", 0)          # a lone problem also takes the multi-workgroup kernel
+        ctx.set_option("eigh_reg", 0)           # (n <= 200: not the single-workgroup register kernel)
+        ctx.set_option("eigh_multi_drop", 1)
+        ev, ec = backend.eigh_topk(torch.from_numpy(Gs.copy()).cuda(), k)
+        ev, ec = ev.cpu().numpy(), ec.cpu().numpy()
+        for b in range(batch):
+            _topk_check(Gs[b], ev[b], ec[b], k)
+        assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0
+        assert _recovered(ctx) == rec0 + 1
+    finally:
+        ctx.set_option("eigh_multi_drop", 0)
+        ctx.set_option("eigh_wave", 1)
+        ctx.set_option("eigh_reg", 1)
+    ev2, ec2 = backend.eigh_topk(torch.from_numpy(Gs.copy()).cuda(), k)
+    for b in range(batch):
+        _topk_check(Gs[b], ev2[b].cpu().numpy(), ec2[b].cpu().numpy(), k)
+    assert ctx.lib.vipmi_check_deferred(ctx.handle) == 0 and _recovered(ctx) == rec0 + 1
 
 
 def B_eigh(G, k):

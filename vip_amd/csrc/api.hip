@@ -275,10 +275,11 @@ int vipmi_trim(vipmi_ctx* ctx) {
     // belong to another thread's pipelined region that checks later)
     auto it = ctx->buffers.find("deferred_fail");
     if (it != ctx->buffers.end() && it->second.ptr) {
-      int h[2] = {0, 0};
+      int h[4] = {0, 0, 0, 0};
       VIPMI_CHECK_HIP(hipMemcpy(h, it->second.ptr, sizeof h, hipMemcpyDeviceToHost));
       ctx->sticky_fail[0] += h[0];
       ctx->sticky_fail[1] += h[1];
+      ctx->options["eigh_recovered"] = ctx->opt("eigh_recovered", 0) + h[3];
     }
   }
   for (auto& kv : ctx->buffers)
@@ -303,7 +304,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
@@ -358,14 +359,17 @@ int vipmi_check_deferred(vipmi_ctx* ctx) {
   auto it = ctx->buffers.find("deferred_fail");
   VIPMI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   int h[2] = {ctx->sticky_fail[0], ctx->sticky_fail[1]};
-  ctx->sticky_fail[0] = ctx->sticky_fail[1] = 0;
   if (it != ctx->buffers.end() && it->second.ptr) {
-    int d[2] = {0, 0};
+    int d[4] = {0, 0, 0, 0};
     VIPMI_CHECK_HIP(hipMemcpy(d, it->second.ptr, sizeof d, hipMemcpyDeviceToHost));
-    if (d[0] != 0 || d[1] != 0) VIPMI_CHECK_HIP(hipMemset(it->second.ptr, 0, sizeof d));
+    if (d[0] != 0 || d[1] != 0) VIPMI_CHECK_HIP(hipMemset(it->second.ptr, 0, 2 * sizeof(int)));
+    if (d[3] != 0) VIPMI_CHECK_HIP(hipMemset(reinterpret_cast<int*>(it->second.ptr) + 3, 0, sizeof(int)));
     h[0] += d[0];
     h[1] += d[1];
+    // cooperating solves that timed out and were solved again by their recovery launch (eigh_tri.hip): not an error, counted
+    ctx->options["eigh_recovered"] = ctx->opt("eigh_recovered", 0) + d[3];
   }
+  ctx->sticky_fail[0] = ctx->sticky_fail[1] = 0;        // (only once the device words have been read: a failed copy keeps them)
   if (h[1] != 0) {
     set_error("eigh: %d inter-workgroup barrier(s) timed out (cooperating workgroups were not co-resident): the results of "
               "those calls are invalid", h[1]);

@@ -221,6 +221,7 @@ struct CoopOrder {
 // (eigh_wave.hip): d, e, tau -> det[3][n], reflectors in the rows of A.  bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8
 // doubles; xcd_slot = 1 + XCD the waves sit on (0 = spread over the chip, agent-scope exchange); fail: deferred-failure words.
 bool tri_wave_supported(int64_t n);
+bool tri_wave_fits(vipmi_ctx* ctx, int64_t n);   // its 64 single-wave workgroups can be co-resident on ONE XCD of this device (occupancy query, cached)
 int tri_wave_reduce(vipmi_ctx* ctx, double* A, int n, double* det, double* gbuf, unsigned* bars, int xcd_slot, int* fail,
                     double* gram,       // gram[ceil((n-2)/4)][8]: products of the reflectors inside each group of four
                     double* det2);      // det2[3 n + 3]: d, e, e^2 scaled to max-norm 1, then scale and the Gershgorin interval

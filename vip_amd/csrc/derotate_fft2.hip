@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * P::WPB) void rs_shear1(const float* __restrict
   // record of task i + 1 are requested before the transforms of task i.  Without it the gather stands at the head of every task
   // (column-wise for half the quadrants) and, vmcnt counting loads and stores in order, the wait for it also waits for the
   // previous task's 16 KB of stores.  Measured on one box, A / B (400 frames of 512 px): 0.821 -> 0.789 ms, parity unchanged.
-  if constexpr (BLK && P::CAN_PRUNE && P::WPB == 8) {
+  if constexpr (BLK && P::CAN_PRUNE && (P::WPB == 8 || P::L == 1024)) {
     using B = Blk<P>;
     constexpr int NIN = P::U1L * P::NCNT;
     float t1n[NIN], t2n[NIN];
@@ -981,7 +981,13 @@ int derotate_fft2(vipmi_ctx* ctx, const float* in, const RotFrame* d_frames, con
     // stand-alone, but with two calls in flight the other call's eigensolver finds no free CU: C4 +11 %); two waves per
     // line at Le = 2048 with 12 or 16 waves per workgroup (3 waves per SIMD, but workgroup barriers and 1.5x the
     // instructions per line: 6.2 against 3.8 ms at C2); four waves per line at Le = 4096.
-    case 1024: return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
+    case 1024:
+      // four lines per workgroup, three workgroups per CU = THREE waves per SIMD (the Le = 1024 kernels hold <= 164 VGPRs; with
+      // eight-wave workgroups only one fits a CU).  Measured (round 5, A / B on one box): 1600 frames of 256 px shear 2 2.46 -> 2.35 and
+      // 2.52 -> 2.31 ms, shear 1 -5 %, shear 3 -2 %; C4 24.8 -> 24.2 ms.  The chip sits at its 1400 W cap either way,
+      // which is why a third wave buys 5 % and not the 15 % its idle issue slots suggest.  rot_1024_q = 0: the eight-wave plan.
+      if (ctx->opt("rot_1024_q", 1)) return run_plan2<Plan1024q>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
+      return run_plan2<Plan1024>(ctx, in, d_frames, g, n, out, mask_nan, mask_zero, mask_v);
     case 2048:
       // (four-wave workgroups, one wave per SIMD, so that the MFMA-bound Gram of another call could share the SIMDs: measured in
       // round 3, 3.90 -> 4.55 ms alone and 5.60 -> 6.20 ms pipelined, removed from the build -- DESIGN 7.1)

@@ -55,7 +55,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double
                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
                                                      double* __restrict__ evecs_all, double* __restrict__ scratch_all,
                                                      int kp, int all_evals, int kc, int phase = 0,
-                                                     double* __restrict__ det_all = nullptr) {
+                                                     double* __restrict__ det_all = nullptr,
+                                                     const unsigned* __restrict__ guard = nullptr,
+                                                     const unsigned* __restrict__ gcount = nullptr,
+                                                     int* __restrict__ fail = nullptr) {
+  // guard != nullptr: this launch is the RECOVERY of a cooperating solve (launch_tri_multi): it follows every such solve in the
+  // stream, returns at once when that solve went through (*guard == 0) and otherwise -- a partner of the cooperating kernel never
+  // became resident within its time-out: another process held the CUs -- solves the problem(s) again from a copy of the input, alone
+  // on one CU each (no workgroup of this kernel waits for another).  The time-outs the dead launch latched (*gcount of them in
+  // fail[1]) are taken back and fail[3] counts the recovery: the caller gets the right eigenpairs and a counter instead of an error.
+  if (guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   // phase: 0 = the whole solve; 1 = tridiagonalisation only (d, e, tau -> det_all[prob][3][n], reflectors in A);
   // 2 = everything after it from those arrays.  Big batches run the two halves as two launches: the second half is a
   // chain of latencies on a few waves, so it runs with 256 threads and four problems per CU while the register-
@@ -812,6 +821,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double
     }
   }
   TRI_STAMP(5);
+  if (guard != nullptr && fail != nullptr && prob == 0 && tid == 0) {
+    atomicSub(fail + 1, (int)__hip_atomic_load(gcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    atomicAdd(fail + 3, 1);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -829,14 +842,19 @@ template <int RPL>
 __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aall, int n, int k, int RW, int VW, int rows_d, int all_evals,
                                                         double* __restrict__ evals_all, double* __restrict__ evecs_all,
                                                         double* __restrict__ gbuf_all, unsigned* __restrict__ bars, int one_xcd,
-                                                        int* __restrict__ fail, const double* __restrict__ det = nullptr) {
+                                                        int* __restrict__ fail, const double* __restrict__ det = nullptr,
+                                                        const unsigned* __restrict__ dead = nullptr, int drop_wg = -1) {
   extern __shared__ double sm[];
   const int prob = blockIdx.y;
+  // dead: the wave-resident reduction that produced `det` timed out (bar[4] of tri_wave_kernel): det and the reflectors in A are
+  // void -- leave (the recovery launch that follows solves the problem again); read before any barrier, the same for everybody
+  if (dead != nullptr && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   // one_xcd = 1 + base: the grid is 8 x wider and only the ids that land on XCD (base + problem) % 8 stay (ids go round-robin
   // over the XCDs):
   // the W workgroups of a problem then share one L2 and exchange through it (wave_util.h, checked below)
   if (one_xcd && (int)(blockIdx.x & 7) != ((one_xcd - 1 + prob) & 7)) return;
   const int W = one_xcd ? gridDim.x >> 3 : gridDim.x, wg = one_xcd ? blockIdx.x >> 3 : blockIdx.x;
+  if (wg == drop_wg) return;                 // (test hook, option eigh_multi_drop: a participant that never arrives -- the others time out)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* rows = sm;                         // [RW][n]  row lr <-> global row lr*W + wg ; reused after phase 1
   double* vbuf0 = rows + rows_d;             // Householder vector, double buffered (rows_d >= RW*n, 6*n*VW)
@@ -1303,9 +1321,34 @@ __global__ __launch_bounds__(TNT) void tri_multi_kernel(double* __restrict__ Aal
 #endif
 }
 
+// The recovery launch of a cooperating solve (see tri_eig_kernel, `guard`): one workgroup per problem on the LDS-resident
+// single-workgroup solver, from the copy `Abak` of the input (destroyed).  A few microseconds in the stream when the solve went through.
+template <int RPL>
+int launch_recovery(vipmi_ctx* ctx, double* Abak, int64_t batch, int n, int k, double* evals, double* evecs, int all_evals,
+                    const unsigned* guard, const unsigned* gcount, int* fail) {
+  static_assert(RPL == 2 || RPL == 4 || RPL == 8, "launch_recovery: up to 512 rows");
+  const int kp = (int)cdiv(k, 16) * 16;
+  double* scratch = nullptr;
+  VIPMI_TRY(ws(ctx, "eigh_fb_scratch", (size_t)batch * 6 * n * kp, &scratch));
+  const size_t lds = ((size_t)(9 + 1024 / 64) * n + 64 + 8) * sizeof(double);
+  auto kern = tri_eig_kernel<RPL, 1024>;
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(1024), lds, ctx->stream, Abak, n, k, (const int32_t*)nullptr, evals, evecs,
+                     scratch, kp, all_evals, k < n ? k : n, 0, (double*)nullptr, guard, gcount, fail);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
 template <int RPL>
 int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, double* evals, double* evecs,
                      int all_evals) {
+  // a copy of the input for the recovery launch (the cooperating kernels overwrite A with their reflectors): n = 400: 1.3 MB
+  constexpr bool RECOVER = (RPL == 2 || RPL == 4 || RPL == 8);
+  double* Abak = nullptr;
+  if (RECOVER && ctx->opt("eigh_recover", 1) != 0) {
+    VIPMI_TRY(ws(ctx, "eigh_fb_A", (size_t)batch * n * n, &Abak));
+    VIPMI_CHECK_HIP(hipMemcpyAsync(Abak, A, sizeof(double) * (size_t)batch * n * n, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   int W = n <= 256 ? 8 : (n <= 448 ? 16 : 32);
   // a lone synchronous call owns the chip: with the workgroups of a problem on ONE XCD (below) twice as many of them halve the
   // row pass at no extra exchange cost (n = 400: 16 / 24 / 32 workgroups 1.74 / 1.66 / 1.63 ms, round 3); the pipelined mode keeps
@@ -1320,7 +1363,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   VIPMI_TRY(ws(ctx, "eigh_tri_bars", (size_t)batch * TRI_BAR_WORDS, &bars));
   // (the wave-resident path below needs neither this buffer nor the barriers' give-up word unless the whole spectrum is asked for:
   //  two fills less in front of a 1 ms solve)
-  const bool wave_only = lone && tri_wave_supported(n) && ctx->opt("eigh_wave", 1) != 0 && !all_evals && k <= 64 &&
+  const bool wave_only = lone && tri_wave_fits(ctx, n) && ctx->opt("eigh_wave", 1) != 0 && !all_evals && k <= 64 &&
                          W <= 64 && W <= ctx->num_cu / 8 && ctx->opt("eigh_one_xcd", -1) != 0;
   if (!wave_only) VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch * TRI_BAR_WORDS, ctx->stream));
   size_t rows_d = (size_t)RW * n;
@@ -1345,9 +1388,15 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
   int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
   VIPMI_TRY(deferred_fail_words(ctx, &fail, !wave_only));
+  auto recover = [&](const unsigned* guard, const unsigned* gcount) -> int {
+    if constexpr (RECOVER) {
+      if (Abak) return launch_recovery<RPL>(ctx, Abak, batch, n, k, evals, evecs, all_evals, guard, gcount, fail);
+    }
+    return VIPMI_OK;
+  };
   // A lone synchronous problem of 129 .. 448 rows: the tridiagonalisation on 64 single-wave workgroups of one XCD with the
   // matrix in registers (eigh_wave.hip), then stages 2-5 of this kernel as a second launch (option eigh_wave = 0: off)
-  if (lone && one_xcd && tri_wave_supported(n) && ctx->opt("eigh_wave", 1) != 0) {
+  if (lone && one_xcd && tri_wave_fits(ctx, n) && ctx->opt("eigh_wave", 1) != 0) {
     double *det = nullptr, *gw = nullptr;
     unsigned* bars2 = nullptr;
     VIPMI_TRY(ws(ctx, "eigh_wave_det", (size_t)3 * n, &det));
@@ -1360,11 +1409,15 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
     VIPMI_TRY(ws(ctx, "eigh_wave_det2", (size_t)3 * n + 8, &det2));
     VIPMI_TRY(tri_wave_reduce(ctx, A, n, det, gw, bars2, (int)(1 + (xcd_base.fetch_add(1u) & 7u)), fail, gram, det2));
     // the leading pairs alone: one workgroup per vector (eigh_wave.hip); with the rest of the spectrum: stages 2-5 of this kernel
-    if (!all_evals && k <= 64) return tri_wave_vectors(ctx, A, n, k, det, det2, gram, evals, evecs, bars2);
+    if (!all_evals && k <= 64) {
+      VIPMI_TRY(tri_wave_vectors(ctx, A, n, k, det, det2, gram, evals, evecs, bars2));
+      return recover(bars2 + 4, bars2 + 5);
+    }
+    // (bars2 + 4: a reduction that timed out leaves det / A void -- stages 2-5 must not run on them)
     hipLaunchKernelGGL(kern, dim3(W, 1), dim3(TNT), lds, ctx->stream, A, n, k, RW, VW, (int)rows_d, all_evals, evals, evecs, gbuf,
-                       bars, 0, fail, (const double*)det);
+                       bars, 0, fail, (const double*)det, (const unsigned*)(bars2 + 4), -1);
     VIPMI_CHECK_HIP(hipGetLastError());
-    return VIPMI_OK;
+    return recover(bars2 + 4, bars2 + 5);
   }
   // one-XCD layout: ordered against every other cooperating one-XCD launch of the device (common.h: CoopOrder)
   std::unique_ptr<CoopOrder> order;
@@ -1377,11 +1430,12 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
     hipLaunchKernelGGL(kern, dim3(one_xcd ? 8 * W : W, (unsigned)nb), dim3(TNT), lds, ctx->stream, A + (size_t)p0 * n * n, n, k, RW, VW,
                        (int)rows_d, all_evals, evals + (size_t)p0 * n, evecs + (size_t)p0 * n * n, gbuf + (size_t)p0 * 5 * n,
                        bars + (size_t)p0 * TRI_BAR_WORDS, one_xcd ? (int)(1 + ((xcd_base.fetch_add((unsigned)nb) + (unsigned)p0) & 7u)) : 0, fail,
-                       (const double*)nullptr);
+                       (const double*)nullptr, (const unsigned*)nullptr, ctx->opt("eigh_multi_drop", 0) != 0 ? W - 1 : -1);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
-  if (order) return order->done();
-  return VIPMI_OK;
+  if (order) VIPMI_TRY(order->done());
+  // fail[2]: non-zero when a barrier of these launches gave up, and how many time-outs they latched
+  return recover(reinterpret_cast<const unsigned*>(fail + 2), reinterpret_cast<const unsigned*>(fail + 2));
 }
 
 // LDS of the register-resident variant: the tridiagonalisation buffers (padded vectors, per-wave column sums), later
@@ -1425,20 +1479,20 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
       const bool split = (split_opt < 0 ? batch >= 4 * ctx->num_cu : split_opt != 0) && k <= 16;
       if (!split) {
         hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch,
-                           kp, all_evals, reg_variant_chunk(n, k), 0, (double*)nullptr);
+                           kp, all_evals, reg_variant_chunk(n, k), 0, (double*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr);
         VIPMI_CHECK_HIP(hipGetLastError());
         return VIPMI_OK;
       }
       double* det = nullptr;
       VIPMI_TRY(ws(ctx, "eigh_tri_det", (size_t)batch * 3 * n, &det));
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
-                         all_evals, reg_variant_chunk(n, k), 1, det);
+                         all_evals, reg_variant_chunk(n, k), 1, det, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr);
       VIPMI_CHECK_HIP(hipGetLastError());
       const size_t lds2 = ((size_t)(9 + 256 / 64) * n + 64 + 8) * sizeof(double);
       auto kern2 = tri_eig_kernel<RPL, 256>;
       VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern2), (int)lds2));
       hipLaunchKernelGGL(kern2, dim3((unsigned)batch), dim3(256), lds2, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
-                         all_evals, k < n ? k : n, 2, det);
+                         all_evals, k < n ? k : n, 2, det, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr);
       VIPMI_CHECK_HIP(hipGetLastError());
       return VIPMI_OK;
     };
@@ -1484,7 +1538,7 @@ int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k
   const bool reg1 = ctx->opt("eigh_reg", 1) != 0 && reg_variant_fits((int)n, (int)k);
   // (a lone synchronous problem of 129 .. 200 rows: the wave-resident path of launch_tri_multi beats the register-resident
   //  single-workgroup kernel as well -- n = 200, k = 10: 0.82 -> see tools/eigh_wave_check.py)
-  const bool wave1 = batch == 1 && !nact && tri_wave_supported(n) && ctx->opt("eigh_wave", 1) != 0 && ctx->opt("eigh_check", 1) != 0 &&
+  const bool wave1 = batch == 1 && !nact && tri_wave_fits(ctx, n) && ctx->opt("eigh_wave", 1) != 0 && ctx->opt("eigh_check", 1) != 0 &&
                      ctx->opt("eigh_one_xcd", -1) != 0 && ctx->num_cu % 8 == 0 && ctx->num_cu >= 64;
   const bool multi = !nact && n >= 96 && batch <= 8 && (!reg1 || wave1) && ctx->opt("eigh_multi", 1) != 0;
   if (multi) {

@@ -77,7 +77,10 @@ __device__ __forceinline__ bool wave_exchange(unsigned* flags, unsigned epoch, i
     if (__all(ok)) break;
     if (++spins > (1u << 20)) {
       if (threadIdx.x == 0) {
-        if (fail) atomicAdd(fail + 1, 1);
+        if (fail) {
+          atomicAdd(fail + 1, 1);
+          atomicAdd(flags - 8 + 5, 1u);                                                      // bar[5]: how many of them this launch latched
+        }
         __hip_atomic_store(flags - 8 + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bar[4]: this call is void
       }
       return false;
@@ -799,6 +802,31 @@ CoopOrder::~CoopOrder() {
 }
 
 bool tri_wave_supported(int64_t n) { return n >= 129 && n <= 448; }
+
+// The reduction spins on 64 single-wave workgroups of ONE XCD (num_cu / 8 CUs): on a part with few CUs per XCD, or with a register
+// budget per wave that lets fewer of them share a SIMD, they cannot all be resident and every call would run into its time-out.
+// Asked once per (device, chunk count) from the occupancy calculator; the callers fall back to the multi-workgroup kernel.
+bool tri_wave_fits(vipmi_ctx* ctx, int64_t n) {
+  if (!tri_wave_supported(n) || ctx->num_cu % 8 != 0) return false;
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, bool> seen;
+  const int nch = (int)cdiv(n, 64);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = seen.find({ctx->device, nch});
+  if (it != seen.end()) return it->second;
+  int per_cu = 0;
+  hipError_t e;
+  switch (nch) {
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tri_wave_kernel<3>, 64, 0); break;
+    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tri_wave_kernel<4>, 64, 0); break;
+    case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tri_wave_kernel<5>, 64, 0); break;
+    case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tri_wave_kernel<6>, 64, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tri_wave_kernel<7>, 64, 0); break;
+  }
+  const bool ok = e == hipSuccess && (int64_t)per_cu * (ctx->num_cu / 8) >= WW;
+  seen[{ctx->device, nch}] = ok;
+  return ok;
+}
 
 // Tridiagonalise A (n x n, symmetric, float64, destroyed): d, e, tau -> det[3][n], reflector s in A[s][s+1 ..], the products of the
 // reflector groups of four -> gram[ceil((n-2)/4)][8], the scaled tridiagonal matrix and its Gershgorin interval -> det2[3 n + 3].  bars: 136 zeroed words; gbuf: 4 * 64 * ceil(n / 64) + 8 doubles.

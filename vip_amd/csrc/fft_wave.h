@@ -237,6 +237,7 @@ struct Plan {
 // keeps the kernels under 128 VGPRs (4 waves/SIMD, no spills); the exchanges then need a workgroup barrier.
 using Plan512 = Plan<8, 8, 8, 72, 72, 9, 8, 1>;
 using Plan1024 = Plan<16, 8, 8, 72, 72, 9, 8, 1, true>;
+using Plan1024q = Plan<16, 8, 8, 72, 72, 9, 4, 1, true>;   // four lines per workgroup: three workgroups per CU = THREE waves per SIMD (the kernels hold <= 164 VGPRs)
 using Plan2048w1 = Plan<16, 16, 8, 136, 152, 9, 8, 1, true>;   // one wave per line: no workgroup barriers, 2 waves/SIMD
 using Plan2048w1h = Plan<16, 16, 8, 136, 152, 9, 4, 1, true>;  // the same with 4 lines per workgroup (ONE wave per SIMD): the per-frame K kernel rs_aux_k runs on it
 using Plan4096w2 = Plan<16, 16, 16, 272, 272, 17, 8, 2>;    // two waves per line, 2 waves/SIMD, 256-VGPR budget

@@ -102,7 +102,7 @@ __device__ __forceinline__ bool barrier_gave_up(unsigned spins, int* report, int
   if (spins > (1u << 22)) {
     if (report) {
       atomicAdd(report + 1, 1);
-      __hip_atomic_store(report + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(report + 2, 1);          // non-zero: the launch is dead; the count is what a recovery launch takes back from [1]
     }
     return true;
   }
