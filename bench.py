@@ -462,7 +462,11 @@ def main():
     # are independent (one cube each, as in a survey / contrast-curve loop), so the latency-bound eigensolver
     # of one call overlaps the FFT derotation of the previous one.  All K frames are on the host when the
     # closing barrier returns.
-    streams = [torch.cuda.Stream() for _ in range(depth)]
+    # (the library's own cached side streams -- the ones pca_many / the annular and 4-D fronts use: HIP maps every stream onto one of
+    #  GPU_MAX_HW_QUEUES = 4 hardware queues, and with more streams than queues in a process two of them share one -- an upload on
+    #  one stream then queues behind the kernels of the other: pca_many(numpy cubes) measured 15.2 instead of 8.4 ms per cube
+    #  after this loop had run on two streams of its own, INTEGRATION.md "Threads, streams")
+    streams = B.side_streams(depth)
     pinned = [torch.empty((N, N), dtype=torch.float32).pin_memory() for _ in range(max(args.steps, args.warmup, 1))]
     if depth > 1:
         B.set_async(True)       # (VIPMI_RESERVE_CUS=<n> keeps n CUs free of the shear kernels; measured best: 0)

@@ -1107,6 +1107,21 @@ def test_eigh_fast_path_is_verified_and_deterministic(B, n, k, kind):
     assert sin < max(1e-9, 1e-12 / gap), (sin, gap)
 
 
+@pytest.mark.parametrize("n,k", [(800, 1), (800, 3), (1300, 4), (3000, 4)])
+def test_eigh_fast_path_few_vectors(B, n, k):
+    """k <= 4: the block used to be ONE 16-column tile, for which the product kernel has no instance (the 64-column kernel ran
+    on it and faulted: svd_wrapper(..., ncomp=4) on more than 6144 frames, round 5); the block is now at least two tiles wide."""
+    import torch
+    G = _spectrum_matrix(n, (1.0 + np.arange(n)) ** -1.5, seed=n + k)
+    got = B.eigh_topk_fast(torch.from_numpy(G).cuda(), k)
+    assert got is not None
+    ev, X = got[0].cpu().numpy(), got[1].cpu().numpy().T
+    w = np.linalg.eigvalsh(G)[::-1]
+    assert np.abs(ev - w[:k]).max() < 1e-12 * w[0]
+    assert np.abs(X.T @ X - np.eye(k)).max() < 1e-12
+    assert np.linalg.norm(G @ X - X * ev, axis=0).max() < 1e-12 * w[0]
+
+
 def test_eigh_fast_path_gives_up_and_the_exact_path_takes_over(B):
     """A spectrum without a gap behind the k-th pair (flat bulk), a rank-deficient matrix and an indefinite one: the fast
     path reports why it stopped, leaves the matrix alone, and the call returns the exact solver's result."""

@@ -726,14 +726,24 @@ def test_more_than_6144_frames(monkeypatch):
     ctx = B.get_context()
     assert ctx.get_option("eigh_fast_last_reason") == 0 and ctx.get_option("eigh_fast_last_locked") == k
     import torch
+    from vip_amd.psfsub.svd import svd_wrapper
+    # svd_wrapper beyond 6144 frames: every call that returns at most ncomp singular values takes the leading-pairs route --
+    # V alone and the (U, S, V) of the non-eigen modes, which truncate S to ncomp (svd.py:454-459,473)
+    mat = cube.reshape(n, -1)
+    U, S, V = svd_wrapper(mat, "lapack", 4, verbose=False, full_output=True)
+    Ur, Sr, Vr = O.svd_wrapper(mat, "lapack", 4, full_output=True)
+    assert U.shape == (n, 4) and S.shape == (4,) and V.shape == (4, N * N)
+    np.testing.assert_allclose(S, Sr, rtol=2e-5)
+    assert np.abs(sign_align(V, Vr) - Vr).max() < TOL
+    with pytest.raises(NotImplementedError):                              # the eigen family returns the WHOLE spectrum
+        svd_wrapper(mat, "eigen", 4, verbose=False, full_output=True)
     called = []
     monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **kw: called.append(1))
     monkeypatch.setattr(B, "eigh_topk_fast", lambda G, k_: None)          # the fast path gives up
     with pytest.raises(NotImplementedError):
         pca(cube, ang, ncomp=k, verbose=False)
-    from vip_amd.psfsub.svd import svd_wrapper
-    with pytest.raises(NotImplementedError):                              # whole spectrum
-        svd_wrapper(cube.reshape(n, -1), "lapack", 4, verbose=False, full_output=True)
+    with pytest.raises(NotImplementedError):
+        svd_wrapper(mat, "lapack", 4, verbose=False, full_output=True)
     assert not called
 
 
@@ -1435,3 +1445,25 @@ def test_msdi_double_with_cube_sig_golden(tag, kw):
         exp = g["%s_%s" % (tag, nm)]
         assert a.shape == exp.shape and np.array_equal(np.isnan(a), np.isnan(exp)), (tag, nm)
         assert np.nanmax(np.abs(a - exp)) < TOL, (tag, nm, np.nanmax(np.abs(a - exp)))
+
+
+@pytest.mark.parametrize("tag,kw", [("k4", dict(ncomp=4)), ("k4_tm", dict(ncomp=4, scaling="temp-mean")),
+                                    ("k9_mask", dict(ncomp=9, mask_center_px=6))])
+def test_float64_cube_of_detector_counts_vs_reference(tag, kw):
+    """A float64 cube with values ~7e3 (g28: the reference's OWN float64 run, oracle/gen_golden_r5.py).  The reference keeps the
+    caller's dtype through svd_wrapper (psfsub/pca_fullfr.py:1552-1737); the device path rounds the cube to float32 on upload
+    (2^-24 x 7e3 = 4e-4 per sample) and computes Gram / eigensolver in float64, projection, shears and median in float32.
+    Pinned here: the deviation from the reference's float64 result is (a) of the order of what the reference itself shows when
+    the same cube is handed over as float32 (at most twice that; measured in round 5: k4 1.9e-3 against 1.6e-3) and (b) below 2^-21 of the cube's largest value (INTEGRATION.md "float64 input")."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g28_f64_counts")
+    cube, ang = g["cube"], g["angles"]
+    assert cube.dtype == np.float64
+    fr = pca(cube, ang, verbose=False, **kw)
+    assert fr.dtype == np.float64                         # numpy in -> numpy out in the caller's dtype
+    dev = np.nanmax(np.abs(fr - g["frame64_" + tag]))
+    ref32 = np.nanmax(np.abs(g["frame_ref_f32_" + tag] - g["frame64_" + tag]))
+    bound = 2.0 ** -21 * np.abs(cube).max()
+    print("g28 %s: device vs reference(f64) %.3e; reference(f32 cube) vs reference(f64) %.3e; bound %.3e" % (tag, dev, ref32, bound))
+    assert dev <= bound
+    assert dev <= max(2.0 * ref32, 1e-4)                 # the same order as the reference's own float32 path

@@ -24,6 +24,18 @@ pass tcc "TCC_HIT_sum TCC_MISS_sum"
 cd $REPO
 python tools/pmc_summary.py $OUT/pmc_hbm.json $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_summary.log 2>&1
 python tools/pmc_sq_summary.py $OUT/pmc_sq.json $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 $OUT/pmc_grbm $OUT/pmc_tcc > $OUT/pmc_sq_summary.log 2>&1
-find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+# per-configuration kernel stats (round 4's single CSV mixed the plans of four configurations): one rocprofv3 --kernel-trace --stats
+# run per BASELINE config through the public API
+cd /tmp
+for cfg in c2 c3 c4; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -o k -- python $REPO/tools/time_configs.py $cfg > $OUT/stats_$cfg.log 2>&1
+  find $OUT/stats_$cfg -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$cfg.csv \;
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o k -- python $REPO/tools/run_c5.py > $OUT/stats_c5.log 2>&1
+find $OUT/stats_c5 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_c5.csv \;
+cd $REPO
+# socket power / shader clock under each chip-filling stage (sysfs hwmon)
+for w in rot512 rot256 rot1024 gram; do timeout 60 python tools/power_probe.py $w 2>&1 | grep -v amdgpu.ids >> $OUT/power.txt; done
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -size +20M -delete
 ls -la $OUT

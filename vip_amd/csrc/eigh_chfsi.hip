@@ -576,7 +576,9 @@ int eigh_chfsi_f64(vipmi_ctx* ctx, const double* G, int64_t n64, int64_t k64, do
   S.G = G;
   const int n = S.n = (int)n64, k = S.k = (int)k64;
   const int want = k + std::max(12, k / 4);
-  const int b = S.b = (int)cdiv(want, 16) * 16;
+  // (at least two column tiles: cheb_step_kernel has no one-tile instance -- k <= 4 used to run the 64-column kernel on a
+  //  16-column block and fault; the wider block costs nothing at these sizes and converges in fewer rounds)
+  const int b = S.b = std::max(32, (int)cdiv(want, 16) * 16);
   S.NT = b / 16;
   S.rows_per = n > 1024 ? 64 : 50;
   S.nsplit = (int)cdiv(n, S.rows_per);

@@ -22,6 +22,9 @@ __host__ __device__ __forceinline__ cf mkcf(float x, float y) { return cf{x, y};
 // the scalar formulas spends ~40 % of the FFT kernels on v_mov / v_xor / unpacked multiplies.
 //   a*b       : t = (a.x b.x, a.x b.y) ; d = (a.y (-b.y) + t.x, a.y b.x + t.y)
 //   a*conj(b) : t = (a.x b.x, -a.x b.y); d = (a.y b.y + t.x,   a.y b.x + t.y)
+// (Measured and dropped, round 5: the two instructions as SEPARATE asm statements, so that the scheduler may put independent work
+//  between the multiply and its dependent multiply-add -- the compiler pads every asm boundary instead (+250 .. +475 s_nop per line
+//  pair) and the shears get slower: 1024 px 4.80 -> 5.20 ms per 100 frames, 512 px 3.87 -> 3.89 per 400.)
 __device__ __forceinline__ cf cmul(cf a, cf b) {
   cf d;      // one asm statement: no compiler-inserted boundary pad between the two instructions
   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"

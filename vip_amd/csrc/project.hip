@@ -109,6 +109,19 @@ __global__ __launch_bounds__(256, 2) void rowspace_kernel(const float* __restric
     }
 }
 
+// A residual that cancels to EXACTLY 0 although its sample is not 0.  The reference's rotation masks by VALUE: pixels equal to
+// `mask_val` are reset after the rotation (preproc/derotation.py:133-140,324-326), and pca(mask_center_px=...) runs it with
+// mask_val = 0 (psfsub/pca_fullfr.py:412-415) -- in its float64 arithmetic only the masked disc is ever exactly 0.  float32
+// residuals are quantised to the ulp of the SAMPLE (5e-4 on detector counts of 7e3, 1e-6 on the benchmark's cubes): one residual in
+// ~1e5 .. 1e6 cancels to 0.0f, would be taken for a masked pixel and replace one of the n values under the median by 0 (found with
+// the float64 golden g28: one pixel of the frame off by 1.3).  Such a residual becomes 1e-30 -- nothing to the shears, and no
+// longer "equal to the mask value".  Masked samples (exactly 0, with every component 0 there) keep their exact 0; NaN stays NaN.
+__device__ __forceinline__ f32x4 keep_nonzero(f32x4 res, f32x4 m) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) res[i] = (res[i] == 0.f && m[i] != 0.f) ? 1e-30f : res[i];
+  return res;
+}
+
 // R[n,P] = M - Ct[k,nld]^T . T[k,P];  Ct row c holds C[0..n)[c] (nld >= n rounded to 32).
 template <bool VEC, bool RECON>
 __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__ M,
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) {
       const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
       f32x4 rec = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-      f32x4 res = m[r] - rec;
+      f32x4 res = keep_nonzero(m[r] - rec, m[r]);
       strow4<VEC>(R, f, n, P, px, res);
       if (RECON) strow4<VEC>(recon, f, n, P, px, rec);
     }
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void subtract_lds_kernel(const float* __res
     for (int r = 0; r < 16; ++r) {
       const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
       f32x4 rec = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-      f32x4 res = m[r] - rec;
+      f32x4 res = keep_nonzero(m[r] - rec, m[r]);
       strow4<VEC>(R, f, n, P, px, res);
       if (RECON) strow4<VEC>(recon, f, n, P, px, rec);
     }

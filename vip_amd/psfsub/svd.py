@@ -22,7 +22,9 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
     torch = B._torch()
     n, P = mat_t.shape
     G = B.gram(mat_t)
-    if leading_only:
+    if leading_only and n > B.MAX_EIGH_N:
+        evals, evecs = B.eigh_beyond_lds(G, ncomp)                 # verified subspace iteration, leading pairs only
+    elif leading_only:
         evals, evecs = B.eigh_topk(G, ncomp)
     elif B.topk_native(n, ncomp):
         evals, evecs = B.eigh_topk(G, ncomp, all_evals=True)       # whole spectrum, leading vectors
@@ -66,7 +68,12 @@ def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=No
         raise NotImplementedError("left_eigv with the 'eigen' modes is outside the accelerated path")
     dev_in = B.is_device_tensor(matrix)
     t = B.to_device_f32(matrix)
-    sig, E, V = _decompose(t, int(ncomp))
+    # Beyond MAX_EIGH_N frames only the leading pairs can be computed (backend.eigh_beyond_lds).  That serves every call that
+    # returns at most ncomp singular values: V alone, and (U, S, V) of the non-eigen modes, which truncate S to ncomp
+    # (svd.py:454-459,473); the eigen family's full_output wants the whole spectrum and raises there.
+    eigen_family = mode in ("eigen", "eigencupy", "eigenpytorch")
+    leading = t.shape[0] > B.MAX_EIGH_N and not (full_output and eigen_family)
+    sig, E, V = _decompose(t, int(ncomp), leading_only=leading)
     if verbose:
         print("Done SVD/PCA on MI355X (Gram on the int8 / float64 matrix cores + Householder-tridiagonal leading-k eigensolver), "
               "requested mode '{}'".format(mode))
