@@ -1353,8 +1353,11 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   // a lone synchronous call owns the chip: with the workgroups of a problem on ONE XCD (below) twice as many of them halve the
   // row pass at no extra exchange cost (n = 400: 16 / 24 / 32 workgroups 1.74 / 1.66 / 1.63 ms, round 3); the pipelined mode keeps
   // 16 -- its eigensolver runs beside the other call's shears and every CU it takes is one they lose
-  const bool lone = batch == 1 && ctx->opt("eigh_check", 1) != 0 && ctx->opt("eigh_one_xcd", -1) != 0 && ctx->num_cu % 8 == 0;
-  if (lone && n > 320 && n <= 448 && ctx->num_cu / 8 >= 32) W = 32;
+  // (option eigh_wave_async, experiment of round 5: the wave-resident path also in the pipelined mode, where its 64 waves must find
+  //  their SIMDs between the other call's persistent shear workgroups: 1 = on one XCD, 2 = spread over the chip)
+  const int64_t wave_async = ctx->opt("eigh_check", 1) == 0 ? ctx->opt("eigh_wave_async", 0) : 0;
+  const bool lone = batch == 1 && (ctx->opt("eigh_check", 1) != 0 || wave_async != 0) && ctx->opt("eigh_one_xcd", -1) != 0 && ctx->num_cu % 8 == 0;
+  if (lone && n > 320 && n <= 448 && ctx->num_cu / 8 >= 32 && wave_async == 0) W = 32;
   if (ctx->opt("eigh_w", 0) >= 2 && ctx->opt("eigh_w", 0) <= 64) W = (int)ctx->opt("eigh_w", 0);       // (experiments)
   const int RW = (int)cdiv(n, W);
   double* gbuf = nullptr;
@@ -1384,7 +1387,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
   static std::atomic<unsigned> xcd_base{(unsigned)getpid() * 2654435761u >> 16};
   const int64_t want_xcd = ctx->opt("eigh_one_xcd", -1);
   const bool xcd_ok = W <= 64 && W <= ctx->num_cu / 8 && ctx->num_cu % 8 == 0;
-  const int one_xcd = xcd_ok && (want_xcd > 0 || (want_xcd < 0 && ctx->opt("eigh_check", 1) != 0)) ? 1 : 0;
+  const int one_xcd = xcd_ok && (want_xcd > 0 || (want_xcd < 0 && (ctx->opt("eigh_check", 1) != 0 || wave_async != 0))) ? 1 : 0;
   const int64_t per_launch = ctx->num_cu / W > 0 ? ctx->num_cu / W : 1;
   int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
   VIPMI_TRY(deferred_fail_words(ctx, &fail, !wave_only));
@@ -1407,7 +1410,7 @@ int launch_tri_multi(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, dou
     VIPMI_TRY(ws(ctx, "eigh_wave_gram", (size_t)8 * cdiv(n, 4), &gram));
     double* det2 = nullptr;
     VIPMI_TRY(ws(ctx, "eigh_wave_det2", (size_t)3 * n + 8, &det2));
-    VIPMI_TRY(tri_wave_reduce(ctx, A, n, det, gw, bars2, (int)(1 + (xcd_base.fetch_add(1u) & 7u)), fail, gram, det2));
+    VIPMI_TRY(tri_wave_reduce(ctx, A, n, det, gw, bars2, wave_async == 2 ? 0 : (int)(1 + (xcd_base.fetch_add(1u) & 7u)), fail, gram, det2));
     // the leading pairs alone: one workgroup per vector (eigh_wave.hip); with the rest of the spectrum: stages 2-5 of this kernel
     if (!all_evals && k <= 64) {
       VIPMI_TRY(tri_wave_vectors(ctx, A, n, k, det, det2, gram, evals, evecs, bars2));
@@ -1538,7 +1541,7 @@ int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k
   const bool reg1 = ctx->opt("eigh_reg", 1) != 0 && reg_variant_fits((int)n, (int)k);
   // (a lone synchronous problem of 129 .. 200 rows: the wave-resident path of launch_tri_multi beats the register-resident
   //  single-workgroup kernel as well -- n = 200, k = 10: 0.82 -> see tools/eigh_wave_check.py)
-  const bool wave1 = batch == 1 && !nact && tri_wave_fits(ctx, n) && ctx->opt("eigh_wave", 1) != 0 && ctx->opt("eigh_check", 1) != 0 &&
+  const bool wave1 = batch == 1 && !nact && tri_wave_fits(ctx, n) && ctx->opt("eigh_wave", 1) != 0 && (ctx->opt("eigh_check", 1) != 0 || ctx->opt("eigh_wave_async", 0) != 0) &&
                      ctx->opt("eigh_one_xcd", -1) != 0 && ctx->num_cu % 8 == 0 && ctx->num_cu >= 64;
   const bool multi = !nact && n >= 96 && batch <= 8 && (!reg1 || wave1) && ctx->opt("eigh_multi", 1) != 0;
   if (multi) {
