@@ -32,7 +32,11 @@ def code_objects(path):
         r = subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path, os.devnull],
                            capture_output=True, text=True)
         if r.returncode != 0 or not os.path.exists(fat):
-            return []
+            # no device code in this object (a host-only translation unit has no .hip_fatbin section) -- or the tool failed
+            sec = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-S", path], capture_output=True, text=True)
+            if sec.returncode == 0 and ".hip_fatbin" not in sec.stdout:
+                return None
+            raise RuntimeError("llvm-objcopy could not extract .hip_fatbin from %s: %s" % (path, r.stderr[:300]))
         data = open(fat, "rb").read()
     out = []
     pos = data.find(MAGIC)
@@ -51,7 +55,13 @@ def code_objects(path):
 
 def lint_file(path):
     hits, ninstr = [], 0
-    for i, (triple, blob) in enumerate(code_objects(path)):
+    objs = code_objects(path)
+    if objs is None:
+        return [], None                      # host-only object: nothing to lint
+    if not objs:
+        raise RuntimeError("%s has a .hip_fatbin section but no readable gfx950 code object (a compressed CCOB bundle of a newer "
+                           "toolchain? unbundle with clang-offload-bundler): lint cannot vouch for it" % path)
+    for i, (triple, blob) in enumerate(objs):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(blob)
             f.flush()
@@ -77,11 +87,24 @@ def main(argv):
     if not files:
         print("isa_lint: nothing to check (build first)")
         return 2
-    allhits, total = [], 0
+    allhits, total, empty = [], 0, []
     for f in files:
         hits, n = lint_file(f)
         allhits += hits
+        if n is None:
+            continue
         total += n
+        if n == 0:
+            empty.append(f)
+    # a gate that cannot see the code is no gate: a file without a readable gfx950 code object (llvm-objcopy failed, no .hip_fatbin,
+    # a compressed CCOB bundle of a newer toolchain) or an implausibly small disassembly fails the build instead of passing it
+    if empty:
+        print("isa_lint: no gfx950 instructions found in %s -- the offload bundle could not be read (compressed bundle? "
+              "missing .hip_fatbin?): lint cannot vouch for these files" % ", ".join(os.path.basename(f) for f in empty))
+        return 3
+    if any(f.endswith(".so") for f in files) and total < 100000:
+        print("isa_lint: only %d instructions disassembled from a library build -- implausible, refusing to pass" % total)
+        return 3
     if allhits:
         kernels = {}
         for path, kernel, ins in allhits:

@@ -234,13 +234,26 @@ def _split(total, world):
 
 
 # ---- per-phase wall times of the sharded paths (bench.py's strong-scaling legs: what did the collectives cost?) ------------------
-_phases = {"on": False, "acc": {}, "last": 0.0}
+import threading as _threading
+
+_phase_tls = _threading.local()       # the clock belongs to the THREAD that switched it on: sharded routines called from several
+                                      # host threads (each rank is one process, but a rank may run them from worker threads) neither
+                                      # see nor disturb each other's phases
+
+
+def _phase_state():
+    st = getattr(_phase_tls, "st", None)
+    if st is None:
+        st = _phase_tls.st = {"on": False, "acc": {}, "last": 0.0}
+    return st
 
 
 def phase_timing(on=True):
-    """Switch the phase clock of the sharded routines on (clears it) or off (returns {phase: milliseconds}).  With the clock
-    on, every phase boundary synchronises the device, so the phases do not overlap: run it on a step of its own."""
+    """Switch the phase clock of the sharded routines on (clears it) or off (returns {phase: milliseconds}) for the calling
+    thread.  With the clock on, every phase boundary synchronises the device, so the phases do not overlap: run it on a step of
+    its own."""
     import time
+    _phases = _phase_state()
     if on:
         _phases.update(on=True, acc={}, last=time.perf_counter())
         return None
@@ -249,6 +262,7 @@ def phase_timing(on=True):
 
 
 def _mark(name):
+    _phases = _phase_state()
     if not _phases["on"]:
         return
     import time
