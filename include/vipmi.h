@@ -211,6 +211,13 @@ int vipmi_annular_residuals_multi_f32(vipmi_ctx* ctx, const float* A, int64_t n,
  * apply: residuals[nk][n][npx] from the leading eigenpairs evals[n][m], evecs[n][m][m] (rows = vectors, descending). */
 int vipmi_annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                                const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H);
+/* eigh (round 5): the eigensolve of ALL libraries of nseg segments (n frames each) in one call WITHOUT the sub-Gram matrices of
+ * `subgrams` -- the solver gathers problem p = seg n + j as G[seg][idx[p][a]][idx[p][b]], a, b < len[p], from the segments' Gram
+ * matrices G[nseg][n][n] (vipmi_gram_f32 of every segment matrix).  lib_idx: [nseg n][m] int32 (rows padded to m >= every
+ * library), lib_len: [nseg n]; work: [nseg n][m][m] float64 workspace; evals [nseg n][m], evecs [nseg n][m][m] as
+ * vipmi_eigh_topk_f64 returns them (leading k).  do_pca_patch, pca_local.py:830-909. */
+int vipmi_annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, const int32_t* lib_idx,
+                           const int32_t* lib_len, int64_t m, int64_t k, double* work, double* evals, double* evecs);
 int vipmi_annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                             const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
                             const double* evecs, const int32_t* ncomps_host, int64_t nk, float* residuals);

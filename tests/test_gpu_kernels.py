@@ -1243,3 +1243,43 @@ def test_gram_int8_non_finite_rows_and_the_default_rule(B):
         assert np.all(np.isfinite(G[~bad][:, ~bad]))
     finally:
         ctx.set_option("gram_i8", -1)
+
+
+@pytest.mark.parametrize("nseg,n,m,k", [(2, 90, 64, 5), (3, 150, 120, 8), (2, 260, 200, 10), (1, 300, 230, 6)])
+def test_annular_eigh_gathers_the_libraries_itself(B, nseg, n, m, k):
+    """vipmi_annular_eigh_f64: the leading pairs of every library's sub-Gram matrix with the solver reading
+    G[seg][idx[a]][idx[b]] itself -- bit-identical to vipmi_eigh_topk_f64 on the materialised, zero-padded matrices (the same
+    values reach the same kernel); m = 230 is beyond the register-resident solver and takes the materialising route inside."""
+    import torch
+    rng = np.random.default_rng(nseg * 1000 + n)
+    Gs, idx, ln, Hs = [], [], [], []
+    for sg in range(nseg):
+        M = rng.standard_normal((n, n + 40)) * (2.0 ** (-np.arange(n + 40) / 50.0))
+        G = M @ M.T
+        Gs.append(G)
+        for j in range(n):
+            lj = int(rng.integers(max(k, 3), m + 1)) if j % 7 else m
+            ij = np.sort(rng.choice(n, size=lj, replace=False)).astype(np.int32)
+            row = np.zeros(m, dtype=np.int32)
+            row[:lj] = ij
+            idx.append(row)
+            ln.append(lj)
+            H = np.zeros((m, m))
+            H[:lj, :lj] = G[np.ix_(ij, ij)]
+            Hs.append(H)
+    Gs, idx, ln, Hs = np.stack(Gs), np.stack(idx), np.array(ln, dtype=np.int32), np.stack(Hs)
+    dev = "cuda"
+    Gt, it, lt = torch.from_numpy(Gs).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(ln).to(dev)
+    total = nseg * n
+    work = torch.empty((total, m, m), dtype=torch.float64, device=dev)
+    ev = torch.zeros((total, m), dtype=torch.float64, device=dev)
+    ec = torch.zeros((total, m, m), dtype=torch.float64, device=dev)
+    ctx = B.get_context()
+    ctx.call("vipmi_annular_eigh_f64", B.ptr(Gt), nseg, n, B.ptr(it), B.ptr(lt), m, k, B.ptr(work), B.ptr(ev), B.ptr(ec))
+    ev2, ec2 = B.eigh_topk(torch.from_numpy(Hs.copy()).to(dev), k, nact=lt)
+    torch.cuda.synchronize()
+    assert torch.equal(ev[:, :k], ev2) and torch.equal(ec[:, :k, :], ec2)
+    for p in (0, total // 2, total - 1):
+        lj = int(ln[p])
+        w = np.linalg.eigvalsh(Hs[p][:lj, :lj])[::-1]
+        np.testing.assert_allclose(ev[p, :k].cpu().numpy(), w[:k], atol=1e-12 * w[0])

@@ -93,6 +93,25 @@ int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
   return VIPMI_OK;
 }
 
+// stage 2 for ALL segments at once (round 5): the leading k eigenpairs of the nseg * n libraries, the solver gathering every
+// sub-Gram matrix itself from its segment's Gram matrix G[seg] (n x n, L2-resident) -- H is never written out and read back
+// (1 GB each way at C3, and the 1 ms of subgram_kernel launches).  lib_idx: [nseg * n][m] (rows padded to m), lib_len: [nseg * n];
+// work[nseg * n][m][m]: workspace (the reflectors).  Sizes the register-resident solver does not serve (m > 200 or k > 32) take the
+// old route: the matrices materialised into `work`, eigh_leading on them.
+int annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, const int32_t* lib_idx, const int32_t* lib_len,
+                     int64_t m, int64_t k, double* work, double* evals, double* evecs) {
+  VIPMI_REQUIRE(G && lib_idx && lib_len && work && evals && evecs, "annular_eigh: null pointer");
+  VIPMI_REQUIRE(nseg > 0 && n > 0 && m > 0 && k > 0 && k <= m, "annular_eigh: bad sizes");
+  if (eigh_gather_supported(m, k) && ctx->opt("eigh_reg", 1) != 0 && ctx->opt("ann_gather", 1) != 0)
+    return eigh_topk_gather_f64(ctx, G, nseg, n, n, lib_idx, lib_len, m, k, work, evals, evecs);
+  for (int64_t sg = 0; sg < nseg; ++sg) {
+    hipLaunchKernelGGL(subgram_kernel, dim3((unsigned)n), dim3(256), sizeof(int32_t) * (size_t)m, ctx->stream, G + (size_t)sg * n * n, (int)n,
+                       lib_idx + (size_t)sg * n * m, lib_len + (size_t)sg * n, (int)m, (int)m, work + (size_t)sg * n * m * m);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  return eigh_leading(ctx, work, nseg * n, m, k, lib_len, evals, evecs);
+}
+
 // stage 3: residuals[i] = (I - C_i) A for every truncation rank ncomps[i] (HOST array), from the leading eigenpairs of the
 // libraries (evals[j][m], evecs[j][m][m]: rows = vectors, as the top-k eigensolver returns them)
 int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,

@@ -304,7 +304,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", "ann_gather", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
@@ -591,6 +591,12 @@ int vipmi_annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_
                                const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H) {
   VIPMI_REQUIRE(ctx, "null ctx");
   return annular_subgrams_f64(ctx, A, n, npx, lib_idx, lib_len, max_lib, m, G, H);
+}
+
+int vipmi_annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, const int32_t* lib_idx,
+                           const int32_t* lib_len, int64_t m, int64_t k, double* work, double* evals, double* evecs) {
+  CTX_GUARD();
+  return annular_eigh_f64(ctx, G, nseg, n, lib_idx, lib_len, m, k, work, evals, evecs);
 }
 
 int vipmi_annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,

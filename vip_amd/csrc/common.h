@@ -233,11 +233,16 @@ int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double
 bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,
                    bool all_evals = false);
+int annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, const int32_t* lib_idx, const int32_t* lib_len,
+                     int64_t m, int64_t k, double* work, double* evals, double* evecs);
 int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                          const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H);
 int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                       const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
                       const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals);
+bool eigh_gather_supported(int64_t m, int64_t k);
+int eigh_topk_gather_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t per_seg, int64_t ldg, const int32_t* idx,
+                         const int32_t* len, int64_t m, int64_t k, double* work, double* evals, double* evecs);
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact,
                  double* evals, double* evecs, bool all_evals = false);
 // verified fast path for the leading pairs of ONE positive semi-definite matrix (eigh_chfsi.hip); G is not modified

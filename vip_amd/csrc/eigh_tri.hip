@@ -50,6 +50,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // (256 threads: capped at 80 VGPRs so that six workgroups share a CU -- that variant runs the latency-bound second half of
 // split batches; 3200 problems 7.10 -> 6.83 ms against four workgroups per CU, eight are slower again)
+// Optional input gather of the register-resident variant: problem p reads its matrix as G[p / per_seg][idx[p][r]][idx[p][c]]
+// (the zero-padded library sub-Gram matrix of annular PCA, straight from the segment's Gram matrix) instead of A[p][r][c];
+// A[p] is then only the workspace that receives the reflectors.  G == nullptr: no gather.
+struct TriGather {
+  const double* G = nullptr;
+  const int32_t* idx = nullptr;
+  int ldg = 0, stride = 0, per_seg = 1;
+};
+
 template <int RPL, int NT, int RPW = 0>
 __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double* __restrict__ Aall, int n, int k,
                                                      const int32_t* __restrict__ nact, double* __restrict__ evals_all,
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double
                                                      double* __restrict__ det_all = nullptr,
                                                      const unsigned* __restrict__ guard = nullptr,
                                                      const unsigned* __restrict__ gcount = nullptr,
-                                                     int* __restrict__ fail = nullptr) {
+                                                     int* __restrict__ fail = nullptr, TriGather gat = TriGather()) {
   // guard != nullptr: this launch is the RECOVERY of a cooperating solve (launch_tri_multi): it follows every such solve in the
   // stream, returns at once when that solve went through (*guard == 0) and otherwise -- a partner of the cooperating kernel never
   // became resident within its time-out: another process held the CUs -- solves the problem(s) again from a copy of the input, alone
@@ -141,22 +150,43 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 1)) void tri_eig_kernel(double
     for (int i = tid; i < 4 * NP; i += TNT) vcur[i] = 0.0;
     __syncthreads();
     double areg[RPW][CH];
+    // gathered input (annular PCA): the library's rows / columns of the segment's Gram matrix -- 1.3 MB per segment, L2-resident;
+    // the sub-Gram matrices are never written out and read back (1 GB each way at C3)
+    const double* Gp = gat.G ? gat.G + (size_t)(prob / gat.per_seg) * gat.ldg * gat.ldg : nullptr;
+    const int32_t* ip = gat.G ? gat.idx + (size_t)prob * gat.stride : nullptr;
+    int gc[CH], gc8 = 0;
+    if (Gp) {
 #pragma unroll
-    for (int j = 0; j < RPW; ++j)
+      for (int ch = 0; ch < CH; ++ch) gc[ch] = (lane + 64 * ch < na) ? ip[lane + 64 * ch] : 0;
+      if constexpr (TAIL8) gc8 = (lane < 8 && 64 * CH + lane < na) ? ip[64 * CH + lane] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int r = wave + TNW * j;
+      const double* src = Gp ? Gp + (size_t)(r < na ? ip[r] : 0) * gat.ldg : A + (size_t)r * n;
 #pragma unroll
       for (int ch = 0; ch < CH; ++ch) {
-        const int r = wave + TNW * j, c = lane + 64 * ch;
-        areg[j][ch] = (r < na && c < na) ? A[(size_t)r * n + c] : 0.0;
+        const int c = lane + 64 * ch;
+        areg[j][ch] = (r < na && c < na) ? src[Gp ? gc[ch] : c] : 0.0;
       }
+    }
     double ablk = 0.0;
     if constexpr (TAIL8) {
       const int r8 = 64 * CH + wave, c8 = 64 * CH + lane;
-      ablk = (lane < 8 && r8 < na && c8 < na) ? A[(size_t)r8 * n + c8] : 0.0;
+      const bool ok8 = lane < 8 && r8 < na && c8 < na;
+      if (Gp) ablk = ok8 ? Gp[(size_t)ip[r8 < na ? r8 : 0] * gat.ldg + gc8] : 0.0;
+      else ablk = ok8 ? A[(size_t)r8 * n + c8] : 0.0;
       // (A v)[192 + w] is written by wave w alone, into the slot of wave 0: the other waves' slots stay zero
       for (int e = tid; e < TNW * 8; e += TNT)
         if (64 * CH + (e & 7) < n) pcolw[(e >> 3) * n + 64 * CH + (e & 7)] = 0.0;
     }
-    for (int c = tid; c < na; c += TNT) nrow[c] = A[(size_t)c * n];  // column 0
+    if (Gp) {
+      const size_t g0 = na > 0 ? (size_t)ip[0] : 0;
+      for (int c = tid; c < na; c += TNT) nrow[c] = Gp[(size_t)ip[c] * gat.ldg + g0];   // column 0
+      if (na == 1 && tid == 0) A[0] = Gp[g0 * gat.ldg + g0];                           // (the closing formulas read it from A)
+    } else {
+      for (int c = tid; c < na; c += TNT) nrow[c] = A[(size_t)c * n];  // column 0
+    }
     __syncthreads();
 #ifdef VIPMI_TRI_PROFILE
     long long seg[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -1334,7 +1364,7 @@ int launch_recovery(vipmi_ctx* ctx, double* Abak, int64_t batch, int n, int k, d
   auto kern = tri_eig_kernel<RPL, 1024>;
   VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(1024), lds, ctx->stream, Abak, n, k, (const int32_t*)nullptr, evals, evecs,
-                     scratch, kp, all_evals, k < n ? k : n, 0, (double*)nullptr, guard, gcount, fail);
+                     scratch, kp, all_evals, k < n ? k : n, 0, (double*)nullptr, guard, gcount, fail, TriGather());
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -1461,7 +1491,7 @@ bool reg_variant_fits(int n, int k) { return k <= 32 && cdiv(n, 8) <= 25 && reg_
 
 template <int RPL>
 int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int32_t* nact, double* evals,
-               double* evecs, int all_evals) {
+               double* evecs, int all_evals, const TriGather& gat = TriGather()) {
   const int kp = (int)cdiv(k, 16) * 16;
   double* scratch = nullptr;
   VIPMI_TRY(ws(ctx, "eigh_tri_scratch", (size_t)batch * 6 * n * kp, &scratch));
@@ -1482,20 +1512,20 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
       const bool split = (split_opt < 0 ? batch >= 4 * ctx->num_cu : split_opt != 0) && k <= 16;
       if (!split) {
         hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch,
-                           kp, all_evals, reg_variant_chunk(n, k), 0, (double*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr);
+                           kp, all_evals, reg_variant_chunk(n, k), 0, (double*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr, gat);
         VIPMI_CHECK_HIP(hipGetLastError());
         return VIPMI_OK;
       }
       double* det = nullptr;
       VIPMI_TRY(ws(ctx, "eigh_tri_det", (size_t)batch * 3 * n, &det));
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds_r, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
-                         all_evals, reg_variant_chunk(n, k), 1, det, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr);
+                         all_evals, reg_variant_chunk(n, k), 1, det, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr, gat);
       VIPMI_CHECK_HIP(hipGetLastError());
       const size_t lds2 = ((size_t)(9 + 256 / 64) * n + 64 + 8) * sizeof(double);
       auto kern2 = tri_eig_kernel<RPL, 256>;
       VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern2), (int)lds2));
       hipLaunchKernelGGL(kern2, dim3((unsigned)batch), dim3(256), lds2, ctx->stream, A, n, k, nact, evals, evecs, scratch, kp,
-                         all_evals, k < n ? k : n, 2, det, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr);
+                         all_evals, k < n ? k : n, 2, det, (const unsigned*)nullptr, (const unsigned*)nullptr, (int*)nullptr, TriGather());
       VIPMI_CHECK_HIP(hipGetLastError());
       return VIPMI_OK;
     };
@@ -1506,6 +1536,7 @@ int launch_tri(vipmi_ctx* ctx, double* A, int64_t batch, int n, int k, const int
       return launch_reg(tri_eig_kernel<4, 512, 25>);       // 129 .. 200 rows
     }
   }
+  VIPMI_REQUIRE(gat.G == nullptr, "eigh_topk: the gathered input needs the register-resident solver (n = %d, k = %d)", n, k);
   const size_t lds = ((size_t)(9 + nt / 64) * n + 64 + 8) * sizeof(double);     // + prow[n], pcolw[waves][n]
   const void* kern = nt == 256   ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 256>)
                      : nt == 512 ? reinterpret_cast<const void*>(tri_eig_kernel<RPL, 512>)
@@ -1552,6 +1583,29 @@ int eigh_topk_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k
   if (n <= 128) return launch_tri<2>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs, all_evals);
   if (n <= 256) return launch_tri<4>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs, all_evals);
   return launch_tri<8>(ctx, A, batch, (int)n, (int)k, nact, evals, evecs, all_evals);
+}
+
+// Leading k eigenpairs of nseg * per_seg zero-padded library sub-Gram matrices (m x m) of annular PCA, gathered by the solver
+// itself from the segments' Gram matrices G[nseg][ldg][ldg]: problem p uses rows / columns idx[p][0 .. len[p]) of G[p / per_seg].
+// work[p][m][m]: workspace for the reflectors.  Returns false when the register-resident solver does not serve (m, k) -- the caller
+// then materialises the matrices and calls eigh_leading.
+bool eigh_gather_supported(int64_t m, int64_t k) {
+  return m >= 1 && m <= 200 && k >= 1 && eigh_topk_supported(m, k) && reg_variant_fits((int)m, (int)k);
+}
+int eigh_topk_gather_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t per_seg, int64_t ldg, const int32_t* idx,
+                         const int32_t* len, int64_t m, int64_t k, double* work, double* evals, double* evecs) {
+  VIPMI_REQUIRE(G && idx && len && work && evals && evecs, "eigh_topk_gather: null pointer");
+  VIPMI_REQUIRE(eigh_gather_supported(m, k) && ctx->opt("eigh_reg", 1) != 0, "eigh_topk_gather: unsupported sizes m=%ld k=%ld", (long)m, (long)k);
+  StageScope sc(ctx, "eigh");
+  TriGather gat;
+  gat.G = G;
+  gat.idx = idx;
+  gat.ldg = (int)ldg;
+  gat.stride = (int)m;
+  gat.per_seg = (int)per_seg;
+  const int64_t batch = nseg * per_seg;
+  if (m <= 128) return launch_tri<2>(ctx, work, batch, (int)m, (int)k, len, evals, evecs, false, gat);
+  return launch_tri<4>(ctx, work, batch, (int)m, (int)k, len, evals, evecs, false, gat);
 }
 
 int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, const int32_t* nact, double* evals,

@@ -338,6 +338,13 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             ev_all = torch.empty((total, m_all), dtype=torch.float64, device=cube.device)
             ec_all = torch.empty((total, m_all, m_all), dtype=torch.float64, device=cube.device)
             nact_all = torch.cat([libs_of(seg)[1] for seg in plan]).contiguous()
+            # One eigensolve that gathers every library's sub-Gram matrix itself from its segment's Gram matrix
+            # (vipmi_annular_eigh_f64): the index lists of all segments padded to m_all columns, the Gram matrices contiguous
+            idx_all = torch.zeros((total, m_all), dtype=torch.int32, device=cube.device)
+            for si, seg in enumerate(plan):
+                it, _lt, ml = libs_of(seg)
+                idx_all[si * nrow:(si + 1) * nrow, :ml] = it.reshape(nrow, ml)
+            G_all = torch.empty((len(plan), nrow, nrow), dtype=torch.float64, device=cube.device)
         for st in streams:
             st.wait_stream(cur)
         B.set_async(True)
@@ -351,15 +358,13 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                 for si, seg in enumerate(plan):
                     with torch.cuda.stream(streams[lane_of(seg["ann"])]):
                         A, S, pix, npx = seg_matrix(si, seg)
-                        idx_t, ln_t, max_lib = libs_of(seg)
-                        G = torch.empty((nrow, nrow), dtype=torch.float64, device=cube.device)
-                        B.get_context(dev).call("vipmi_annular_subgrams_f64", B.ptr(A), nrow, npx, B.ptr(idx_t), B.ptr(ln_t),
-                                                max_lib, m_all, B.ptr(G), B.ptr(H_all[si * nrow:(si + 1) * nrow]))
+                        G = G_all[si]
+                        B.get_context(dev).call("vipmi_gram_f32", B.ptr(A), nrow, npx, npx, B.ptr(G))
                         states.append((A, S, pix, npx, G))
                 for st in streams:
                     cur.wait_stream(st)
-                ctx0.call("vipmi_eigh_topk_f64", B.ptr(H_all), total, m_all, k_all, B.ptr(nact_all), B.ptr(ev_all),
-                          B.ptr(ec_all))
+                ctx0.call("vipmi_annular_eigh_f64", B.ptr(G_all), len(plan), nrow, B.ptr(idx_all), B.ptr(nact_all), m_all, k_all,
+                          B.ptr(H_all), B.ptr(ev_all), B.ptr(ec_all))
                 for st in streams:
                     st.wait_stream(cur)
                 for si, seg in enumerate(plan):
