@@ -569,7 +569,9 @@ def main():
                     "avg_launch_ms": dur_ms, "frames_per_launch": frames_per_launch,
                     "note": "duration = hipEvents around the kernel inside the timed region, where it shares the GPU "
                             "with the kernels of the other calls in flight (isolated_*: same kernel in a serial "
-                            "call); the kernel is VALU/LDS-bound (FFT), see DESIGN.md for the flop-based fraction"}
+                            "call); the kernel is an FFT on the vector pipe that runs AT the board's power cap (`power`: "
+                            "1380 of 1400 W under the shears, shader clock 1.8-1.96 of 2.4 GHz; DESIGN.md 4), so neither the "
+                            "HBM nor the nominal vector peak is its ceiling"}
 
     if depth > 1:
         B.set_async(False)
