@@ -68,3 +68,29 @@ def test_the_aggressor_instruction_is_still_where_we_think_it_is():
             elif re.search(r"v_mfma_(i32_16x16x64_i8|f32_16x16x32_(bf16|f16))", line):
                 users.add(kernel)
     assert users and all("gram_i8_kernel" in k for k in users), users
+
+
+def test_lint_cannot_pass_vacuously(tmp_path):
+    """a gate that cannot see the device code must fail, not pass.  A host-only object has nothing to lint; a file whose
+    offload bundle cannot be read raises; a library build with an implausibly small disassembly is refused."""
+    import subprocess
+    lint = _lint()
+    src = tmp_path / "host_only.c"
+    src.write_text("int f(int x) { return x + 1; }\n")
+    obj = tmp_path / "host_only.o"
+    subprocess.run(["gcc", "-c", str(src), "-o", str(obj)], check=True)
+    assert lint.code_objects(str(obj)) is None
+    assert lint.lint_file(str(obj)) == ([], None)
+    # an object that HAS a .hip_fatbin section without a readable gfx950 code object (here: garbage in the section)
+    bad = tmp_path / "bad.o"
+    blob = tmp_path / "blob.bin"
+    blob.write_bytes(b"\0" * 256)
+    r = subprocess.run([os.path.join(lint.LLVM, "llvm-objcopy"), "--add-section", ".hip_fatbin=" + str(blob), str(obj), str(bad)],
+                       capture_output=True, text=True)
+    if r.returncode == 0:
+        with pytest.raises(RuntimeError):
+            lint.lint_file(str(bad))
+    # a "library" with next to no device instructions is not a pass
+    fake = tmp_path / "fake.so"
+    fake.write_bytes(obj.read_bytes())
+    assert lint.main([str(fake)]) != 0
