@@ -58,7 +58,9 @@ int vipmi_trim(vipmi_ctx* ctx);
 int vipmi_set_stream(vipmi_ctx* ctx, void* stream);
 int vipmi_synchronize(vipmi_ctx* ctx);
 /* With option "eigh_check"=0 calls never synchronise; convergence failures are latched on the device.
- * vipmi_check_deferred synchronises the stream and returns VIPMI_ERR_NOCONV if any occurred since the last check. */
+ * vipmi_check_deferred synchronises the stream and returns VIPMI_ERR_NOCONV if any occurred since the last check, VIPMI_ERR_HIP
+ * if a cooperating eigensolver kernel timed out waiting for a participant AND could not be recovered (more than 512 frames, or
+ * option "eigh_recover"=0); recovered time-outs are not errors, vipmi_get_option(ctx, "eigh_recovered") counts them. */
 int vipmi_check_deferred(vipmi_ctx* ctx);
 
 /* Pipelining independent pca calls issued on several streams (one ctx per stream, asynchronous mode).  Contexts
