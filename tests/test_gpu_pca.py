@@ -1467,3 +1467,34 @@ def test_float64_cube_of_detector_counts_vs_reference(tag, kw):
     print("g28 %s: device vs reference(f64) %.3e; reference(f32 cube) vs reference(f64) %.3e; bound %.3e" % (tag, dev, ref32, bound))
     assert dev <= bound
     assert dev <= max(2.0 * ref32, 1e-4)                 # the same order as the reference's own float32 path
+
+
+def test_annular_library_window_skipping_is_bit_identical():
+    """The (I - C) A product of annular PCA skips the frames outside every row group's library window (`ann_range`), and the
+    libraries' sub-Gram matrices are gathered inside the eigensolver (`ann_gather`): both must leave the residual cube bit-identical
+    to the dense product on materialised matrices (only exact zeros are skipped; the same values reach the same kernels)."""
+    import torch
+    from vip_amd import backend as B
+    from vip_amd.psfsub import pca_annular
+    cube, ang = O.synth_adi(130, 96, seed=77)
+    ct = torch.from_numpy(cube).cuda()
+    ang = np.linspace(0, 140, 130)
+    kw = dict(asize=12, ncomp=4, fwhm=4, delta_rot=(0.3, 1), full_output=True, verbose=False, max_frames_lib=60)
+    outs = {}
+    for opts in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        for c in [B.get_context()] + list(B.all_contexts()):
+            c.set_option("ann_range", opts[0])
+            c.set_option("ann_gather", opts[1])
+        os.environ["VIPMI_OPTS"] = "ann_range=%d,ann_gather=%d" % opts          # (contexts of the side streams created later)
+        try:
+            outs[opts] = [t.clone() for t in pca_annular(ct, ang, **kw)]
+        finally:
+            os.environ.pop("VIPMI_OPTS", None)
+    for c in B.all_contexts():
+        c.set_option("ann_range", 1)
+        c.set_option("ann_gather", 1)
+    ref = outs[(0, 0)]
+    for opts, got in outs.items():
+        for a, b in zip(got, ref):
+            assert torch.equal(torch.nan_to_num(a, nan=7.5), torch.nan_to_num(b, nan=7.5)), opts
+    assert np.abs(ref[2].cpu().numpy() - O.pca_annular(cube, ang, asize=12, ncomp=4, fwhm=4, delta_rot=(0.3, 1), max_frames_lib=60)).max() < TOL

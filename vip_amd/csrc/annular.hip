@@ -75,6 +75,34 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
   if (threadIdx.x == 0) C[(size_t)j * n + j] += 1.0f;
 }
 
+// frange[2 g], [2 g + 1]: the frames outside which row group g (32 rows) of D = I - C has no coefficient, as multiples of 8 -- the
+// union over its rows j of [min(lib_j), max(lib_j)] and j itself.  One workgroup of 32 lanes per group.
+__global__ __launch_bounds__(32) void coeff_range_kernel(int n, const int32_t* __restrict__ idx, const int32_t* __restrict__ len,
+                                                         int max_lib, int* __restrict__ frange) {
+  const int g = blockIdx.x, j = g * 32 + threadIdx.x;
+  int lo = n, hi = 0;
+  if (j < n) {
+    lo = j;
+    hi = j + 1;
+    const int32_t* ij = idx + (size_t)j * max_lib;
+    for (int a = 0; a < len[j]; ++a) {
+      const int v = ij[a];
+      lo = v < lo ? v : lo;
+      hi = v + 1 > hi ? v + 1 : hi;
+    }
+  }
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) {
+    const int ol = __shfl_xor(lo, m, 32), oh = __shfl_xor(hi, m, 32);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if (threadIdx.x == 0) {
+    frange[2 * g] = lo & ~7;
+    frange[2 * g + 1] = (hi + 7) & ~7;
+  }
+}
+
 }  // namespace
 
 // The three stages of a segment.  annular_residuals_multi_f32 below runs them back to back; the Python front runs stage 1
@@ -126,6 +154,14 @@ int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, co
   }
   float* C = nullptr;
   VIPMI_TRY(ws(ctx, "ann_C", (size_t)n * n, &C));
+  // the frames each group of 32 rows of I - C reaches (its rows' library windows): the product skips the rest
+  int* frange = nullptr;
+  const int groups = (int)cdiv(n, 32);
+  if (ctx->opt("ann_range", 1) != 0) {
+    VIPMI_TRY(ws(ctx, "ann_frange", (size_t)2 * groups, &frange));
+    hipLaunchKernelGGL(coeff_range_kernel, dim3(groups), dim3(32), 0, ctx->stream, (int)n, lib_idx, lib_len, (int)max_lib, frange);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
   const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
   for (int64_t i = 0; i < nk; ++i) {
     VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
@@ -134,7 +170,7 @@ int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, co
     VIPMI_CHECK_HIP(hipGetLastError());
     // residuals = A - C A = (I - C) A: one (n x n) x (n x npx) product on the matrix cores.  (Round 1 ran it through the
     // skinny-k subtract kernel, k = n components: 14 TF/s, 4.7 of C3's 35 ms; the row-space kernel does it at ~60 TF/s.)
-    VIPMI_TRY(rowspace_gemm_f32(ctx, C, A, n, n, npx, nullptr, residuals + (size_t)i * n * npx));
+    VIPMI_TRY(rowspace_gemm_f32(ctx, C, A, n, n, npx, nullptr, residuals + (size_t)i * n * npx, frange));
   }
   return VIPMI_OK;
 }

@@ -251,7 +251,7 @@ int64_t eigh_chfsi_pays_from(int64_t k);      // smallest n at which the fast pa
 int eigh_chfsi_f64(vipmi_ctx* ctx, const double* G, int64_t n, int64_t k, double* evals, double* evecs, int* converged,
                    int* info);
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,
-                      const float* rowscale, float* B);
+                      const float* rowscale, float* B, const int* frange = nullptr);
 int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,
                       int64_t k, int64_t P, float* R, float* recon);
 int scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P, int mode);

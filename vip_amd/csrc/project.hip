@@ -58,7 +58,11 @@ template <bool VEC, int NG>
 __global__ __launch_bounds__(256, 2) void rowspace_kernel(const float* __restrict__ Wt, int kld,
                                                        const float* __restrict__ M, int k, int n,
                                                        int64_t P, const float* __restrict__ rowscale,
-                                                       float* __restrict__ T, int64_t sWt, int64_t sM, int64_t sT) {
+                                                       float* __restrict__ T, int64_t sWt, int64_t sM, int64_t sT,
+                                                       const int* __restrict__ frange = nullptr) {
+  // frange (optional): [2 g], [2 g + 1] = the rows f of M outside which EVERY coefficient of output group g (32 rows of T) is zero,
+  // as multiples of 8 -- the (I - C) A product of annular PCA, whose row j only has coefficients inside its library window: the
+  // rows of M outside the union of the wave's groups are neither loaded nor multiplied (bit-identical: they would have added zeros)
   Wt += blockIdx.z * sWt;                    // blockIdx.z = problem of the batch (strides 0 for a single one)
   M += blockIdx.z * sM;
   T += blockIdx.z * sT;
@@ -78,7 +82,20 @@ __global__ __launch_bounds__(256, 2) void rowspace_kernel(const float* __restric
       for (int r = 0; r < 16; ++r) acc[g][c][r] = 0.f;
   const float* wrow = Wt + grp0 * 32 + jl;  // A operand: W[grp*32 + i][f], i = lane&31
   constexpr int U = 4;
-  for (int f0 = 0; f0 < n; f0 += 2 * U) {
+  int flo = 0, fhi = n;
+  if (frange) {
+    flo = n;
+    fhi = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if ((grp0 + g) * 32 < k) {
+        const int lo = frange[2 * (grp0 + g)], hi = frange[2 * (grp0 + g) + 1];
+        flo = lo < flo ? lo : flo;
+        fhi = hi > fhi ? hi : fhi;
+      }
+    fhi = fhi < n ? fhi : n;
+  }
+  for (int f0 = flo; f0 < fhi; f0 += 2 * U) {
     f32x4 b[U];
     float a[NG][U];
 #pragma unroll
@@ -287,13 +304,13 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // internal: operands already in the layouts the kernels want
 int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n,
-                    int64_t P, const float* rowscale, float* T) {
+                    int64_t P, const float* rowscale, float* T, const int* frange) {
   const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(T);
   const int groups = (int)cdiv(k, 32), ng = groups >= 2 ? 2 : 1;     // two groups of 32 components per pass over M from 33 on
   dim3 grid((unsigned)cdiv(cdiv(P, 128), 4), (unsigned)cdiv(groups, ng)), block(256);
 #define LAUNCH(V, G)                                                                                          \
   hipLaunchKernelGGL((rowspace_kernel<V, G>), grid, block, 0, ctx->stream, Wt, kld, M, (int)k, (int)n, P, rowscale, T, \
-                     (int64_t)0, (int64_t)0, (int64_t)0)
+                     (int64_t)0, (int64_t)0, (int64_t)0, frange)
   if (vec) {
     if (ng == 2) LAUNCH(true, 2); else LAUNCH(true, 1);
   } else {
@@ -341,7 +358,7 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
 }
 
 int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k, int64_t n, int64_t P,
-                      const float* rowscale, float* B) {
+                      const float* rowscale, float* B, const int* frange) {
   VIPMI_REQUIRE(W && M && B, "rowspace_gemm: null pointer");
   VIPMI_REQUIRE(k > 0 && n > 0 && P > 0, "rowspace_gemm: bad sizes");
   StageScope sc(ctx, "project");
@@ -350,7 +367,7 @@ int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k,
   VIPMI_TRY(ws(ctx, "proj_wt", (size_t)n * kld, &Wt));
   hipLaunchKernelGGL(transpose_pad_kernel, dim3(64), dim3(256), 0, ctx->stream, W, (int)k, (int)n, Wt, kld);
   VIPMI_CHECK_HIP(hipGetLastError());
-  return rowspace_gemm_t(ctx, Wt, kld, M, k, n, P, rowscale, B);
+  return rowspace_gemm_t(ctx, Wt, kld, M, k, n, P, rowscale, B, frange);
 }
 
 int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,
