@@ -1451,10 +1451,12 @@ def test_msdi_double_with_cube_sig_golden(tag, kw):
                                     ("k9_mask", dict(ncomp=9, mask_center_px=6))])
 def test_float64_cube_of_detector_counts_vs_reference(tag, kw):
     """A float64 cube with values ~7e3 (g28: the reference's OWN float64 run, oracle/gen_golden_r5.py).  The reference keeps the
-    caller's dtype through svd_wrapper (psfsub/pca_fullfr.py:1552-1737); the device path rounds the cube to float32 on upload
-    (2^-24 x 7e3 = 4e-4 per sample) and computes Gram / eigensolver in float64, projection, shears and median in float32.
-    Pinned here: the deviation from the reference's float64 result is (a) of the order of what the reference itself shows when
-    the same cube is handed over as float32 (at most twice that; measured in round 5: k4 1.9e-3 against 1.6e-3) and (b) below 2^-21 of the cube's largest value (INTEGRATION.md "float64 input")."""
+    caller's dtype through svd_wrapper (psfsub/pca_fullfr.py:1552-1737).  The float64 route of the device path
+    (vipmi_pca_fullframe_f64, csrc/pca_f64.hip) carries the per-pixel temporal mean in float64 and runs the float32 kernels on what
+    is left: the BASELINE gate 1e-4 holds on this cube although its samples are 700 times the benchmark's (measured 2.2e-5 .. 3.5e-5;
+    the float32 route -- the cube rounded on upload -- ends 1.9e-3 away, the reference itself 1.6e-3 .. 4.7e-2 when it is handed the
+    cube as float32)."""
+    import torch
     from vip_amd.psfsub import pca
     g = load_golden("g28_f64_counts")
     cube, ang = g["cube"], g["angles"]
@@ -1463,10 +1465,31 @@ def test_float64_cube_of_detector_counts_vs_reference(tag, kw):
     assert fr.dtype == np.float64                         # numpy in -> numpy out in the caller's dtype
     dev = np.nanmax(np.abs(fr - g["frame64_" + tag]))
     ref32 = np.nanmax(np.abs(g["frame_ref_f32_" + tag] - g["frame64_" + tag]))
-    bound = 2.0 ** -21 * np.abs(cube).max()
-    print("g28 %s: device vs reference(f64) %.3e; reference(f32 cube) vs reference(f64) %.3e; bound %.3e" % (tag, dev, ref32, bound))
-    assert dev <= bound
-    assert dev <= max(2.0 * ref32, 1e-4)                 # the same order as the reference's own float32 path
+    print("g28 %s: float64 route vs reference(f64) %.3e; reference(f32 cube) vs reference(f64) %.3e" % (tag, dev, ref32))
+    assert dev < TOL and dev < 0.2 * ref32
+    # a float64 cuda tensor takes the same route: bit-identical frame, returned on the device
+    frt = pca(torch.from_numpy(cube).cuda(), ang, verbose=False, **kw)
+    assert frt.is_cuda and np.array_equal(np.nan_to_num(frt.cpu().numpy().astype(np.float64), nan=3.5), np.nan_to_num(fr, nan=3.5))
+    # the float32 route (what every other call shape still takes for float64 input): bounded by 2^-21 of the largest sample
+    fo = pca(cube, ang, verbose=False, full_output=True, **kw)
+    assert np.nanmax(np.abs(fo[0] - g["frame64_" + tag])) <= 2.0 ** -21 * np.abs(cube).max()
+
+
+def test_float64_route_scalings_collapses_and_fallbacks():
+    """vipmi_pca_fullframe_f64 beyond the goldens: 'temp-standard', every collapse it serves, ncomp > n clamped; the shapes it does
+    not serve (spatial scalings, cube_ref, a tuple of ncomp) fall back on the float32 route -- all against the float64 oracle."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g28_f64_counts")
+    cube, ang = g["cube"][:, 8:56, 8:56].copy(), g["angles"]
+    for kw in (dict(ncomp=5, scaling="temp-standard"), dict(ncomp=3, collapse="mean"), dict(ncomp=3, collapse="max"),
+               dict(ncomp=6, collapse="sum"), dict(ncomp=100), dict(ncomp=2, scaling="temp-mean", mask_center_px=4)):
+        ref = O.pca_fullframe(cube, ang, **{k_: min(v, cube.shape[0]) if k_ == "ncomp" else v for k_, v in kw.items()})
+        fr = pca(cube, ang, verbose=False, **kw)
+        scale = max(1.0, np.nanmax(np.abs(ref)))
+        assert np.nanmax(np.abs(fr - ref)) < TOL * max(1.0, scale / 10.0), kw
+    for kw in (dict(ncomp=3, scaling="spat-mean"), dict(ncomp=3, cube_ref=cube[:9].copy()), dict(ncomp=(1, 3))):
+        out = pca(cube, ang, verbose=False, **kw)          # float32 route: runs, same shapes as ever
+        assert out is not None
 
 
 def test_annular_library_window_skipping_is_bit_identical():

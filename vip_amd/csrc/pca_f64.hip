@@ -1,0 +1,189 @@
+// pca_f64.hip -- full-frame ADI PCA of a FLOAT64 cube (psfsub/pca_fullfr.py:1552-1737 with a float64 `cube`: the reference keeps
+// the caller's dtype through prepare_matrix / svd_wrapper, SURVEY a9 "f64 if f64 in").
+//
+// Rounding a cube of detector counts (7000 +- 45) to float32 costs 2^-24 * 7000 = 4e-4 per sample before anything is computed, and the
+// float32 projection then cancels counts of 7e3 down to residuals of ~45: the final frame ends 2e-3 from the reference's float64
+// result (golden g28).  Both losses come from the OFFSET, not from the signal, so the offset is carried in float64 and the float32
+// kernels only ever see what is left:
+//     mu_p = mean over the frames of M[., p]  (float64),      D = float32(M - 1 mu^T)          (|D| ~ 45: rounding 4e-6)
+//   scaling 'temp-mean' / 'temp-standard': the scaled matrix IS D (/ sigma): the ordinary float32 pipeline on it is the reference's.
+//   scaling None: the decomposition is that of M = D + 1 mu^T,
+//     G = M M^T = D D^T + 1 (D mu)^T + (D mu) 1^T + |mu|^2 1 1^T         (D D^T: the exact Gram kernels; the rest in float64)
+//     residual = (I - E^T E) M = [D - E^T (E D)] + r mu^T,   r = 1 - E^T (E 1)   (float64, n numbers)
+//   -- the bracket is the ordinary projection of the small matrix D, and the rank-one term is one more "component" of the
+//   subtraction kernel (coefficients -r, image mu): nothing of size 7e3 is ever subtracted from anything of size 7e3 in float32.
+// Everything after the residuals (FFT derotation, median) is the float32 path: residuals are small whatever the counts were.
+#include "common.h"
+
+namespace vipmi {
+
+namespace {
+
+// one thread per pixel column (coalesced across threads): temporal mean (and population std) in float64, D = float32((x - mu) / sd)
+// mode 0 / 1: centre only; 2: 'temp-standard' (sklearn: sd < 10 eps(float64) -> 1).  mask: 1 = masked (the sample is 0).
+__global__ void center_f64_kernel(const double* __restrict__ M, int n, int64_t P, const uint8_t* __restrict__ mask, int mode,
+                                  float* __restrict__ D, double* __restrict__ mu, float* __restrict__ mu32) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    if (mask && mask[p]) {
+      for (int f = 0; f < n; ++f) D[(int64_t)f * P + p] = 0.f;
+      mu[p] = 0.0;
+      if (mu32) mu32[p] = 0.f;
+      continue;
+    }
+    double s = 0.0;
+    for (int f = 0; f < n; ++f) s += M[(int64_t)f * P + p];
+    const double m = s / n;
+    double sd = 1.0;
+    if (mode == 2) {
+      double v = 0.0;
+      for (int f = 0; f < n; ++f) {
+        const double d = M[(int64_t)f * P + p] - m;
+        v += d * d;
+      }
+      sd = sqrt(v / n);
+      if (sd < 10.0 * 2.220446049250313e-16) sd = 1.0;
+    }
+    const double inv = 1.0 / sd;
+    for (int f = 0; f < n; ++f) D[(int64_t)f * P + p] = (float)((M[(int64_t)f * P + p] - m) * inv);
+    mu[p] = m;
+    if (mu32) mu32[p] = (float)m;
+  }
+}
+
+__device__ __forceinline__ double block_sum256(double v, double* sh) {      // 256 threads, fixed order: deterministic
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// g[f] = sum_p D[f, p] mu[p] (block f < n), g[n] = sum_p mu[p]^2 (block n): float64
+__global__ __launch_bounds__(256) void offset_dots_kernel(const float* __restrict__ D, const double* __restrict__ mu, int n, int64_t P,
+                                                          double* __restrict__ g) {
+  __shared__ double sh[4];
+  const int f = blockIdx.x;
+  double s = 0.0;
+  if (f < n) {
+    const float* row = D + (int64_t)f * P;
+    for (int64_t p = threadIdx.x; p < P; p += 256) s += (double)row[p] * mu[p];
+  } else {
+    for (int64_t p = threadIdx.x; p < P; p += 256) s += mu[p] * mu[p];
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) g[f] = s;
+}
+
+// G[i, j] += g[i] + g[j] + g[n]
+__global__ void gram_offset_kernel(double* __restrict__ G, const double* __restrict__ g, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * n) return;
+  const int i = e / n, j = e - i * n;
+  G[e] += g[i] + g[j] + g[n];
+}
+
+// r = 1 - E^T (E 1) over the components that convert_evecs keeps (eigenvalue > 1e-12 of the largest); row k of the subtraction's
+// coefficient matrix Ct[k][nld] = -r (zero padded): the rank-one term r mu^T as one more component.  One workgroup.
+__global__ __launch_bounds__(256) void offset_coeff_kernel(const double* __restrict__ evecs, const double* __restrict__ evals, int n,
+                                                           int k, float* __restrict__ Ct_row, int nld) {
+  extern __shared__ double e1[];          // [k]
+  const double thr = evals[0] * 1e-12;
+  for (int c = threadIdx.x; c < k; c += blockDim.x) {
+    double s = 0.0;
+    if (evals[c] > thr)
+      for (int f = 0; f < n; ++f) s += evecs[(int64_t)c * n + f];
+    e1[c] = s;
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < nld; f += blockDim.x) {
+    double r = 0.0;
+    if (f < n) {
+      double s = 0.0;
+      for (int c = 0; c < k; ++c) s += evecs[(int64_t)c * n + f] * e1[c];
+      r = 1.0 - s;
+    }
+    Ct_row[f] = (float)(-r);
+  }
+}
+
+}  // namespace
+
+int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n, int64_t P, const float* rowscale,
+                    float* T, const int* frange = nullptr);
+int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, const float* T, int64_t n, int64_t k, int64_t P, float* R,
+                    float* recon);
+
+int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int scaling,
+                      const uint8_t* mask, int collapse_mode, float* frame, float* residuals, float* residuals_der) {
+  VIPMI_REQUIRE(cube && angles_host && frame, "pca_fullframe_f64: null pointer");
+  VIPMI_REQUIRE(n > 0 && N > 1, "pca_fullframe_f64: bad sizes");
+  VIPMI_REQUIRE(ncomp > 0, "Number of PCs too low. It should be > 0.");
+  if (scaling < 0 || scaling > 2) {
+    set_error("pca_fullframe_f64: scaling mode %d is not served in float64 (None, temp-mean, temp-standard are)", scaling);
+    return VIPMI_ERR_UNSUPPORTED;
+  }
+  const int64_t P = N * N;
+  const int64_t k = ncomp > n ? n : ncomp;          // pca_fullfr.py:876-881 (clamp, not an error)
+  VIPMI_REQUIRE(k <= P, "%ld PCs cannot be obtained from a matrix with size [%ld,%ld].", (long)k, (long)n, (long)P);
+  const bool offset = scaling == 0;
+  const int64_t kk = offset ? k + 1 : k;            // components of the subtraction: the k PCs (+ the rank-one offset term)
+  float *D = nullptr, *T = nullptr;
+  double *mu = nullptr, *G = nullptr, *evals = nullptr, *evecs = nullptr, *g = nullptr;
+  VIPMI_TRY(ws(ctx, "pca64_D", (size_t)n * P, &D));
+  VIPMI_TRY(ws(ctx, "pca64_mu", (size_t)P, &mu));
+  VIPMI_TRY(ws(ctx, "pca64_T", (size_t)kk * P, &T));
+  VIPMI_TRY(ws(ctx, "pca_G", (size_t)n * n, &G));
+  VIPMI_TRY(ws(ctx, "pca_evals", (size_t)n, &evals));
+  VIPMI_TRY(ws(ctx, "pca_evecs", (size_t)n * n, &evecs));
+  {
+    StageScope sc(ctx, "scale");
+    const int64_t blocks = cdiv(P, 256);
+    hipLaunchKernelGGL(center_f64_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, cube, (int)n, P, mask,
+                       scaling, D, mu, offset ? T + (size_t)k * P : (float*)nullptr);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  VIPMI_TRY(gram_f32(ctx, D, n, D, n, P, P, G));
+  if (offset) {
+    StageScope sc(ctx, "gram");
+    VIPMI_TRY(ws(ctx, "pca64_g", (size_t)n + 1, &g));
+    hipLaunchKernelGGL(offset_dots_kernel, dim3((unsigned)n + 1), dim3(256), 0, ctx->stream, D, mu, (int)n, P, g);
+    hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256)), dim3(256), 0, ctx->stream, G, g, (int)n);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  float* res = residuals;
+  if (!res) VIPMI_TRY(ws(ctx, "pca_res", (size_t)n * P, &res));
+  ctx->gate_armed = ctx->gate != nullptr;
+  VIPMI_TRY(eigh_leading(ctx, G, 1, n, k, nullptr, evals, evecs, false));
+  VIPMI_TRY(ctx->gate_enter());
+  const int nld = (int)cdiv(n, 32) * 32, kld = (int)cdiv(k, 32) * 32;
+  float *Ekn = nullptr, *Enk = nullptr, *isig = nullptr;
+  VIPMI_TRY(ws(ctx, "pca64_Ekn", (size_t)(cdiv(kk, 32) * 32) * nld, &Ekn));
+  VIPMI_TRY(ws(ctx, "pca_Enk", (size_t)nld * kld, &Enk));
+  VIPMI_TRY(ws(ctx, "pca_isig", (size_t)kld, &isig));
+  VIPMI_TRY(convert_evecs(ctx, evecs, evals, n, k, Ekn, Enk, isig));
+  {
+    StageScope sc(ctx, "project");
+    VIPMI_TRY(rowspace_gemm_t(ctx, Enk, kld, D, k, n, P, nullptr, T));           // T[c] = E[c] D, c < k  (row k: mu, from the centring)
+    if (offset) {
+      hipLaunchKernelGGL(offset_coeff_kernel, dim3(1), dim3(256), sizeof(double) * (size_t)k, ctx->stream, evecs, evals, (int)n, (int)k,
+                         Ekn + (size_t)k * nld, nld);
+      VIPMI_CHECK_HIP(hipGetLastError());
+    }
+    VIPMI_TRY(subtract_gemm_t(ctx, D, Ekn, nld, T, n, kk, P, res, nullptr));
+  }
+  float* der = residuals_der;
+  if (!der) VIPMI_TRY(ws(ctx, "pca_der", (size_t)n * P, &der));
+  // pca(): mask_center_px without rot_options -> mask_val=0 (pca_fullfr.py:412-415)
+  VIPMI_TRY(derotate_f32(ctx, res, angles_host, n, N, der, mask ? 0 : 1, mask ? 1 : 0, VIPMI_ROT_AUTO));
+  VIPMI_TRY(collapse_f32(ctx, der, n, P, collapse_mode, nullptr, 50, frame));
+  VIPMI_TRY(ctx->gate_leave());
+  if (mask) {
+    if (residuals_der) VIPMI_TRY(apply_mask_f32(ctx, der, der, n, P, mask, 0.f));
+    VIPMI_TRY(apply_mask_f32(ctx, frame, frame, 1, P, mask, 0.f));
+  }
+  return VIPMI_OK;
+}
+
+}  // namespace vipmi

@@ -370,6 +370,51 @@ def _adi_pca_channels_batched(cube4, angle_list, ncomp, scaling, mask_center_px,
     return frames
 
 
+def _float64_fused(algo_params, rot_options, cube):
+    """Plain 3-D ADI PCA of a FLOAT64 cube, final frame only: the fused float64 entry (csrc/pca_f64.hip), which carries the
+    per-pixel temporal mean in float64 -- the reference keeps the caller's dtype through svd_wrapper (pca_fullfr.py:1552-1737), and
+    rounding a cube of detector counts to float32 first costs 2e-3 on the final frame (golden g28).  Returns the frame (cuda
+    tensor) or None when the call is not of that shape (everything else converts to float32 as before)."""
+    torch = B._torch() if B.is_device_tensor(cube) else None
+    is64 = (cube.dtype == np.float64) if torch is None else (cube.dtype == torch.float64)
+    ap = algo_params
+    if not is64 or cube.ndim != 3 or ap.full_output or ap.left_eigv:
+        return None
+    if any(getattr(ap, name, None) is not None for name in ("cube_ref", "cube_sig", "scale_list", "source_xy", "batch", "mask_rdi", "smooth")):
+        return None
+    if not isinstance(ap.ncomp, (int, np.integer)) or isinstance(ap.ncomp, bool) or ap.ncomp <= 0:
+        return None
+    scaling, collapse = _s(ap.scaling), _s(ap.collapse)
+    if scaling not in (None, "temp-mean", "temp-standard") or collapse not in ("median", "mean", "sum", "max", "absmean"):
+        return None
+    if _s(ap.imlib) != "vip-fft" or _s(ap.svd_mode) not in SVD_MODES or rot_options.get("edge_blend") not in (None, ""):
+        return None
+    n, y, x = cube.shape
+    mask_val = rot_options.get("mask_val", np.nan)
+    mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
+    if y != x or n > B.MAX_EIGH_N or B.other_mask_value(mask_val) is not None or (bool(ap.mask_center_px) == mv_nan):
+        return None
+    angle_list = check_pa_vector(np.asarray(ap.angle_list, dtype=np.float64))
+    if angle_list.shape[0] != n:
+        raise ValueError("`angle_list` vector has wrong length. It must equal the number of frames in the cube")
+    ncomp = int(ap.ncomp)
+    if ncomp > n:
+        ncomp = n
+        print("Number of PCs too high (max PCs={}), using {} PCs instead.".format(n, ncomp))
+    torch = B.require_gpu()
+    if B.is_device_tensor(cube):
+        c64 = cube.to(device=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        c64 = torch.from_numpy(np.ascontiguousarray(cube)).to(torch.device("cuda", torch.cuda.current_device()))
+    mask = None
+    if ap.mask_center_px:
+        mask = B.to_device_f32(center_mask_u8((y, x), ap.mask_center_px).astype(np.float32)).to(torch.uint8)
+    frame = B.pca_fullframe_f64(c64, angle_list, ncomp, scaling=scaling, mask_u8=mask, collapse_mode=collapse)
+    if ap.verbose:
+        print("Done PCA (float64 cube: temporal mean carried in float64), de-rotating and combining on MI355X")
+    return frame
+
+
 def pca(*all_args: List, **all_kwargs: dict):
     """Full-frame PCA (ADI, ADI+RDI, 4-D per-channel) on the MI355X.  See the reference docstring
     (psfsub/pca_fullfr.py:137-395) for the meaning of every parameter; returns
@@ -447,6 +492,9 @@ def pca(*all_args: List, **all_kwargs: dict):
             return t
         return t.cpu().numpy().astype(dtype or out_dtype, copy=False)
 
+    frame64 = _float64_fused(algo_params, rot_options, cube)
+    if frame64 is not None:
+        return host(frame64)
     cube_t = B.to_device_f32(cube)
     if algo_params.scale_list is not None:
         # ADI+mSDI (pca_fullfr.py:478-540): 4-D cube, channels rescaled by scale_list
