@@ -251,15 +251,15 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
                             int64_t N, int64_t ncomp, int scaling, const uint8_t* mask,
                             int collapse_mode, float* frame, float* pcs, float* recon,
                             float* residuals, float* residuals_der);
-/* The same for a FLOAT64 cube (device pointer), final frame (and optionally the residual cubes) only.  The reference keeps the
+/* The same for a FLOAT64 cube (device pointer); outputs as vipmi_pca_fullframe_f32 (float32; pcs [k][N][N], recon / residuals / residuals_der [n][N][N], each optional).  The reference keeps the
  * caller's dtype through prepare_matrix / svd_wrapper (psfsub/pca_fullfr.py:1552-1737, psfsub/svd.py:342-620); here the per-pixel
  * temporal mean -- the part of a cube of detector counts that float32 cannot hold beside the signal -- is carried in float64:
  * D = float32(cube - 1 mu^T) goes through the float32 kernels, the decomposition is that of D + 1 mu^T (Gram corrected in float64),
  * residual = [D - E^T (E D)] + (1 - E^T E 1) mu^T.  scaling: 0 (None), 1 (temp-mean), 2 (temp-standard); others return
- * VIPMI_ERR_UNSUPPORTED (convert to float32 and call vipmi_pca_fullframe_f32).  residuals / residuals_der: float32 [n][N][N] or NULL. */
+ * VIPMI_ERR_UNSUPPORTED (convert to float32 and call vipmi_pca_fullframe_f32). */
 int vipmi_pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp,
-                            int scaling, const uint8_t* mask, int collapse_mode, float* frame, float* residuals,
-                            float* residuals_der);
+                            int scaling, const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon,
+                            float* residuals, float* residuals_der);
 
 /* ---- 4-D (IFS) cube without scale_list: psfsub/pca_fullfr.py:544-658 ----
  * cube4[nch,n,N,N] float32: one full-frame ADI PCA per spectral channel (same integer ncomp, no reference cube), then

@@ -1470,9 +1470,21 @@ def test_float64_cube_of_detector_counts_vs_reference(tag, kw):
     # a float64 cuda tensor takes the same route: bit-identical frame, returned on the device
     frt = pca(torch.from_numpy(cube).cuda(), ang, verbose=False, **kw)
     assert frt.is_cuda and np.array_equal(np.nan_to_num(frt.cpu().numpy().astype(np.float64), nan=3.5), np.nan_to_num(fr, nan=3.5))
-    # the float32 route (what every other call shape still takes for float64 input): bounded by 2^-21 of the largest sample
+    # full_output through the same route: frame, pcs, recon, residuals, derotated residuals against the float64 oracle
     fo = pca(cube, ang, verbose=False, full_output=True, **kw)
-    assert np.nanmax(np.abs(fo[0] - g["frame64_" + tag])) <= 2.0 ** -21 * np.abs(cube).max()
+    ro = O.pca_fullframe(cube, ang, full_output=True, **kw)
+    assert np.array_equal(np.nan_to_num(fo[0], nan=3.5), np.nan_to_num(fr, nan=3.5))
+    assert np.nanmax(np.abs(fo[3] - g["res64_" + tag])) < 2 * TOL                       # the reference's own residual cube
+    for nm, a, b in zip(("frame", "pcs", "recon", "res", "resder"), fo, ro):
+        assert a.dtype == np.float64 and a.shape == b.shape, nm
+        if nm == "pcs":
+            a = sign_align(a, b)
+        tol = {"pcs": 1e-6, "recon": 2e-3}.get(nm, 2 * TOL)          # (recon holds the counts themselves: float32 of 7e3)
+        assert np.nanmax(np.abs(a - b)) < tol, (nm, np.nanmax(np.abs(a - b)))
+    # the float32 route (what every other call shape still takes for float64 input): bounded by 2^-21 of the largest sample
+    f32r = pca(cube, ang, verbose=False, cube_sig=np.zeros_like(cube), **kw) if "mask_center_px" not in kw else None
+    if f32r is not None:
+        assert np.nanmax(np.abs(f32r - g["frame64_" + tag])) <= 2.0 ** -21 * np.abs(cube).max()
 
 
 def test_float64_route_scalings_collapses_and_fallbacks():

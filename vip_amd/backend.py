@@ -611,10 +611,10 @@ def collapse_batched(cubes, mode="median", w=None, trim_n=50):
     return out
 
 
-def pca_fullframe_f64(cube64, angles, ncomp, scaling=None, mask_u8=None, collapse_mode="median", want_residuals=False):
+def pca_fullframe_f64(cube64, angles, ncomp, scaling=None, mask_u8=None, collapse_mode="median", full_output=False):
     """Fused 3-D ADI path for a FLOAT64 cuda cube (vipmi_pca_fullframe_f64: the per-pixel temporal mean carried in float64, the
     float32 kernels on what is left).  ``scaling``: None, 'temp-mean' or 'temp-standard'.  Returns the frame (float32 cuda
-    tensor), or (frame, residuals, residuals_der) with ``want_residuals``."""
+    tensor), or (frame, pcs, recon, residuals, residuals_der) with ``full_output``."""
     torch = _torch()
     assert cube64.dtype == torch.float64 and cube64.is_cuda
     cube64 = cube64.contiguous()
@@ -622,14 +622,17 @@ def pca_fullframe_f64(cube64, angles, ncomp, scaling=None, mask_u8=None, collaps
     n, N, _ = cube64.shape
     dev = cube64.device.index
     frame = empty((N, N), device=dev)
-    res = der = None
-    if want_residuals:
+    pcs = recon = res = der = None
+    if full_output:
+        k = min(int(ncomp), n)
+        pcs = empty((k, N, N), device=dev)
+        recon = empty((n, N, N), device=dev)
         res = empty((n, N, N), device=dev)
         der = empty((n, N, N), device=dev)
     ah, ap = host_f64(angles)
     ctx.call("vipmi_pca_fullframe_f64", ptr(cube64), ap, n, N, int(ncomp), SCALE_MODES[scaling], ptr(mask_u8),
-             COLLAPSE_MODES[collapse_mode], ptr(frame), ptr(res), ptr(der))
-    return (frame, res, der) if want_residuals else frame
+             COLLAPSE_MODES[collapse_mode], ptr(frame), ptr(pcs), ptr(recon), ptr(res), ptr(der))
+    return (frame, pcs, recon, res, der) if full_output else frame
 
 
 def pca_fullframe(cube, angles, ncomp, scaling=None, mask_u8=None, collapse_mode="median",

@@ -704,9 +704,10 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
 }
 
 int vipmi_pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp,
-                            int scaling, const uint8_t* mask, int collapse_mode, float* frame, float* residuals, float* residuals_der) {
+                            int scaling, const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon,
+                            float* residuals, float* residuals_der) {
   CTX_GUARD();
-  return pca_fullframe_f64(ctx, cube, angles_host, n, N, ncomp, scaling, mask, collapse_mode, frame, residuals, residuals_der);
+  return pca_fullframe_f64(ctx, cube, angles_host, n, N, ncomp, scaling, mask, collapse_mode, frame, pcs, recon, residuals, residuals_der);
 }
 
 // 4-D cube without scale_list (psfsub/pca_fullfr.py:544-658): one full-frame ADI PCA per spectral channel with the

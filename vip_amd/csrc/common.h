@@ -234,7 +234,8 @@ bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,
                    bool all_evals = false);
 int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int scaling,
-                      const uint8_t* mask, int collapse_mode, float* frame, float* residuals, float* residuals_der);
+                      const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon, float* residuals,
+                      float* residuals_der);
 int annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, const int32_t* lib_idx, const int32_t* lib_len,
                      int64_t m, int64_t k, double* work, double* evals, double* evecs);
 int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,

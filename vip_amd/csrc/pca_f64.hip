@@ -87,7 +87,7 @@ __global__ void gram_offset_kernel(double* __restrict__ G, const double* __restr
 // r = 1 - E^T (E 1) over the components that convert_evecs keeps (eigenvalue > 1e-12 of the largest); row k of the subtraction's
 // coefficient matrix Ct[k][nld] = -r (zero padded): the rank-one term r mu^T as one more component.  One workgroup.
 __global__ __launch_bounds__(256) void offset_coeff_kernel(const double* __restrict__ evecs, const double* __restrict__ evals, int n,
-                                                           int k, float* __restrict__ Ct_row, int nld) {
+                                                           int k, float* __restrict__ Ct_row, int nld, float* __restrict__ e1_out) {
   extern __shared__ double e1[];          // [k]
   const double thr = evals[0] * 1e-12;
   for (int c = threadIdx.x; c < k; c += blockDim.x) {
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void offset_coeff_kernel(const double* __restr
     if (evals[c] > thr)
       for (int f = 0; f < n; ++f) s += evecs[(int64_t)c * n + f];
     e1[c] = s;
+    e1_out[c] = (float)s;                 // E 1: the offset's share of the principal components (pcs_offset_kernel)
   }
   __syncthreads();
   for (int f = threadIdx.x; f < nld; f += blockDim.x) {
@@ -108,6 +109,23 @@ __global__ __launch_bounds__(256) void offset_coeff_kernel(const double* __restr
   }
 }
 
+// pcs[c] = (T[c] + e1[c] mu) / sigma_c   (V = S^-1 E^T M with M = D + 1 mu^T; e1 == nullptr: the scaled modes, V = S^-1 E^T D)
+__global__ void pcs_offset_kernel(const float* __restrict__ T, const float* __restrict__ isig, const float* __restrict__ e1,
+                                  const float* __restrict__ mu32, int64_t k, int64_t P, float* __restrict__ out) {
+  const int64_t total = k * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = e / P, p = e - c * P;
+    out[e] = (T[e] + (e1 ? e1[c] * mu32[p] : 0.f)) * isig[c];
+  }
+}
+// recon = (the matrix the decomposition saw) - residuals = D (+ mu) - residuals
+__global__ void recon_offset_kernel(const float* __restrict__ D, const float* __restrict__ mu32, const float* __restrict__ res,
+                                    int64_t n, int64_t P, float* __restrict__ out) {
+  const int64_t total = n * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = D[e] + (mu32 ? mu32[e % P] : 0.f) - res[e];
+}
+
 }  // namespace
 
 int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n, int64_t P, const float* rowscale,
@@ -116,7 +134,8 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
                     float* recon);
 
 int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int scaling,
-                      const uint8_t* mask, int collapse_mode, float* frame, float* residuals, float* residuals_der) {
+                      const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon, float* residuals,
+                      float* residuals_der) {
   VIPMI_REQUIRE(cube && angles_host && frame, "pca_fullframe_f64: null pointer");
   VIPMI_REQUIRE(n > 0 && N > 1, "pca_fullframe_f64: bad sizes");
   VIPMI_REQUIRE(ncomp > 0, "Number of PCs too low. It should be > 0.");
@@ -166,12 +185,26 @@ int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_h
   {
     StageScope sc(ctx, "project");
     VIPMI_TRY(rowspace_gemm_t(ctx, Enk, kld, D, k, n, P, nullptr, T));           // T[c] = E[c] D, c < k  (row k: mu, from the centring)
+    float* e1 = nullptr;
     if (offset) {
+      VIPMI_TRY(ws(ctx, "pca64_e1", (size_t)k, &e1));
       hipLaunchKernelGGL(offset_coeff_kernel, dim3(1), dim3(256), sizeof(double) * (size_t)k, ctx->stream, evecs, evals, (int)n, (int)k,
-                         Ekn + (size_t)k * nld, nld);
+                         Ekn + (size_t)k * nld, nld, e1);
       VIPMI_CHECK_HIP(hipGetLastError());
     }
     VIPMI_TRY(subtract_gemm_t(ctx, D, Ekn, nld, T, n, kk, P, res, nullptr));
+    const float* mu32 = offset ? T + (size_t)k * P : nullptr;
+    if (pcs) {
+      const int64_t blocks = cdiv(k * P, 2048);
+      hipLaunchKernelGGL(pcs_offset_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, T, isig, e1, mu32, k,
+                         P, pcs);
+    }
+    if (recon) {
+      const int64_t blocks = cdiv(n * P, 2048);
+      hipLaunchKernelGGL(recon_offset_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, D, mu32, res, n, P,
+                         recon);
+    }
+    VIPMI_CHECK_HIP(hipGetLastError());
   }
   float* der = residuals_der;
   if (!der) VIPMI_TRY(ws(ctx, "pca_der", (size_t)n * P, &der));

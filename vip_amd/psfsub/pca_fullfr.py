@@ -371,14 +371,14 @@ def _adi_pca_channels_batched(cube4, angle_list, ncomp, scaling, mask_center_px,
 
 
 def _float64_fused(algo_params, rot_options, cube):
-    """Plain 3-D ADI PCA of a FLOAT64 cube, final frame only: the fused float64 entry (csrc/pca_f64.hip), which carries the
+    """Plain 3-D ADI PCA of a FLOAT64 cube: the fused float64 entry (csrc/pca_f64.hip), which carries the
     per-pixel temporal mean in float64 -- the reference keeps the caller's dtype through svd_wrapper (pca_fullfr.py:1552-1737), and
-    rounding a cube of detector counts to float32 first costs 2e-3 on the final frame (golden g28).  Returns the frame (cuda
-    tensor) or None when the call is not of that shape (everything else converts to float32 as before)."""
+    rounding a cube of detector counts to float32 first costs 2e-3 on the final frame (golden g28).  Returns the frame -- (frame, pcs, recon, residuals, residuals_der) with full_output -- as cuda
+    tensors, or None when the call is not of that shape (everything else converts to float32 as before)."""
     torch = B._torch() if B.is_device_tensor(cube) else None
     is64 = (cube.dtype == np.float64) if torch is None else (cube.dtype == torch.float64)
     ap = algo_params
-    if not is64 or cube.ndim != 3 or ap.full_output or ap.left_eigv:
+    if not is64 or cube.ndim != 3 or ap.left_eigv:
         return None
     if any(getattr(ap, name, None) is not None for name in ("cube_ref", "cube_sig", "scale_list", "source_xy", "batch", "mask_rdi", "smooth")):
         return None
@@ -409,10 +409,11 @@ def _float64_fused(algo_params, rot_options, cube):
     mask = None
     if ap.mask_center_px:
         mask = B.to_device_f32(center_mask_u8((y, x), ap.mask_center_px).astype(np.float32)).to(torch.uint8)
-    frame = B.pca_fullframe_f64(c64, angle_list, ncomp, scaling=scaling, mask_u8=mask, collapse_mode=collapse)
+    out = B.pca_fullframe_f64(c64, angle_list, ncomp, scaling=scaling, mask_u8=mask, collapse_mode=collapse,
+                              full_output=bool(ap.full_output))
     if ap.verbose:
         print("Done PCA (float64 cube: temporal mean carried in float64), de-rotating and combining on MI355X")
-    return frame
+    return out
 
 
 def pca(*all_args: List, **all_kwargs: dict):
@@ -492,9 +493,9 @@ def pca(*all_args: List, **all_kwargs: dict):
             return t
         return t.cpu().numpy().astype(dtype or out_dtype, copy=False)
 
-    frame64 = _float64_fused(algo_params, rot_options, cube)
-    if frame64 is not None:
-        return host(frame64)
+    out64 = _float64_fused(algo_params, rot_options, cube)
+    if out64 is not None:
+        return tuple(host(t) for t in out64) if algo_params.full_output else host(out64)
     cube_t = B.to_device_f32(cube)
     if algo_params.scale_list is not None:
         # ADI+mSDI (pca_fullfr.py:478-540): 4-D cube, channels rescaled by scale_list
