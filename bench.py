@@ -215,8 +215,18 @@ def numpy_in_legs(n, N, k, angles, seed0, pca, B, torch):
     outs = pca_many(many, [angles] * len(many), ncomp=k, check_memory=False)
     many_ms = (time.perf_counter() - t0) / len(many) * 1e3
     assert len(outs) == len(many) and isinstance(outs[0], np.ndarray)
+    # a float64 cube (twice the bytes over PCIe; the float64 route: temporal mean carried in float64, csrc/pca_f64.hip)
+    c64 = hosts[0].astype(np.float64)
+    pca(c64, angles, ncomp=k, verbose=False, check_memory=False)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        f64 = pca(c64, angles, ncomp=k, verbose=False, check_memory=False)
+    f64_ms = (time.perf_counter() - t0) / 3 * 1e3
+    assert f64.dtype == np.float64
+    del c64
     gb = hosts[0].nbytes / 1e9
     return {"h2d_ms": h2d_ms, "h2d_gbs": gb / (h2d_ms * 1e-3), "host_memory": "pageable (a caller's numpy array)",
+            "float64_latency_ms_per_call": f64_ms,
             "latency_ms_per_call": lat_ms, "value": n / (lat_ms * 1e-3), "unit": "frames/s",
             "pipelined": {"value": n / (many_ms * 1e-3), "ms_per_cube": many_ms, "cubes": len(many),
                           "note": "pca_many: the (synchronous, pageable) upload of cube i+1 runs beside the kernels of cube i; "
