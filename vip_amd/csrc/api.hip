@@ -221,7 +221,7 @@ __global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const do
 
 extern "C" {
 
-int vipmi_version(void) { return 104; }
+int vipmi_version(void) { return 105; }   // 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64; recovery of cooperating solves
 
 const char* vipmi_last_error(void) { return g_err; }
 
