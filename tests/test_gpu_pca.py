@@ -1504,6 +1504,25 @@ def test_float64_route_scalings_collapses_and_fallbacks():
         assert out is not None
 
 
+def test_float64_route_4d_cube():
+    """A 4-D float64 cube of detector counts without scale_list: every channel through the float64 route, then collapse_ifs --
+    against the float64 oracle at the BASELINE gate; the float32 route (a float32 copy of the cube) is 50 times further away."""
+    from vip_amd.psfsub import pca
+    g = load_golden("g28_f64_counts")
+    c3, ang = g["cube"][:, 4:60, 4:60], g["angles"]
+    cube4 = np.stack([c3, 0.5 * c3[::-1] + 100.0, c3 * 1.25 - 50.0])
+    for kw in (dict(ncomp=4), dict(ncomp=[3, 5, 4], collapse_ifs="median"), dict(ncomp=5, scaling="temp-mean", mask_center_px=4)):
+        ks = kw["ncomp"] if isinstance(kw["ncomp"], list) else [kw["ncomp"]] * 3
+        okw = {a: b for a, b in kw.items() if a not in ("ncomp", "collapse_ifs")}
+        per = np.stack([O.pca_fullframe(cube4[ch], ang, ncomp=ks[ch], **okw) for ch in range(3)])
+        ref = {"median": np.nanmedian, "mean": np.nanmean}[kw.get("collapse_ifs", "mean")](per, axis=0)
+        fr = pca(cube4, ang, verbose=False, **kw)
+        assert fr.dtype == np.float64 and fr.shape == ref.shape
+        d64 = np.nanmax(np.abs(fr - ref))
+        d32 = np.nanmax(np.abs(pca(cube4.astype(np.float32), ang, verbose=False, **kw) - ref))
+        assert d64 < TOL and d32 > 10 * d64, (kw, d64, d32)
+
+
 def test_annular_library_window_skipping_is_bit_identical():
     """The (I - C) A product of annular PCA skips the frames outside every row group's library window (`ann_range`), and the
     libraries' sub-Gram matrices are gathered inside the eigensolver (`ann_gather`): both must leave the residual cube bit-identical

@@ -416,6 +416,31 @@ def _float64_fused(algo_params, rot_options, cube):
     return out
 
 
+def _float64_fused_4d(algo_params, rot_options, cube):
+    """4-D float64 cube without ``scale_list`` (pca_fullfr.py:544-658), final frame only: every spectral channel through the
+    float64 route of ``_float64_fused``, then ``collapse_ifs`` of the per-channel frames.  None when the call is not of that shape."""
+    import copy
+    ap = algo_params
+    torch = B._torch() if B.is_device_tensor(cube) else None
+    is64 = (cube.dtype == np.float64) if torch is None else (cube.dtype == torch.float64)
+    if not is64 or cube.ndim != 4 or ap.full_output or ap.scale_list is not None:
+        return None
+    if _s(ap.collapse_ifs) not in ("median", "mean", "sum", "max", "absmean"):
+        return None
+    nch = cube.shape[0]
+    ncomp = ap.ncomp
+    ncomps = list(ncomp) if isinstance(ncomp, list) and len(ncomp) == nch else [ncomp] * nch
+    frames = []
+    for ch in range(nch):
+        apc = copy.copy(ap)
+        apc.cube, apc.ncomp = cube[ch], ncomps[ch]
+        fr = _float64_fused(apc, rot_options, cube[ch])
+        if fr is None:
+            return None                      # (some channel is not a plain integer-ncomp ADI call: the float32 route for all)
+        frames.append(fr)
+    return B.collapse(B._torch().stack(frames), _s(ap.collapse_ifs))
+
+
 def pca(*all_args: List, **all_kwargs: dict):
     """Full-frame PCA (ADI, ADI+RDI, 4-D per-channel) on the MI355X.  See the reference docstring
     (psfsub/pca_fullfr.py:137-395) for the meaning of every parameter; returns
@@ -496,6 +521,9 @@ def pca(*all_args: List, **all_kwargs: dict):
     out64 = _float64_fused(algo_params, rot_options, cube)
     if out64 is not None:
         return tuple(host(t) for t in out64) if algo_params.full_output else host(out64)
+    out64 = _float64_fused_4d(algo_params, rot_options, cube)
+    if out64 is not None:
+        return host(out64, np.float64)
     cube_t = B.to_device_f32(cube)
     if algo_params.scale_list is not None:
         # ADI+mSDI (pca_fullfr.py:478-540): 4-D cube, channels rescaled by scale_list
