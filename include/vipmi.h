@@ -220,6 +220,18 @@ int vipmi_annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_
  * vipmi_eigh_topk_f64 returns them (leading k).  do_pca_patch, pca_local.py:830-909. */
 int vipmi_annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, const int32_t* lib_idx,
                            const int32_t* lib_len, int64_t m, int64_t k, double* work, double* evals, double* evecs);
+/* float64 cubes (round 5): the per-pixel temporal mean -- what float32 cannot hold beside the signal in a cube of detector counts --
+ * is carried in float64 (csrc/pca_f64.hip; the reference keeps the caller's dtype through svd_wrapper / do_pca_patch):
+ * center: D[n][P] = float32((M - 1 mu^T) / sd), mu[P] float64, mu32[P] = float32(mu) (optional); mode 0 / 1: centre ('temp-mean'),
+ *   2: 'temp-standard';  gram_offset: G (= D D^T from vipmi_gram_f32) += 1 (D mu)^T + (D mu) 1^T + |mu|^2 1 1^T, the Gram matrix of
+ *   D + 1 mu^T (scaling None);  annular_apply_mu: vipmi_annular_apply_f32 on D with residuals += rho mu32^T, rho = (I - C) 1 (mu32 NULL:
+ *   plain apply). */
+int vipmi_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32);
+int vipmi_gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G);
+int vipmi_annular_apply_mu_f32(vipmi_ctx* ctx, const float* D, int64_t n, int64_t npx, const int32_t* lib_idx,
+                               const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
+                               const double* evecs, const int32_t* ncomps_host, int64_t nk, const float* mu32,
+                               float* residuals);
 int vipmi_annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                             const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
                             const double* evecs, const int32_t* ncomps_host, int64_t nk, float* residuals);

@@ -1523,6 +1523,30 @@ def test_float64_route_4d_cube():
         assert d64 < TOL and d32 > 10 * d64, (kw, d64, d32)
 
 
+@pytest.mark.parametrize("kw", [dict(ncomp=3), dict(ncomp=(2, 3, 4, 3), delta_rot=(0.2, 0.8)), dict(ncomp=3, scaling="temp-mean"),
+                                dict(ncomp=2, scaling="temp-standard"), dict(ncomp=3, n_segments=2, radius_int=4)])
+def test_float64_route_annular(kw):
+    """pca_annular on a float64 cube of detector counts: every segment matrix centred in float64 (vipmi_center_f64), the Gram
+    matrix corrected by the offset terms, residuals = (I - C) D + rho mu^T -- against the float64 oracle at the BASELINE gate;
+    the float32 route (a float32 copy of the cube) ends at least ten times further away."""
+    from vip_amd.psfsub import pca_annular
+    g = load_golden("g28_f64_counts")
+    cube, ang = g["cube"], np.linspace(0, 120, g["cube"].shape[0])
+    base = dict(asize=8, fwhm=4, delta_rot=(0.3, 1), verbose=False)
+    base.update(kw)
+    okw = {a: b for a, b in base.items() if a != "verbose"}
+    ref = O.pca_annular(cube, ang, **okw)
+    fr = pca_annular(cube, ang, **base)
+    assert fr.dtype == np.float64
+    d64 = np.nanmax(np.abs(fr - ref))
+    d32 = np.nanmax(np.abs(pca_annular(cube.astype(np.float32), ang, **base) - ref))
+    print("annular float64 route %s: %.3e (float32 route %.3e)" % (kw, d64, d32))
+    scale = max(10.0, np.nanmax(np.abs(ref)))
+    assert d64 < TOL * scale / 10.0
+    if kw.get("scaling") != "temp-standard":
+        assert d32 > 5 * d64
+
+
 def test_annular_library_window_skipping_is_bit_identical():
     """The (I - C) A product of annular PCA skips the frames outside every row group's library window (`ann_range`), and the
     libraries' sub-Gram matrices are gathered inside the eigensolver (`ann_gather`): both must leave the residual cube bit-identical

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
                                                     const int32_t* __restrict__ len, int max_lib, int m,
                                                     const double* __restrict__ evals,
                                                     const double* __restrict__ evecs, int k, int npx,
-                                                    float* __restrict__ C) {
+                                                    float* __restrict__ C, float* __restrict__ rho) {
+  // rho (optional): rho[j] = 1 - sum_a c_j[a], the row sum of I - C in float64: with A = D + 1 mu^T (a float64 cube whose per-pixel
+  // temporal mean is carried apart, pca_f64.hip) the residuals are (I - C) D + rho mu^T
   extern __shared__ double sh[];      // g[m] | proj[k]
   double* g = sh;
   double* proj = sh + m;
@@ -66,13 +68,34 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
     if (lane == 0) proj[c] = (ev[c] > thr && ev[c] > 0) ? s / ev[c] : 0.0;
   }
   __syncthreads();
+  double csum = 0.0;
   for (int a = threadIdx.x; a < lj; a += blockDim.x) {
     double s = 0;
     for (int c = 0; c < kk; ++c) s += E[(size_t)c * m + a] * proj[c];
     C[(size_t)j * n + ij[a]] = (float)(-s);
+    csum += s;
   }
   __syncthreads();                       // (the frame may belong to its own library: add the identity afterwards)
   if (threadIdx.x == 0) C[(size_t)j * n + j] += 1.0f;
+  if (rho) {                             // (uniform) fixed-order sum of the 256 partial sums
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) csum += __shfl_xor(csum, off, 64);
+    __syncthreads();
+    if (lane == 0) sh[wave] = csum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < nw; ++w) t += sh[w];
+      rho[j] = (float)(1.0 - t);
+    }
+  }
+}
+
+// R[j, p] += rho[j] mu[p]
+__global__ void rank1_add_kernel(float* __restrict__ R, const float* __restrict__ rho, const float* __restrict__ mu, int64_t n, int64_t P) {
+  const int64_t total = n * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    R[e] += rho[e / P] * mu[e % P];
 }
 
 // frange[2 g], [2 g + 1]: the frames outside which row group g (32 rows) of D = I - C has no coefficient, as multiples of 8 -- the
@@ -144,7 +167,7 @@ int annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, c
 // libraries (evals[j][m], evecs[j][m][m]: rows = vectors, as the top-k eigensolver returns them)
 int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                       const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
-                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals) {
+                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals, const float* mu32) {
   VIPMI_REQUIRE(A && lib_idx && lib_len && G && evals && evecs && ncomps && residuals, "annular_apply: null pointer");
   VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && m >= max_lib && nk > 0, "annular_apply: bad sizes");
   int64_t kmax = 0;
@@ -163,14 +186,22 @@ int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, co
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
+  float* rho = nullptr;                  // mu32: A is D = M - 1 mu^T of a float64 cube; residuals = (I - C) D + rho mu^T
+  if (mu32) VIPMI_TRY(ws(ctx, "ann_rho", (size_t)n, &rho));
   for (int64_t i = 0; i < nk; ++i) {
     VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
     hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
-                       (int)max_lib, (int)m, evals, evecs, (int)ncomps[i], (int)npx, C);
+                       (int)max_lib, (int)m, evals, evecs, (int)ncomps[i], (int)npx, C, rho);
     VIPMI_CHECK_HIP(hipGetLastError());
     // residuals = A - C A = (I - C) A: one (n x n) x (n x npx) product on the matrix cores.  (Round 1 ran it through the
     // skinny-k subtract kernel, k = n components: 14 TF/s, 4.7 of C3's 35 ms; the row-space kernel does it at ~60 TF/s.)
     VIPMI_TRY(rowspace_gemm_f32(ctx, C, A, n, n, npx, nullptr, residuals + (size_t)i * n * npx, frange));
+    if (mu32) {
+      const int64_t blocks = cdiv(n * npx, 2048);
+      hipLaunchKernelGGL(rank1_add_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream,
+                         residuals + (size_t)i * n * npx, rho, mu32, n, npx);
+      VIPMI_CHECK_HIP(hipGetLastError());
+    }
   }
   return VIPMI_OK;
 }

@@ -221,7 +221,7 @@ __global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const do
 
 extern "C" {
 
-int vipmi_version(void) { return 105; }   // 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64; recovery of cooperating solves
+int vipmi_version(void) { return 105; }   // 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64, vipmi_center_f64, vipmi_gram_offset_f64, vipmi_annular_apply_mu_f32; recovery of cooperating solves
 
 const char* vipmi_last_error(void) { return g_err; }
 
@@ -701,6 +701,23 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
     VIPMI_TRY(apply_mask_f32(ctx, frame, frame, 1, P, mask, 0.f));
   }
   return VIPMI_OK;
+}
+
+int vipmi_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32) {
+  CTX_GUARD();
+  return center_f64(ctx, M, n, P, mode, D, mu, mu32);
+}
+
+int vipmi_gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G) {
+  CTX_GUARD();
+  return gram_offset_f64(ctx, D, mu, n, P, G);
+}
+
+int vipmi_annular_apply_mu_f32(vipmi_ctx* ctx, const float* D, int64_t n, int64_t npx, const int32_t* lib_idx, const int32_t* lib_len,
+                               int64_t max_lib, int64_t m, const double* G, const double* evals, const double* evecs,
+                               const int32_t* ncomps_host, int64_t nk, const float* mu32, float* residuals) {
+  CTX_GUARD();
+  return annular_apply_f32(ctx, D, n, npx, lib_idx, lib_len, max_lib, m, G, evals, evecs, ncomps_host, nk, residuals, mu32);
 }
 
 int vipmi_pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp,

@@ -233,6 +233,8 @@ int tri_wave_vectors(vipmi_ctx* ctx, const double* A, int n, int k, const double
 bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,
                    bool all_evals = false);
+int center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32);
+int gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G);
 int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int scaling,
                       const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon, float* residuals,
                       float* residuals_der);
@@ -242,7 +244,7 @@ int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
                          const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H);
 int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                       const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
-                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals);
+                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals, const float* mu32 = nullptr);
 bool eigh_gather_supported(int64_t m, int64_t k);
 int eigh_topk_gather_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t per_seg, int64_t ldg, const int32_t* idx,
                          const int32_t* len, int64_t m, int64_t k, double* work, double* evals, double* evecs);

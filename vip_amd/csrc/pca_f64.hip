@@ -133,6 +133,29 @@ int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, in
 int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, const float* T, int64_t n, int64_t k, int64_t P, float* R,
                     float* recon);
 
+// The two building blocks on their own (the annular front applies them to every segment matrix of a float64 cube):
+// D = float32((M - 1 mu^T) / sd), mu (float64) and optionally float32(mu) -- mode 0 / 1: centre, 2: 'temp-standard'
+int center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32) {
+  VIPMI_REQUIRE(M && D && mu && n > 0 && P > 0 && mode >= 0 && mode <= 2, "center_f64: bad arguments");
+  StageScope sc(ctx, "scale");
+  const int64_t blocks = cdiv(P, 256);
+  hipLaunchKernelGGL(center_f64_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, M, (int)n, P,
+                     (const uint8_t*)nullptr, mode, D, mu, mu32);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+// G (= D D^T, n x n float64) += 1 (D mu)^T + (D mu) 1^T + |mu|^2 1 1^T : the Gram matrix of D + 1 mu^T
+int gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G) {
+  VIPMI_REQUIRE(D && mu && G && n > 0 && P > 0, "gram_offset_f64: bad arguments");
+  StageScope sc(ctx, "gram");
+  double* g = nullptr;
+  VIPMI_TRY(ws(ctx, "pca64_g", (size_t)n + 1, &g));
+  hipLaunchKernelGGL(offset_dots_kernel, dim3((unsigned)n + 1), dim3(256), 0, ctx->stream, D, mu, (int)n, P, g);
+  hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256)), dim3(256), 0, ctx->stream, G, g, (int)n);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
 int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int scaling,
                       const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon, float* residuals,
                       float* residuals_der) {

@@ -169,8 +169,10 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                  svd_mode="lapack", nproc=None, min_frames_lib=2, max_frames_lib=200, tol=1e-1,
                  scaling=None, imlib="vip-fft", interpolation="lanczos4", collapse="median",
                  full_output=False, verbose=1, cube_ref=None, theta_init=0, weights=None, cube_sig=None,
-                 left_eigv=False, **rot_options):
-    """Device version of the reference's ``_pca_adi_rdi``; ``cube`` is a float32 cuda tensor."""
+                 left_eigv=False, cube64=None, **rot_options):
+    """Device version of the reference's ``_pca_adi_rdi``; ``cube`` is a float32 cuda tensor.  ``cube64``: the same cube as a
+    float64 cuda tensor (the caller's dtype): every segment matrix is then centred in float64 first (csrc/pca_f64.hip) and
+    the float32 kernels work on what is left -- the reference's do_pca_patch keeps float64 (pca_local.py:830-909)."""
     torch = B._torch()
     if cube.ndim != 3:
         raise TypeError("Input array is not a cube or 3d array")
@@ -308,13 +310,49 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                 Rn = Rn.contiguous()
                 ctx.call("vipmi_scatter_f32", B.ptr(Rn), n, P, B.ptr(pix), npx, B.ptr(cube_out[nn]))
 
+    def do_segment_f64(si, seg):
+        """The float64 route of one segment: A = D + 1 mu^T with the per-pixel temporal mean mu in float64,
+        G = D D^T (+ the offset terms when the matrix is not scaled), libraries gathered from G by the solver,
+        residuals = (I - C) D + rho mu^T."""
+        ctx = B.get_context(dev)
+        pix = pix_of(si, seg)
+        npx = int(pix.numel())
+        A64 = cube64.reshape(n, P).index_select(1, pix.clamp(min=0).long())
+        if bool((pix < 0).any()):
+            A64[:, pix < 0] = 0.0                                   # (the zero columns that pad the rows to 16 bytes)
+        aug = B.empty((n + 1, npx), device=dev)                     # rows 0 .. n-1: D, row n: float32(mu)
+        mu = torch.empty((npx,), dtype=torch.float64, device=cube.device)
+        mode = {None: 0, "temp-mean": 1, "temp-standard": 2}[scaling]
+        ctx.call("vipmi_center_f64", B.ptr(A64), n, npx, mode, B.ptr(aug), B.ptr(mu), B.ptr(aug[n]))
+        G = torch.empty((n, n), dtype=torch.float64, device=cube.device)
+        ctx.call("vipmi_gram_f32", B.ptr(aug), n, npx, npx, B.ptr(G))
+        if scaling is None:
+            ctx.call("vipmi_gram_offset_f64", B.ptr(aug), B.ptr(mu), n, npx, B.ptr(G))
+        idx_t, ln_t, max_lib = libs_of(seg)
+        kseg = min(int(seg["ncomp"]), max_lib)
+        work = torch.empty((n, max_lib, max_lib), dtype=torch.float64, device=cube.device)
+        ev = torch.zeros((n, max_lib), dtype=torch.float64, device=cube.device)
+        ec = torch.zeros((n, max_lib, max_lib), dtype=torch.float64, device=cube.device)
+        ctx.call("vipmi_annular_eigh_f64", B.ptr(G), 1, n, B.ptr(idx_t), B.ptr(ln_t), max_lib, kseg, B.ptr(work), B.ptr(ev), B.ptr(ec))
+        kk_ = np.array([int(seg["ncomp"])], dtype=np.int32)
+        R = B.empty((1, n, npx), device=dev)
+        ctx.call("vipmi_annular_apply_mu_f32", B.ptr(aug), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib, max_lib, B.ptr(G), B.ptr(ev),
+                 B.ptr(ec), kk_.ctypes.data_as(ctypes.c_void_p), 1, B.ptr(aug[n]) if scaling is None else None, B.ptr(R))
+        ctx.call("vipmi_scatter_f32", B.ptr(R[0].contiguous()), n, P, B.ptr(pix), npx, B.ptr(cube_out))
+
+    f64_route = (cube64 is not None and nref == 0 and cube_sig is None and ks is None
+                 and scaling in (None, "temp-mean", "temp-standard"))
+
     # Independent segments: issue the annuli round-robin on a few streams in asynchronous mode, so that the 400 per-frame
     # eigenproblems of one annulus (1.6 rounds of workgroups on 256 CUs) fill the idle tail of the previous one, and
     # one annulus' Gram / projection runs beside the other's eigensolver.  The last two annuli overlap by one pixel ring
     # and the later one must win (pca_local.py:786-787): they share a stream, which keeps their order.
     n_ann = plan[-1]["ann"] + 1 if plan else 0
-    pipelined = n_ann >= 3 and not B.is_async()
-    if pipelined:
+    pipelined = n_ann >= 3 and not B.is_async() and not f64_route
+    if f64_route:
+        for si, seg in enumerate(plan):
+            do_segment_f64(si, seg)
+    elif pipelined:
         for si, seg in enumerate(plan):               # index uploads before the fork
             pix_of(si, seg)
             libs_of(seg)
@@ -498,6 +536,14 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
         extra["cube_ref"] = B.to_device_f32(algo_params.cube_ref)
     if algo_params.cube_sig is not None:
         extra["cube_sig"] = B.to_device_f32(algo_params.cube_sig)
+    # a float64 cube keeps its dtype through the decomposition (the reference's do_pca_patch): the float64 copy goes along and the
+    # segment matrices are centred in float64 (plain ADI, scaling None / temp-mean / temp-standard; _pca_adi_rdi decides)
+    if algo_params.cube_ref is None and algo_params.cube_sig is None:
+        torch = B._torch()
+        if dev_in and cube.dtype == torch.float64:
+            extra["cube64"] = cube.to(cube_t.device).contiguous()
+        elif not dev_in and cube.dtype == np.float64:
+            extra["cube64"] = torch.from_numpy(np.ascontiguousarray(cube)).to(cube_t.device)
     fp = setup_parameters(algo_params, _pca_adi_rdi, cube=cube_t, full_output=True, **extra)
     cube_out, cube_der, frame = _pca_adi_rdi(**fp, **rot_options)
     if isinstance(frame, list):
