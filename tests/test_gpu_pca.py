@@ -1547,6 +1547,25 @@ def test_float64_route_annular(kw):
         assert d32 > 5 * d64
 
 
+def test_float64_route_median_sub():
+    """median_sub on a float64 cube of detector counts: the per-pixel temporal mean taken off in float64 first (the subtraction of
+    medians is invariant under it) -- full-frame and annular mode against the float64 oracle."""
+    from vip_amd.psfsub import median_sub
+    g = load_golden("g28_f64_counts")
+    cube, ang = g["cube"], np.linspace(0, 120, g["cube"].shape[0])
+    for kw in (dict(), dict(mode="annular", asize=8, delta_rot=0.5, nframes=4, fwhm=4)):
+        if kw:
+            ref = O.median_sub_annular(cube, ang, **{k: v for k, v in kw.items() if k != "mode"})
+        else:
+            ref = O.median_sub_fullfr(cube, ang)
+        fr = median_sub(cube, ang, verbose=False, **kw)
+        assert fr.dtype == np.float64
+        d64 = np.nanmax(np.abs(fr - ref))
+        d32 = np.nanmax(np.abs(median_sub(cube.astype(np.float32), ang, verbose=False, **kw) - ref))
+        print("median_sub float64 %s: %.3e (float32 cube %.3e)" % (kw, d64, d32))
+        assert d64 < TOL and d32 > 3 * d64
+
+
 def test_annular_library_window_skipping_is_bit_identical():
     """The (I - C) A product of annular PCA skips the frames outside every row group's library window (`ann_range`), and the
     libraries' sub-Gram matrices are gathered inside the eigensolver (`ann_gather`): both must leave the residual cube bit-identical

@@ -135,7 +135,20 @@ def median_sub(*all_args: List, **all_kwargs: dict):
     angle_list = check_pa_vector(np.asarray(algo_params.angle_list, dtype=np.float64))
     dev_in = B.is_device_tensor(cube)
     out_dtype = None if dev_in else (cube.dtype if cube.dtype.kind == "f" else np.float64)
-    t = B.to_device_f32(cube)
+    is64 = (cube.dtype == torch.float64) if dev_in else (cube.dtype == np.float64)
+    if is64 and algo_params.cube_ref is None:
+        # a float64 cube (the reference subtracts in the caller's dtype): cube - median(cube) does not change when a per-pixel
+        # constant is taken off every frame first, so the temporal mean is removed in float64 (vipmi_center_f64) and the float32
+        # kernels subtract medians of what is left -- counts of 7e3 rounded to float32 first would cost 4e-4 per sample
+        c64 = (cube if dev_in else torch.from_numpy(np.ascontiguousarray(cube))).to(torch.device("cuda", torch.cuda.current_device()))
+        c64 = c64.contiguous()
+        n_, y_, x_ = c64.shape
+        t = B.empty((n_, y_, x_), device=c64.device.index)
+        mu = torch.empty((y_ * x_,), dtype=torch.float64, device=c64.device)
+        B.get_context(c64.device.index).call("vipmi_center_f64", B.ptr(c64), n_, y_ * x_, 1, B.ptr(t), B.ptr(mu), None)
+        del c64
+    else:
+        t = B.to_device_f32(cube)
     n, y, x = t.shape
     P = y * x
     if algo_params.cube_ref is not None:
