@@ -114,59 +114,96 @@ __device__ __forceinline__ int lane_rank_in(unsigned long long mask) {   // set 
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-// Lower median key (rank k = (m-1)/2 of the m valid keys) and, for even m, the upper one (rank k+1); invalid entries
-// carry the key 0xffffffff.
-template <int RPL>
-__device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, unsigned* __restrict__ hist, int lane,
-                                            unsigned& klow, unsigned& khigh) {
-  // hist: HIST_WORDS words of LDS private to the wave: 256 bins, then (from word 257) one dump word per lane for the keys outside the current range
-  // (keeps the loops free of divergent branches), then 64 dump slots for the lanes that have no candidate to store
-  const int k = (m - 1) >> 1;
-  const bool even = (m & 1) == 0;
-  unsigned lo = 0xffffffffu, hi = 0u;
+// ---- the selection in the FLOAT domain (round 5) ---------------------------------------------------------------------------
+// Round 4's selection carried order-preserving uint32 keys: 3 operations per sample to form the key, 3 to turn it back into the
+// value the bins are linear in, 3 to keep the 0xffffffff of a NaN out of the maximum, two unsigned range tests per sample and level
+// -- 25 vector instructions per sample row where the arithmetic needs 15 (the kernel is issue-bound: 384 per pixel at n = 400).
+// Here a sample stays the float it is.  NaNs (quieted when the sample is read) drop out of v_min_f32 / v_max_f32 by themselves (IEEE
+// minNum / maxNum: the other operand), fail every ordered comparison -- so they never enter a bin range, a count or a candidate
+// list -- and the m valid samples are the ones an order statistic of rank < m is taken from, as with the keys.  Equal floats are
+// equal keys except for -0.0 / +0.0, which compare equal here: the result can differ from the key version in the sign of a zero
+// only (numpy's partition does not order them either).
+__device__ __forceinline__ float fmin_raw(float a, float b) {      // v_min_f32 itself (fminf adds a canonicalising v_max per operand)
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (kernels that carry VIPMI_NO_PK32 cannot inline the HIP header's plain-inline functions -- different target features -- and
+// would CALL __ballot / __popcll / __uint_as_float; inside a forceinline helper they are inlined bottom-up first)
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
+__device__ __forceinline__ int lanes_true(bool p) { return (int)__popcll(__ballot(p)); }
+__device__ __forceinline__ float quiet_nan() { return __uint_as_float(0x7fc00000u); }
+// wave reductions of values that are never NaN, through the key domain (the compiler folds the DPP moves into v_min_u32 / v_max_u32)
+__device__ __forceinline__ float wave_min_f32(float v) { return key2f(wave_min_u32(f2key(v))); }
+__device__ __forceinline__ float wave_max_f32(float v) { return key2f(wave_max_u32(f2key(v))); }
+
+// bins of one level: linear in value over [lo, hi]; everything outside (NaN included) to the lane's own dump word
+template <int RPL, bool FIRST>
+__device__ __forceinline__ void bin_level(const float (&v)[RPL], float lo, float hi, float scale, int lane, int (&bin)[RPL]) {
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
-    lo = umin_(lo, key[r]);
-    hi = umax_(hi, key[r] == 0xffffffffu ? 0u : key[r]);
+    int b = (int)((v[r] - lo) * scale);
+    b = b > 255 ? 255 : b;
+    // first level: [lo, hi] holds every valid sample, so "in range" is "not NaN"
+    const bool in = FIRST ? (v[r] == v[r]) : (v[r] >= lo && v[r] <= hi);
+    bin[r] = in ? b : 257 + lane;
   }
-  lo = wave_min_u32(lo);
-  hi = wave_max_u32(hi);
-  int rank = k;                                  // rank of the wanted key among the keys in [lo, hi]
+}
+
+// Lower median (rank k = (m-1)/2 of the m valid samples) and, for even m, the upper one (rank k+1).  v: RPL samples per lane,
+// NaN = no sample (quiet NaNs only).
+// hist: HIST_WORDS words of LDS private to the wave: 256 bins, then (from word 257) one dump word per lane for the samples outside
+// the current range (keeps the loops free of divergent branches), then 64 dump slots for the lanes that have no candidate to store
+template <int RPL>
+__device__ __forceinline__ void median_vals(const float (&v)[RPL], int m, unsigned* __restrict__ hist, int lane, float& vlow, float& vhigh) {
+  const int k = (m - 1) >> 1;
+  const bool even = (m & 1) == 0;
+  const float inf = __builtin_inff();
+  float lo = inf, hi = -inf;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    lo = fmin_raw(lo, v[r]);
+    hi = fmax_raw(hi, v[r]);
+  }
+  lo = wave_min_f32(lo);
+  hi = wave_max_f32(hi);
+  int rank = k;                                  // rank of the wanted sample among the samples in [lo, hi]
   bool done = false;
   for (int level = 0; level < 3 && !done; ++level) {
-    if (lo == hi) {                              // every remaining key is the same value
-      klow = lo;
-      khigh = lo;
+    if (lo == hi) {                              // every remaining sample is the same value
+      vlow = lo;
+      vhigh = lo;
       done = true;
-      if (even) {                                // upper median: the same value again, or the smallest key above it
+      if (even) {                                // upper median: the same value again, or the smallest sample above it
         int cle = 0;
-        unsigned nxt = 0xffffffffu;
+        float nxt = inf;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          cle += (key[r] <= lo) ? 1 : 0;
-          if (key[r] > lo && key[r] < nxt) nxt = key[r];
+          cle += (v[r] <= lo) ? 1 : 0;
+          nxt = (v[r] > lo) ? fmin_raw(nxt, v[r]) : nxt;
         }
-        if (wave_count<RPL>(cle) < k + 2) khigh = wave_min_u32(nxt);
+        if (wave_count<RPL>(cle) < k + 2) vhigh = wave_min_f32(nxt);
       }
       break;
     }
-    const float flo = key2f(lo), fhi = key2f(hi);
-    const float scale = 256.0f / (fhi - flo);
+    // (an approximate reciprocal will do: the binning only has to be one weakly monotone function for every sample of the level)
+    const float scale = 256.0f * __builtin_amdgcn_rcpf(hi - lo);
     if (!(scale > 0.f && scale < 3.0e38f)) break;          // range overflows / underflows: bisection
     reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_sync();
-    // bin of every key (>= 257: outside the range) and, from the returning atomic, its ordinal inside the bin
+    // bin of every sample (>= 257: outside the range) and, from the returning atomic, its ordinal inside the bin.
+    // Outside the range: a dump word of the lane's own (257 + lane).  ONE shared dump bin made every atomic of a second level
+    // a 64-way same-address collision (at level >= 1 nearly all samples are outside the range): real residual cubes, where a fifth
+    // of the pixels need a second level, paid for it -- C5 10.5 ms against 5.8 on Gaussian noise (tools/time_median_c5.py)
     int bin[RPL];
     unsigned ord[RPL];
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-      int b = (int)((key2f(key[r]) - flo) * scale);
-      b = b > 255 ? 255 : b;
-      // outside the range: a dump word of the lane's own (257 + lane).  ONE shared dump bin made every atomic of a second level
-      // a 64-way same-address collision (at level >= 1 nearly all keys are outside the range): real residual cubes, where a fifth
-      // of the pixels need a second level, paid for it -- C5 10.5 ms against 5.8 on Gaussian noise (tools/time_median_c5.py)
-      bin[r] = (key[r] >= lo && key[r] <= hi) ? b : 257 + lane;
-    }
+    if (level == 0) bin_level<RPL, true>(v, lo, hi, scale, lane, bin);
+    else bin_level<RPL, false>(v, lo, hi, scale, lane, bin);
 #pragma unroll
     for (int r = 0; r < RPL; ++r) ord[r] = atomicAdd(&hist[bin[r]], 1u);
     wave_lds_sync();
@@ -174,7 +211,7 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
     const unsigned s4 = h.x + h.y + h.z + h.w;
     const unsigned incl = wave_inclusive_sum(s4);
     const unsigned long long above = __ballot(incl > (unsigned)rank);
-    const int L = __builtin_ctzll(above);        // (never empty: the range holds more than `rank` keys)
+    const int L = __builtin_ctzll(above);        // (never empty: the range holds more than `rank` samples)
     const unsigned hx = (unsigned)__builtin_amdgcn_readlane((int)h.x, L), hy = (unsigned)__builtin_amdgcn_readlane((int)h.y, L);
     const unsigned hz = (unsigned)__builtin_amdgcn_readlane((int)h.z, L), hw = (unsigned)__builtin_amdgcn_readlane((int)h.w, L);
     unsigned rem = (unsigned)rank - ((unsigned)__builtin_amdgcn_readlane((int)incl, L) - (hx + hy + hz + hw));
@@ -187,49 +224,51 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
     rank = (int)rem;
     wave_lds_sync();
     if (c <= 64u) {
-      // the bin's keys go to slots 0..c-1 of the (dead) histogram by their ordinals, everything else to the dump slots
+      // the bin's samples go to slots 0..c-1 of the (dead) histogram by their ordinals, everything else to the dump slots
 #pragma unroll
-      for (int r = 0; r < RPL; ++r) hist[bin[r] == bstar ? ord[r] : 257u + (unsigned)lane] = key[r];
+      for (int r = 0; r < RPL; ++r) hist[bin[r] == bstar ? ord[r] : 257u + (unsigned)lane] = __float_as_uint(v[r]);
       wave_lds_sync();
-      const unsigned cand = (unsigned)lane < c ? hist[lane] : 0xffffffffu;
+      const bool mine = (unsigned)lane < c;
+      const float cand = __uint_as_float(hist[mine ? lane : 0]);
       int less = 0;
       for (unsigned q = 0; q < c; ++q) {
-        const unsigned kq = (unsigned)__builtin_amdgcn_readlane((int)cand, (int)q);
-        less += (kq < cand) ? 1 : 0;
+        const float vq = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cand), (int)q));
+        less += (vq < cand) ? 1 : 0;
       }
-      const bool mine = (unsigned)lane < c;
-      klow = wave_max_u32(mine && less <= rank ? cand : 0u);     // largest key with at most `rank` keys below it
-      khigh = klow;
+      vlow = wave_max_f32(mine && less <= rank ? cand : -inf);     // largest sample with at most `rank` samples below it
+      vhigh = vlow;
       if (even) {
         if ((unsigned)rank + 1u < c) {
-          khigh = wave_max_u32(mine && less <= rank + 1 ? cand : 0u);
-        } else {                                 // the next key lives in a later bin: the smallest key above klow
-          unsigned nxt = 0xffffffffu;
+          vhigh = wave_max_f32(mine && less <= rank + 1 ? cand : -inf);
+        } else {                                 // the next sample lives in a later bin: the smallest one above vlow
+          float nxt = inf;
 #pragma unroll
-          for (int r = 0; r < RPL; ++r)
-            if (key[r] > klow && key[r] < nxt) nxt = key[r];
-          khigh = wave_min_u32(nxt);
+          for (int r = 0; r < RPL; ++r) nxt = (v[r] > vlow) ? fmin_raw(nxt, v[r]) : nxt;
+          vhigh = wave_min_f32(nxt);
         }
       }
       wave_lds_sync();
       done = true;
     } else {
-      // crowded bin: its own key range becomes the next level's range
-      unsigned nlo = 0xffffffffu, nhi = 0u;
+      // crowded bin: its own value range becomes the next level's range
+      float nlo = inf, nhi = -inf;
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
         if (bin[r] == bstar) {
-          nlo = umin_(nlo, key[r]);
-          nhi = umax_(nhi, key[r]);
+          nlo = fmin_raw(nlo, v[r]);
+          nhi = fmax_raw(nhi, v[r]);
         }
       }
-      lo = wave_min_u32(nlo);
-      hi = wave_max_u32(nhi);
+      lo = wave_min_f32(nlo);
+      hi = wave_max_f32(nhi);
     }
   }
-  if (!done) {                                   // bisection on all keys (global rank k)
-    klow = select_rank<RPL>(key, k);
-    khigh = klow;
+  if (!done) {                                   // bisection on the order-preserving keys of all samples (global rank k)
+    unsigned key[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) key[r] = (v[r] == v[r]) ? f2key(v[r]) : 0xffffffffu;
+    const unsigned klow = select_rank<RPL>(key, k);
+    unsigned khigh = klow;
     if (even) {
       int cle = 0;
       unsigned nxt = 0xffffffffu;
@@ -240,18 +279,22 @@ __device__ __forceinline__ void median_keys(const unsigned (&key)[RPL], int m, u
       }
       if (wave_count<RPL>(cle) < k + 2) khigh = wave_min_u32(nxt);
     }
+    vlow = key2f(klow);
+    vhigh = key2f(khigh);
   }
 }
 
 constexpr int HIST_WORDS = 384;                  // 256 bins + dump bin + 64 dump slots, padded to a multiple of 64 words
 
-// Result for ONE pixel from the keys a wave holds (RPL per lane, invalid / NaN = 0xffffffff, nvalid_lane valid ones in this lane):
+// Result for ONE pixel from the samples a wave holds (RPL per lane, NaN = no sample, nvalid_lane valid ones in this lane):
 // nanmedian (TRIM = false) or the reference's trimmed mean of sorted[t0 : t0 + tn] (TRIM = true).
 template <int RPL, bool TRIM>
-__device__ __forceinline__ float pixel_result(const unsigned (&key)[RPL], int nvalid_lane, int n, int t0, int tn, unsigned* hist, int lane) {
-  const int m = wave_count<RPL>(nvalid_lane);
+__device__ __forceinline__ float pixel_result(const float (&val)[RPL], int m, int n, int t0, int tn, unsigned* hist, int lane) {
   float res;
   if (TRIM) {
+    unsigned key[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) key[r] = (val[r] == val[r]) ? f2key(val[r]) : 0xffffffffu;
     int hi_end = t0 + tn;                    // slice [t0, hi_end) of the sorted samples, NaNs (rank >= m) dropped
     if (hi_end > n) hi_end = n;
     if (hi_end > m) hi_end = m;
@@ -259,11 +302,10 @@ __device__ __forceinline__ float pixel_result(const unsigned (&key)[RPL], int nv
       res = __uint_as_float(0x7fc00000u);
     } else {
       const unsigned klo = select_rank<RPL>(key, t0), khi = select_rank<RPL>(key, hi_end - 1);
-      int clt_lo = 0, cle_lo = 0, clt_hi = 0;
+      int cle_lo = 0, clt_hi = 0;
       double mid = 0.0;
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
-        clt_lo += __popcll(__ballot(key[r] < klo));
         cle_lo += __popcll(__ballot(key[r] <= klo));
         clt_hi += __popcll(__ballot(key[r] < khi));
         if (key[r] > klo && key[r] < khi) mid += (double)key2f(key[r]);
@@ -278,15 +320,14 @@ __device__ __forceinline__ float pixel_result(const unsigned (&key)[RPL], int nv
         const int nhi = hi_end - clt_hi;                                 // copies of the high value inside the slice
         tot = mid + (double)key2f(klo) * nlo + (double)key2f(khi) * nhi;
       }
-      (void)clt_lo;
       res = (float)(tot / (double)(hi_end - t0));
     }
   } else if (m == 0) {
     res = __uint_as_float(0x7fc00000u);
   } else {
-    unsigned klow, khigh;
-    median_keys<RPL>(key, m, hist, lane, klow, khigh);
-    res = (m & 1) ? key2f(klow) : (key2f(klow) + key2f(khigh)) * 0.5f;    // even: (a+b)*0.5 in float32, as numpy
+    float vlow, vhigh;
+    median_vals<RPL>(val, m, hist, lane, vlow, vhigh);
+    res = (m & 1) ? vlow : (vlow + vhigh) * 0.5f;    // even: (a+b)*0.5 in float32, as numpy
   }
   return res;
 }
@@ -348,26 +389,23 @@ __global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_kernel(const float* 
       tile[f * ldt + j] = (p < P) ? cube[(int64_t)f * P + p] : 0.f;
     }
   }
-  __syncthreads();
+  block_sync();
   for (int j = wave; j < TP; j += nw) {
     const int64_t p = p0 + j;
     if (p >= P) break;
-    unsigned key[RPL];
-    int nvalid_lane = 0;
+    float val[RPL];
+    int m = 0;
+    const float qnan = quiet_nan();
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
       const int f = lane + 64 * r;
-      unsigned kk = 0xffffffffu;                // padding and NaN sort last
-      if (f < n) {
-        const float v = tile[f * ldt + j];
-        if (v == v) {
-          kk = f2key(v);
-          ++nvalid_lane;
-        }
-      }
-      key[r] = kk;
+      const bool inside = f < n;                // (a padding lane reads row n - 1 and drops it: no divergent branch)
+      const float v = tile[(inside ? f : n - 1) * ldt + j];
+      const bool ok = inside && v == v;         // padding and NaN: no sample (every NaN becomes the quiet one)
+      val[r] = ok ? v : qnan;
+      m += lanes_true(ok);
     }
-    const float res = pixel_result<RPL, TRIM>(key, nvalid_lane, n, t0, tn, hist, lane);
+    const float res = pixel_result<RPL, TRIM>(val, m, n, t0, tn, hist, lane);
     if (lane == 0) out[p] = res;
   }
 }
@@ -436,7 +474,7 @@ __global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_reg_kernel(const flo
   const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // tiles blockIdx.x + j gridDim.x
   const int items = my_tiles * NCHUNK;
   float4 pre[CH];
-  unsigned key[PPW][RPL];
+  float key[PPW][RPL];                               // the samples themselves (NaN = none)
   int nvalid[PPW];
   if (items > 0) {
     mreg_issue<CH, NCHUNK>(pre, 0, cube, n, P, seg, r0, vec_ok);
@@ -445,7 +483,7 @@ __global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_reg_kernel(const flo
   for (int item = 0; item < items; ++item) {
     const int chunk = item % NCHUNK;
     if (item + 1 < items) mreg_issue<CH, NCHUNK>(pre, item + 1, cube, n, P, seg, r0, vec_ok);
-    __syncthreads();                                // the buffer of this item is complete; the other one is free again
+    block_sync();                                // the buffer of this item is complete; the other one is free again
     const float* b = stage + (item & 1) * (CF * LDT);
     if (chunk == 0) {
 #pragma unroll
@@ -460,7 +498,7 @@ __global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_reg_kernel(const flo
           for (int i = 0; i < CH; ++i) {
             const float v = b[(lane + 64 * i) * LDT + wave + 8 * q];
             const bool ok = v == v;
-            key[q][c * CH + i] = ok ? f2key(v) : 0xffffffffu;
+            key[q][c * CH + i] = ok ? v : quiet_nan();
             nvalid[q] += ok ? 1 : 0;
           }
       }
@@ -471,7 +509,7 @@ __global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_reg_kernel(const flo
       for (int q = 0; q < PPW; ++q) {
         const int64_t p = p0 + wave + 8 * q;
         if (p < P) {                                // (wave-uniform)
-          const float res = pixel_result<RPL, TRIM>(key[q], nvalid[q], n, t0, tn, hist, lane);
+          const float res = pixel_result<RPL, TRIM>(key[q], wave_count<RPL>(nvalid[q]), n, t0, tn, hist, lane);
           if (lane == 0) out[p] = res;
         }
       }
