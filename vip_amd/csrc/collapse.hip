@@ -136,19 +136,55 @@ __device__ __forceinline__ float fmax_raw(float a, float b) {
 // (kernels that carry VIPMI_NO_PK32 cannot inline the HIP header's plain-inline functions -- different target features -- and
 // would CALL __ballot / __popcll / __uint_as_float; inside a forceinline helper they are inlined bottom-up first)
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
-__device__ __forceinline__ int lanes_true(bool p) { return (int)__popcll(__ballot(p)); }
+__device__ __forceinline__ int lanes_true(bool p) { return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 __device__ __forceinline__ float quiet_nan() { return __uint_as_float(0x7fc00000u); }
-// wave reductions of values that are never NaN, through the key domain (the compiler folds the DPP moves into v_min_u32 / v_max_u32)
-__device__ __forceinline__ float wave_min_f32(float v) { return key2f(wave_min_u32(f2key(v))); }
-__device__ __forceinline__ float wave_max_f32(float v) { return key2f(wave_max_u32(f2key(v))); }
+// Wave reductions of floats that are never NaN: v_min_f32 / v_max_f32 with the DPP operand directly (the compiler can fold a DPP move
+// only into an operation it generates itself, and its fminf carries a canonicalising v_max per operand; through the key domain a
+// reduction cost 20 vector instructions, four per pixel).  Six steps: inside quads, inside rows of 16, then row_bcast:15 / :31 carry
+// the row results up to lane 63.  A DPP source written by the previous vector instruction needs two wait states: the two
+// reductions of a pair are interleaved, one s_nop between steps.
+#define VIPMI_DPP_ALL " row_mask:0xf bank_mask:0xf\n\t"
+#define VIPMI_RED2(OPA, OPB)                                                                                                  \
+  "s_nop 1\n\t"                                                                                                              \
+  OPA " %0, %0, %0 quad_perm:[1,0,3,2]" VIPMI_DPP_ALL OPB " %1, %1, %1 quad_perm:[1,0,3,2]" VIPMI_DPP_ALL "s_nop 0\n\t"       \
+  OPA " %0, %0, %0 quad_perm:[2,3,0,1]" VIPMI_DPP_ALL OPB " %1, %1, %1 quad_perm:[2,3,0,1]" VIPMI_DPP_ALL "s_nop 0\n\t"       \
+  OPA " %0, %0, %0 row_half_mirror" VIPMI_DPP_ALL OPB " %1, %1, %1 row_half_mirror" VIPMI_DPP_ALL "s_nop 0\n\t"               \
+  OPA " %0, %0, %0 row_mirror" VIPMI_DPP_ALL OPB " %1, %1, %1 row_mirror" VIPMI_DPP_ALL "s_nop 0\n\t"                         \
+  OPA " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" OPB " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+  "s_nop 0\n\t"                                                                                                              \
+  OPA " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" OPB " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
+#define VIPMI_RED1(OP)                                                                                                        \
+  "s_nop 1\n\t"                                                                                                              \
+  OP " %0, %0, %0 quad_perm:[1,0,3,2]" VIPMI_DPP_ALL "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1]" VIPMI_DPP_ALL         \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror" VIPMI_DPP_ALL "s_nop 1\n\t" OP " %0, %0, %0 row_mirror" VIPMI_DPP_ALL        \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                                 \
+  "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+__device__ __forceinline__ float lane63(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63)); }
+__device__ __forceinline__ float wave_min_f32(float v) {
+  asm(VIPMI_RED1("v_min_f32_dpp") : "+v"(v));
+  return lane63(v);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  asm(VIPMI_RED1("v_max_f32_dpp") : "+v"(v));
+  return lane63(v);
+}
+__device__ __forceinline__ void wave_min_max_f32(float& a, float& b) {        // a <- wave minimum of a, b <- wave maximum of b
+  asm(VIPMI_RED2("v_min_f32_dpp", "v_max_f32_dpp") : "+v"(a), "+v"(b));
+  a = lane63(a);
+  b = lane63(b);
+}
+__device__ __forceinline__ void wave_max_max_f32(float& a, float& b) {
+  asm(VIPMI_RED2("v_max_f32_dpp", "v_max_f32_dpp") : "+v"(a), "+v"(b));
+  a = lane63(a);
+  b = lane63(b);
+}
 
 // bins of one level: linear in value over [lo, hi]; everything outside (NaN included) to the lane's own dump word
 template <int RPL, bool FIRST>
 __device__ __forceinline__ void bin_level(const float (&v)[RPL], float lo, float hi, float scale, int lane, int (&bin)[RPL]) {
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
-    int b = (int)((v[r] - lo) * scale);
-    b = b > 255 ? 255 : b;
+    const int b = (int)((v[r] - lo) * scale);   // (in range: 0 .. 255)
     // first level: [lo, hi] holds every valid sample, so "in range" is "not NaN"
     const bool in = FIRST ? (v[r] == v[r]) : (v[r] >= lo && v[r] <= hi);
     bin[r] = in ? b : 257 + lane;
@@ -170,8 +206,7 @@ __device__ __forceinline__ void median_vals(const float (&v)[RPL], int m, unsign
     lo = fmin_raw(lo, v[r]);
     hi = fmax_raw(hi, v[r]);
   }
-  lo = wave_min_f32(lo);
-  hi = wave_max_f32(hi);
+  wave_min_max_f32(lo, hi);
   int rank = k;                                  // rank of the wanted sample among the samples in [lo, hi]
   bool done = false;
   for (int level = 0; level < 3 && !done; ++level) {
@@ -192,7 +227,8 @@ __device__ __forceinline__ void median_vals(const float (&v)[RPL], int m, unsign
       break;
     }
     // (an approximate reciprocal will do: the binning only has to be one weakly monotone function for every sample of the level)
-    const float scale = 256.0f * __builtin_amdgcn_rcpf(hi - lo);
+    // 255.9 instead of 256: (hi - lo) * scale stays below 256 whatever the last bits of the reciprocal, so no bin needs clipping
+    const float scale = 255.9f * __builtin_amdgcn_rcpf(hi - lo);
     if (!(scale > 0.f && scale < 3.0e38f)) break;          // range overflows / underflows: bisection
     reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_sync();
@@ -235,11 +271,15 @@ __device__ __forceinline__ void median_vals(const float (&v)[RPL], int m, unsign
         const float vq = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cand), (int)q));
         less += (vq < cand) ? 1 : 0;
       }
-      vlow = wave_max_f32(mine && less <= rank ? cand : -inf);     // largest sample with at most `rank` samples below it
+      // largest sample with at most `rank` samples below it -- and, while at it, with at most rank + 1 (the upper median when it
+      // lies in this bin)
+      float a = mine && less <= rank ? cand : -inf, b = mine && less <= rank + 1 ? cand : -inf;
+      wave_max_max_f32(a, b);
+      vlow = a;
       vhigh = vlow;
       if (even) {
         if ((unsigned)rank + 1u < c) {
-          vhigh = wave_max_f32(mine && less <= rank + 1 ? cand : -inf);
+          vhigh = b;
         } else {                                 // the next sample lives in a later bin: the smallest one above vlow
           float nxt = inf;
 #pragma unroll
@@ -259,8 +299,9 @@ __device__ __forceinline__ void median_vals(const float (&v)[RPL], int m, unsign
           nhi = fmax_raw(nhi, v[r]);
         }
       }
-      lo = wave_min_f32(nlo);
-      hi = wave_max_f32(nhi);
+      wave_min_max_f32(nlo, nhi);
+      lo = nlo;
+      hi = nhi;
     }
   }
   if (!done) {                                   // bisection on the order-preserving keys of all samples (global rank k)
@@ -351,7 +392,16 @@ __global__ VIPMI_NO_PK32 __launch_bounds__(512) void median_kernel(const float* 
   // -- C2: 0.319 -> 0.300 ms.  With one workgroup per CU (n = 2000: a 148 KB tile) the plain order is the faster one
   // (9.7 against 10.2 ms): xcd_ranges = 0.
   const int per_xcd = gridDim.x >> 3;
-  const int64_t tile_id = xcd_ranges ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  int64_t tile_id = (int64_t)blockIdx.x;
+  if (xcd_ranges == 1) {
+    tile_id = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  } else if (xcd_ranges > 1) {
+    // chunks of xcd_ranges consecutive tiles dealt round-robin to the XCDs: neighbours still share an L2, but the XCDs no longer
+    // own one horizontal band of the image each -- the bands at the top and bottom edge hold the slow pixels of a derotated cube
+    // (partly outside the rotated footprint: crowded bins, second levels), and the kernel ended when those two XCDs did
+    const int loc = blockIdx.x >> 3;
+    tile_id = ((int64_t)(loc / xcd_ranges) * 8 + (blockIdx.x & 7)) * xcd_ranges + loc % xcd_ranges;
+  }
   if (tile_id >= ntiles) return;
   const int64_t p0 = tile_id * TP;
   // stage: TP consecutive pixels of every frame.  The kernel is bound by this load (400 row segments of 128 bytes,
@@ -755,8 +805,20 @@ int launch_median(vipmi_ctx* ctx, const float* cube, int64_t batch, int n, int64
   auto kern = median_kernel<RPL, TRIM>;
   VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
   const int64_t ntiles = cdiv(P, TP);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(cdiv(ntiles, 8) * 8), (unsigned)batch), dim3(512), lds, ctx->stream, cube, n, P, TP, out,
-                     t0, tn, (int)ntiles, lds <= 80 * 1024 ? 1 : 0);
+  // tile -> XCD map: chunks of consecutive tiles dealt round-robin (default: 64 tiles, at least 16 chunks per XCD; option
+  // median_xcd_chunk: 1 = one contiguous range per XCD as in rounds 2-4, 0 = plain order).  Derotated residuals of a C2 call:
+  // 0.192 ms with ranges, 0.157 with chunks of 64 (tools/median_xcd_ab.py)
+  int xr = 0;
+  if (lds <= 80 * 1024) {
+    xr = (int)ctx->opt("median_xcd_chunk", -1);
+    if (xr < 0) {
+      xr = (int)(ntiles / 128 < 64 ? ntiles / 128 : 64);
+      if (xr < 2) xr = 1;
+    }
+  }
+  const int64_t round_to = xr > 1 ? (int64_t)8 * xr : 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(cdiv(ntiles, round_to) * round_to), (unsigned)batch), dim3(512), lds, ctx->stream, cube, n, P,
+                     TP, out, t0, tn, (int)ntiles, xr);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
