@@ -5,11 +5,13 @@
 //    the cube (HBM-bound: n*P*4 bytes in, P*4 out).
 //  * median (nanmedian): a workgroup stages a [n frames][TP pixels] tile in LDS with coalesced
 //    128-byte row segments (row stride TP+1 floats: the transposed read is bank-conflict free);
-//    then ONE WAVE PER PIXEL holds the pixel's n values in registers (n/64 per lane) as
-//    order-preserving uint32 keys and finds the rank-k key by a 32-step bitwise bisection; each
-//    step is RPL v_cmp + s_bcnt1 (wave ballots), no sort and no further LDS traffic.  For an even
-//    number of valid samples the upper median is the smallest key above the lower one (or the lower
-//    one again if it is duplicated) and the result is (a+b)*0.5 in float32, as numpy computes it.
+//    then ONE WAVE PER PIXEL holds the pixel's n values in registers (n/64 per lane) and selects
+//    the middle one(s) by bucket selection (median_vals below: 256 linear bins between the pixel's
+//    minimum and maximum, exact finish on the <= 64 samples of the bin the rank falls into); the
+//    32-step bitwise bisection on order-preserving uint32 keys of round 1 (RPL v_cmp + wave ballots
+//    per step) is the fallback and serves trimmean.  For an even number of valid samples the upper
+//    median is the smallest sample above the lower one (or the lower one again if it is duplicated)
+//    and the result is (a+b)*0.5 in float32, as numpy computes it.
 #include "common.h"
 
 namespace vipmi {
