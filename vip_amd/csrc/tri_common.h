@@ -157,5 +157,37 @@ __device__ __forceinline__ double multisect(const double* __restrict__ d, const 
   return 0.5 * (a + b);
 }
 
+// The kk largest eigenvalues by ONE wave at once (kk <= 32): the 64 lanes are split into kk segments of P = 64 / kk interior points,
+// segment e works on the bracket of the e-th largest eigenvalue, which shrinks (P + 1)x per sweep.  One wave per eigenvalue
+// (multisect) gains log2(65) = 6 bits per sweep and eigenvalue; this gains kk log2(P + 1) bits per sweep -- 28 bits for kk = 10 --, so
+// the kk values cost ~20 sweeps of one wave instead of 9 kk: where the solver is bound by the number of vector instructions it
+// issues (the second launch of big batches: six workgroups per CU, 98 % VALU busy, half of it Sturm counts) that is what counts.
+// out[e] (e < kk): the e-th largest eigenvalue, written by the first lane of its segment.  n1 = ascending index of the largest.
+template <bool SQ = false>
+__device__ __forceinline__ void multisect_many(const double* __restrict__ d, const double* __restrict__ e2, int n, int kk, double a0,
+                                               double b0, int lane, double* __restrict__ out) {
+  const int P = 64 / kk;
+  const int seg = lane / P, j = lane - seg * P;
+  const bool active = seg < kk;
+  const int target = n - 1 - (active ? seg : 0);
+  const unsigned long long segmask = (P >= 64) ? ~0ull : ((1ull << P) - 1ull);
+  const int shift = (active ? seg : 0) * P;
+  const double ip = 1.0 / (double)(P + 1);
+  double a = a0, b = b0;
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double h = (b - a) * ip;
+    const int cnt = sturm_count<SQ>(d, e2, n, a + h * (double)(j + 1));
+    const unsigned long long m = __ballot(cnt <= target);       // inside a segment: sigma <= lambda_target for its first L lanes
+    const int L = __popcll((m >> shift) & segmask);
+    const double na = (L == 0) ? a : a + h * (double)L;
+    const double nb = (L == P) ? b : a + h * (double)(L + 1);
+    a = na;
+    b = nb;
+    const bool done = !active || (b - a <= 2.0 * EPS * fmax(fabs(a), fabs(b)) + 1e-290);
+    if (__all(done)) break;
+  }
+  if (active && j == 0) out[seg] = 0.5 * (a + b);
+}
+
 }  // namespace tri
 }  // namespace vipmi
