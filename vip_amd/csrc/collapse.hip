@@ -193,14 +193,14 @@ __device__ __forceinline__ void bin_level(const float (&v)[RPL], float lo, float
   }
 }
 
-// Lower median (rank k = (m-1)/2 of the m valid samples) and, for even m, the upper one (rank k+1).  v: RPL samples per lane,
-// NaN = no sample (quiet NaNs only).
+// Order statistics of the valid samples of a pixel (the median: rank k = (m-1)/2 of the m valid samples and, for even m, the
+// upper one, rank k+1; the trimmed mean: the two ends of its slice).  v: RPL samples per lane, NaN = no sample (quiet NaNs only).
 // hist: HIST_WORDS words of LDS private to the wave: 256 bins, then (from word 257) one dump word per lane for the samples outside
 // the current range (keeps the loops free of divergent branches), then 64 dump slots for the lanes that have no candidate to store
 template <int RPL>
-__device__ __forceinline__ void median_vals(const float (&v)[RPL], int m, unsigned* __restrict__ hist, int lane, float& vlow, float& vhigh) {
-  const int k = (m - 1) >> 1;
-  const bool even = (m & 1) == 0;
+__device__ __forceinline__ void rank_vals(const float (&v)[RPL], int k, bool even, unsigned* __restrict__ hist, int lane, float& vlow,
+                                          float& vhigh) {
+  // vlow = the valid sample of rank k (0-based, k < number of valid samples); vhigh = the one of rank k + 1 when `even` (it exists)
   const float inf = __builtin_inff();
   float lo = inf, hi = -inf;
 #pragma unroll
@@ -335,33 +335,34 @@ template <int RPL, bool TRIM>
 __device__ __forceinline__ float pixel_result(const float (&val)[RPL], int m, int n, int t0, int tn, unsigned* hist, int lane) {
   float res;
   if (TRIM) {
-    unsigned key[RPL];
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) key[r] = (val[r] == val[r]) ? f2key(val[r]) : 0xffffffffu;
     int hi_end = t0 + tn;                    // slice [t0, hi_end) of the sorted samples, NaNs (rank >= m) dropped
     if (hi_end > n) hi_end = n;
     if (hi_end > m) hi_end = m;
     if (t0 >= hi_end) {
       res = __uint_as_float(0x7fc00000u);
     } else {
-      const unsigned klo = select_rank<RPL>(key, t0), khi = select_rank<RPL>(key, hi_end - 1);
+      // the two ends of the slice by the bucket selection (round 5; rounds 1-4: two 32-step bisections on the keys), then one
+      // pass for the sum strictly between them and the copies of the end values that fall inside the slice
+      float vlo, vhi, dummy;
+      rank_vals<RPL>(val, t0, false, hist, lane, vlo, dummy);
+      rank_vals<RPL>(val, hi_end - 1, false, hist, lane, vhi, dummy);
       int cle_lo = 0, clt_hi = 0;
       double mid = 0.0;
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
-        cle_lo += __popcll(__ballot(key[r] <= klo));
-        clt_hi += __popcll(__ballot(key[r] < khi));
-        if (key[r] > klo && key[r] < khi) mid += (double)key2f(key[r]);
+        cle_lo += lanes_true(val[r] <= vlo);
+        clt_hi += lanes_true(val[r] < vhi);
+        if (val[r] > vlo && val[r] < vhi) mid += (double)val[r];
       }
 #pragma unroll
       for (int s = 32; s >= 1; s >>= 1) mid += __shfl_xor(mid, s, 64);
       double tot;
-      if (klo == khi) {
-        tot = (double)key2f(klo) * (double)(hi_end - t0);
+      if (vlo == vhi) {
+        tot = (double)vlo * (double)(hi_end - t0);
       } else {
         const int nlo = (cle_lo < hi_end ? cle_lo : hi_end) - t0;      // copies of the low value inside the slice
         const int nhi = hi_end - clt_hi;                                 // copies of the high value inside the slice
-        tot = mid + (double)key2f(klo) * nlo + (double)key2f(khi) * nhi;
+        tot = mid + (double)vlo * nlo + (double)vhi * nhi;
       }
       res = (float)(tot / (double)(hi_end - t0));
     }
@@ -369,7 +370,7 @@ __device__ __forceinline__ float pixel_result(const float (&val)[RPL], int m, in
     res = __uint_as_float(0x7fc00000u);
   } else {
     float vlow, vhigh;
-    median_vals<RPL>(val, m, hist, lane, vlow, vhigh);
+    rank_vals<RPL>(val, (m - 1) >> 1, (m & 1) == 0, hist, lane, vlow, vhigh);
     res = (m & 1) ? vlow : (vlow + vhigh) * 0.5f;    // even: (a+b)*0.5 in float32, as numpy
   }
   return res;
