@@ -1370,11 +1370,22 @@ int launch_recovery(vipmi_ctx* ctx, double* Abak, int64_t batch, int n, int k, d
   const int kp = (int)cdiv(k, 16) * 16;
   double* scratch = nullptr;
   VIPMI_TRY(ws(ctx, "eigh_fb_scratch", (size_t)batch * 6 * n * kp, &scratch));
-  const size_t lds = ((size_t)(9 + 1024 / 64) * n + 64 + 8) * sizeof(double);
-  auto kern = tri_eig_kernel<RPL, 1024>;
-  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(1024), lds, ctx->stream, Abak, n, k, (const int32_t*)nullptr, evals, evecs,
-                     scratch, kp, all_evals, k < n ? k : n, 0, (double*)nullptr, guard, gcount, fail, TriGather());
+  // 512 threads up to 32 vectors (the Gram-Schmidt stage holds four per wave): the 1024-thread instance of the 512-row layout
+  // spills (96 bytes of scratch per lane), and a dispatch that needs scratch costs ~20 us even when its workgroup leaves in the
+  // first instruction -- on the critical path of every lone synchronous solve
+  const int nt = k <= 32 ? 512 : 1024;
+  const size_t lds = ((size_t)(9 + nt / 64) * n + 64 + 8) * sizeof(double);
+  if (nt == 512) {
+    auto kern = tri_eig_kernel<RPL, 512>;
+    VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(512), lds, ctx->stream, Abak, n, k, (const int32_t*)nullptr, evals, evecs,
+                       scratch, kp, all_evals, k < n ? k : n, 0, (double*)nullptr, guard, gcount, fail, TriGather());
+  } else {
+    auto kern = tri_eig_kernel<RPL, 1024>;
+    VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(1024), lds, ctx->stream, Abak, n, k, (const int32_t*)nullptr, evals, evecs,
+                       scratch, kp, all_evals, k < n ? k : n, 0, (double*)nullptr, guard, gcount, fail, TriGather());
+  }
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
