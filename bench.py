@@ -21,6 +21,7 @@ import argparse
 import json
 import os
 import sys
+import gc
 import time
 
 import numpy as np
@@ -525,6 +526,12 @@ def main():
     torch.cuda.synchronize()
     for c in B.all_contexts():
         c.reset_timers()
+    # A full collection of the interpreter's cyclic GC walks the ~170 k objects that importing torch leaves tracked: 65 ms on
+    # this host, once every few dozen calls -- 13 of the 5 ms steps timed here (tools/c3_small_kernels.py: one C3 call in fifteen
+    # took 45-107 instead of 15 ms; none with the objects frozen).  As timeit does for its own loops, the collector is kept out
+    # of the timed regions: everything alive now moves to the permanent generation, new garbage is still collected.
+    gc.collect()
+    gc.freeze()
     # timed region
     barrier()
     if os.environ.get("VIPMI_BENCH_TRACE") and depth > 1:

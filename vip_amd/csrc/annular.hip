@@ -99,28 +99,47 @@ __global__ void rank1_add_kernel(float* __restrict__ R, const float* __restrict_
 }
 
 // frange[2 g], [2 g + 1]: the frames outside which row group g (32 rows) of D = I - C has no coefficient, as multiples of 8 -- the
-// union over its rows j of [min(lib_j), max(lib_j)] and j itself.  One workgroup of 32 lanes per group.
-__global__ __launch_bounds__(32) void coeff_range_kernel(int n, const int32_t* __restrict__ idx, const int32_t* __restrict__ len,
-                                                         int max_lib, int* __restrict__ frange) {
-  const int g = blockIdx.x, j = g * 32 + threadIdx.x;
+// union over its rows j of [min(lib_j), max(lib_j)] and j itself.  One workgroup of 16 waves per group, two rows per wave, the lanes
+// stride over a row's library (coalesced; one thread per row walking its 200 indices took 32 us per segment, one wave walking the 32
+// rows one after the other 50: every row starts with a dependent load of its length).
+__global__ __launch_bounds__(1024) void coeff_range_kernel(int n, const int32_t* __restrict__ idx, const int32_t* __restrict__ len,
+                                                           int max_lib, int* __restrict__ frange) {
+  __shared__ int slo[16], shi[16];
+  const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int lo = n, hi = 0;
-  if (j < n) {
-    lo = j;
-    hi = j + 1;
-    const int32_t* ij = idx + (size_t)j * max_lib;
-    for (int a = 0; a < len[j]; ++a) {
-      const int v = ij[a];
-      lo = v < lo ? v : lo;
-      hi = v + 1 > hi ? v + 1 : hi;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int j = g * 32 + 2 * wave + r;
+    if (j < n) {
+      if (lane == 0) {
+        lo = j < lo ? j : lo;
+        hi = j + 1 > hi ? j + 1 : hi;
+      }
+      const int32_t* ij = idx + (size_t)j * max_lib;
+      const int lj = len[j];
+      for (int a = lane; a < lj; a += 64) {
+        const int v = ij[a];
+        lo = v < lo ? v : lo;
+        hi = v + 1 > hi ? v + 1 : hi;
+      }
     }
   }
 #pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) {
-    const int ol = __shfl_xor(lo, m, 32), oh = __shfl_xor(hi, m, 32);
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int ol = __shfl_xor(lo, m, 64), oh = __shfl_xor(hi, m, 64);
     lo = ol < lo ? ol : lo;
     hi = oh > hi ? oh : hi;
   }
+  if (lane == 0) {
+    slo[wave] = lo;
+    shi[wave] = hi;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      lo = slo[w] < lo ? slo[w] : lo;
+      hi = shi[w] > hi ? shi[w] : hi;
+    }
     frange[2 * g] = lo & ~7;
     frange[2 * g + 1] = (hi + 7) & ~7;
   }
@@ -182,7 +201,7 @@ int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, co
   const int groups = (int)cdiv(n, 32);
   if (ctx->opt("ann_range", 1) != 0) {
     VIPMI_TRY(ws(ctx, "ann_frange", (size_t)2 * groups, &frange));
-    hipLaunchKernelGGL(coeff_range_kernel, dim3(groups), dim3(32), 0, ctx->stream, (int)n, lib_idx, lib_len, (int)max_lib, frange);
+    hipLaunchKernelGGL(coeff_range_kernel, dim3(groups), dim3(1024), 0, ctx->stream, (int)n, lib_idx, lib_len, (int)max_lib, frange);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);

@@ -266,8 +266,17 @@ __global__ void gram_reduce_kernel(const void* __restrict__ partial_, const int2
     int gj = (t.y * TB + bj) * 16 + (idx & 15);
     if (gi >= na || gj >= nb) continue;
     if (symmetric && t.x == t.y && bj < bi) continue;
+    // (the slices in their order, sixteen loads in flight: a load per dependent add left this kernel at 76 us for a 400 x 400 matrix)
     double s = 0.0;
-    for (int sl = 0; sl < nslices; ++sl) s += (double)partial[(int64_t)sl * total + e];
+    int sl = 0;
+    for (; sl + 16 <= nslices; sl += 16) {
+      sc_t v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)(sl + u) * total + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (double)v[u];
+    }
+    for (; sl < nslices; ++sl) s += (double)partial[(int64_t)sl * total + e];
     G[(int64_t)gi * nb + gj] = s;
     if (symmetric) G[(int64_t)gj * nb + gi] = s;
   }

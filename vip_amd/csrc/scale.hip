@@ -96,25 +96,36 @@ __global__ void mask_kernel(const float* __restrict__ in, float* __restrict__ ou
     out[e] = mask[e % P] ? fill : in[e];
 }
 
+// blockIdx.x over the pixel list, blockIdx.y over groups of FPB frames: no 64-bit division per element (the flat-index version
+// spent most of its 55 us per annulus of C3 on e / npx and e % npx), the pixel index loaded once per thread, FPB independent
+// loads in flight per thread (one element per thread -- a workgroup per frame and 256 pixels -- was slower than the division: 84 us)
+constexpr int GS_FPB = 8;
 __global__ void gather_kernel(const float* __restrict__ cube, int64_t n, int64_t P,
                               const int32_t* __restrict__ pix, int64_t npx, float* __restrict__ A) {
-  const int64_t total = n * npx;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t f = e / npx, j = e % npx;
+  const int64_t f0 = (int64_t)blockIdx.y * GS_FPB;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npx; j += (int64_t)gridDim.x * blockDim.x) {
     const int32_t p = pix[j];                 // negative = padding column (npx rounded up to 4)
-    A[e] = (p >= 0) ? cube[f * P + p] : 0.f;
+    float v[GS_FPB];
+#pragma unroll
+    for (int u = 0; u < GS_FPB; ++u) v[u] = (p >= 0 && f0 + u < n) ? cube[(f0 + u) * P + p] : 0.f;
+#pragma unroll
+    for (int u = 0; u < GS_FPB; ++u)
+      if (f0 + u < n) A[(f0 + u) * npx + j] = v[u];
   }
 }
 
 __global__ void scatter_kernel(const float* __restrict__ A, int64_t n, int64_t P,
                                const int32_t* __restrict__ pix, int64_t npx, float* __restrict__ cube) {
-  const int64_t total = n * npx;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t f = e / npx, j = e % npx;
+  const int64_t f0 = (int64_t)blockIdx.y * GS_FPB;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npx; j += (int64_t)gridDim.x * blockDim.x) {
     const int32_t p = pix[j];
-    if (p >= 0) cube[f * P + p] = A[e];
+    if (p < 0) continue;
+    float v[GS_FPB];
+#pragma unroll
+    for (int u = 0; u < GS_FPB; ++u) v[u] = (f0 + u < n) ? A[(f0 + u) * npx + j] : 0.f;
+#pragma unroll
+    for (int u = 0; u < GS_FPB; ++u)
+      if (f0 + u < n) cube[(f0 + u) * P + p] = v[u];
   }
 }
 
@@ -208,7 +219,7 @@ int apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64
 int gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix,
                int64_t npx, float* A) {
   VIPMI_REQUIRE(cube && pix && A && n > 0 && P > 0 && npx > 0, "gather: bad arguments");
-  hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n * npx, 16384)), dim3(256), 0, ctx->stream, cube, n, P,
+  hipLaunchKernelGGL(gather_kernel, dim3(grid_for(npx, 1024), (unsigned)cdiv(n, GS_FPB)), dim3(256), 0, ctx->stream, cube, n, P,
                      pix, npx, A);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
@@ -217,7 +228,7 @@ int gather_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const in
 int scatter_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t P, const int32_t* pix, int64_t npx,
                 float* cube) {
   VIPMI_REQUIRE(cube && pix && A && n > 0 && P > 0 && npx > 0, "scatter: bad arguments");
-  hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n * npx, 16384)), dim3(256), 0, ctx->stream, A, n, P,
+  hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(npx, 1024), (unsigned)cdiv(n, GS_FPB)), dim3(256), 0, ctx->stream, A, n, P,
                      pix, npx, cube);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
