@@ -19,13 +19,33 @@ __global__ void temp_stats_kernel(const float* __restrict__ in, int n, int64_t P
                                   float* __restrict__ mean, float* __restrict__ inv_std) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
        p += (int64_t)gridDim.x * blockDim.x) {
+    // eight loads in flight per thread (one load per dependent add left the pass at a third of the HBM rate); same order of additions
     double s = 0;
-    for (int f = 0; f < n; ++f) s += (double)in[(int64_t)f * P + p];
+    int f = 0;
+    for (; f + 8 <= n; f += 8) {
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = in[(int64_t)(f + u) * P + p];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v8[u];
+    }
+    for (; f < n; ++f) s += (double)in[(int64_t)f * P + p];
     const double mu = s / n;
     mean[p] = (float)mu;
     if (with_std) {
       double v = 0;
-      for (int f = 0; f < n; ++f) {
+      f = 0;
+      for (; f + 8 <= n; f += 8) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = in[(int64_t)(f + u) * P + p];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double d = (double)v8[u] - mu;
+          v += d * d;
+        }
+      }
+      for (; f < n; ++f) {
         double d = (double)in[(int64_t)f * P + p] - mu;
         v += d * d;
       }
@@ -36,15 +56,23 @@ __global__ void temp_stats_kernel(const float* __restrict__ in, int n, int64_t P
   }
 }
 
+// blockIdx.x over the pixels, blockIdx.y over groups of 8 frames: the per-pixel statistics are loaded once per thread and no
+// 64-bit e % P is paid per element (the flat-index loop spent more instructions on it than on everything else)
 __global__ void temp_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int64_t P,
                                   const float* __restrict__ mean, const float* __restrict__ sd) {
-  const int64_t total = (int64_t)n * P;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = e % P;
-    float v = in[e] - mean[p];
-    if (sd) v /= sd[p];
-    out[e] = v;
+  const int f0 = blockIdx.y * 8;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const float m = mean[p];
+    const float s = sd ? sd[p] : 1.f;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (f0 + u < n) ? in[(int64_t)(f0 + u) * P + p] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float r = v[u] - m;
+      if (sd) r /= s;
+      if (f0 + u < n) out[(int64_t)(f0 + u) * P + p] = r;
+    }
   }
 }
 
@@ -90,10 +118,16 @@ __global__ __launch_bounds__(1024) void spat_scale_kernel(const float* __restric
 
 __global__ void mask_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int64_t P,
                             const uint8_t* __restrict__ mask, float fill) {
-  const int64_t total = n * P;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x)
-    out[e] = mask[e % P] ? fill : in[e];
+  const int64_t f0 = (int64_t)blockIdx.y * 8;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const bool m = mask[p] != 0;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (!m && f0 + u < n) ? in[(f0 + u) * P + p] : fill;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (f0 + u < n) out[(f0 + u) * P + p] = v[u];
+  }
 }
 
 // blockIdx.x over the pixel list, blockIdx.y over groups of FPB frames: no 64-bit division per element (the flat-index version
@@ -194,7 +228,7 @@ int scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
     hipLaunchKernelGGL(temp_stats_kernel, dim3(grid_for(P, 8192)), dim3(256), 0, ctx->stream, in, (int)n,
                        P, with_std, mean, sd);
     VIPMI_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(temp_apply_kernel, dim3(grid_for(n * P, 16384)), dim3(256), 0, ctx->stream, in, out,
+    hipLaunchKernelGGL(temp_apply_kernel, dim3(grid_for(P, 2048), (unsigned)cdiv(n, 8)), dim3(256), 0, ctx->stream, in, out,
                        (int)n, P, mean, with_std ? sd : nullptr);
     VIPMI_CHECK_HIP(hipGetLastError());
   } else {
@@ -210,7 +244,7 @@ int apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64
                    const uint8_t* mask, float fill) {
   VIPMI_REQUIRE(in && out && mask, "apply_mask: null pointer");
   VIPMI_REQUIRE(n > 0 && P > 0, "apply_mask: bad sizes");
-  hipLaunchKernelGGL(mask_kernel, dim3(grid_for(n * P, 16384)), dim3(256), 0, ctx->stream, in, out, n, P,
+  hipLaunchKernelGGL(mask_kernel, dim3(grid_for(P, 2048), (unsigned)cdiv(n, 8)), dim3(256), 0, ctx->stream, in, out, n, P,
                      mask, fill);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
