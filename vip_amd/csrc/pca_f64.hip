@@ -30,8 +30,16 @@ __global__ void center_f64_kernel(const double* __restrict__ M, int n, int64_t P
       if (mu32) mu32[p] = 0.f;
       continue;
     }
-    double s = 0.0;
-    for (int f = 0; f < n; ++f) s += M[(int64_t)f * P + p];
+    double s = 0.0;                          // (eight loads in flight; the frames still summed in index order)
+    int f0 = 0;
+    for (; f0 + 8 <= n; f0 += 8) {
+      double v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = M[(int64_t)(f0 + u) * P + p];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v8[u];
+    }
+    for (; f0 < n; ++f0) s += M[(int64_t)f0 * P + p];
     const double m = s / n;
     double sd = 1.0;
     if (mode == 2) {
@@ -44,7 +52,15 @@ __global__ void center_f64_kernel(const double* __restrict__ M, int n, int64_t P
       if (sd < 10.0 * 2.220446049250313e-16) sd = 1.0;
     }
     const double inv = 1.0 / sd;
-    for (int f = 0; f < n; ++f) D[(int64_t)f * P + p] = (float)((M[(int64_t)f * P + p] - m) * inv);
+    f0 = 0;
+    for (; f0 + 8 <= n; f0 += 8) {
+      double v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = M[(int64_t)(f0 + u) * P + p];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) D[(int64_t)(f0 + u) * P + p] = (float)((v8[u] - m) * inv);
+    }
+    for (; f0 < n; ++f0) D[(int64_t)f0 * P + p] = (float)((M[(int64_t)f0 * P + p] - m) * inv);
     mu[p] = m;
     if (mu32) mu32[p] = (float)m;
   }
