@@ -1283,3 +1283,90 @@ def test_annular_eigh_gathers_the_libraries_itself(B, nseg, n, m, k):
         lj = int(ln[p])
         w = np.linalg.eigvalsh(Hs[p][:lj, :lj])[::-1]
         np.testing.assert_allclose(ev[p, :k].cpu().numpy(), w[:k], atol=1e-12 * w[0])
+
+
+@pytest.mark.parametrize("n,k", [(200, 10), (120, 16), (96, 32), (150, 8)])
+def test_eigh_batched_all_leading_values_from_one_wave(B, n, k):
+    """Second launch of a big batch (>= 4 problems per CU, k >= 8): the k leading eigenvalues of every tridiagonal matrix come
+    from ONE wave at once (tri::multisect_many, option eigh_many) -- same values as one wave per eigenvalue to the bracket width
+    (2 eps), ragged and degenerate problems included; eigenpairs against numpy."""
+    import torch
+    rng = np.random.default_rng(n * 100 + k)
+    batch = 1100
+    X = rng.standard_normal((batch, n, 2 * n)) * (2.0 ** (-np.arange(2 * n) / 6.0))
+    G = X @ X.transpose(0, 2, 1)
+    G[5] = np.eye(n) * 3.0                                   # one eigenvalue n times
+    G[6] = 0.0
+    G[7] = np.diag(np.r_[np.ones(n // 2) * 2.0, np.ones(n - n // 2)])
+    nact = rng.integers(1, n + 1, size=batch).astype(np.int32)
+    nact[:8] = (1, 2, 3, k, n, n, n, n)
+    for p in range(batch):
+        G[p, nact[p]:, :] = 0
+        G[p, :, nact[p]:] = 0
+    ctx = B.get_context()
+    res = {}
+    try:
+        for many in (0, 1):
+            ctx.set_option("eigh_many", many)
+            ev, E = B.eigh_topk(torch.from_numpy(G).cuda(), k, nact=torch.from_numpy(nact).cuda())
+            torch.cuda.synchronize()
+            res[many] = (ev.cpu().numpy(), E.cpu().numpy())
+    finally:
+        ctx.set_option("eigh_many", 1)
+    scale = np.abs(res[0][0]).max(axis=1, keepdims=True) + 1e-300
+    assert np.max(np.abs(res[0][0][:, :k] - res[1][0][:, :k]) / scale) < 1e-14
+    ev, E = res[1]
+    for p in list(range(8)) + list(range(8, batch, 97)):
+        kk = min(k, int(nact[p]))
+        w = np.linalg.eigvalsh(G[p])[::-1]
+        sc = max(w[0], 1e-300)
+        assert np.abs(ev[p, :kk] - w[:kk]).max() <= 1e-13 * sc
+        V = E[p, :kk]
+        assert np.abs(G[p] @ V.T - V.T * ev[p, :kk]).max() <= 1e-12 * sc
+        assert np.abs(V @ V.T - np.eye(kk)).max() < 1e-12
+
+
+def test_median_tile_order_options_are_bit_identical(B):
+    """The median's tile -> XCD map (option median_xcd_chunk: chunks dealt round-robin, one range per XCD, plain order) only moves
+    work between compute units: every variant returns the bits of np.nanmedian, on a cube whose edge pixels are the slow ones
+    (part NaN, part a spike of near-zero values beside the real samples)."""
+    import torch
+    rng = np.random.default_rng(3)
+    n, N = 400, 160
+    x = rng.standard_normal((n, N, N)).astype(np.float32)
+    yy, xx = np.mgrid[:N, :N]
+    edge = (yy - N / 2) ** 2 + (xx - N / 2) ** 2 > (0.42 * N) ** 2
+    x[:150, edge] *= 1e-3
+    x[150:200, (yy + xx) % 7 == 0] = np.nan
+    ref = np.nanmedian(x, axis=0)
+    ctx = B.get_context()
+    xt = torch.from_numpy(x).cuda()
+    try:
+        for ch in (-1, 0, 1, 2, 16, 64):
+            ctx.set_option("median_xcd_chunk", ch)
+            got = B.collapse(xt, "median").cpu().numpy()
+            assert np.array_equal(got, ref, equal_nan=True), ch
+    finally:
+        ctx.set_option("median_xcd_chunk", -1)
+
+
+def test_gather_scatter_round_trip_and_padding(B):
+    """vipmi_gather_f32 / vipmi_scatter_f32 (annular fronts): A[f][j] = cube[f][pix[j]] with 0 in padding columns (pix < 0), and the
+    scatter writes exactly the listed pixels -- frame counts that are not multiples of the kernels' frame groups included."""
+    import torch
+    rng = np.random.default_rng(11)
+    for n, P, npx in ((13, 1000, 257), (400, 4096, 1024), (7, 50, 3)):
+        cube = rng.standard_normal((n, P)).astype(np.float32)
+        pix = rng.choice(P, size=npx, replace=False).astype(np.int32)
+        pix[rng.random(npx) < 0.1] = -1
+        ct, pt = torch.from_numpy(cube).cuda(), torch.from_numpy(pix).cuda()
+        A = torch.full((n, npx), 7.0, device="cuda")
+        ctx = B.get_context()
+        ctx.call("vipmi_gather_f32", B.ptr(ct), n, P, B.ptr(pt), npx, B.ptr(A))
+        want = np.where(pix[None, :] >= 0, cube[:, np.maximum(pix, 0)], 0.0).astype(np.float32)
+        assert np.array_equal(A.cpu().numpy(), want)
+        out = torch.full((n, P), -3.0, device="cuda")
+        ctx.call("vipmi_scatter_f32", B.ptr(A), n, P, B.ptr(pt), npx, B.ptr(out))
+        exp = np.full((n, P), -3.0, dtype=np.float32)
+        exp[:, pix[pix >= 0]] = cube[:, pix[pix >= 0]]
+        assert np.array_equal(out.cpu().numpy(), exp)
