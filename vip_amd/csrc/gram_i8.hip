@@ -324,8 +324,23 @@ __global__ void gram_i8_reduce_kernel(const double* __restrict__ partial, const 
     if (t.x == t.y && (wi > wj || (wi == wj && bj < bi))) continue;          // never written: lower part of a diagonal tile
     const int gi = t.x * 64 + wi * 32 + bi * 16 + (idx >> 4), gj = t.y * 64 + wj * 32 + bj * 16 + (idx & 15);
     if (gi >= n || gj >= n) continue;
-    double s = 0.0;
-    for (int sl = 0; sl < nslices; ++sl) s += partial[(int64_t)sl * total + e];
+    double s = 0.0;                         // (the slices in their order, sixteen loads in flight: see gram_reduce_kernel)
+    int sl = 0;
+    for (; sl + 16 <= nslices; sl += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)(sl + u) * total + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; sl + 4 <= nslices; sl += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = partial[(int64_t)(sl + u) * total + e];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u];
+    }
+    for (; sl < nslices; ++sl) s += partial[(int64_t)sl * total + e];
     G[(int64_t)gi * n + gj] = s;
     G[(int64_t)gj * n + gi] = s;
   }
