@@ -232,8 +232,10 @@ def numpy_in_legs(n, N, k, angles, seed0, pca, B, torch):
             "pipelined": {"value": n / (many_ms * 1e-3), "ms_per_cube": many_ms, "cubes": len(many),
                           "note": "pca_many: the (synchronous, pageable) upload of cube i+1 runs beside the kernels of cube i; "
                                   "bounded by PCIe: %.1f ms per %.0f MB cube" % (h2d_ms, hosts[0].nbytes / 1e6)},
-            "note": "one synchronous call = upload + the serial call (the Gram needs every frame, and everything after it needs "
-                    "the Gram: only its 0.2 ms digit split could overlap the copy, DESIGN 7.8)"}
+            "note": "one synchronous call = upload + the serial call: everything after the Gram needs the Gram, and the Gram needs "
+                    "every frame -- but its tile (i, j) only the row blocks i and j, so the library uploads the cube in blocks of 64 "
+                    "frames and forms the Gram of the blocks that have arrived under the copy (vipmi_pca_fullframe_hostin_f32: "
+                    "~0.4 ms of the 0.7 ms Gram stage hidden, bit-identical; DESIGN 7.8)"}
 
 
 def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512, ncomp=20, spectrum=None):

@@ -1595,3 +1595,29 @@ def test_annular_library_window_skipping_is_bit_identical():
         for a, b in zip(got, ref):
             assert torch.equal(torch.nan_to_num(a, nan=7.5), torch.nan_to_num(b, nan=7.5)), opts
     assert np.abs(ref[2].cpu().numpy() - O.pca_annular(cube, ang, asize=12, ncomp=4, fwhm=4, delta_rot=(0.3, 1), max_frames_lib=60)).max() < TOL
+
+
+def test_numpy_cube_through_the_host_input_entry_is_bit_identical():
+    """pca(float32 numpy cube) takes vipmi_pca_fullframe_hostin_f32 when the call is the plain ADI one and the cube is big enough for
+    the int8 Gram path: the library uploads the cube in blocks of 64 frames and advances the Gram matrix behind every block.  Same
+    partial sums in the same order: the frame and every full_output array equal the upload-then-call route bit for bit -- frame
+    counts that are no multiple of 64 and a count just above a block boundary included; smaller cubes and masked / scaled calls
+    keep the old route."""
+    from vip_amd.psfsub import pca
+    for n, N, k in ((320, 512, 6), (257, 384, 5)):
+        cube, ang = O.synth_adi(n, N, seed=n)
+        res = {}
+        try:
+            for h in ("0", "1"):
+                os.environ["VIPMI_HOSTIN"] = h
+                res[h] = pca(cube, ang, ncomp=k, verbose=False, check_memory=False, full_output=True)
+        finally:
+            os.environ.pop("VIPMI_HOSTIN", None)
+        for a, b in zip(res["0"], res["1"]):
+            assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True)
+    # (not eligible: scaling changes the matrix the Gram is taken of -> the ordinary route, same result as a tensor input)
+    import torch
+    cube, ang = O.synth_adi(280, 512, seed=5)
+    a = pca(cube, ang, ncomp=4, scaling="temp-mean", verbose=False, check_memory=False)
+    b = pca(torch.from_numpy(cube).cuda(), ang, ncomp=4, scaling="temp-mean", verbose=False, check_memory=False).cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True)

@@ -221,7 +221,7 @@ __global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const do
 
 extern "C" {
 
-int vipmi_version(void) { return 105; }   // 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64, vipmi_center_f64, vipmi_gram_offset_f64, vipmi_annular_apply_mu_f32; recovery of cooperating solves
+int vipmi_version(void) { return 106; }   // 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64, vipmi_center_f64, vipmi_gram_offset_f64, vipmi_annular_apply_mu_f32; recovery of cooperating solves
 
 const char* vipmi_last_error(void) { return g_err; }
 
@@ -262,6 +262,11 @@ int vipmi_destroy(vipmi_ctx* ctx) {
       (void)hipEventDestroy(pr.second);
     }
   if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+  for (auto e : ctx->copy_events) (void)hipEventDestroy(e);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
   delete ctx;
   return VIPMI_OK;
 }
@@ -304,7 +309,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_many", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "median_xcd_chunk", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", "ann_gather", "ann_range", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_many", "hostin_overlap", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "median_xcd_chunk", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", "ann_gather", "ann_range", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
@@ -626,7 +631,12 @@ int vipmi_pca_project_f32(vipmi_ctx* ctx, const float* M, int64_t n, const float
   VIPMI_TRY(ws(ctx, "pca_G", (size_t)nref * nref, &G));
   VIPMI_TRY(ws(ctx, "pca_evals", (size_t)nref, &evals));
   VIPMI_TRY(ws(ctx, "pca_evecs", (size_t)nref * nref, &evecs));
-  VIPMI_TRY(gram_f32(ctx, ref, nref, ref, nref, P, P, G));
+  if (ctx->gram_given_ref == ref && ctx->gram_given_n == nref) {
+    ctx->gram_given_ref = nullptr;                 // the host-input front formed ref ref^T while the rows arrived
+  } else {
+    ctx->gram_given_ref = nullptr;
+    VIPMI_TRY(gram_f32(ctx, ref, nref, ref, nref, P, P, G));
+  }
   // evals_out: the caller wants the whole spectrum (values only beyond the k leading pairs)
   VIPMI_TRY(eigh_leading(ctx, G, 1, nref, k, nullptr, evals, evecs, evals_out != nullptr));
   VIPMI_TRY(ctx->gate_enter());
@@ -701,6 +711,58 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
     VIPMI_TRY(apply_mask_f32(ctx, frame, frame, 1, P, mask, 0.f));
   }
   return VIPMI_OK;
+}
+
+// The fused call for a cube that is still in HOST memory (a caller's numpy array: psfsub/pca_fullfr.py:137 takes nothing else).
+// The upload of a C2 cube takes longer than the whole PCA (8.0 against 6.2 ms) and nothing can start before its last frame --
+// except the Gram matrix, whose tile (i, j) needs only the row blocks i and j: the cube is copied in blocks of 64 frames on a
+// copy stream, and behind every block the compute stream splits it into digit planes and multiplies it with the blocks that are
+// already there (gram_i8_inc_*).  After the last block a quarter of the product and the reduction are left: ~0.5 of the 0.7 ms of
+// the Gram stage disappear under the copy.  Bit-identical to vipmi_pca_fullframe_f32 on the uploaded cube (same partial sums, same
+// order).  cube: device buffer [n][N][N] that receives the copy (the caller keeps it: residuals etc. refer to it).
+int vipmi_pca_fullframe_hostin_f32(vipmi_ctx* ctx, const float* host_cube, float* cube, const double* angles_host, int64_t n, int64_t N,
+                                   int64_t ncomp, int collapse_mode, float* frame, float* pcs, float* recon, float* residuals,
+                                   float* residuals_der) {
+  CTX_GUARD();
+  VIPMI_REQUIRE(host_cube && cube && angles_host && frame, "pca_fullframe_hostin: null pointer");
+  VIPMI_REQUIRE(n > 0 && N > 1, "pca_fullframe_hostin: bad sizes");
+  const int64_t P = N * N;
+  const bool overlap = gram_i8_default_path(ctx, n, P) && ctx->opt("hostin_overlap", 1) != 0 && ncomp > 0 &&
+                       (reinterpret_cast<uintptr_t>(cube) & 15) == 0;
+  if (!overlap) {
+    VIPMI_CHECK_HIP(hipMemcpyAsync(cube, host_cube, sizeof(float) * (size_t)n * P, hipMemcpyHostToDevice, ctx->stream));
+    return vipmi_pca_fullframe_f32(ctx, cube, angles_host, n, N, ncomp, 0, nullptr, collapse_mode, frame, pcs, recon, residuals,
+                                   residuals_der);
+  }
+  if (!ctx->copy_stream) VIPMI_CHECK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  GramI8Inc st;
+  VIPMI_TRY(gram_i8_inc_begin(ctx, n, P, P, &st));
+  while ((int)ctx->copy_events.size() < st.nt + 1) {
+    hipEvent_t e = nullptr;
+    VIPMI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->copy_events.push_back(e);
+  }
+  double* G = nullptr;
+  VIPMI_TRY(ws(ctx, "pca_G", (size_t)n * n, &G));
+  // the copy stream starts behind whatever the compute stream has queued (the destination may still be in use there)
+  VIPMI_CHECK_HIP(hipEventRecord(ctx->copy_events[st.nt], ctx->stream));
+  VIPMI_CHECK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_events[st.nt], 0));
+  for (int b = 0; b < st.nt; ++b) {
+    const int64_t r0 = (int64_t)64 * b, r1 = r0 + 64 < n ? r0 + 64 : n;
+    if (r1 > r0)
+      VIPMI_CHECK_HIP(hipMemcpyAsync(cube + r0 * P, host_cube + r0 * P, sizeof(float) * (size_t)(r1 - r0) * P, hipMemcpyHostToDevice,
+                                     ctx->copy_stream));
+    VIPMI_CHECK_HIP(hipEventRecord(ctx->copy_events[b], ctx->copy_stream));
+    VIPMI_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_events[b], 0));
+    VIPMI_TRY(gram_i8_inc_block(ctx, st, cube, b));
+  }
+  VIPMI_TRY(gram_i8_inc_end(ctx, st, G));
+  ctx->gram_given_ref = cube;
+  ctx->gram_given_n = n;
+  const int rc = vipmi_pca_fullframe_f32(ctx, cube, angles_host, n, N, ncomp, 0, nullptr, collapse_mode, frame, pcs, recon, residuals,
+                                         residuals_der);
+  ctx->gram_given_ref = nullptr;
+  return rc;
 }
 
 int vipmi_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32) {

@@ -99,6 +99,10 @@ struct vipmi_ctx {
   std::map<std::string, int> pinned_next;
   void* host_pinned = nullptr;     // grow-only pinned scratch for small read-backs (host_scratch)
   size_t host_pinned_bytes = 0;
+  hipStream_t copy_stream = nullptr;       // host -> device copies that run beside the kernels of `stream` (vipmi_pca_fullframe_hostin_f32)
+  std::vector<hipEvent_t> copy_events;
+  const void* gram_given_ref = nullptr;    // set by the host-input front: workspace "pca_G" already holds ref ref^T for this matrix
+  int64_t gram_given_n = 0;
   int sticky_fail[2] = {0, 0};    // deferred failures latched on the host when their device words are freed (vipmi_trim)
   int num_cu = 256;
   int timing = 0;                 // 0 off, 1 every stage / kernel, 2 only the roofline kernel (k_rot_s2)
@@ -135,6 +139,20 @@ struct vipmi_ctx {
 };
 
 namespace vipmi {
+
+// incremental int8 Gram matrix (gram_i8.hip)
+struct GramI8Inc {
+  int64_t n = 0, P = 0, ld = 0, klen = 0, Ppad = 0, plane = 0;
+  int npad = 0, nt = 0, nslices = 0, nwg = 0;
+  int8_t* D = nullptr;
+  double* sc = nullptr;
+  double* partial = nullptr;
+  int2* d_tiles = nullptr;
+};
+int gram_i8_inc_begin(vipmi_ctx* ctx, int64_t n, int64_t P, int64_t ld, GramI8Inc* st);
+int gram_i8_inc_block(vipmi_ctx* ctx, const GramI8Inc& st, const float* M, int block);
+int gram_i8_inc_end(vipmi_ctx* ctx, const GramI8Inc& st, double* G);
+bool gram_i8_default_path(vipmi_ctx* ctx, int64_t n, int64_t P);
 
 template <typename T>
 inline int ws(vipmi_ctx* ctx, const char* name, size_t count, T** out) {

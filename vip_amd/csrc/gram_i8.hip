@@ -40,11 +40,11 @@ template <int S, int NP>                           // NP = passes of 256 x 16 sa
 __global__ __launch_bounds__(256) void gram_split_kernel(const float* __restrict__ M, int n, int64_t P, int64_t ld,
                                                          int klen, int nslices, int64_t Ppad, int64_t plane,
                                                          int8_t* __restrict__ D, double* __restrict__ sc,
-                                                         int64_t bstride_in) {
+                                                         int64_t bstride_in, int npad, int row0) {
+  // (blockIdx.y + row0 = row: the incremental front below splits one block of 64 rows at a time, as the rows arrive from the host)
   __shared__ float red[256];
-  const int slice = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  const int slice = blockIdx.x, row = blockIdx.y + row0, tid = threadIdx.x;
   M += (int64_t)blockIdx.z * bstride_in;
-  const int npad = gridDim.y;
   D += (int64_t)blockIdx.z * S * plane;
   sc += (int64_t)blockIdx.z * npad * nslices;
   const int64_t k0 = (int64_t)slice * klen;
@@ -245,7 +245,7 @@ template <int S, int KEEP, bool DMA>
 __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ D, const double* __restrict__ sc, int npad,
                                                       int klen, int nslices, int64_t Ppad, int64_t plane,
                                                       const int2* __restrict__ wgtiles, int nwg,
-                                                      double* __restrict__ partial, int gram_i8_nbuf) {
+                                                      double* __restrict__ partial, int gram_i8_nbuf, int wg0) {
   constexpr int LMIN = S - 1 - KEEP, NL = 2 * S - 2 - LMIN + 1;
   extern __shared__ __attribute__((aligned(16))) int8_t smem[];          // [1 or 2 buffers][2 sides][S planes][64 rows][64 bytes]
   constexpr int SIDE = S * 64 * 64;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   // blockIdx.x = (slice % 8) + 8 * tile, blockIdx.y = slice / 8: workgroup ids go round-robin over the 8 XCDs, so every tile of
   // a slice runs on ONE XCD at the same time and the slice's digit rows are fetched once into that L2 (each row block is an
   // operand of n / 64 tiles; with the slices fastest the same product moved 3.7 GB from HBM: 0.99 ms)
-  const int slice = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7), wg = (int)blockIdx.x >> 3;
+  const int slice = (int)blockIdx.y * 8 + ((int)blockIdx.x & 7), wg = ((int)blockIdx.x >> 3) + wg0;     // wg0: first tile of a partial launch
   if (slice >= nslices) return;                      // (uniform for the workgroup: before any barrier)
   D += (int64_t)blockIdx.z * S * plane;
   sc += (int64_t)blockIdx.z * npad * nslices;
@@ -394,10 +394,10 @@ int run(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double
     const dim3 sg((unsigned)nslices, (unsigned)npad, (unsigned)batch);
     if (klen <= 4096)
       hipLaunchKernelGGL((gram_split_kernel<S, 1>), sg, dim3(256), 0, ctx->stream, M, (int)n, P, ld, (int)klen, nslices, Ppad, plane,
-                         D, sc, (int64_t)n * ld);
+                         D, sc, (int64_t)n * ld, npad, 0);
     else
       hipLaunchKernelGGL((gram_split_kernel<S, 2>), sg, dim3(256), 0, ctx->stream, M, (int)n, P, ld, (int)klen, nslices, Ppad, plane,
-                         D, sc, (int64_t)n * ld);
+                         D, sc, (int64_t)n * ld, npad, 0);
   }
   VIPMI_CHECK_HIP(hipGetLastError());
   int nbuf = (int)ctx->opt("gram_i8_nbuf", 0);                            // LDS buffers per workgroup (0 = default: 5 digits 2 x 40 KB,
@@ -408,7 +408,7 @@ int run(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double
   auto kern = dma ? gram_i8_kernel<S, KEEP, true> : gram_i8_kernel<S, KEEP, false>;
   VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * nwg), (unsigned)cdiv(nslices, 8), (unsigned)batch), dim3(256), lds, ctx->stream, D, sc, npad,
-                     (int)klen, nslices, Ppad, plane, d_tiles, nwg, partial, nbuf == 2 ? 2 : 1);
+                     (int)klen, nslices, Ppad, plane, d_tiles, nwg, partial, nbuf == 2 ? 2 : 1, 0);
   VIPMI_CHECK_HIP(hipGetLastError());
   int rb = (int)cdiv((int64_t)nwg * 4096, 256);
   if (rb > 4096) rb = 4096;
@@ -420,6 +420,82 @@ int run(vipmi_ctx* ctx, const float* M, int64_t n, int64_t P, int64_t ld, double
 }
 
 }  // namespace
+
+// ---- the same Gram matrix one block of 64 rows at a time (rows arriving from the host: vipmi_pca_fullframe_hostin_f32) ----------
+// G = M M^T needs every row, but tile (i, j) only the row blocks i and j: while the upload of block b + 1 is on the link, block b is
+// split into its digit planes and multiplied with the blocks 0 .. b that are already there.  Same slices, same partial sums, same
+// order of additions in the reduction as run(): the matrix is bit-identical to gram_i8_f32's (mode 1).  The tile list is ordered by
+// the later block: tiles (0, b) .. (b, b) are workgroups b (b + 1) / 2 .. of the list.
+int gram_i8_inc_begin(vipmi_ctx* ctx, int64_t n, int64_t P, int64_t ld, GramI8Inc* st) {
+  constexpr int S = 5;
+  st->n = n; st->P = P; st->ld = ld;
+  st->npad = (int)cdiv(n, 64) * 64;
+  st->nt = st->npad / 64;
+  std::vector<int2> tiles;
+  for (int j = 0; j < st->nt; ++j)
+    for (int i = 0; i <= j; ++i) tiles.push_back(int2{i, j});
+  st->nwg = (int)tiles.size();
+  int64_t want = cdiv((int64_t)6 * ctx->num_cu, (int64_t)st->nwg);          // (the slice rule of run(): identical partial sums)
+  if (ctx->opt("gram_i8_slices", 0) > 0) want = ctx->opt("gram_i8_slices", 0);
+  if (want < 1) want = 1;
+  int64_t klen = cdiv(cdiv(P, want), 64) * 64;
+  if (klen < 256) klen = 256;
+  if (klen > 8192) klen = 8192;
+  st->klen = klen;
+  st->nslices = (int)cdiv(P, klen);
+  st->Ppad = (int64_t)st->nslices * klen;
+  st->plane = (int64_t)st->npad * st->Ppad;
+  VIPMI_TRY(ws(ctx, "gram_i8_digits", (size_t)S * st->plane, &st->D));
+  VIPMI_TRY(ws(ctx, "gram_i8_scale", (size_t)st->npad * st->nslices, &st->sc));
+  VIPMI_TRY(ws(ctx, "gram_i8_partial", (size_t)st->nslices * st->nwg * 4096, &st->partial));
+  char key[64];
+  snprintf(key, sizeof key, "i8inc/%d", st->nt);
+  void* p = nullptr;
+  VIPMI_TRY(ctx->upload_cached("gram_i8_tiles_inc", key, tiles.data(), sizeof(int2) * st->nwg, &p));
+  st->d_tiles = reinterpret_cast<int2*>(p);
+  return VIPMI_OK;
+}
+
+int gram_i8_inc_block(vipmi_ctx* ctx, const GramI8Inc& st, const float* M, int block) {
+  constexpr int S = 5, KEEP = 1;
+  StageScope sc(ctx, "gram");
+  {
+    const dim3 sg((unsigned)st.nslices, 64u, 1u);
+    if (st.klen <= 4096)
+      hipLaunchKernelGGL((gram_split_kernel<S, 1>), sg, dim3(256), 0, ctx->stream, M, (int)st.n, st.P, st.ld, (int)st.klen, st.nslices, st.Ppad,
+                         st.plane, st.D, st.sc, (int64_t)0, st.npad, 64 * block);
+    else
+      hipLaunchKernelGGL((gram_split_kernel<S, 2>), sg, dim3(256), 0, ctx->stream, M, (int)st.n, st.P, st.ld, (int)st.klen, st.nslices, st.Ppad,
+                         st.plane, st.D, st.sc, (int64_t)0, st.npad, 64 * block);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  int nbuf = (int)ctx->opt("gram_i8_nbuf", 0);
+  if (nbuf != 1 && nbuf != 2) nbuf = 2;
+  const size_t lds = (size_t)(nbuf == 2 ? 2 : 1) * 2 * S * 64 * 64;
+  const bool dma = nbuf == 2 && ctx->opt("gram_i8_dma", 1) != 0;
+  auto kern = dma ? gram_i8_kernel<S, KEEP, true> : gram_i8_kernel<S, KEEP, false>;
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+  const int wg0 = block * (block + 1) / 2, cnt = block + 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * cnt), (unsigned)cdiv(st.nslices, 8), 1u), dim3(256), lds, ctx->stream, st.D, st.sc, st.npad,
+                     (int)st.klen, st.nslices, st.Ppad, st.plane, st.d_tiles, st.nwg, st.partial, nbuf == 2 ? 2 : 1, wg0);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+int gram_i8_inc_end(vipmi_ctx* ctx, const GramI8Inc& st, double* G) {
+  StageScope sc(ctx, "gram");
+  int rb = (int)cdiv((int64_t)st.nwg * 4096, 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(gram_i8_reduce_kernel, dim3((unsigned)rb, 1u), dim3(256), 0, ctx->stream, st.partial, st.d_tiles, st.nwg, st.nslices,
+                     (int)st.n, G);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+// where gram_f32 takes the int8 path by itself (the rule of gram.hip: measured to pay from 256 rows and 2^25 elements)
+bool gram_i8_default_path(vipmi_ctx* ctx, int64_t n, int64_t P) {
+  return ctx->opt("gram_i8", -1) < 0 && ctx->opt("gram_f32", 0) == 0 && n >= 256 && P >= 32768 && n * P >= ((int64_t)1 << 25);
+}
 
 // G[batch][n][n] = M M^T for `batch` float32 matrices [n][P] (row length ld; problems n * ld apart) on the int8 matrix cores.
 // mode 1: 5 digits, 19 products (7e-12 max|G|); mode 2: 6 digits, 26 products (2e-15).

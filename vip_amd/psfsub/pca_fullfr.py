@@ -15,6 +15,8 @@ from dataclasses import dataclass
 from enum import Enum
 from typing import List, Tuple, Union
 
+import os
+
 import numpy as np
 
 from .. import backend as B
@@ -416,6 +418,42 @@ def _float64_fused(algo_params, rot_options, cube):
     return out
 
 
+def _hostin_fused(algo_params, rot_options, cube):
+    """Plain 3-D ADI PCA of a float32 NUMPY cube (what the reference's callers pass, pca_fullfr.py:137): the fused entry that
+    uploads the cube itself, in blocks of 64 frames, and forms the Gram matrix of the blocks that have arrived while the next one
+    is on the link (vipmi_pca_fullframe_hostin_f32; bit-identical to uploading first).  Returns cuda tensors like
+    ``_float64_fused`` or None when the call is not of that shape."""
+    ap = algo_params
+    if B.is_device_tensor(cube) or not isinstance(cube, np.ndarray) or cube.dtype != np.float32 or cube.ndim != 3 or ap.left_eigv:
+        return None
+    if os.environ.get("VIPMI_HOSTIN", "1") == "0" or cube.nbytes < (64 << 20):
+        return None
+    if any(getattr(ap, name, None) is not None for name in ("cube_ref", "cube_sig", "scale_list", "source_xy", "batch", "mask_rdi", "smooth")):
+        return None
+    if not isinstance(ap.ncomp, (int, np.integer)) or isinstance(ap.ncomp, bool) or ap.ncomp <= 0:
+        return None
+    if _s(ap.scaling) is not None or ap.mask_center_px or _s(ap.collapse) not in ("median", "mean", "sum", "max", "absmean"):
+        return None
+    if _s(ap.imlib) != "vip-fft" or _s(ap.svd_mode) not in SVD_MODES or rot_options.get("edge_blend") not in (None, ""):
+        return None
+    n, y, x = cube.shape
+    mask_val = rot_options.get("mask_val", np.nan)
+    if y != x or n > B.MAX_EIGH_N or not (isinstance(mask_val, float) and np.isnan(mask_val)):
+        return None
+    angle_list = check_pa_vector(np.asarray(ap.angle_list, dtype=np.float64))
+    if angle_list.shape[0] != n:
+        raise ValueError("`angle_list` vector has wrong length. It must equal the number of frames in the cube")
+    ncomp = int(ap.ncomp)
+    if ncomp > n:
+        ncomp = n
+        print("Number of PCs too high (max PCs={}), using {} PCs instead.".format(n, ncomp))
+    out = B.pca_fullframe_hostin(np.ascontiguousarray(cube), angle_list, ncomp, collapse_mode=_s(ap.collapse),
+                                 full_output=bool(ap.full_output))
+    if ap.verbose:
+        print("Done PCA (Gram matrix formed under the upload), de-rotating and combining on MI355X")
+    return out
+
+
 def _float64_fused_4d(algo_params, rot_options, cube):
     """4-D float64 cube without ``scale_list`` (pca_fullfr.py:544-658), final frame only: every spectral channel through the
     float64 route of ``_float64_fused``, then ``collapse_ifs`` of the per-channel frames.  None when the call is not of that shape."""
@@ -519,6 +557,8 @@ def pca(*all_args: List, **all_kwargs: dict):
         return t.cpu().numpy().astype(dtype or out_dtype, copy=False)
 
     out64 = _float64_fused(algo_params, rot_options, cube)
+    if out64 is None:
+        out64 = _hostin_fused(algo_params, rot_options, cube)
     if out64 is not None:
         return tuple(host(t) for t in out64) if algo_params.full_output else host(out64)
     out64 = _float64_fused_4d(algo_params, rot_options, cube)
