@@ -277,12 +277,13 @@ int vipmi_pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* an
  * metrics/contrcurve.py:768-790).  host_cube[n][N][N] float32 (pageable or pinned) is copied into the device buffer `cube`
  * (kept by the caller: n*N*N floats) in blocks of 64 frames on a copy stream of the context, and behind every block the Gram
  * matrix of the blocks that have arrived is advanced on the context's stream -- where vipmi_gram_f32 would take the int8 path by
- * itself; otherwise: plain copy, then vipmi_pca_fullframe_f32.  No scaling / mask (both change the matrix the Gram is taken of:
- * upload, then call vipmi_pca_fullframe_f32).  Results bit-identical to vipmi_pca_fullframe_f32 on the uploaded cube.  The host
- * array has been read completely when the call returns. */
+ * itself; otherwise: plain copy, then vipmi_pca_fullframe_f32.  mask (N*N bytes on the device, or NULL) as in
+ * vipmi_pca_fullframe_f32: every block is masked as it arrives.  No scaling (the temporal statistics need every frame: upload,
+ * then call vipmi_pca_fullframe_f32).  Results bit-identical to vipmi_pca_fullframe_f32 on the uploaded cube.  A pageable host
+ * array has been read completely when the call returns; a pinned one once the context's stream has passed the call. */
 int vipmi_pca_fullframe_hostin_f32(vipmi_ctx* ctx, const float* host_cube, float* cube, const double* angles_host, int64_t n,
-                                   int64_t N, int64_t ncomp, int collapse_mode, float* frame, float* pcs, float* recon,
-                                   float* residuals, float* residuals_der);
+                                   int64_t N, int64_t ncomp, const uint8_t* mask, int collapse_mode, float* frame, float* pcs,
+                                   float* recon, float* residuals, float* residuals_der);
 
 /* ---- 4-D (IFS) cube without scale_list: psfsub/pca_fullfr.py:544-658 ----
  * cube4[nch,n,N,N] float32: one full-frame ADI PCA per spectral channel (same integer ncomp, no reference cube), then

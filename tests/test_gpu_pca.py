@@ -1601,16 +1601,16 @@ def test_numpy_cube_through_the_host_input_entry_is_bit_identical():
     """pca(float32 numpy cube) takes vipmi_pca_fullframe_hostin_f32 when the call is the plain ADI one and the cube is big enough for
     the int8 Gram path: the library uploads the cube in blocks of 64 frames and advances the Gram matrix behind every block.  Same
     partial sums in the same order: the frame and every full_output array equal the upload-then-call route bit for bit -- frame
-    counts that are no multiple of 64 and a count just above a block boundary included; smaller cubes and masked / scaled calls
-    keep the old route."""
+    counts that are no multiple of 64, a count just above a block boundary and a masked call (every block masked as it arrives)
+    included; smaller cubes and scaled calls keep the old route."""
     from vip_amd.psfsub import pca
-    for n, N, k in ((320, 512, 6), (257, 384, 5)):
+    for n, N, k, mpx in ((320, 512, 6, None), (257, 384, 5, None), (300, 512, 4, 9)):
         cube, ang = O.synth_adi(n, N, seed=n)
         res = {}
         try:
             for h in ("0", "1"):
                 os.environ["VIPMI_HOSTIN"] = h
-                res[h] = pca(cube, ang, ncomp=k, verbose=False, check_memory=False, full_output=True)
+                res[h] = pca(cube, ang, ncomp=k, mask_center_px=mpx, verbose=False, check_memory=False, full_output=True)
         finally:
             os.environ.pop("VIPMI_HOSTIN", None)
         for a, b in zip(res["0"], res["1"]):

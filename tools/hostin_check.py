@@ -5,19 +5,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vip_amd.synth import synth_adi
 from vip_amd.psfsub import pca
-for n, N, k in ((400, 512, 20), (300, 512, 7), (257, 384, 5), (520, 320, 30)):
+for n, N, k, mpx in ((400, 512, 20, None), (300, 512, 7, 8), (257, 384, 5, None), (520, 320, 30, 5)):
     cube, ang = synth_adi(n, N, 1)
     outs = {}
     for h in ("0", "1"):
         os.environ["VIPMI_HOSTIN"] = h
-        outs[h] = pca(cube, ang, ncomp=k, verbose=False, check_memory=False)
+        outs[h] = pca(cube, ang, ncomp=k, mask_center_px=mpx, verbose=False, check_memory=False)
     same = np.array_equal(outs["0"], outs["1"], equal_nan=True)
     full = {}
     for h in ("0", "1"):
         os.environ["VIPMI_HOSTIN"] = h
-        full[h] = pca(cube, ang, ncomp=k, verbose=False, check_memory=False, full_output=True)
+        full[h] = pca(cube, ang, ncomp=k, mask_center_px=mpx, verbose=False, check_memory=False, full_output=True)
     same_full = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(full["0"], full["1"]))
-    print("n %d N %d k %d: frame identical %s, full_output identical %s" % (n, N, k, same, same_full), flush=True)
+    print("n %d N %d k %d mask %s: frame identical %s, full_output identical %s" % (n, N, k, mpx, same, same_full), flush=True)
 cube, ang = synth_adi(400, 512, 0)
 gc.collect(); gc.freeze()
 for h in ("0", "1", "0", "1"):

@@ -82,8 +82,8 @@ _SIGS = {
                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p], True, ctypes.c_int),
     "vipmi_pca_fullframe_f32": ([c_f32p, ctypes.c_void_p, i64, i64, i64, ctypes.c_int, ctypes.c_void_p,
                                  ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p], True, ctypes.c_int),
-    "vipmi_pca_fullframe_hostin_f32": ([ctypes.c_void_p, c_f32p, ctypes.c_void_p, i64, i64, i64, ctypes.c_int, c_f32p, c_f32p, c_f32p,
-                                        c_f32p, c_f32p], True, ctypes.c_int),
+    "vipmi_pca_fullframe_hostin_f32": ([ctypes.c_void_p, c_f32p, ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_int, c_f32p,
+                                        c_f32p, c_f32p, c_f32p, c_f32p], True, ctypes.c_int),
     "vipmi_rccl_load": ([ctypes.c_char_p], False, ctypes.c_int),
     "vipmi_rccl_unique_id": ([ctypes.c_void_p], False, ctypes.c_int),
     "vipmi_rccl_comm_create": ([ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)], True,

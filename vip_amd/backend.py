@@ -635,7 +635,7 @@ def pca_fullframe_f64(cube64, angles, ncomp, scaling=None, mask_u8=None, collaps
     return (frame, pcs, recon, res, der) if full_output else frame
 
 
-def pca_fullframe_hostin(cube_np, angles, ncomp, collapse_mode="median", full_output=False, device=None):
+def pca_fullframe_hostin(cube_np, angles, ncomp, mask_u8=None, collapse_mode="median", full_output=False, device=None):
     """Fused 3-D ADI path for a float32 numpy cube still in host memory (vipmi_pca_fullframe_hostin_f32: the library uploads it in
     blocks of 64 frames and forms the Gram matrix under the copy).  Returns like ``pca_fullframe``; the full_output tuple ends with
     nothing extra -- the uploaded cube is dropped."""
@@ -654,7 +654,7 @@ def pca_fullframe_hostin(cube_np, angles, ncomp, collapse_mode="median", full_ou
         res = empty((n, N, N), device=dev)
         der = empty((n, N, N), device=dev)
     ah, ap = host_f64(angles)
-    ctx.call("vipmi_pca_fullframe_hostin_f32", cube_np.ctypes.data_as(ctypes.c_void_p), ptr(cube), ap, n, N, int(ncomp),
+    ctx.call("vipmi_pca_fullframe_hostin_f32", cube_np.ctypes.data_as(ctypes.c_void_p), ptr(cube), ap, n, N, int(ncomp), ptr(mask_u8),
              COLLAPSE_MODES[collapse_mode], ptr(frame), ptr(pcs), ptr(recon), ptr(res), ptr(der))
     if full_output:
         return frame, pcs, recon, res, der

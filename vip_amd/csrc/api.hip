@@ -721,17 +721,17 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
 // the Gram stage disappear under the copy.  Bit-identical to vipmi_pca_fullframe_f32 on the uploaded cube (same partial sums, same
 // order).  cube: device buffer [n][N][N] that receives the copy (the caller keeps it: residuals etc. refer to it).
 int vipmi_pca_fullframe_hostin_f32(vipmi_ctx* ctx, const float* host_cube, float* cube, const double* angles_host, int64_t n, int64_t N,
-                                   int64_t ncomp, int collapse_mode, float* frame, float* pcs, float* recon, float* residuals,
-                                   float* residuals_der) {
+                                   int64_t ncomp, const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon,
+                                   float* residuals, float* residuals_der) {
   CTX_GUARD();
   VIPMI_REQUIRE(host_cube && cube && angles_host && frame, "pca_fullframe_hostin: null pointer");
   VIPMI_REQUIRE(n > 0 && N > 1, "pca_fullframe_hostin: bad sizes");
   const int64_t P = N * N;
   const bool overlap = gram_i8_default_path(ctx, n, P) && ctx->opt("hostin_overlap", 1) != 0 && ncomp > 0 &&
-                       (reinterpret_cast<uintptr_t>(cube) & 15) == 0;
+                       (reinterpret_cast<uintptr_t>(cube) & 15) == 0 && (P & 3) == 0;
   if (!overlap) {
     VIPMI_CHECK_HIP(hipMemcpyAsync(cube, host_cube, sizeof(float) * (size_t)n * P, hipMemcpyHostToDevice, ctx->stream));
-    return vipmi_pca_fullframe_f32(ctx, cube, angles_host, n, N, ncomp, 0, nullptr, collapse_mode, frame, pcs, recon, residuals,
+    return vipmi_pca_fullframe_f32(ctx, cube, angles_host, n, N, ncomp, 0, mask, collapse_mode, frame, pcs, recon, residuals,
                                    residuals_der);
   }
   if (!ctx->copy_stream) VIPMI_CHECK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -744,6 +744,10 @@ int vipmi_pca_fullframe_hostin_f32(vipmi_ctx* ctx, const float* host_cube, float
   }
   double* G = nullptr;
   VIPMI_TRY(ws(ctx, "pca_G", (size_t)n * n, &G));
+  // mask_center_px: the decomposition is that of the MASKED matrix (pca_fullfr.py:1627-1630); the mask is per pixel, so every
+  // block is masked as it arrives, into the workspace the fused call below masks the whole cube into again (same values)
+  float* masked = nullptr;
+  if (mask) VIPMI_TRY(ws(ctx, "pca_M", (size_t)n * P, &masked));
   // the copy stream starts behind whatever the compute stream has queued (the destination may still be in use there)
   VIPMI_CHECK_HIP(hipEventRecord(ctx->copy_events[st.nt], ctx->stream));
   VIPMI_CHECK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_events[st.nt], 0));
@@ -754,12 +758,13 @@ int vipmi_pca_fullframe_hostin_f32(vipmi_ctx* ctx, const float* host_cube, float
                                      ctx->copy_stream));
     VIPMI_CHECK_HIP(hipEventRecord(ctx->copy_events[b], ctx->copy_stream));
     VIPMI_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_events[b], 0));
-    VIPMI_TRY(gram_i8_inc_block(ctx, st, cube, b));
+    if (mask && r1 > r0) VIPMI_TRY(apply_mask_f32(ctx, cube + r0 * P, masked + r0 * P, r1 - r0, P, mask, 0.f));
+    VIPMI_TRY(gram_i8_inc_block(ctx, st, mask ? masked : cube, b));
   }
   VIPMI_TRY(gram_i8_inc_end(ctx, st, G));
-  ctx->gram_given_ref = cube;
+  ctx->gram_given_ref = mask ? masked : cube;
   ctx->gram_given_n = n;
-  const int rc = vipmi_pca_fullframe_f32(ctx, cube, angles_host, n, N, ncomp, 0, nullptr, collapse_mode, frame, pcs, recon, residuals,
+  const int rc = vipmi_pca_fullframe_f32(ctx, cube, angles_host, n, N, ncomp, 0, mask, collapse_mode, frame, pcs, recon, residuals,
                                          residuals_der);
   ctx->gram_given_ref = nullptr;
   return rc;

@@ -432,13 +432,14 @@ def _hostin_fused(algo_params, rot_options, cube):
         return None
     if not isinstance(ap.ncomp, (int, np.integer)) or isinstance(ap.ncomp, bool) or ap.ncomp <= 0:
         return None
-    if _s(ap.scaling) is not None or ap.mask_center_px or _s(ap.collapse) not in ("median", "mean", "sum", "max", "absmean"):
+    if _s(ap.scaling) is not None or _s(ap.collapse) not in ("median", "mean", "sum", "max", "absmean"):
         return None
     if _s(ap.imlib) != "vip-fft" or _s(ap.svd_mode) not in SVD_MODES or rot_options.get("edge_blend") not in (None, ""):
         return None
     n, y, x = cube.shape
     mask_val = rot_options.get("mask_val", np.nan)
-    if y != x or n > B.MAX_EIGH_N or not (isinstance(mask_val, float) and np.isnan(mask_val)):
+    mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
+    if y != x or n > B.MAX_EIGH_N or B.other_mask_value(mask_val) is not None or (bool(ap.mask_center_px) == mv_nan):
         return None
     angle_list = check_pa_vector(np.asarray(ap.angle_list, dtype=np.float64))
     if angle_list.shape[0] != n:
@@ -447,7 +448,10 @@ def _hostin_fused(algo_params, rot_options, cube):
     if ncomp > n:
         ncomp = n
         print("Number of PCs too high (max PCs={}), using {} PCs instead.".format(n, ncomp))
-    out = B.pca_fullframe_hostin(np.ascontiguousarray(cube), angle_list, ncomp, collapse_mode=_s(ap.collapse),
+    mask = None
+    if ap.mask_center_px:
+        mask = B.to_device_f32(center_mask_u8((y, x), ap.mask_center_px).astype(np.float32)).to(B._torch().uint8)
+    out = B.pca_fullframe_hostin(np.ascontiguousarray(cube), angle_list, ncomp, mask_u8=mask, collapse_mode=_s(ap.collapse),
                                  full_output=bool(ap.full_output))
     if ap.verbose:
         print("Done PCA (Gram matrix formed under the upload), de-rotating and combining on MI355X")
