@@ -1,4 +1,4 @@
-"""One C3-like batch (3200 problems of 200 x 200, k = 10) through the batched eigensolver, for a counter run: python tools/prof_reg.py [reg2]"""
+"""One C3-like batch (3200 problems of 200 x 200, k = 10) through the batched eigensolver, for a counter run: python tools/prof_reg.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +7,7 @@ rng = np.random.default_rng(0)
 n, k, batch = 200, 10, 3200
 X = rng.standard_normal((n, 3 * n)); X[:, :5] *= 10
 G = X @ X.T
-ctx = B.get_context(); ctx.set_option("eigh_reg2", int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ctx = B.get_context()
 Gt = torch.from_numpy(np.stack([G] * batch)).cuda()
 nact = torch.full((batch,), n, dtype=torch.int32, device="cuda")
 evals = torch.zeros((batch, n), dtype=torch.float64, device="cuda"); evecs = torch.zeros((batch, n, n), dtype=torch.float64, device="cuda")
