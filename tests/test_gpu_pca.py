@@ -1621,3 +1621,23 @@ def test_numpy_cube_through_the_host_input_entry_is_bit_identical():
     a = pca(cube, ang, ncomp=4, scaling="temp-mean", verbose=False, check_memory=False)
     b = pca(torch.from_numpy(cube).cuda(), ang, ncomp=4, scaling="temp-mean", verbose=False, check_memory=False).cpu().numpy()
     assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_numpy_4d_cube_uploaded_in_channel_groups_is_bit_identical():
+    """pca(4-D float32 numpy cube, int ncomp, no scale_list): the channels go up in groups on a copy stream (an uploader thread)
+    while the batched per-channel path works on the group before; the Gram launch of every group is pinned to the split-K
+    slicing of the whole batch, everything else is per problem / per frame: the frame equals upload-then-call bit for bit,
+    with and without mask_center_px."""
+    from vip_amd.psfsub import pca
+    rng = np.random.default_rng(4)
+    for nch, n, N, k, mpx in ((13, 140, 256, 4, None), (9, 130, 320, 6, 5)):
+        cube = rng.standard_normal((nch, n, N, N), dtype=np.float32) + rng.standard_normal((nch, 1, N, N), dtype=np.float32) * 3
+        ang = np.linspace(0, 90, n)
+        res = {}
+        try:
+            for h in ("0", "1"):
+                os.environ["VIPMI_HOSTIN"] = h
+                res[h] = pca(cube, ang, ncomp=k, mask_center_px=mpx, verbose=False, check_memory=False)
+        finally:
+            os.environ.pop("VIPMI_HOSTIN", None)
+        assert res["0"].dtype == res["1"].dtype and np.array_equal(res["0"], res["1"], equal_nan=True)

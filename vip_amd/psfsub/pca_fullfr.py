@@ -458,6 +458,99 @@ def _hostin_fused(algo_params, rot_options, cube):
     return out
 
 
+def _hostin_4d(algo_params, rot_options, cube):
+    """4-D float32 NUMPY cube without ``scale_list``, final frame only (pca_fullfr.py:544-658): the channels are uploaded in a few
+    groups on a copy stream while the batched per-channel path (``_adi_pca_channels_batched``) works on the group before -- the
+    upload of an IFS cube takes longer than its PCA (C4: 36 ms against 24).  Every group's Gram launch is pinned to the split-K
+    slicing the whole batch would get, and every other stage is per problem / per frame: bit-identical to uploading first.  None
+    when the call is not of that shape."""
+    ap = algo_params
+    if B.is_device_tensor(cube) or not isinstance(cube, np.ndarray) or cube.dtype != np.float32 or cube.ndim != 4:
+        return None
+    if os.environ.get("VIPMI_HOSTIN", "1") == "0" or cube.nbytes < (256 << 20) or ap.full_output or ap.left_eigv:
+        return None
+    if any(getattr(ap, name, None) is not None for name in ("cube_ref", "cube_sig", "scale_list", "source_xy", "batch", "mask_rdi", "smooth")):
+        return None
+    nch, nz, ny, nx = cube.shape
+    ncomp = ap.ncomp
+    if not isinstance(ncomp, (int, np.integer)) or isinstance(ncomp, bool) or not (0 < int(ncomp) <= min(64, nz)) or nz > 512:
+        return None
+    if _s(ap.imlib) != "vip-fft" or _s(ap.svd_mode) not in SVD_MODES or rot_options.get("edge_blend") not in (None, ""):
+        return None
+    mask_val = rot_options.get("mask_val", np.nan)
+    mv_nan = isinstance(mask_val, float) and np.isnan(mask_val)
+    if ny != nx or not (mv_nan or mask_val == 0) or _s(ap.collapse) not in ("median", "mean", "sum", "max", "absmean"):
+        return None
+    if _s(ap.collapse_ifs) not in ("median", "mean", "sum", "max", "absmean") or _s(ap.scaling) is not None or ap.ifs_collapse_range != "all":
+        return None
+    P = ny * nx
+    ngrp = min(int(os.environ.get("VIPMI_HOSTIN_GROUPS", "8")), nch // 4)      # (C4: 2 groups 53 ms, 4: 49, 8: 48 median / 43 best; 62 without)
+    bounds = [round(g * nch / ngrp) for g in range(ngrp + 1)] if ngrp >= 2 else []
+    # the int8 Gram path must be the one every group AND the whole batch would take (gram.hip: gram_batched_f32)
+    if ngrp < 2 or nz < 128 or P < 16384 or min(b1 - b0 for b0, b1 in zip(bounds, bounds[1:])) * nz * P < (1 << 25):
+        return None
+    torch = B.require_gpu()
+    if B.is_async():
+        return None
+    angles = check_pa_vector(np.asarray(ap.angle_list, dtype=np.float64))
+    if angles.shape[0] != nz:
+        raise ValueError("`angle_list` vector has wrong length. It must equal the number of frames in the cube")
+    dev = torch.cuda.current_device()
+    cur = torch.cuda.current_stream()
+    copy_stream = B.side_streams(1, dev)[0]
+    ctx = B.get_context(dev)
+    # split-K slices of the whole batch's Gram launch (gram_i8.hip run(): ~6 workgroups per CU over tiles x problems)
+    nt = -(-nz // 64)
+    want = max(1, -(-6 * torch.cuda.get_device_properties(dev).multi_processor_count // (nt * (nt + 1) // 2 * nch)))
+    had = ctx.get_option("gram_i8_slices")
+    frames = []
+    B.set_async(True)
+    try:
+        ctx.set_option("gram_i8_slices", want)
+        copy_stream.wait_stream(cur)
+        # the (blocking, pageable) copies run on a thread of their own: the interpreter lock is released inside the copy, so this
+        # thread enqueues the kernels of group g while group g + 1 is on the link (host time per group ~2.5 ms: in one thread the
+        # call took upload + 4 x that)
+        import queue
+        import threading
+        q = queue.Queue()
+
+        def uploader():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(copy_stream):
+                    for g in range(ngrp):
+                        t_ = torch.from_numpy(np.ascontiguousarray(cube[bounds[g]:bounds[g + 1]])).to(torch.device("cuda", dev))
+                        q.put((t_, copy_stream.record_event()))
+            except BaseException as e:          # (handed to the consumer: it must not wait for a group that will never come)
+                q.put(e)
+
+        th = threading.Thread(target=uploader, name="vipmi-upload", daemon=True)
+        th.start()
+        try:
+            for g in range(ngrp):
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                t, ev = item
+                cur.wait_event(ev)
+                t.record_stream(cur)
+                frames.append(_adi_pca_channels_batched(t, angles, int(ncomp), None, ap.mask_center_px, _s(ap.collapse), ap.weights, mv_nan))
+                del t, item
+        finally:
+            th.join()
+        ifs = torch.cat(frames)
+        frame = B.collapse(ifs, _s(ap.collapse_ifs))
+        cur.synchronize()
+        B.check_deferred()
+    finally:
+        ctx.set_option("gram_i8_slices", had)
+        B.set_async(False)
+    if ap.verbose:
+        print("Done PCA per channel (channel groups uploaded beside the PCA of the group before), combining on MI355X")
+    return frame
+
+
 def _float64_fused_4d(algo_params, rot_options, cube):
     """4-D float64 cube without ``scale_list`` (pca_fullfr.py:544-658), final frame only: every spectral channel through the
     float64 route of ``_float64_fused``, then ``collapse_ifs`` of the per-channel frames.  None when the call is not of that shape."""
@@ -566,6 +659,8 @@ def pca(*all_args: List, **all_kwargs: dict):
     if out64 is not None:
         return tuple(host(t) for t in out64) if algo_params.full_output else host(out64)
     out64 = _float64_fused_4d(algo_params, rot_options, cube)
+    if out64 is None:
+        out64 = _hostin_4d(algo_params, rot_options, cube)
     if out64 is not None:
         return host(out64, np.float64)
     cube_t = B.to_device_f32(cube)
