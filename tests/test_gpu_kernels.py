@@ -1370,3 +1370,25 @@ def test_gather_scatter_round_trip_and_padding(B):
         exp = np.full((n, P), -3.0, dtype=np.float32)
         exp[:, pix[pix >= 0]] = cube[:, pix[pix >= 0]]
         assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_cube_derotate_numpy_pipelined_is_bit_identical():
+    """cube_derotate of a big numpy cube uploads, rotates and downloads blocks of frames at the same time (uploader / downloader
+    threads on two copy streams): same kernels on the same frames -- identical to the one-shot path for float32 and float64 input
+    (dtype kept), NaN pixels and angles in every quadrant included."""
+    import os
+    from vip_amd.preproc import cube_derotate
+    rng = np.random.default_rng(8)
+    for n, N, dt in ((130, 384, np.float32), (70, 512, np.float64), (64, 511, np.float32)):
+        cube = rng.standard_normal((n, N, N)).astype(dt)
+        cube[:, :4, :7] = np.nan
+        ang = np.linspace(-179, 178, n)
+        res = {}
+        try:
+            for h in ("0", "1"):
+                os.environ["VIPMI_HOSTIN"] = h
+                res[h] = cube_derotate(cube, ang)
+        finally:
+            os.environ.pop("VIPMI_HOSTIN", None)
+        assert res["1"].dtype == dt and res["0"].dtype == dt
+        assert np.array_equal(res["0"], res["1"], equal_nan=True)

@@ -3,6 +3,8 @@
 Reference: preproc/derotation.py:51-328 (frame_rotate), :331-399 (cube_derotate), :410-496
 (_find_indices_adi), :499-504 (_compute_pa_thresh), :507-539 (_define_annuli).
 """
+import os
+
 import numpy as np
 
 from .. import backend as B
@@ -39,6 +41,9 @@ def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", 
     if angle_list.shape[0] != array.shape[0]:
         raise ValueError("`angle_list` must have one angle per frame")
     dev_in = B.is_device_tensor(array)
+    if (not dev_in and mv_nan is not None and isinstance(array, np.ndarray) and array.dtype in (np.float32, np.float64)
+            and array.nbytes >= (64 << 20) and array.shape[0] >= 32 and os.environ.get("VIPMI_HOSTIN", "1") != "0" and not B.is_async()):
+        return _derotate_numpy_pipelined(array, angle_list, mv_nan, method, mask_val)
     t = B.to_device_f32(array)
     if mv_nan is None:
         out = B.rotate_interp(t, angle_list, str(getattr(interpolation, "value", interpolation)), cxy=cxy,
@@ -48,6 +53,82 @@ def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", 
     if dev_in:
         return out
     return out.cpu().numpy().astype(array.dtype if array.dtype.kind == "f" else np.float64, copy=False)
+
+
+def _derotate_numpy_pipelined(array, angle_list, mv_nan, method, mask_val):
+    """cube_derotate of a numpy cube: upload, rotation and download of a 400 x 512 x 512 cube take 8 + 3.8 + 8 ms one after the
+    other, but the rotation is per frame and the link is full duplex -- blocks of frames go up on one copy stream (uploader
+    thread), are rotated on the calling thread's stream, and come down on a second copy stream (downloader thread) straight
+    into the result array, all three at once.  Same kernels on the same frames: bit-identical to the one-shot path."""
+    import queue
+    import threading
+    torch = B.require_gpu()
+    n = array.shape[0]
+    out = np.empty(array.shape, dtype=array.dtype)
+    nblk = max(2, min(8, n // 16))
+    bounds = [round(b * n / nblk) for b in range(nblk + 1)]
+    dev = torch.cuda.current_device()
+    cur = torch.cuda.current_stream()
+    s_in, s_out = B.side_streams(2, dev)
+    s_in.wait_stream(cur)
+    q_in, q_out = queue.Queue(maxsize=2), queue.Queue()
+    err = []
+
+    def uploader():
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(s_in):
+                for b in range(nblk):
+                    t_ = torch.from_numpy(np.ascontiguousarray(array[bounds[b]:bounds[b + 1]])).to(torch.device("cuda", dev))
+                    if t_.dtype != torch.float32:
+                        t_ = t_.to(torch.float32)          # (on the device: numpy's astype of a float64 cube costs more than the copy)
+                    q_in.put((t_, s_in.record_event()))
+        except BaseException as e:
+            q_in.put(e)
+
+    def downloader():
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(s_out):
+                while True:
+                    item = q_out.get()
+                    if item is None:
+                        return
+                    r_, ev_, b0, b1 = item
+                    s_out.wait_event(ev_)
+                    dst = torch.from_numpy(out[b0:b1])
+                    dst.copy_(r_ if dst.dtype == r_.dtype else r_.to(dst.dtype))     # (blocking: pageable destination)
+        except BaseException as e:
+            err.append(e)
+
+    tu = threading.Thread(target=uploader, name="vipmi-upload", daemon=True)
+    td = threading.Thread(target=downloader, name="vipmi-download", daemon=True)
+    tu.start()
+    td.start()
+    try:
+        for b in range(nblk):
+            item = q_in.get()
+            if isinstance(item, BaseException):
+                raise item
+            t_, ev = item
+            cur.wait_event(ev)
+            t_.record_stream(cur)
+            r_ = B.derotate(t_, angle_list[bounds[b]:bounds[b + 1]], mask_nan=mv_nan, mask_zero=not mv_nan, method=method, mask_val=mask_val)
+            r_.record_stream(s_out)
+            q_out.put((r_, cur.record_event(), bounds[b], bounds[b + 1]))
+            del t_, r_, item
+    finally:
+        q_out.put(None)
+        td.join()
+        while tu.is_alive():                 # (drain after an early exit: the uploader may be blocked on a full queue)
+            try:
+                q_in.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        tu.join()
+    if err:
+        raise err[0]
+    return out
 
 
 def frame_rotate(array, angle, imlib="vip-fft", interpolation="lanczos4", cxy=None,
