@@ -950,12 +950,47 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
     streams = B.side_streams(depth)       # cached: every stream owns a context with its own workspaces (backend._ctx_cache)
     dev_in = [B.is_device_tensor(c) for c in cubes]
     outs = [None] * n_items
+    # numpy cubes: uploaded by a thread of their own on a copy stream, up to two ahead of the cube whose kernels this thread is
+    # enqueueing (the interpreter lock is released inside the blocking pageable copy): the link never waits for the ~0.4 ms of
+    # host work per call (8.45 -> 8.1 ms per C2 cube, the upload alone being 8.05)
+    feeder = None
+    if n_items > 1 and not any(dev_in) and os.environ.get("VIPMI_HOSTIN", "1") != "0":
+        import queue
+        import threading
+        dev = torch.cuda.current_device()
+        copy_stream = B.side_streams(depth + 1, dev)[depth]
+        copy_stream.wait_stream(torch.cuda.current_stream())
+        q = queue.Queue(maxsize=2)
+
+        def uploader():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(copy_stream):
+                    for c in cubes:
+                        t_ = B.to_device_f32(c)
+                        q.put((t_, copy_stream.record_event()))
+            except BaseException as e:
+                q.put(e)
+
+        feeder = threading.Thread(target=uploader, name="vipmi-upload", daemon=True)
+        feeder.start()
     B.set_async(True)
     try:
         cur = torch.cuda.current_stream()
         for i, (c, a) in enumerate(zip(cubes, angle_lists)):
             st = streams[i % depth]
             st.wait_stream(cur)
+            if feeder is not None:
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                t, ev = item
+                st.wait_event(ev)
+                t.record_stream(st)
+                with torch.cuda.stream(st):
+                    outs[i] = pca(t, a, **kwargs)
+                del t, item
+                continue
             with torch.cuda.stream(st):
                 t = B.to_device_f32(c)
                 outs[i] = pca(t, a, **kwargs)
@@ -963,6 +998,13 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
             st.synchronize()
         B.check_deferred()
     finally:
+        if feeder is not None:
+            while feeder.is_alive():            # (drain after an early exit: the uploader may be blocked on a full queue)
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            feeder.join()
         for st in streams:                      # (a no-op after the normal path; joins the streams on the error path)
             st.synchronize()
         B.set_async(False)
