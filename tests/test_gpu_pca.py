@@ -443,6 +443,26 @@ def test_median_sub_annular_golden(tag, kw):
         median_sub(g["cube"], g["angles"], mode="nope", verbose=False)
 
 
+@pytest.mark.parametrize("tag,kw", [("ff", dict(radius_int=5)), ("ff_mean", dict(radius_int=3, collapse="mean")),
+                                    ("ann", dict(mode="annular", asize=4, fwhm=4, radius_int=4, nframes=4))])
+def test_median_sub_odd_frame_count_keeps_its_exact_zeros(tag, kw):
+    """g29 (round 6, round-5 ADVICE): with an odd frame count the median IS one of the samples, `cube - median` is exactly 0 for one
+    frame per pixel, and the reference's mask_val = 0 rotation (radius_int > 0) resets exactly those pixels.  The projection's zero
+    guard (project.hip keep_nonzero, option sub_guard) must not touch this subtraction."""
+    from vip_amd.psfsub import median_sub
+    g = load_golden("g29_medsub_odd")
+    co, cd, fr = median_sub(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    exp = g["ms_%s_out" % tag]
+    assert co.shape == exp.shape and co.dtype == exp.dtype
+    assert np.array_equal(co == 0, exp == 0), "the exact zeros of cube - median differ from the reference's"
+    assert np.nanmax(np.abs(co - exp)) < 2e-6
+    assert np.nanmax(np.abs(cd - g["ms_%s_der" % tag])) < 2e-5, np.nanmax(np.abs(cd - g["ms_%s_der" % tag]))
+    assert np.nanmax(np.abs(fr - g["ms_%s_frame" % tag])) < 2e-5
+    # and the guard is back on for the PCA calls of the same context
+    from vip_amd import backend as B
+    assert int(B.get_context().get_option("sub_guard")) == 1
+
+
 def test_stim_maps_golden():
     from vip_amd.metrics import stim_map, inverse_stim_map, normalized_stim_map
     g = load_golden("g8_medsub_stim")
@@ -470,6 +490,23 @@ def test_pca_many_matches_serial():
         pca_many(list(cubes), list(angs), ncomp=0)
     from vip_amd import backend
     assert backend.is_async() is False
+
+
+def test_pca_many_keeps_float64_cubes_on_the_float64_route():
+    """pca_many(cubes) == [pca(c, a) ...] also for float64 cubes of detector counts (round-5 ADVICE): the uploader must not round
+    them to float32 (golden g28: that alone costs 2e-3 on the frame)."""
+    from vip_amd.psfsub import pca, pca_many
+    g = load_golden("g28_f64_counts")
+    cubes = [g["cube"], g["cube"] + 3.0, g["cube"][:30].copy()]
+    angs = [g["angles"], g["angles"], g["angles"][:30]]
+    serial = [pca(c, a, ncomp=4, verbose=False) for c, a in zip(cubes, angs)]
+    many = pca_many(cubes, angs, depth=2, ncomp=4)
+    for s_, m in zip(serial, many):
+        assert m.dtype == np.float64 and np.array_equal(s_, m, equal_nan=True)
+    assert np.nanmax(np.abs(many[0] - g["frame64_k4"])) < 1e-4
+    import torch
+    many_dev = pca_many([torch.from_numpy(c).cuda() for c in cubes], angs, depth=2, ncomp=4)
+    assert np.array_equal(many_dev[0].cpu().numpy().astype(np.float64), many[0], equal_nan=True)
 
 
 @pytest.mark.parametrize("n,N,k", [(50, 128, 5), (120, 256, 8)])

@@ -16,12 +16,6 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// internal layouts (project.hip)
-int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n,
-                    int64_t P, const float* rowscale, float* T, const int* frange = nullptr);
-int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, const float* T, int64_t n,
-                    int64_t k, int64_t P, float* R, float* recon);
-
 }  // namespace vipmi
 
 using namespace vipmi;
@@ -221,7 +215,11 @@ __global__ void evecs_rows_f32_kernel(const double* __restrict__ evecs, const do
 
 extern "C" {
 
-int vipmi_version(void) { return 106; }   // 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64, vipmi_center_f64, vipmi_gram_offset_f64, vipmi_annular_apply_mu_f32; recovery of cooperating solves
+// 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64, vipmi_center_f64, vipmi_gram_offset_f64, vipmi_annular_apply_mu_f32;
+//                 recovery of cooperating solves
+// 106 (round 5): + vipmi_pca_fullframe_hostin_f32 (the Gram under the upload); float-domain median selection
+// 107 (round 6): option sub_guard (the subtraction's zero guard is opt-out per call: median_sub), see the round-6 entries of vipmi.h
+int vipmi_version(void) { return 107; }
 
 const char* vipmi_last_error(void) { return g_err; }
 
@@ -309,7 +307,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_many", "hostin_overlap", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "median_xcd_chunk", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", "ann_gather", "ann_range", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_many", "hostin_overlap", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "median_xcd_chunk", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", "ann_gather", "ann_range", "sub_guard", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);
@@ -729,14 +727,24 @@ int vipmi_pca_fullframe_hostin_f32(vipmi_ctx* ctx, const float* host_cube, float
   const int64_t P = N * N;
   const bool overlap = gram_i8_default_path(ctx, n, P) && ctx->opt("hostin_overlap", 1) != 0 && ncomp > 0 &&
                        (reinterpret_cast<uintptr_t>(cube) & 15) == 0 && (P & 3) == 0;
-  if (!overlap) {
+  auto plain = [&]() -> int {
     VIPMI_CHECK_HIP(hipMemcpyAsync(cube, host_cube, sizeof(float) * (size_t)n * P, hipMemcpyHostToDevice, ctx->stream));
     return vipmi_pca_fullframe_f32(ctx, cube, angles_host, n, N, ncomp, 0, mask, collapse_mode, frame, pcs, recon, residuals,
                                    residuals_der);
-  }
+  };
+  if (!overlap) return plain();
   if (!ctx->copy_stream) VIPMI_CHECK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   GramI8Inc st;
-  VIPMI_TRY(gram_i8_inc_begin(ctx, n, P, P, &st));
+  {
+    // the digit planes take 5 bytes per sample on top of the cube: when they do not fit, upload first and let gram_f32 choose
+    // (it falls back to the float64-MFMA kernel on its own, gram.hip) -- a cube that worked through upload + pca must not fail here
+    const int rc0 = gram_i8_inc_begin(ctx, n, P, P, &st);
+    if (rc0 == VIPMI_ERR_NOMEM) {
+      (void)hipGetLastError();
+      return plain();
+    }
+    VIPMI_TRY(rc0);
+  }
   while ((int)ctx->copy_events.size() < st.nt + 1) {
     hipEvent_t e = nullptr;
     VIPMI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

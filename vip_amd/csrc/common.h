@@ -277,6 +277,11 @@ int rowspace_gemm_f32(vipmi_ctx* ctx, const float* W, const float* M, int64_t k,
                       const float* rowscale, float* B, const int* frange = nullptr);
 int subtract_gemm_f32(vipmi_ctx* ctx, const float* M, const float* C, const float* B, int64_t n,
                       int64_t k, int64_t P, float* R, float* recon);
+// the same two with the small operand already in the layout the kernels read (project.hip): Wt [n][kld], Ct [k][nld]
+int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n, int64_t P, const float* rowscale,
+                    float* T, const int* frange = nullptr);
+int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, const float* T, int64_t n, int64_t k, int64_t P, float* R,
+                    float* recon);
 int scale_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P, int mode);
 int apply_mask_f32(vipmi_ctx* ctx, const float* in, float* out, int64_t n, int64_t P,
                    const uint8_t* mask, float fill);

@@ -144,11 +144,6 @@ __global__ void recon_offset_kernel(const float* __restrict__ D, const float* __
 
 }  // namespace
 
-int rowspace_gemm_t(vipmi_ctx* ctx, const float* Wt, int kld, const float* M, int64_t k, int64_t n, int64_t P, const float* rowscale,
-                    float* T, const int* frange = nullptr);
-int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, const float* T, int64_t n, int64_t k, int64_t P, float* R,
-                    float* recon);
-
 // The two building blocks on their own (the annular front applies them to every segment matrix of a float64 cube):
 // D = float32((M - 1 mu^T) / sd), mu (float64) and optionally float32(mu) -- mode 0 / 1: centre, 2: 'temp-standard'
 int center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32) {

@@ -133,9 +133,12 @@ __global__ __launch_bounds__(256, 2) void rowspace_kernel(const float* __restric
 // ~1e5 .. 1e6 cancels to 0.0f, would be taken for a masked pixel and replace one of the n values under the median by 0 (found with
 // the float64 golden g28: one pixel of the frame off by 1.3).  Such a residual becomes 1e-30 -- nothing to the shears, and no
 // longer "equal to the mask value".  Masked samples (exactly 0, with every component 0 there) keep their exact 0; NaN stays NaN.
-__device__ __forceinline__ f32x4 keep_nonzero(f32x4 res, f32x4 m) {
+// OPT-IN per call (`guard`; context option `sub_guard`, default 1): median_sub's `cube - median` wants the exact zeros -- for an odd
+// frame count np.median returns one of the samples, the reference's residual IS 0 there in float64 too, and its mask_val = 0 rotation
+// resets those pixels (psfsub/medsub.py:279-285 with radius_int > 0): psfsub/medsub.py clears the option around its subtraction.
+__device__ __forceinline__ f32x4 keep_nonzero(f32x4 res, f32x4 m, int guard) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) res[i] = (res[i] == 0.f && m[i] != 0.f) ? 1e-30f : res[i];
+  for (int i = 0; i < 4; ++i) res[i] = (guard && res[i] == 0.f && m[i] != 0.f) ? 1e-30f : res[i];
   return res;
 }
 
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
                                                        const float* __restrict__ Ct, int nld,
                                                        const float* __restrict__ T, int n, int k,
                                                        int64_t P, float* __restrict__ R,
-                                                       float* __restrict__ recon, int64_t sM, int64_t sCt, int64_t sT) {
+                                                       float* __restrict__ recon, int64_t sM, int64_t sCt, int64_t sT, int guard) {
   M += blockIdx.y * sM;                      // blockIdx.y = problem of the batch (strides 0 for a single one)
   R += blockIdx.y * sM;
   Ct += blockIdx.y * sCt;
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) {
       const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
       f32x4 rec = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-      f32x4 res = keep_nonzero(m[r] - rec, m[r]);
+      f32x4 res = keep_nonzero(m[r] - rec, m[r], guard);
       strow4<VEC>(R, f, n, P, px, res);
       if (RECON) strow4<VEC>(recon, f, n, P, px, rec);
     }
@@ -216,7 +219,7 @@ template <bool VEC, bool RECON>
 __global__ __launch_bounds__(256, 2) void subtract_lds_kernel(const float* __restrict__ M, const float* __restrict__ Ct, int nld,
                                                            const float* __restrict__ T, int n, int k, int64_t P,
                                                            float* __restrict__ R, float* __restrict__ recon,
-                                                           int64_t sM, int64_t sCt, int64_t sT) {
+                                                           int64_t sM, int64_t sCt, int64_t sT, int guard) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];          // [kp][128], kp = k rounded up to even
   M += blockIdx.y * sM;                      // blockIdx.y = problem of the batch (strides 0 for a single one)
   R += blockIdx.y * sM;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void subtract_lds_kernel(const float* __res
     for (int r = 0; r < 16; ++r) {
       const int f = fb + (r & 3) + 8 * (r >> 2) + 4 * kh;
       f32x4 rec = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-      f32x4 res = keep_nonzero(m[r] - rec, m[r]);
+      f32x4 res = keep_nonzero(m[r] - rec, m[r], guard);
       strow4<VEC>(R, f, n, P, px, res);
       if (RECON) strow4<VEC>(recon, f, n, P, px, rec);
     }
@@ -326,6 +329,7 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
   const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(T) && aligned16(R) &&
                    (!recon || aligned16(recon));
   dim3 grid((unsigned)cdiv(cdiv(P, 128), 4)), block(256);
+  const int guard = ctx->opt("sub_guard", 1) != 0;           // (see keep_nonzero)
   if (k <= 128 && ctx->opt("subtract_lds", 1) != 0) {      // (see subtract_lds_kernel)
     const size_t lds = (size_t)((k + 1) & ~(int64_t)1) * 128 * sizeof(float);
     dim3 g1((unsigned)cdiv(P, 128));
@@ -333,7 +337,7 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
   do {                                                                                                               \
     auto kern = subtract_lds_kernel<V, RC>;                                                                          \
     VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)); \
-    hipLaunchKernelGGL(kern, g1, block, lds, ctx->stream, M, Ct, nld, T, (int)n, (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0); \
+    hipLaunchKernelGGL(kern, g1, block, lds, ctx->stream, M, Ct, nld, T, (int)n, (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0, guard); \
   } while (0)
     if (vec) {
       if (recon) LAUNCHL(true, true); else LAUNCHL(true, false);
@@ -346,7 +350,7 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
   }
 #define LAUNCH(V, RC)                                                                             \
   hipLaunchKernelGGL((subtract_kernel<V, RC>), grid, block, 0, ctx->stream, M, Ct, nld, T, (int)n, \
-                     (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0)
+                     (int)k, P, R, recon, (int64_t)0, (int64_t)0, (int64_t)0, guard)
   if (vec) {
     if (recon) LAUNCH(true, true); else LAUNCH(true, false);
   } else {
@@ -402,6 +406,7 @@ int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t 
   VIPMI_TRY(ws(ctx, "projb_t", (size_t)chunk * k * P, &T));
   const bool vec = (P % 4 == 0) && aligned16(M) && aligned16(R) && aligned16(T);
   const bool use_lds = k <= 128 && ctx->opt("subtract_lds", 1) != 0;
+  const int guard = ctx->opt("sub_guard", 1) != 0;
   const size_t lds_t = (size_t)((k + 1) & ~(int64_t)1) * 128 * sizeof(float);
   if (use_lds) {
     VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(subtract_lds_kernel<true, false>), (int)lds_t));
@@ -420,19 +425,19 @@ int project_batched_f32(vipmi_ctx* ctx, const float* M, const float* E, int64_t 
                          (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
       if (use_lds)
         hipLaunchKernelGGL((subtract_lds_kernel<true, false>), g3, dim3(256), lds_t, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
-                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P, guard);
       else
         hipLaunchKernelGGL((subtract_kernel<true, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
-                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P, guard);
     } else {
       hipLaunchKernelGGL((rowspace_kernel<false, 1>), g1, dim3(256), 0, ctx->stream, Wt, kld, Mb, (int)k, (int)n, P,
                          (const float*)nullptr, T, (int64_t)n * kld, (int64_t)n * P, (int64_t)k * P);
       if (use_lds)
         hipLaunchKernelGGL((subtract_lds_kernel<false, false>), g3, dim3(256), lds_t, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
-                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P, guard);
       else
         hipLaunchKernelGGL((subtract_kernel<false, false>), g2, dim3(256), 0, ctx->stream, Mb, Ct, nld, T, (int)n, (int)k, P, Rb,
-                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P);
+                           (float*)nullptr, (int64_t)n * P, (int64_t)k * nld, (int64_t)k * P, guard);
     }
     VIPMI_CHECK_HIP(hipGetLastError());
   }

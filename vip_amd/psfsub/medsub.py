@@ -173,8 +173,14 @@ def median_sub(*all_args: List, **all_kwargs: dict):
     ones = torch.ones((n, 1), dtype=torch.float32, device=t.device)
     cube_out = B.empty((n, P), device=t.device.index)
     model_row = model.reshape(1, P).contiguous()          # (named: a temporary must outlive the enqueued kernel's launch)
-    ctx.call("vipmi_subtract_gemm_f32", B.ptr(t.reshape(n, P)), B.ptr(ones), B.ptr(model_row),
-             n, 1, P, B.ptr(cube_out), None)
+    # (without the projection's zero guard: for an odd frame count the median IS one of the samples and the reference's
+    #  `cube - median` is exactly 0 there; with radius_int > 0 its mask_val = 0 rotation resets exactly those pixels, medsub.py:279-285)
+    ctx.set_option("sub_guard", 0)
+    try:
+        ctx.call("vipmi_subtract_gemm_f32", B.ptr(t.reshape(n, P)), B.ptr(ones), B.ptr(model_row),
+                 n, 1, P, B.ptr(cube_out), None)
+    finally:
+        ctx.set_option("sub_guard", 1)
     cube_out = cube_out.reshape(n, y, x)
     if annular:
         cube_out = _annular_pass(t, cube_out, angle_list, algo_params, rdi=algo_params.cube_ref is not None)

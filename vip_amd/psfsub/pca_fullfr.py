@@ -943,6 +943,16 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
         raise NotImplementedError("pca_many returns final frames only")
     kwargs = dict(kwargs, full_output=False, verbose=False)
     torch = B.require_gpu()
+
+    def upload(c):
+        # a float64 cube stays float64 on the device: pca() then takes the route that carries the temporal mean in float64
+        # (_float64_fused), exactly as pca(c, a) on the caller's array does -- rounding it to float32 here cost 2e-3 on the
+        # frame of golden g28 (round-5 ADVICE)
+        if B.is_device_tensor(c):
+            return c.contiguous() if c.dtype == torch.float64 else B.to_device_f32(c)
+        if isinstance(c, np.ndarray) and c.dtype == np.float64:
+            return torch.from_numpy(np.ascontiguousarray(c)).to(torch.device("cuda", torch.cuda.current_device()))
+        return B.to_device_f32(c)
     n_items = len(cubes)
     if n_items != len(angle_lists):
         raise ValueError("cubes and angle_lists must have the same length")
@@ -967,7 +977,7 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(copy_stream):
                     for c in cubes:
-                        t_ = B.to_device_f32(c)
+                        t_ = upload(c)
                         q.put((t_, copy_stream.record_event()))
             except BaseException as e:
                 q.put(e)
@@ -992,7 +1002,7 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
                 del t, item
                 continue
             with torch.cuda.stream(st):
-                t = B.to_device_f32(c)
+                t = upload(c)
                 outs[i] = pca(t, a, **kwargs)
         for st in streams:
             st.synchronize()

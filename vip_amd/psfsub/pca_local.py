@@ -318,8 +318,9 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         pix = pix_of(si, seg)
         npx = int(pix.numel())
         A64 = cube64.reshape(n, P).index_select(1, pix.clamp(min=0).long())
-        if bool((pix < 0).any()):
-            A64[:, pix < 0] = 0.0                                   # (the zero columns that pad the rows to 16 bytes)
+        npad = npx - int(seg["pix"].size)                           # (known on the host: no device read-back per segment)
+        if npad:
+            A64[:, npx - npad:] = 0.0                               # (the zero columns that pad the rows to 16 bytes)
         aug = B.empty((n + 1, npx), device=dev)                     # rows 0 .. n-1: D, row n: float32(mu)
         mu = torch.empty((npx,), dtype=torch.float64, device=cube.device)
         mode = {None: 0, "temp-mean": 1, "temp-standard": 2}[scaling]
