@@ -238,6 +238,81 @@ def numpy_in_legs(n, N, k, angles, seed0, pca, B, torch):
                     "~0.4 ms of the 0.7 ms Gram stage hidden, bit-identical; DESIGN 7.8)"}
 
 
+def shape_legs(pca, B, torch, c2_latency_ms):
+    """The reference's OWN shapes (round-5 VERDICT #2): its frames are odd-sized by convention (`frame_center`, metrics/contrcurve.py:725
+    insists on odd PSFs, fm/fakecomp.py:704-711 forces odd sizes), and an odd N makes the padded period Le = 4 N a non-power of two:
+    the derotation then runs as power-of-two circular convolutions (csrc/derotate_conv.inc) instead of the plain transforms of the
+    BASELINE shapes.  (a) 61 x 101 x 101, ncomp = 5 -- the shape of the only timing the reference publishes for `pca`
+    (docs/source/tutorials/01A_quickstart.ipynb cell 53: 2.37 s on an unspecified laptop => 25.7 frames/s; BASELINE.md section 1);
+    (b) 400 x 511 x 511, ncomp = 20 beside C2.  One synchronous call each, cube resident (the metric's definition) and numpy in."""
+    from vip_amd.psfsub.pca_fullfr import pca_many
+    from vip_amd.synth import synth_adi
+    ctx = B.get_context()
+
+    def lat(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def stages_of(fn):
+        ctx.set_option("timing", 1)
+        ctx.reset_timers()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        st = {s_: ctx.stage_ms(s_) / 3 for s_ in LEG_STAGES if ctx.stage_count(s_) > 0}
+        ctx.set_option("timing", 0)
+        return {k_: round(v_, 4) for k_, v_ in st.items()}
+
+    out = {}
+    # (a) the tutorial's shape
+    n, N, k = 61, 101, 5
+    cube, ang = synth_adi(n, N, seed=11)
+    ct = torch.from_numpy(cube).cuda()
+    ms_res = lat(lambda: pca(ct, ang, ncomp=k, verbose=False, check_memory=False).cpu(), 50)
+    ms_np = lat(lambda: pca(cube, ang, ncomp=k, verbose=False, check_memory=False), 50)
+    many = [ct] * 64
+    pca_many(many[:4], [ang] * 4, ncomp=k, check_memory=False)
+    t0 = time.perf_counter()
+    outs = pca_many(many, [ang] * len(many), ncomp=k, check_memory=False)
+    torch.cuda.synchronize()
+    ms_many = (time.perf_counter() - t0) / len(many) * 1e3
+    assert len(outs) == len(many)
+    pub = 61 / 2.37
+    out["tutorial_61x101x101_k5"] = {
+        "metric": "ADI cube frames/sec at ncomp=5, 61x101x101 (one synchronous pca() call, cube resident, frame to the host)",
+        "value": n / (ms_res * 1e-3), "unit": "frames/s", "latency_ms_per_call": ms_res,
+        "value_numpy_in": n / (ms_np * 1e-3), "latency_ms_numpy_in": ms_np,
+        "value_pipelined": n / (ms_many * 1e-3), "ms_per_cube_pipelined": ms_many,
+        "stages_serial_ms": stages_of(lambda: pca(ct, ang, ncomp=k, verbose=False, check_memory=False).cpu()),
+        "vs_baseline": n / (ms_res * 1e-3) / pub, "vs_baseline_numpy_in": n / (ms_np * 1e-3) / pub,
+        "baseline": {"value": pub, "unit": "frames/s", "source": "docs/source/tutorials/01A_quickstart.ipynb cell 53: "
+                     "pca(cube 61x101x101, ncomp=5) 2.37 s (BASELINE.md section 1)",
+                     "caveat": "an incidental notebook output on an unspecified laptop (17 GB RAM), not a benchmark: the same "
+                               "shape and call, other hardware, other data (the tutorial's NACO cube; synthetic here)"}}
+    del ct
+    # (b) C2 with odd frames
+    n, N, k = 400, 511, 20
+    cube, ang = synth_adi(n, N, seed=12)
+    ct = torch.from_numpy(cube).cuda()
+    del cube
+    fn = lambda: pca(ct, ang, ncomp=k, verbose=False, check_memory=False).cpu()
+    ms_odd = lat(fn, 8)
+    out["odd_400x511x511_k20"] = {
+        "metric": "ADI cube frames/sec at ncomp=20, 400x511x511 (one synchronous pca() call, cube resident)",
+        "value": n / (ms_odd * 1e-3), "unit": "frames/s", "latency_ms_per_call": ms_odd, "stages_serial_ms": stages_of(fn),
+        "vs_512_px": (ms_odd / c2_latency_ms if c2_latency_ms else None),
+        "note": "Le = 2044 = 4 x 7 x 73: every real shift of the three shears as a circular convolution of 1024 points "
+                "(derotate_conv.inc); vs_512_px = this call's latency over the 400x512x512 call's"}
+    del ct
+    torch.cuda.empty_cache()
+    return out
+
+
 def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512, ncomp=20, spectrum=None):
     """One problem sharded over all ranks (strong scaling): every rank holds the same synthetic input in HBM; a step is
     one complete sharded call ending with the final frame on every rank.  Returns the record (every rank).
@@ -304,6 +379,14 @@ def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512,
         t = torch.tensor([phases[k_] for k_ in names], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         phases = dict(zip(names, [float(v) for v in t.tolist()]))
+    # one more step with the library's stage timers on (hipEvent pairs around every stage and around the three shear kernels, on
+    # the streams they run on; not part of the timed region): the leg's own roofline object
+    leg_roof = None
+    if world == 1:
+        try:
+            leg_roof = leg_roofline(mode, step, 1e3 * elapsed / steps, n, N, k, nch if mode == "4d" else 1)
+        except Exception as e:                  # (never costs the leg)
+            sys.stderr.write("leg roofline (%s) failed: %r\n" % (mode, e))
     # the frame's corners are NaN by design (mask_val of the vip-fft rotation): check the disk the rotation keeps
     out = np.asarray(out)
     c = out.shape[-1] // 2
@@ -319,7 +402,90 @@ def sharded_leg(mode, world, rank, backend, steps, warmup, frames=400, size=512,
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "phases_ms": {k_: round(v_, 3) for k_, v_ in (phases or {}).items()},
+            "roofline": leg_roof,
             "config": {"workload": what, "parallelism": "one problem over %d GPU(s), collectives of SURVEY 8(e)" % world}}
+
+
+LEG_STAGES = ("scale", "gram", "eigh", "project", "derotate", "collapse", "k_rot_s1", "k_rot_s2", "k_rot_s3", "k_rot_aux")
+
+
+def leg_pmc_traffic(tag, kernel="rs_shear2"):
+    """HBM bytes per launch of a leg's dominant kernel from the round's committed PMC passes of THAT configuration
+    (profiles/rNN_pmc_hbm_<tag>.json, tools/pmc_summary.py); None when no such pass is committed."""
+    import glob
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_%s.json" % tag))
+                   if re.fullmatch(r"r\d+_pmc_hbm_%s\.json" % tag, os.path.basename(f)))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        for name, e in doc["kernels"].items():
+            if name.startswith(kernel):
+                return 1024.0 * (e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"])
+    except Exception:
+        return None
+    return None
+
+
+def leg_roofline(mode, step, ms_per_step, n, N, k, nch):
+    """The roofline object of one strong leg (one GPU): SURVEY 8(d)'s algorithmic bytes of the configuration over the measured
+    step (`call_frac`), the per-stage times of one step (hipEvents of the library's stage timers, summed over the contexts of
+    the streams the call uses), and the dominant kernel's own fraction: `rs_shear2*` -- the column shear of the FFT derotation, as
+    at C2 -- with the derotation stage's algorithmic bytes (2 P 4 per frame) over its launch time; for the annular configuration
+    the stage that takes most of the step is the batched library eigensolver, reported beside it with its nominal flops."""
+    import torch
+    from vip_amd import backend as B
+    ctxs = B.all_contexts()
+    for c in ctxs:
+        c.set_option("timing", 1)
+        c.reset_timers()
+    step()
+    torch.cuda.synchronize()
+    st = {}
+    for s_ in LEG_STAGES:
+        ms = sum(max(c.stage_ms(s_), 0.0) for c in ctxs)
+        cnt = sum(c.stage_count(s_) for c in ctxs)
+        if cnt > 0:
+            st[s_] = {"ms": ms, "launches": cnt}
+    for c in ctxs:
+        c.set_option("timing", 0)
+    P = float(N * N)
+    frames = n * nch
+    if mode == "annular":
+        # SURVEY 8(d): "bytes per annulus as above with P -> npx_ann" (Gram 1 + project 2 passes over the annuli's pixels)
+        # + derotation 2 n P 4 + collapse n P 4
+        from vip_amd.psfsub.pca_local import cached_annulus_plan
+        plan, _ = cached_annulus_plan((N, N), np.linspace(0, 90, n), 0, 4, 32, 1, (0.1, 1), 10, 2, 200, 0)
+        npx = float(sum(len(sg["pix"]) for sg in plan))               # 205,609 at C3
+        call_bytes = 3.0 * n * npx * 4 + 3.0 * n * P * 4
+        tag = "c3"
+    else:
+        call_bytes = 6.0 * frames * P * 4                     # 24 n P bytes per cube (per channel)
+        tag = "c4" if mode == "4d" else "c5"
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "call_bytes": call_bytes,
+            "call_frac": call_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "stages_ms": {k_: round(v_["ms"], 3) for k_, v_ in st.items()},
+            "dominant_stage": (max((k_ for k_ in st if not k_.startswith("k_")), key=lambda k_: st[k_]["ms"]) if st else None)}
+    if "k_rot_s2" in st:
+        launches = st["k_rot_s2"]["launches"]
+        dur_ms = st["k_rot_s2"]["ms"] / launches
+        alg = 2.0 * P * 4 * frames / launches
+        Le = 4 * N
+        fft_flops = (frames / launches) * (Le / 2) * (2 * 5 * Le * np.log2(Le) + 16 * Le)
+        roof.update({"kernel": "rs_shear2 (Le = %d)" % Le, "achieved": alg / (dur_ms * 1e-3) / 1e9,
+                     "frac": alg / (dur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": dur_ms, "launches_per_step": launches,
+                     "flop_frac": fft_flops / (dur_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TF,
+                     "traffic": leg_pmc_traffic(tag) if tag != "c3" else pmc_traffic(n / launches, N)})
+        if "derotate" in st:
+            roof["stage_frac"] = 2.0 * frames * P * 4 / (st["derotate"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if mode == "annular" and "eigh" in st:
+        # 8 annuli x n libraries of <= 200 frames: Householder tridiagonalisation 4/3 m^3 flops each (the k leading vectors add little)
+        m = min(200, n)
+        flops = 8.0 * n * (4.0 / 3.0) * m ** 3
+        roof["eigh"] = {"kernel": "tri_eig_kernel (batched library eigensolver, float64 vector pipe)", "ms": st["eigh"]["ms"],
+                        "flops": flops, "f64_valu_frac": flops / (st["eigh"]["ms"] * 1e-3) / 1e12 / 78.6}
+    return roof
 
 
 def sharded_mode(args, world, rank, backend):
@@ -364,7 +530,7 @@ def strong_scaling_legs(world, rank, backend):
                               ("ifs_4d_c4", "4d", dict(frames=200, size=256, ncomp=20), 10)):
         r = sharded_leg(mode, world, rank, backend, st, 1, **kw)
         out[key] = {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": st,
-                    "workload": r["config"]["workload"], "eigh_fast_last": r["eigh_fast_last"],
+                    "workload": r["config"]["workload"], "eigh_fast_last": r["eigh_fast_last"], "roofline": r["roofline"],
                     "phases_ms": r["phases_ms"]}      # (one extra step, synchronised at every phase boundary; MAX over ranks)
     return out
 
@@ -412,6 +578,10 @@ def main():
                     help="survey (default, the BASELINE metric): one cube per GPU, no data-path collective, weak scaling; "
                          "single-cube / annular / 4d: ONE problem sharded over the GPUs with the collectives of SURVEY 8(e) "
                          "(vip_amd.dist.pca_single_cube / pca_annular / pca_4d), strong scaling")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
+                    help="length of the sustained leg (pipelined calls back to back, power sampled): long enough for an outside "
+                         "observer (rocm-smi, the driver's gpu_busy samples) to see the card busy")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the legs on the reference's own (odd-sized) shapes")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="independent pca() calls in flight (one torch stream each); 1 = strictly serial")
     args = ap.parse_args()
@@ -630,14 +800,15 @@ def main():
             roof["call_frac"] = roof["call_bytes"] / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["call_frac_pipelined"] = roof["call_bytes"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
 
-    # steady state over >= ~1.5 s of pipelined calls (the K timed steps above include the pipeline's fill and drain, and
-    # K = 20 lasts 0.1 s): reported beside `value`, never instead of it
+    # steady state over >= 10 s of pipelined calls (the K timed steps above include the pipeline's fill and drain, and
+    # K = 20 lasts 0.1 s; rounds 1-5 ran this leg for 1.5 s, too short for the driver's gpu_busy samples to see): reported beside
+    # `value`, never instead of it; runs before the CPU baseline and the strong legs
     sustained = None
     power = None
     if depth > 1 and not args.no_latency:
         B.set_async(True)
         ns = min(len(pinned), max(args.steps, 1))
-        reps = max(1, int(np.ceil(1.5 / max(elapsed * ns / args.steps, 1e-3))))
+        reps = max(1, int(np.ceil(args.sustained_seconds / max(elapsed * ns / args.steps, 1e-3))))
         barrier()
         sampler = PowerSampler(torch.cuda.current_device()).start()
         t1 = time.perf_counter()
@@ -654,6 +825,12 @@ def main():
             ts = float(t.item())
         sustained = {"value": world * n * ns * reps / ts, "unit": "frames/s", "steps": ns * reps, "seconds": ts}
 
+    shapes = None
+    if rank == 0 and not args.no_latency and not args.no_shapes and (n, N, k) == (400, 512, 20):
+        try:
+            shapes = shape_legs(pca, B, torch, latency_ms)
+        except Exception as e:                  # (never costs the headline line)
+            sys.stderr.write("shape legs failed: %r\n" % (e,))
     numpy_in = None
     if rank == 0 and not args.no_latency and not args.no_numpy_in:
         try:
@@ -668,7 +845,8 @@ def main():
         value = world * n * args.steps / elapsed
         rec = {
             "metric": "ADI cube frames/sec at ncomp=%d, %dx%dx%d" % (k, n, N, N) +
-                      (" (%d independent pca() calls in flight, one distinct cube each)" % depth if depth > 1 else ""),
+                      (" (%d independent pca() calls in flight, one distinct cube each; `value_serial` = n / wall of ONE pca() call, "
+                       "the SURVEY 8(d) definition)" % depth if depth > 1 else ""),
             "value": value, "value_serial": (n / (latency_ms * 1e-3) if latency_ms else None), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "latency_ms_per_call": latency_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -686,6 +864,7 @@ def main():
             "h2d_ms": (numpy_in or {}).get("h2d_ms"),
             "value_numpy_in": (numpy_in or {}).get("value"),
             "numpy_in": numpy_in,
+            "shapes": shapes,
             "strong": None,
         }
         if not args.no_cpu_baseline:

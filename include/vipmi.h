@@ -220,6 +220,23 @@ int vipmi_annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_
  * vipmi_eigh_topk_f64 returns them (leading k).  do_pca_patch, pca_local.py:830-909. */
 int vipmi_annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, const int32_t* lib_idx,
                            const int32_t* lib_len, int64_t m, int64_t k, double* work, double* evals, double* evecs);
+/* The fronts of ALL segments of an annular PCA in a handful of launches (round 6; _pca_adi_rdi's loop over annuli and segments,
+ * pca_local.py:710-787, with do_pca_patch :830-909 for every frame of every segment):
+ * gram_all: A_all[n][Ptot] = the segment matrices side by side -- column p is pixel pix_all[p] of the cube (flat index; -1 = zero
+ *   column), every segment padded to a whole number of K-slices of klen columns (klen a multiple of 64 in 256..4096, Ptot a multiple
+ *   of klen) -- and their Gram matrices G_all[nseg][n][n] (float64) in ONE ragged product on the int8 matrix cores (the exact-integer
+ *   scheme of vipmi_gram_f32, 3e-12 of max|G|); seg_slice: device int32[nseg + 1], the segments' first slices (seg_slice[nseg] =
+ *   Ptot / klen).  cube NULL: A_all already holds the matrix (a caller that scaled it first, matrix_scaling of every segment).
+ * apply_all: after vipmi_annular_eigh_f64 on G_all -- the coefficient matrices of all segments and ONE product
+ *   residuals = (I - C_seg) A_seg written straight into cube_out[n][P] through pix_out[Ptot] (as pix_all, with -1 also for the pixels
+ *   a LATER segment owns: the reference applies the segments in order, pca_local.py:786-787); tile_seg: device int32[Ptot / 128], the
+ *   segment of every 128-column tile (-1: padding only); kseg: device int32[nseg], min(ncomp, pixels) of every segment, <= kmax. */
+int vipmi_annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot,
+                               int64_t klen, const int32_t* seg_slice, int64_t nseg, float* A_all, double* G_all);
+int vipmi_annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg,
+                                const int32_t* pix_out, int64_t nseg, const int32_t* lib_idx, const int32_t* lib_len, int64_t m,
+                                const double* G_all, const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax,
+                                int64_t P, float* cube_out);
 /* float64 cubes (round 5): the per-pixel temporal mean -- what float32 cannot hold beside the signal in a cube of detector counts --
  * is carried in float64 (csrc/pca_f64.hip; the reference keeps the caller's dtype through svd_wrapper / do_pca_patch):
  * center: D[n][P] = float32((M - 1 mu^T) / sd), mu[P] float64, mu32[P] = float32(mu) (optional); mode 0 / 1: centre ('temp-mean'),

@@ -57,6 +57,13 @@ def test_pca_fullframe_random_parameters(seed):
         assert np.abs(a[ok] - b[ok]).max() < tol, (seed, nm, n, N, kw, np.abs(a[ok] - b[ok]).max())
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_pca_annular_random_parameters_fused_front(seed, monkeypatch):
+    """The same random annular calls through the fused front of round 6 (forced: these cubes are below its size threshold)."""
+    monkeypatch.setenv("VIPMI_ANNULAR_FUSED", "1")
+    test_pca_annular_random_parameters(100 + seed)
+
+
 @pytest.mark.parametrize("seed", range(30))
 def test_pca_annular_random_parameters(seed):
     from vip_amd.psfsub import pca_annular

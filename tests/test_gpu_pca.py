@@ -716,6 +716,46 @@ def test_annular_staged_eigensolve_matches_the_per_segment_route(monkeypatch):
             assert np.nanmax(np.abs(x - z)) < TOL
 
 
+@pytest.mark.parametrize("tag,kw", [("a", dict(asize=8, ncomp=3, fwhm=4, delta_rot=(0.1, 1))),
+                                    ("b", dict(asize=8, ncomp=2, fwhm=4, delta_rot=0.5, radius_int=4, max_frames_lib=12)),
+                                    ("c", dict(asize=10, ncomp=(1, 2, 3), fwhm=4, delta_rot=(0.1, 1), n_segments=2))])
+def test_annular_fused_front_golden(tag, kw, monkeypatch):
+    """Round 6: the fronts of all segments in a handful of launches (one gather, one ragged int8 Gram product, one eigensolve, one
+    coefficient launch, one residual product that scatters through the pixel list; csrc/annular.hip annular_gram_all_f32 /
+    annular_apply_all_f32).  Forced on the small goldens of the reference: the one-pixel overlap of the last two annuli (the later
+    segment wins), per-annulus ncomp, radius_int and two segments per annulus included; and against the per-segment route."""
+    from vip_amd.psfsub import pca_annular
+    g = load_golden("g6_pca_annular")
+    monkeypatch.setenv("VIPMI_ANNULAR_FUSED", "1")
+    cube_out, cube_der, frame = pca_annular(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    monkeypatch.setenv("VIPMI_ANNULAR_FUSED", "0")
+    co0, cd0, fr0 = pca_annular(g["cube"], g["angles"], full_output=True, verbose=False, **kw)
+    assert cube_out.shape == g["cube"].shape and cube_out.dtype == np.float32
+    assert np.abs(cube_out - g[tag + "_cube_out"]).max() < TOL
+    assert np.abs(frame - g[tag + "_frame"]).max() < TOL
+    assert np.array_equal(cube_out == 0, co0 == 0)                 # the same pixels written, the rest untouched
+    assert np.abs(cube_out - co0).max() < 5e-6 and np.nanmax(np.abs(frame - fr0)) < 5e-6
+
+
+@pytest.mark.parametrize("scaling", [None, "temp-mean", "temp-standard"])
+def test_annular_fused_front_matches_the_per_segment_route(scaling, monkeypatch):
+    """The fused front at a size where it is the default (130 frames x 96 px would not be: forced), with temporal scalings (applied to
+    the whole gathered matrix at once), a tuple ncomp and several segments per annulus, against the per-segment route and the oracle."""
+    from vip_amd.psfsub import pca_annular
+    cube, _ = O.synth_adi(130, 96, seed=61)
+    ang = np.linspace(0, 150, 130)
+    kw = dict(asize=12, ncomp=(2, 3, 4, 3), fwhm=4, delta_rot=(0.2, 1), n_segments=[1, 2, 3, 2], max_frames_lib=70, scaling=scaling)
+    monkeypatch.setenv("VIPMI_ANNULAR_FUSED", "1")
+    a = pca_annular(cube, ang, full_output=True, verbose=False, **kw)
+    monkeypatch.setenv("VIPMI_ANNULAR_FUSED", "0")
+    b = pca_annular(cube, ang, full_output=True, verbose=False, **kw)
+    ref = O.pca_annular(cube, ang, full_output=True, **kw)
+    for x, y, z in zip(a, b, ref):
+        assert np.array_equal(np.isfinite(x), np.isfinite(y))
+        assert np.nanmax(np.abs(x - y)) < 5e-6, np.nanmax(np.abs(x - y))
+        assert np.nanmax(np.abs(x - z)) < TOL
+
+
 def test_annular_libraries_beyond_512_frames():
     """PCA libraries of more than 512 frames per annulus (max_frames_lib raised far above the reference's default 200)
     leave the batched eigensolver for the matrix-in-L2 one, library after library (zero-padded sub-Gram matrices, no

@@ -43,17 +43,26 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
                                                     const int32_t* __restrict__ len, int max_lib, int m,
                                                     const double* __restrict__ evals,
                                                     const double* __restrict__ evecs, int k, int npx,
-                                                    float* __restrict__ C, float* __restrict__ rho) {
+                                                    float* __restrict__ C, float* __restrict__ rho,
+                                                    const int32_t* __restrict__ kseg = nullptr, int ldt = 0) {
+  // blockIdx.y = segment of a batch (round 6: all annuli in one launch): G[seg][n][n], C[seg][n][ldt or n]; the per-library arrays
+  // (idx, len, evals, evecs, rho) are indexed by seg * n + j; kseg (optional): the segment's number of components.
+  // ldt > 0: the matrix is written TRANSPOSED with row length ldt -- element (row j, frame f) at C[f * ldt + j], the layout the
+  // row-space kernels read (no transposition pass afterwards).
   // rho (optional): rho[j] = 1 - sum_a c_j[a], the row sum of I - C in float64: with A = D + 1 mu^T (a float64 cube whose per-pixel
   // temporal mean is carried apart, pca_f64.hip) the residuals are (I - C) D + rho mu^T
   extern __shared__ double sh[];      // g[m] | proj[k]
   double* g = sh;
   double* proj = sh + m;
   const int j = blockIdx.x;
-  const int lj = len[j];
-  const int32_t* ij = idx + (size_t)j * max_lib;
-  const double* ev = evals + (size_t)j * m;
-  const double* E = evecs + (size_t)j * m * m;
+  const size_t jj = (size_t)blockIdx.y * n + j;
+  G += (size_t)blockIdx.y * n * n;
+  C += (size_t)blockIdx.y * n * (ldt > 0 ? ldt : n);
+  if (kseg) k = kseg[blockIdx.y];
+  const int lj = len[jj];
+  const int32_t* ij = idx + jj * max_lib;
+  const double* ev = evals + jj * m;
+  const double* E = evecs + jj * m * m;
   int kk = k < lj ? k : lj;                    // get_eigenvectors: min(ncomp, min(shape)), svd.py:696
   if (kk > npx) kk = npx;
   for (int a = threadIdx.x; a < m; a += blockDim.x) g[a] = (a < lj) ? G[(size_t)ij[a] * n + j] : 0.0;
@@ -72,11 +81,12 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
   for (int a = threadIdx.x; a < lj; a += blockDim.x) {
     double s = 0;
     for (int c = 0; c < kk; ++c) s += E[(size_t)c * m + a] * proj[c];
-    C[(size_t)j * n + ij[a]] = (float)(-s);
+    if (ldt > 0) C[(size_t)ij[a] * ldt + j] = (float)(-s);
+    else C[(size_t)j * n + ij[a]] = (float)(-s);
     csum += s;
   }
   __syncthreads();                       // (the frame may belong to its own library: add the identity afterwards)
-  if (threadIdx.x == 0) C[(size_t)j * n + j] += 1.0f;
+  if (threadIdx.x == 0) C[ldt > 0 ? (size_t)j * ldt + j : (size_t)j * n + j] += 1.0f;
   if (rho) {                             // (uniform) fixed-order sum of the 256 partial sums
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) csum += __shfl_xor(csum, off, 64);
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
     if (threadIdx.x == 0) {
       double t = 0.0;
       for (int w = 0; w < nw; ++w) t += sh[w];
-      rho[j] = (float)(1.0 - t);
+      rho[jj] = (float)(1.0 - t);
     }
   }
 }
@@ -106,6 +116,9 @@ __global__ __launch_bounds__(1024) void coeff_range_kernel(int n, const int32_t*
                                                            int max_lib, int* __restrict__ frange) {
   __shared__ int slo[16], shi[16];
   const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  idx += (size_t)blockIdx.y * n * max_lib;                 // blockIdx.y = segment of a batch
+  len += (size_t)blockIdx.y * n;
+  frange += (size_t)blockIdx.y * 2 * gridDim.x;
   int lo = n, hi = 0;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -223,6 +236,45 @@ int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, co
     }
   }
   return VIPMI_OK;
+}
+
+// ---- round 6: the fronts of ALL segments in a handful of launches ---------------------------------------------------------------
+// annular_gram_all_f32: ONE gather of every segment's pixels into A_all [n][Ptot] (pix_all: flat pixel indices, the segments side
+// by side, each padded with -1 = zero column to a whole number of K-slices of klen columns) and ONE ragged Gram product on the int8
+// matrix cores (gram_i8_ragged_f32; seg_slice: device array of nseg + 1 slice offsets) -> G_all [nseg][n][n].
+int annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot, int64_t klen,
+                         const int32_t* seg_slice, int64_t nseg, float* A_all, double* G_all) {
+  VIPMI_REQUIRE(seg_slice && A_all && G_all && (!cube || pix_all), "annular_gram_all: null pointer");
+  VIPMI_REQUIRE(n > 0 && P > 0 && Ptot > 0 && nseg > 0, "annular_gram_all: bad sizes");
+  if (cube) VIPMI_TRY(gather_f32(ctx, cube, n, P, pix_all, Ptot, A_all));       // (NULL: A_all already holds the matrix, e.g. scaled)
+  return gram_i8_ragged_f32(ctx, A_all, n, Ptot, klen, seg_slice, nseg, G_all);
+}
+
+// annular_apply_all_f32: the coefficient matrices I - C of all segments (one launch, written transposed), their library windows
+// (one launch) and ONE product over all segments that writes the residuals through the pixel list into cube_out
+// (rowspace_scatter_kernel, project.hip).  lib_idx [nseg * n][m], lib_len [nseg * n], evals [nseg * n][m], evecs [nseg * n][m][m]
+// as vipmi_annular_eigh_f64 leaves them; kseg: device array of the segments' numbers of components (<= kmax).
+int annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg, const int32_t* pix_out,
+                          int64_t nseg, const int32_t* lib_idx, const int32_t* lib_len, int64_t m, const double* G_all,
+                          const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax, int64_t P, float* cube_out) {
+  VIPMI_REQUIRE(A_all && tile_seg && pix_out && lib_idx && lib_len && G_all && evals && evecs && kseg && cube_out,
+                "annular_apply_all: null pointer");
+  VIPMI_REQUIRE(n > 0 && Ptot > 0 && nseg > 0 && nseg <= 65535 && m > 0 && kmax > 0 && P > 0, "annular_apply_all: bad sizes");
+  const int kld = (int)cdiv(n, 32) * 32, groups = (int)cdiv(n, 32);
+  float* Wt = nullptr;
+  int* frange = nullptr;
+  VIPMI_TRY(ws(ctx, "ann_Wt_all", (size_t)nseg * n * kld, &Wt));
+  if (ctx->opt("ann_range", 1) != 0) {
+    VIPMI_TRY(ws(ctx, "ann_frange_all", (size_t)nseg * 2 * groups, &frange));
+    hipLaunchKernelGGL(coeff_range_kernel, dim3(groups, (unsigned)nseg), dim3(1024), 0, ctx->stream, (int)n, lib_idx, lib_len, (int)m, frange);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  VIPMI_CHECK_HIP(hipMemsetAsync(Wt, 0, sizeof(float) * (size_t)nseg * n * kld, ctx->stream));
+  const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
+  hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n, (unsigned)nseg), dim3(256), shm, ctx->stream, G_all, (int)n, lib_idx, lib_len, (int)m,
+                     (int)m, evals, evecs, (int)kmax, (int)(Ptot < 2147483647 ? Ptot : 2147483647), Wt, (float*)nullptr, kseg, kld);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return rowspace_scatter_f32(ctx, Wt, kld, A_all, n, Ptot, tile_seg, pix_out, frange, P, cube_out);
 }
 
 // ncomps: HOST array of nk truncation ranks (the reference's list `ncomp`, pca_local.py:665-668,892-902: one

@@ -218,7 +218,8 @@ extern "C" {
 // 105 (round 5): + vipmi_annular_eigh_f64, vipmi_pca_fullframe_f64, vipmi_center_f64, vipmi_gram_offset_f64, vipmi_annular_apply_mu_f32;
 //                 recovery of cooperating solves
 // 106 (round 5): + vipmi_pca_fullframe_hostin_f32 (the Gram under the upload); float-domain median selection
-// 107 (round 6): option sub_guard (the subtraction's zero guard is opt-out per call: median_sub), see the round-6 entries of vipmi.h
+// 107 (round 6): option sub_guard (the subtraction's zero guard is opt-out per call: median_sub); + vipmi_annular_gram_all_f32,
+//                 vipmi_annular_apply_all_f32 (the fronts of all annulus segments in a handful of launches)
 int vipmi_version(void) { return 107; }
 
 const char* vipmi_last_error(void) { return g_err; }
@@ -600,6 +601,21 @@ int vipmi_annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_
                            const int32_t* lib_len, int64_t m, int64_t k, double* work, double* evals, double* evecs) {
   CTX_GUARD();
   return annular_eigh_f64(ctx, G, nseg, n, lib_idx, lib_len, m, k, work, evals, evecs);
+}
+
+int vipmi_annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot,
+                               int64_t klen, const int32_t* seg_slice, int64_t nseg, float* A_all, double* G_all) {
+  CTX_GUARD();
+  return annular_gram_all_f32(ctx, cube, n, P, pix_all, Ptot, klen, seg_slice, nseg, A_all, G_all);
+}
+
+int vipmi_annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg,
+                                const int32_t* pix_out, int64_t nseg, const int32_t* lib_idx, const int32_t* lib_len, int64_t m,
+                                const double* G_all, const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax,
+                                int64_t P, float* cube_out) {
+  CTX_GUARD();
+  return annular_apply_all_f32(ctx, A_all, n, Ptot, tile_seg, pix_out, nseg, lib_idx, lib_len, m, G_all, evals, evecs, kseg, kmax, P,
+                               cube_out);
 }
 
 int vipmi_annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,

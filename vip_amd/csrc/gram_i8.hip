@@ -492,6 +492,93 @@ int gram_i8_inc_end(vipmi_ctx* ctx, const GramI8Inc& st, double* G) {
   return VIPMI_OK;
 }
 
+// ---- ragged batch: the Gram matrices of the SEGMENTS of one matrix (annular PCA: every annulus segment a column range) --------
+// M[n][Ptot] holds the segment matrices side by side, every segment a whole number of K-slices of klen columns (zero padded);
+// G_all[s] = M[:, seg s] M[:, seg s]^T.  ONE split launch and ONE product launch over all slices -- the partial tiles of a slice
+// do not care whose segment the slice belongs to -- and a reduction that sums every segment's own slice range
+// (seg_slice[s] .. seg_slice[s + 1], device array).  Eight annuli of C3: 8 float64-MFMA Gram launches + 8 reductions
+// (1.43 ms) become three launches.
+__global__ void gram_i8_reduce_ragged_kernel(const double* __restrict__ partial, const int2* __restrict__ wgtiles, int nwg,
+                                             const int32_t* __restrict__ seg_slice, int n, double* __restrict__ G) {
+  const int64_t total = (int64_t)nwg * 4096;
+  const int s0 = seg_slice[blockIdx.y], s1 = seg_slice[blockIdx.y + 1];
+  G += (int64_t)blockIdx.y * n * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int wg = (int)(e >> 12), wave = (int)(e >> 10) & 3, rem = (int)(e & 1023);
+    const int blk = rem >> 8, idx = rem & 255;
+    const int bi = blk >> 1, bj = blk & 1, wi = wave >> 1, wj = wave & 1;
+    const int2 t = wgtiles[wg];
+    if (t.x == t.y && (wi > wj || (wi == wj && bj < bi))) continue;          // never written: lower part of a diagonal tile
+    const int gi = t.x * 64 + wi * 32 + bi * 16 + (idx >> 4), gj = t.y * 64 + wj * 32 + bj * 16 + (idx & 15);
+    if (gi >= n || gj >= n) continue;
+    double s = 0.0;                         // (the slices in their order: deterministic)
+    int sl = s0;
+    for (; sl + 8 <= s1; sl += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(sl + u) * total + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < s1; ++sl) s += partial[(int64_t)sl * total + e];
+    G[(int64_t)gi * n + gj] = s;
+    G[(int64_t)gj * n + gi] = s;
+  }
+}
+
+int gram_i8_ragged_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t Ptot, int64_t klen, const int32_t* seg_slice,
+                       int64_t nseg, double* G_all) {
+  constexpr int S = 5, KEEP = 1;
+  VIPMI_REQUIRE(M && seg_slice && G_all && n > 0 && nseg > 0, "gram_i8_ragged: bad arguments");
+  VIPMI_REQUIRE(klen >= 256 && klen <= 4096 && (klen & 63) == 0 && Ptot > 0 && Ptot % klen == 0, "gram_i8_ragged: bad slice length");
+  VIPMI_REQUIRE((reinterpret_cast<uintptr_t>(M) & 15) == 0 && nseg <= 65535, "gram_i8_ragged: unaligned input / too many segments");
+  StageScope scope(ctx, "gram");
+  const int npad = (int)cdiv(n, 64) * 64, nt = npad / 64;
+  std::vector<int2> tiles;
+  if (nt <= 8) {
+    for (int i = 0; i < nt; ++i)
+      for (int j = i + 1; j < nt; ++j) tiles.push_back(int2{i, j});
+    for (int i = 0; i < nt; ++i) tiles.push_back(int2{i, i});
+  } else {
+    for (int I = 0; I < nt; I += 8)
+      for (int J = I; J < nt; J += 8)
+        for (int i = I; i < std::min(I + 8, nt); ++i)
+          for (int j = std::max(J, i); j < std::min(J + 8, nt); ++j) tiles.push_back(int2{i, j});
+  }
+  const int nwg = (int)tiles.size();
+  const int nslices = (int)(Ptot / klen);
+  const int64_t plane = (int64_t)npad * Ptot;
+  int8_t* D = nullptr;
+  double *sc = nullptr, *partial = nullptr;
+  VIPMI_TRY(ws(ctx, "gram_i8_digits", (size_t)S * plane, &D));
+  VIPMI_TRY(ws(ctx, "gram_i8_scale", (size_t)npad * nslices, &sc));
+  VIPMI_TRY(ws(ctx, "gram_i8_partial", (size_t)nslices * nwg * 4096, &partial));
+  int2* d_tiles = nullptr;
+  {
+    char key[64];
+    snprintf(key, sizeof key, "i8/%d", nt);                 // (the tile list of run(): same key, same table)
+    void* p = nullptr;
+    VIPMI_TRY(ctx->upload_cached("gram_i8_tiles", key, tiles.data(), sizeof(int2) * nwg, &p));
+    d_tiles = reinterpret_cast<int2*>(p);
+  }
+  hipLaunchKernelGGL((gram_split_kernel<S, 1>), dim3((unsigned)nslices, (unsigned)npad, 1u), dim3(256), 0, ctx->stream, M, (int)n, Ptot, Ptot,
+                     (int)klen, nslices, Ptot, plane, D, sc, (int64_t)0, npad, 0);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  const size_t lds = (size_t)2 * 2 * S * 64 * 64;
+  const bool dma = ctx->opt("gram_i8_dma", 1) != 0;
+  auto kern = dma ? gram_i8_kernel<S, KEEP, true> : gram_i8_kernel<S, KEEP, false>;
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * nwg), (unsigned)cdiv(nslices, 8), 1u), dim3(256), lds, ctx->stream, D, sc, npad, (int)klen,
+                     nslices, Ptot, plane, d_tiles, nwg, partial, 2, 0);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  int rb = (int)cdiv((int64_t)nwg * 4096, 256);
+  if (rb > 128) rb = 128;
+  hipLaunchKernelGGL(gram_i8_reduce_ragged_kernel, dim3((unsigned)rb, (unsigned)nseg), dim3(256), 0, ctx->stream, partial, d_tiles, nwg,
+                     seg_slice, (int)n, G_all);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
 // where gram_f32 takes the int8 path by itself (the rule of gram.hip: measured to pay from 256 rows and 2^25 elements)
 bool gram_i8_default_path(vipmi_ctx* ctx, int64_t n, int64_t P) {
   return ctx->opt("gram_i8", -1) < 0 && ctx->opt("gram_f32", 0) == 0 && n >= 256 && P >= 32768 && n * P >= ((int64_t)1 << 25);

@@ -126,6 +126,104 @@ __global__ __launch_bounds__(256, 2) void rowspace_kernel(const float* __restric
     }
 }
 
+// The (I - C) A product of annular PCA for ALL segments in one launch (round 6): M holds the segment matrices side by side
+// ([n][Ptot], every segment a whole number of 128-pixel tiles), tile -> segment through `tile_seg`, the n x n coefficient matrix of
+// the tile's segment at Wt_all + seg * n * kld (transposed layout, as rowspace_kernel reads it), its library windows at
+// frange_all + seg * 2 * groups.  The result is not written as a matrix: row i of a tile goes straight to frame i of the output cube
+// THROUGH the pixel list (pix_out[p] = flat pixel index of column p, -1 = padding or a pixel a later segment owns) -- the scatter
+// pass, the residual matrix and seven of eight launches disappear.  Four consecutive list entries are four consecutive pixels of an
+// image row almost everywhere: one 16-byte store when the address allows, 8 + 8 or 4 + 8 + 4 otherwise, single pixels at the ends
+// of a run.  Same accumulation order per element as rowspace_kernel<true, 2>: bit-identical residuals.
+__global__ __launch_bounds__(256, 2) void rowspace_scatter_kernel(const float* __restrict__ Wt_all, int kld, const float* __restrict__ M,
+                                                                int n, int64_t Ptot, const int32_t* __restrict__ tile_seg,
+                                                                const int32_t* __restrict__ pix_out, const int* __restrict__ frange_all,
+                                                                int64_t P, float* __restrict__ out) {
+  constexpr int NG = 2;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t px0 = tile * 128;
+  if (px0 >= Ptot) return;
+  const int seg = __builtin_amdgcn_readfirstlane(tile_seg[tile]);
+  if (seg < 0) return;                                  // (a tile of padding only)
+  const int groups = (n + 31) / 32;
+  const float* Wt = Wt_all + (int64_t)seg * n * kld;
+  const int* frange = frange_all ? frange_all + (int64_t)seg * 2 * groups : nullptr;
+  const int grp0 = blockIdx.y * NG;
+  const int jl = lane & 31, kh = lane >> 5;
+  const int64_t px = px0 + 4 * jl;
+  f32x16 acc[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][c][r] = 0.f;
+  const float* wrow = Wt + grp0 * 32 + jl;
+  constexpr int U = 4;
+  int flo = 0, fhi = n;
+  if (frange) {
+    flo = n;
+    fhi = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if ((grp0 + g) * 32 < n) {
+        const int lo = frange[2 * (grp0 + g)], hi = frange[2 * (grp0 + g) + 1];
+        flo = lo < flo ? lo : flo;
+        fhi = hi > fhi ? hi : fhi;
+      }
+    fhi = fhi < n ? fhi : n;
+  }
+  for (int f0 = flo; f0 < fhi; f0 += 2 * U) {
+    f32x4 b[U];
+    float a[NG][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + 2 * u + kh;
+      b[u] = ldrow4<true>(M, f, n, Ptot, px);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) a[g][u] = (f < n && (grp0 + g) * 32 < kld) ? wrow[(int64_t)f * kld + 32 * g] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[g][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u], b[u][c], acc[g][c], 0, 0, 0);
+  }
+  const int4 q = *reinterpret_cast<const int4*>(pix_out + px);
+  const bool run4 = q.x >= 0 && q.y == q.x + 1 && q.z == q.x + 2 && q.w == q.x + 3;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (grp0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (i < n) {
+        float* row = out + (int64_t)i * P;
+        const float v0 = acc[g][0][r], v1 = acc[g][1][r], v2 = acc[g][2][r], v3 = acc[g][3][r];
+        if (run4) {
+          float* d = row + q.x;
+          const int al = (int)((reinterpret_cast<uintptr_t>(d) >> 2) & 3);
+          if (al == 0) {
+            *reinterpret_cast<f32x4*>(d) = f32x4{v0, v1, v2, v3};
+          } else if (al == 2) {
+            *reinterpret_cast<float2*>(d) = float2{v0, v1};
+            *reinterpret_cast<float2*>(d + 2) = float2{v2, v3};
+          } else {
+            d[0] = v0;
+            *reinterpret_cast<float2*>(d + 1) = float2{v1, v2};
+            d[3] = v3;
+          }
+        } else {
+          if (q.x >= 0) row[q.x] = v0;
+          if (q.y >= 0) row[q.y] = v1;
+          if (q.z >= 0) row[q.z] = v2;
+          if (q.w >= 0) row[q.w] = v3;
+        }
+      }
+    }
+}
+
 // A residual that cancels to EXACTLY 0 although its sample is not 0.  The reference's rotation masks by VALUE: pixels equal to
 // `mask_val` are reset after the rotation (preproc/derotation.py:133-140,324-326), and pca(mask_center_px=...) runs it with
 // mask_val = 0 (psfsub/pca_fullfr.py:412-415) -- in its float64 arithmetic only the masked disc is ever exactly 0.  float32
@@ -357,6 +455,19 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
     if (recon) LAUNCH(false, true); else LAUNCH(false, false);
   }
 #undef LAUNCH
+  VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+int rowspace_scatter_f32(vipmi_ctx* ctx, const float* Wt_all, int kld, const float* M, int64_t n, int64_t Ptot,
+                         const int32_t* tile_seg, const int32_t* pix_out, const int* frange_all, int64_t P, float* out) {
+  VIPMI_REQUIRE(Wt_all && M && tile_seg && pix_out && out, "rowspace_scatter: null pointer");
+  VIPMI_REQUIRE(n > 0 && Ptot > 0 && Ptot % 128 == 0 && aligned16(M) && aligned16(pix_out), "rowspace_scatter: bad sizes / alignment");
+  StageScope sc(ctx, "project");
+  const int groups = (int)cdiv(n, 32);
+  dim3 grid((unsigned)cdiv(Ptot / 128, 4), (unsigned)cdiv(groups, 2));
+  hipLaunchKernelGGL(rowspace_scatter_kernel, grid, dim3(256), 0, ctx->stream, Wt_all, kld, M, (int)n, Ptot, tile_seg, pix_out, frange_all, P,
+                     out);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }

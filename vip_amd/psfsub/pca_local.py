@@ -153,6 +153,39 @@ def cached_annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, 
     return hit
 
 
+def _fused_front_plan(plan, n):
+    """Host tables of the fused front (csrc/annular.hip annular_gram_all_f32 / annular_apply_all_f32): the pixel lists of all
+    segments side by side, every segment padded to a whole number of K-slices of ``klen`` columns; ``pix_out`` is ``pix_all`` with
+    -1 for the pixels that a LATER segment also holds (the reference applies the segments in order: the later one wins,
+    pca_local.py:786-787); ``tile_seg``: the segment of every 128-column tile; ``seg_slice``: first slice of every segment."""
+    sizes = [int(sg["pix"].size) for sg in plan]
+    total = sum(sizes)
+    klen = 512
+    for cand in (2048, 1024, 512):                # the longest slice whose padding costs at most 8 % more columns
+        if sum(-(-sz // cand) * cand for sz in sizes) <= 1.08 * total:
+            klen = cand
+            break
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + -(-sz // klen) * klen)
+    Ptot = offs[-1]
+    pix_all = np.full(Ptot, -1, dtype=np.int32)
+    tile_seg = np.full(Ptot // 128, -1, dtype=np.int32)
+    for si, sg in enumerate(plan):
+        pix_all[offs[si]:offs[si] + sizes[si]] = sg["pix"]
+        tile_seg[offs[si] // 128:(offs[si] + sizes[si] + 127) // 128] = si
+    pix_out = pix_all.copy()
+    live = np.nonzero(pix_all >= 0)[0]
+    # last occurrence of every pixel wins: np.unique on the reversed list returns the first index there = the last one here
+    rev = pix_all[live][::-1]
+    _u, first_rev = np.unique(rev, return_index=True)
+    keep = np.zeros(live.size, dtype=bool)
+    keep[live.size - 1 - first_rev] = True
+    pix_out[live[~keep]] = -1
+    seg_slice = (np.asarray(offs, dtype=np.int64) // klen).astype(np.int32)
+    return dict(klen=klen, Ptot=Ptot, pix_all=pix_all, pix_out=pix_out, tile_seg=tile_seg, seg_slice=seg_slice, offs=offs)
+
+
 def _pack_libs(libs):
     n = len(libs)
     max_lib = max(len(li) for li in libs)
@@ -350,6 +383,56 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     # and the later one must win (pca_local.py:786-787): they share a stream, which keeps their order.
     n_ann = plan[-1]["ann"] + 1 if plan else 0
     pipelined = n_ann >= 3 and not B.is_async() and not f64_route
+    # Fused fronts (round 6): ONE gather of all segments, ONE ragged Gram product on the int8 matrix cores, ONE batched eigensolve,
+    # ONE coefficient launch and ONE residual product that writes through the pixel list into cube_out -- for the plain ADI call
+    # (no reference cube, no cube_sig, one ncomp per annulus, temporal or no scaling) from the size at which the int8 Gram pays
+    # (VIPMI_ANNULAR_FUSED=1 forces it: the parity tests run it on the small goldens, =0 disables it)
+    fused_env = os.environ.get("VIPMI_ANNULAR_FUSED", "")
+    if plan and not f64_route and nref == 0 and cube_sig is None and ks is None and pad_ok and fused_env != "0":
+        npx_tot = sum(int(sg["pix"].size) for sg in plan)
+        m_all = max(max(len(li) for li in sg["libs"]) for sg in plan)
+        k_all = min(m_all, max(int(sg["ncomp"]) for sg in plan))
+        big = n >= 128 and n * npx_tot >= (1 << 25)
+        if (big or fused_env == "1") and m_all <= 512 and k_all <= 64 and n * len(plan) * m_all * m_all * 16 <= 8e9 and P < 2 ** 31:
+            fp_ = plan_dev.get(("fused", dev))
+            if fp_ is None:
+                h = _fused_front_plan(plan, n)
+                total = n * len(plan)
+                idx_h = np.zeros((total, m_all), dtype=np.int32)
+                len_h = np.zeros(total, dtype=np.int32)
+                for si, sg in enumerate(plan):
+                    ih, lh, ml = _pack_libs(sg["libs"])
+                    idx_h[si * n:(si + 1) * n, :ml] = ih
+                    len_h[si * n:(si + 1) * n] = lh
+                kseg_h = np.asarray([min(int(sg["ncomp"]), int(sg["pix"].size)) for sg in plan], dtype=np.int32)
+                up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cube.device)
+                fp_ = plan_dev[("fused", dev)] = dict(klen=h["klen"], Ptot=h["Ptot"], pix_all=up(h["pix_all"]), pix_out=up(h["pix_out"]),
+                                                      tile_seg=up(h["tile_seg"]), seg_slice=up(h["seg_slice"]), idx=up(idx_h),
+                                                      len=up(len_h), kseg=up(kseg_h), m_all=m_all, k_all=k_all)
+            ctx = B.get_context(dev)
+            nseg, Ptot = len(plan), fp_["Ptot"]
+            A_all = B.empty((n, Ptot), device=dev)
+            G_all = torch.empty((nseg, n, n), dtype=torch.float64, device=cube.device)
+            if scaling is None:
+                ctx.call("vipmi_annular_gram_all_f32", B.ptr(cube), n, P, B.ptr(fp_["pix_all"]), Ptot, fp_["klen"],
+                         B.ptr(fp_["seg_slice"]), nseg, B.ptr(A_all), B.ptr(G_all))
+            else:
+                # temporal scalings are per pixel column: the whole gathered matrix at once, then the same ragged Gram
+                ctx.call("vipmi_gather_f32", B.ptr(cube), n, P, B.ptr(fp_["pix_all"]), Ptot, B.ptr(A_all))
+                A_all = B.scale(A_all, scaling)
+                ctx.call("vipmi_annular_gram_all_f32", None, n, P, None, Ptot, fp_["klen"], B.ptr(fp_["seg_slice"]), nseg,
+                         B.ptr(A_all), B.ptr(G_all))          # (cube NULL: A_all already holds the matrix)
+            m_all, k_all = fp_["m_all"], fp_["k_all"]
+            H_all = torch.empty((nseg * n, m_all, m_all), dtype=torch.float64, device=cube.device)
+            ev_all = torch.empty((nseg * n, m_all), dtype=torch.float64, device=cube.device)
+            ec_all = torch.empty((nseg * n, m_all, m_all), dtype=torch.float64, device=cube.device)
+            ctx.call("vipmi_annular_eigh_f64", B.ptr(G_all), nseg, n, B.ptr(fp_["idx"]), B.ptr(fp_["len"]), m_all, k_all,
+                     B.ptr(H_all), B.ptr(ev_all), B.ptr(ec_all))
+            ctx.call("vipmi_annular_apply_all_f32", B.ptr(A_all), n, Ptot, B.ptr(fp_["tile_seg"]), B.ptr(fp_["pix_out"]), nseg,
+                     B.ptr(fp_["idx"]), B.ptr(fp_["len"]), m_all, B.ptr(G_all), B.ptr(ev_all), B.ptr(ec_all), B.ptr(fp_["kseg"]),
+                     k_all, P, B.ptr(cube_out))
+            plan = []                                 # (nothing left for the per-segment routes below)
+            pipelined = False
     if f64_route:
         for si, seg in enumerate(plan):
             do_segment_f64(si, seg)
