@@ -788,13 +788,16 @@ def test_annular_libraries_beyond_512_frames():
     assert 0.2 < np.abs(big[ok]).std() / np.abs(small[ok]).std() < 5.0
 
 
-def test_more_than_6144_frames(monkeypatch):
-    """beyond the exact leading-k solvers (n > backend.MAX_EIGH_N = 6144) the front keeps the device Gram / projection
-    kernels; the decomposition comes from the verified fast path (csrc/eigh_chfsi.hip, up to 16384 frames).  No library call
-    anywhere: when the fast path gives up, or the whole spectrum is asked for, the call raises NotImplementedError."""
+def test_more_than_6144_frames():
+    """Beyond 6144 frames the three n-vectors of the exact leading-k solver no longer fit the LDS.  The leading pairs still come
+    from the verified fast path when the spectrum allows (csrc/eigh_chfsi.hip); since round 6 everything else -- a fast path that
+    gives up, the whole spectrum of the eigen family's full output, CEVR / a float ncomp -- is served by the same exact solver with
+    its vectors in global memory (eigh_tri_large.hip, tri_xl_kernel<32, true>; slow, behind a RuntimeWarning) instead of raising.
+    No library call anywhere."""
+    import warnings
     from vip_amd import backend as B
     from vip_amd.psfsub import pca
-    n, N, k = B.MAX_EIGH_N + 56, 16, 6
+    n, N, k = B.MAX_EIGH_LDS_N + 56, 16, 6
     cube, _ = O.synth_adi(n, N, seed=3)
     ang = np.linspace(0, 170, n)
     ref = O.pca_fullframe(cube, ang, ncomp=k)
@@ -802,26 +805,66 @@ def test_more_than_6144_frames(monkeypatch):
     assert np.abs(got - ref).max() < TOL
     ctx = B.get_context()
     assert ctx.get_option("eigh_fast_last_reason") == 0 and ctx.get_option("eigh_fast_last_locked") == k
-    import torch
     from vip_amd.psfsub.svd import svd_wrapper
-    # svd_wrapper beyond 6144 frames: every call that returns at most ncomp singular values takes the leading-pairs route --
-    # V alone and the (U, S, V) of the non-eigen modes, which truncate S to ncomp (svd.py:454-459,473)
     mat = cube.reshape(n, -1)
     U, S, V = svd_wrapper(mat, "lapack", 4, verbose=False, full_output=True)
     Ur, Sr, Vr = O.svd_wrapper(mat, "lapack", 4, full_output=True)
     assert U.shape == (n, 4) and S.shape == (4,) and V.shape == (4, N * N)
     np.testing.assert_allclose(S, Sr, rtol=2e-5)
     assert np.abs(sign_align(V, Vr) - Vr).max() < TOL
-    with pytest.raises(NotImplementedError):                              # the eigen family returns the WHOLE spectrum
-        svd_wrapper(mat, "eigen", 4, verbose=False, full_output=True)
-    called = []
-    monkeypatch.setattr(torch.linalg, "eigh", lambda *a, **kw: called.append(1))
-    monkeypatch.setattr(B, "eigh_topk_fast", lambda G, k_: None)          # the fast path gives up
-    with pytest.raises(NotImplementedError):
-        pca(cube, ang, ncomp=k, verbose=False)
-    with pytest.raises(NotImplementedError):
-        svd_wrapper(mat, "lapack", 4, verbose=False, full_output=True)
-    assert not called
+    # the eigen family returns the WHOLE spectrum (svd.py:454-462): the exact solver, vectors in global memory, with a warning
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        Ue, Se, Ve = svd_wrapper(mat, "eigen", 4, verbose=False, full_output=True)
+    assert any("vectors in global memory" in str(w_.message) for w_ in rec)
+    Uo, So, Vo = O.svd_wrapper(mat, "eigen", 4, full_output=True)
+    assert Se.shape == So.shape
+    np.testing.assert_allclose(Se[:N * N - 1], So[:N * N - 1], rtol=5e-5, atol=1e-3 * So[0])
+    assert np.abs(sign_align(Ve, Vo) - Vo).max() < TOL
+    # the fast path switched off (as if it had given up): same frame from the exact path
+    for c in B.all_contexts():
+        c.set_option("eigh_fast", 0)
+    try:
+        got2 = pca(cube, ang, ncomp=k, verbose=False)
+        U2, S2, V2 = svd_wrapper(mat, "lapack", 4, verbose=False, full_output=True)
+    finally:
+        for c in B.all_contexts():
+            c.set_option("eigh_fast", 1)
+    assert np.abs(got2 - ref).max() < TOL
+    np.testing.assert_allclose(S2, Sr, rtol=2e-5)
+    assert np.abs(sign_align(V2, Vr) - Vr).max() < TOL
+
+
+def test_8192_frames_whole_spectrum_and_cevr():
+    """Round-5 VERDICT #7: svd_wrapper(M, 'lapack', k, full_output=True), the eigen family's whole spectrum and a float ncomp (CEVR,
+    svd.py:216-339) on an 8192-frame cube of 64 x 64 px against numpy."""
+    import warnings
+    from vip_amd.psfsub import pca
+    from vip_amd.psfsub.svd import svd_wrapper
+    n, N, k = 8192, 64, 5
+    rng = np.random.default_rng(8192)
+    base, _ = O.synth_adi(256, N, seed=81)
+    cube = (base[rng.integers(0, 256, n)] + 0.3 * rng.standard_normal((n, N, N))).astype(np.float32)
+    ang = np.linspace(0, 120, n)
+    mat = cube.reshape(n, -1)
+    _, w, Vt = np.linalg.svd(mat.astype(np.float64), full_matrices=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        U, S, V = svd_wrapper(mat, "lapack", k, verbose=False, full_output=True)
+        np.testing.assert_allclose(S, w[:k], rtol=2e-5)
+        assert U.shape == (n, k) and V.shape == (k, N * N)
+        assert np.abs(V @ V.T - np.eye(k)).max() < 1e-4
+        # the leading row space against numpy's
+        assert np.linalg.norm(V @ Vt[k:].T, 2) < 1e-3
+        Ue, Se, Ve = svd_wrapper(mat, "eigen", k, verbose=False, full_output=True)
+        m = min(n, N * N)
+        np.testing.assert_allclose(Se[:m - 1], w[:m - 1], rtol=1e-4, atol=1e-4 * w[0])
+        # float ncomp: the number of components from the cumulative explained variance ratio
+        fr = pca(cube, ang, ncomp=0.5, verbose=False)
+    exp_var = w ** 2 / (w.shape[0] - 1)
+    kc = int(np.searchsorted(np.cumsum(exp_var / exp_var.sum()), 0.5) + 1)
+    ref = O.pca_fullframe(cube, ang, ncomp=kc)
+    assert fr.shape == (N, N) and np.nanmax(np.abs(fr - ref)) < TOL, (kc, np.nanmax(np.abs(fr - ref)))
 
 
 def test_more_than_2048_frames():

@@ -358,21 +358,33 @@ def eigh_topk(G, k, nact=None, all_evals=False):
     evals = torch.zeros((batch, n), dtype=torch.float64, device=G.device)
     evecs = torch.zeros((batch, n, n), dtype=torch.float64, device=G.device)
     if all_evals:
+        if n > MAX_EIGH_LDS_N:
+            _warn_slow_eigh(n, "the whole spectrum was requested")
         ctx.call("vipmi_eigh_spectrum_f64", ptr(Gb), batch, n, int(k), ptr(evals), ptr(evecs))
         ev, ec = evals, evecs[:, :k, :]
     else:
         ctx.call("vipmi_eigh_topk_f64", ptr(Gb), batch, n, int(k), ptr(nact), ptr(evals), ptr(evecs))
+        if n > MAX_EIGH_LDS_N and int(ctx.get_option("eigh_fast_last_reason")) != 0:
+            _warn_slow_eigh(n, "the verified subspace iteration gave up (reason %d)" % int(ctx.get_option("eigh_fast_last_reason")))
         ev, ec = evals[:, :k], evecs[:, :k, :]
     return (ev[0], ec[0]) if single else (ev, ec)
 
 
+def _warn_slow_eigh(n, why):
+    import warnings
+    warnings.warn("vip_amd: %d frames (more than %d): %s -- solved by the exact tridiagonal path with its vectors in global memory "
+                  "(slow: seconds, not milliseconds)" % (n, MAX_EIGH_LDS_N, why), RuntimeWarning, stacklevel=3)
+
+
 def topk_native(n, k):
     """True when the leading-k tridiagonal solvers serve (n, k): up to 512 frames and 64 vectors in LDS
-    (eigh_tri.hip), 128..6144 frames and any number of vectors with the matrix in L2 (eigh_tri_large.hip)."""
+    (eigh_tri.hip), 128..16384 frames and any number of vectors with the matrix in L2 / HBM (eigh_tri_large.hip)."""
     return 0 < k <= n and ((n <= 512 and k <= 64) or 128 <= n <= MAX_EIGH_N)
 
 
-MAX_EIGH_N = 6144        # the leading-k solver keeps three vectors of n doubles in LDS: matrices up to 6144 x 6144
+MAX_EIGH_LDS_N = 6144    # the leading-k solver keeps three vectors of n doubles in LDS: matrices up to 6144 x 6144 that way
+MAX_EIGH_N = 16384       # beyond (round 6): the same solver with those vectors in global memory -- slow, exact, any request
+                         # (leading pairs when the verified fast path gives up, the whole spectrum, CEVR); 2.1 GB matrix at 16384
 
 
 def eigh_topk_fast(G, k):
@@ -391,18 +403,20 @@ def eigh_topk_fast(G, k):
 
 
 def eigh_beyond_lds(G, k=None):
-    """Leading pairs of a Gram matrix of more than MAX_EIGH_N frames: the exact hand-written solvers hold 3 n doubles of vectors
-    in LDS and stop at n = 6144; beyond, the verified Chebyshev subspace iteration (csrc/eigh_chfsi.hip, up to 16384 frames)
-    serves the leading ``k`` pairs and returns (evals (k,), evecs (k, n)).  There is NO library fallback (round 3 called
-    rocSOLVER here): a request for the whole spectrum (``k`` None: CEVR / full svd_wrapper output), or a fast path that does not
-    converge within its budget, raises NotImplementedError -- such cubes are outside every configuration of the benchmark and
-    the caller can subsample frames or ask for fewer components."""
+    """Leading pairs of a Gram matrix of more than MAX_EIGH_N = 16384 frames (up to there the exact hand-written solvers serve every
+    request, eigh_tri_large.hip): only the verified Chebyshev subspace iteration (csrc/eigh_chfsi.hip) is tried, for the leading
+    ``k`` pairs; returns (evals (k,), evecs (k, n)).  There is NO library fallback: a request for the whole spectrum (``k`` None),
+    a size outside the fast path's range or a fast path that does not converge raises NotImplementedError."""
     torch = _torch()
     n = int(G.shape[0])
     if k is None:
         raise NotImplementedError("the whole spectrum of a cube / library of %d frames (more than %d) is not available on the "
                                   "device eigensolvers; ask for the leading components only" % (n, MAX_EIGH_N))
-    fast = eigh_topk_fast(G.to(torch.float64), k)
+    fast = None
+    try:
+        fast = eigh_topk_fast(G.to(torch.float64), k)
+    except ValueError:
+        pass                                       # (sizes outside the fast path's range)
     if fast is None:
         ctx = get_context(G.device.index)
         raise NotImplementedError("the leading %d eigenpairs of a %d-frame Gram matrix (more than %d frames) did not converge in the "

@@ -430,14 +430,17 @@ __global__ __launch_bounds__(LNT) void tri_large_kernel(double* __restrict__ A, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// More than 2048 rows (up to 512 * XPT = 6144): the same algorithm with THREE vectors of n doubles in LDS instead of
+// More than 2048 rows (up to 512 * 12 = 6144 with the vectors in LDS, 16384 with them in global memory): the same algorithm with THREE vectors of n doubles in LDS instead of
 // nine.  Tridiagonalisation: the gathered vectors p and c (column s+1) stay in registers (element c = s+1 + tid + 512 j
 // belongs to thread tid: 12 per thread at most), the reductions over them are workgroup sums, and the next reflector is
 // written into the buffer of v_{s-1}, which is dead once the row pass of the step is over.  Later phases: d, e and the
 // vector under construction in LDS; the Sturm counts square e as they fetch it; the factors of the inverse iteration
 // live in global memory (written once, read back in blocks of 16 rows); the back-transformation holds the vector in
 // registers and reads the reflectors from the (L2 / Infinity-Cache resident) matrix, the next one prefetched.
-constexpr int XPT = 12;
+// XPT: elements of a gathered vector per thread (n <= 512 XPT).  GV (round 6, more than 6144 rows): the three n-vectors of the
+// workgroup live in GLOBAL memory (gvec: 3 n doubles per workgroup, L2-resident) instead of LDS -- the slow, correct path for any
+// matrix that fits the device: every vector element of the row pass is one more load, the reductions are unchanged.
+constexpr int XL_XPT_MAX = 32;          // 512 threads x 32 elements: matrices of up to 16384 rows (2.1 GB)
 constexpr int XBS = 16;                 // rows per block of the substitutions
 constexpr int XCG = 16;                 // chunks of 64 columns per group of the row pass
 
@@ -452,17 +455,19 @@ __device__ __forceinline__ double xl_block_sum(double x, double* __restrict__ re
   return t;
 }
 
+template <int XPT, bool GV>
 __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int n, int k, double* __restrict__ evals,
                                                      double* __restrict__ evecs, double* __restrict__ gb,
                                                      double* __restrict__ scr_all, unsigned* __restrict__ bar,
-                                                     int all_evals, int* __restrict__ fail) {
+                                                     int all_evals, int* __restrict__ fail, double* __restrict__ gvec) {
   extern __shared__ double sm[];
   const int W = gridDim.x, wg = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* vb0 = sm;                // v_s / v_{s-1}, rotating
+  double* const vec3 = GV ? gvec + (size_t)wg * 3 * n : sm;      // the workgroup's three n-vectors
+  double* vb0 = vec3;              // v_s / v_{s-1}, rotating
   double* vb1 = vb0 + n;
   double* wprev = vb1 + n;
-  double* red = wprev + n;         // [6][LNW] reduction slots, then [8] broadcast values
+  double* red = GV ? sm : wprev + n;         // [6][LNW] reduction slots, then [8] broadcast values (always LDS)
   double* bc = red + 6 * LNW;
   double* Pb = gb;                 // [2][n]
   double* Cb = gb + 2 * n;         // [2][n]
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
   grid_barrier(bar, bar_target, W, fail);
 
   // ---------------- 2. T into LDS (scaled) ----------------
-  double* dd = sm;                 // [n]
+  double* dd = vec3;               // [n]
   double* ee = dd + n;             // [n]
   double* Zl = ee + n;             // [n] right-hand side / solution of the inverse iteration
   double* lamv = bc;               // [8]
@@ -839,8 +844,8 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
   if (wg != 0) return;
 
   // ---------------- 5. workgroup 0: modified Gram-Schmidt in place (vectors in global / L2), sign convention ---------
-  double* qv = sm;                               // [n] pivot vector
-  double* red5 = sm + n;
+  double* qv = vec3;                             // [n] pivot vector
+  double* red5 = GV ? sm : sm + n;
   for (int cp = 0; cp < kk; ++cp) {
     double sq = 0.0;
     for (int i = tid; i < na; i += LNT) {
@@ -906,18 +911,21 @@ __global__ __launch_bounds__(LNT) void tri_xl_kernel(double* __restrict__ A, int
 int launch_xl(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double* evecs, int all_evals) {
   int W = 128;
   if (W > ctx->num_cu) W = 64;
-  double *gbuf = nullptr, *scr = nullptr;
+  double *gbuf = nullptr, *scr = nullptr, *gvec = nullptr;
   unsigned* bars = nullptr;
+  const bool gv = n > 512 * 12;                        // beyond 6144 rows the three n-vectors no longer fit the LDS
   VIPMI_TRY(ws(ctx, "eigh_large_gbuf", (size_t)8 * n, &gbuf));
   VIPMI_TRY(ws(ctx, "eigh_xl_factors", (size_t)W * 5 * n, &scr));
   VIPMI_TRY(ws(ctx, "eigh_large_bar", (size_t)1, &bars));
+  if (gv) VIPMI_TRY(ws(ctx, "eigh_xl_vectors", (size_t)W * 3 * n, &gvec));
   VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned), ctx->stream));
   int* fail = nullptr;                                  // barrier time-outs are latched here (vipmi_check_deferred)
   VIPMI_TRY(deferred_fail_words(ctx, &fail));
-  const size_t lds = ((size_t)3 * n + 6 * LNW + 8 + 16) * sizeof(double);
+  const size_t lds = ((size_t)(gv ? 0 : 3 * n) + 6 * LNW + 8 + 16) * sizeof(double);
   VIPMI_REQUIRE(lds <= 160 * 1024, "eigh_topk(xl): LDS budget exceeded (%zu)", lds);
-  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(tri_xl_kernel), (int)lds));
-  hipLaunchKernelGGL(tri_xl_kernel, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, scr, bars, all_evals, fail);
+  auto kern = gv ? tri_xl_kernel<XL_XPT_MAX, true> : tri_xl_kernel<12, false>;
+  VIPMI_CHECK_HIP(set_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+  hipLaunchKernelGGL(kern, dim3(W), dim3(LNT), lds, ctx->stream, A, n, k, evals, evecs, gbuf, scr, bars, all_evals, fail, gvec);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }
@@ -947,7 +955,7 @@ int launch_large(vipmi_ctx* ctx, double* A, int n, int k, double* evals, double*
 }  // namespace
 
 // (n below 512 is served when more than 64 vectors are wanted: the LDS-resident solvers of eigh_tri.hip stop there)
-bool eigh_large_supported(int64_t n, int64_t k) { return n >= 128 && n <= 512 * XPT && k >= 1 && k <= n; }
+bool eigh_large_supported(int64_t n, int64_t k) { return n >= 128 && n <= 512 * XL_XPT_MAX && k >= 1 && k <= n; }
 
 // one problem (batch entries are solved one after the other)
 int eigh_large_f64(vipmi_ctx* ctx, double* A, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,

@@ -15,10 +15,11 @@ SVD_MODES = ("lapack", "arpack", "eigen", "randsvd", "cupy", "eigencupy", "randc
              "eigenpytorch", "randpytorch")
 
 
-def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
+def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False, full_n=False):
     """mat_t: (n, P) float32 cuda tensor.  Returns (sigma[min(n,P)] f64, E[k, n] f64 rows = left
     vectors, V[k,P]).  ``leading_only``: only the first ``ncomp`` singular values are needed (lets the
-    library use the top-k eigensolver); sigma then has ``ncomp`` entries."""
+    library use the top-k eigensolver); sigma then has ``ncomp`` entries.  ``full_n``: all n values sqrt(|eigenvalue|), what the
+    reference's eigen modes return also when n > P (svd.py:449-456)."""
     torch = B._torch()
     n, P = mat_t.shape
     G = B.gram(mat_t)
@@ -32,7 +33,7 @@ def _decompose(mat_t, ncomp, want_pcs=True, leading_only=False):
         evals, evecs = B.eigh_beyond_lds(G)                        # more than 6144 frames: raises (no library fallback)
     else:
         evals, evecs = B.eigh(G)
-    sig_all = torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
+    sig_all = torch.sqrt(torch.abs(evals)) if full_n else torch.sqrt(torch.clamp(evals[:min(n, P)], min=0))
     sig = sig_all[:ncomp]
     E = evecs[:ncomp]
     V = None
@@ -68,12 +69,13 @@ def svd_wrapper(matrix, mode, ncomp, verbose, full_output=False, random_state=No
         raise NotImplementedError("left_eigv with the 'eigen' modes is outside the accelerated path")
     dev_in = B.is_device_tensor(matrix)
     t = B.to_device_f32(matrix)
-    # Beyond MAX_EIGH_N frames only the leading pairs can be computed (backend.eigh_beyond_lds).  That serves every call that
-    # returns at most ncomp singular values: V alone, and (U, S, V) of the non-eigen modes, which truncate S to ncomp
-    # (svd.py:454-459,473); the eigen family's full_output wants the whole spectrum and raises there.
+    # Beyond 6144 frames the whole spectrum costs seconds (the exact solver with its vectors in global memory; nothing at all serves
+    # it beyond MAX_EIGH_N = 16384): every call that returns at most ncomp singular values -- V alone, and (U, S, V) of the non-eigen
+    # modes, which truncate S to ncomp (svd.py:454-459,473) -- asks for the leading pairs only; the eigen family's full_output
+    # wants all n values.
     eigen_family = mode in ("eigen", "eigencupy", "eigenpytorch")
-    leading = t.shape[0] > B.MAX_EIGH_N and not (full_output and eigen_family)
-    sig, E, V = _decompose(t, int(ncomp), leading_only=leading)
+    leading = t.shape[0] > B.MAX_EIGH_LDS_N and not (full_output and eigen_family)
+    sig, E, V = _decompose(t, int(ncomp), leading_only=leading, full_n=bool(full_output and eigen_family))
     if verbose:
         print("Done SVD/PCA on MI355X (Gram on the int8 / float64 matrix cores + Householder-tridiagonal leading-k eigensolver), "
               "requested mode '{}'".format(mode))
