@@ -216,6 +216,17 @@ def numpy_in_legs(n, N, k, angles, seed0, pca, B, torch):
     outs = pca_many(many, [angles] * len(many), ncomp=k, check_memory=False)
     many_ms = (time.perf_counter() - t0) / len(many) * 1e3
     assert len(outs) == len(many) and isinstance(outs[0], np.ndarray)
+    # full_output=True (the reference's most common diagnostic call, pca_fullfr.py:759-793): frame, pcs and three cube-sized arrays
+    # back to numpy -- into pinned blocks the arrays own (backend.to_host_many), reused once the caller drops the previous results
+    fo = pca(hosts[0], angles, ncomp=k, verbose=False, check_memory=False, full_output=True)
+    fo_first_bytes = sum(a.nbytes for a in fo)
+    del fo
+    t0 = time.perf_counter()
+    for i in range(4):
+        fo = pca(hosts[i % len(hosts)], angles, ncomp=k, verbose=False, check_memory=False, full_output=True)
+        assert isinstance(fo[3], np.ndarray) and fo[3].shape == hosts[0].shape
+        del fo
+    fo_ms = (time.perf_counter() - t0) / 4 * 1e3
     # a float64 cube (twice the bytes over PCIe; the float64 route: temporal mean carried in float64, csrc/pca_f64.hip)
     c64 = hosts[0].astype(np.float64)
     pca(c64, angles, ncomp=k, verbose=False, check_memory=False)
@@ -228,6 +239,10 @@ def numpy_in_legs(n, N, k, angles, seed0, pca, B, torch):
     gb = hosts[0].nbytes / 1e9
     return {"h2d_ms": h2d_ms, "h2d_gbs": gb / (h2d_ms * 1e-3), "host_memory": "pageable (a caller's numpy array)",
             "float64_latency_ms_per_call": f64_ms,
+            "full_output_latency_ms_per_call": fo_ms, "full_output_bytes_to_host": fo_first_bytes,
+            "full_output_note": "pca(numpy cube, full_output=True) -> five numpy arrays (1.26 GB at C2): the PCIe floor is upload + "
+                                "download of four cubes; results land in pinned blocks that the arrays own (round 5: t.cpu() into "
+                                "fresh pageable pages, 25-44 ms per array)",
             "latency_ms_per_call": lat_ms, "value": n / (lat_ms * 1e-3), "unit": "frames/s",
             "pipelined": {"value": n / (many_ms * 1e-3), "ms_per_cube": many_ms, "cubes": len(many),
                           "note": "pca_many: the (synchronous, pageable) upload of cube i+1 runs beside the kernels of cube i; "

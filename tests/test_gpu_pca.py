@@ -788,6 +788,38 @@ def test_annular_libraries_beyond_512_frames():
     assert 0.2 < np.abs(big[ok]).std() / np.abs(small[ok]).std() < 5.0
 
 
+def test_full_output_for_numpy_callers_lands_in_owned_pinned_blocks():
+    """Round 6: cube-sized results (full_output) are copied straight into pinned host memory and handed over as numpy arrays that own
+    their block (backend.to_host_many): bit-identical to the device tensors, untouched by later calls while the caller holds them,
+    float64 in -> float64 out converted on the device."""
+    import gc
+    import torch
+    from vip_amd import backend as B
+    from vip_amd.psfsub import pca, pca_annular
+    cube, ang = O.synth_adi(40, 256, seed=5)                    # 10.5 MB per cube-sized array: above the pinned threshold
+    dev = pca(torch.from_numpy(cube).cuda(), ang, ncomp=4, full_output=True, verbose=False)
+    out1 = pca(cube, ang, ncomp=4, full_output=True, verbose=False)
+    keep = [a.copy() for a in out1]
+    for a, d in zip(out1, dev):
+        assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.writeable
+        assert np.array_equal(a, d.cpu().numpy(), equal_nan=True)
+    held = B._pin_out["bytes"]
+    assert held >= 3 * cube.nbytes
+    out2 = pca(cube * 0.5, ang, ncomp=4, full_output=True, verbose=False)          # a second call must not touch the first results
+    for a, k_ in zip(out1, keep):
+        assert np.array_equal(a, k_, equal_nan=True)
+    assert not np.array_equal(out2[3], out1[3])
+    del out1, out2, a
+    gc.collect()
+    assert B._pin_out["bytes"] < held                          # blocks handed back when the arrays die
+    c64 = cube.astype(np.float64)
+    o64 = pca(c64, ang, ncomp=4, full_output=True, verbose=False)
+    assert all(a.dtype == np.float64 for a in o64) and np.nanmax(np.abs(o64[0] - keep[0])) < 1e-4
+    co, cd, fr = pca_annular(cube, ang, ncomp=2, asize=32, fwhm=4, full_output=True, verbose=False)
+    cod, cdd, frd = pca_annular(torch.from_numpy(cube).cuda(), ang, ncomp=2, asize=32, fwhm=4, full_output=True, verbose=False)
+    assert np.array_equal(co, cod.cpu().numpy()) and np.array_equal(cd, cdd.cpu().numpy(), equal_nan=True)
+
+
 def test_more_than_6144_frames():
     """Beyond 6144 frames the three n-vectors of the exact leading-k solver no longer fit the LDS.  The leading pairs still come
     from the verified fast path when the spectrum allows (csrc/eigh_chfsi.hip); since round 6 everything else -- a fast path that

@@ -258,6 +258,83 @@ def to_device_f32(x, device=None):
     return t.contiguous()
 
 
+# ---- results back to numpy --------------------------------------------------------------------------------------------------
+# A cube-sized result (full_output: recon, residuals, derotated residuals -- 419 MB each at C2) copied with t.cpu() lands in freshly
+# mapped pageable memory: the runtime stages it through a pinned bounce buffer and the host copy faults every page in, 25-44 ms per
+# array (10-17 GB/s) on a 6 ms computation.  Big results therefore go straight into PINNED host memory from torch's caching host
+# allocator and are handed to the caller as numpy arrays that own their block: one DMA at link speed (~56 GB/s), and once the caller
+# drops an array its block goes back to the allocator's pool and serves the next call already pinned and mapped (the usual loop --
+# `out = pca(..., full_output=True)` per iteration -- reuses the same few blocks).  A caller that keeps every result keeps the blocks
+# too: beyond VIPMI_PINNED_OUT_MB (default 16384) of blocks handed out and still alive, results fall back to pageable memory.
+_PIN_MIN_BYTES = 8 << 20
+_pin_out = {"bytes": 0}
+_pin_lock = threading.Lock()
+
+
+class _PinnedBlock:
+    """Owner of one pinned host block: numpy arrays made from it keep it (and the torch tensor whose storage the block is) alive."""
+
+    def __init__(self, h):
+        self.h = h
+        self.__array_interface__ = h.numpy().__array_interface__
+
+
+def _np_to_torch_dtype(dt):
+    torch = _torch()
+    return {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(np.dtype(dt))
+
+
+def to_host_many(tensors, dtypes=None):
+    """cuda tensors -> numpy arrays (see above); ``dtypes``: one numpy dtype (or None = the tensor's) per tensor, the conversion
+    float32 <-> float64 done on the device before the copy.  All copies are enqueued before the one synchronisation."""
+    import weakref
+    torch = _torch()
+    dtypes = list(dtypes) if dtypes is not None else [None] * len(tensors)
+    cap = int(os.environ.get("VIPMI_PINNED_OUT_MB", "16384")) << 20
+    outs, pend = [], []
+    for t, dt in zip(tensors, dtypes):
+        want = _np_to_torch_dtype(dt) if dt is not None else None
+        if want is not None and t.dtype != want and t.dtype.is_floating_point:
+            t = t.to(want)                         # (on the device: numpy's astype of a cube costs more than its copy)
+        nbytes = t.numel() * t.element_size()
+        h = None
+        if nbytes >= _PIN_MIN_BYTES and cap > 0:
+            with _pin_lock:
+                ok = _pin_out["bytes"] + nbytes <= cap
+                if ok:
+                    _pin_out["bytes"] += nbytes
+            if ok:
+                try:
+                    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                except RuntimeError:
+                    h = None
+                if h is None:
+                    with _pin_lock:
+                        _pin_out["bytes"] -= nbytes
+        if h is None:
+            a = t.cpu().numpy()
+        else:
+            h.copy_(t.contiguous(), non_blocking=True)
+            pend.append(h)
+            blk = _PinnedBlock(h)
+            a = np.asarray(blk)                    # (a.base is blk, and so is the base of every view the caller takes of a)
+
+            def _release(nb=nbytes):
+                with _pin_lock:
+                    _pin_out["bytes"] -= nb
+            weakref.finalize(blk, _release)        # (blk -- and with it the pinned tensor -- lives as long as those arrays)
+        if dt is not None and a.dtype != np.dtype(dt):
+            a = a.astype(dt, copy=False)
+        outs.append(a)
+    if pend:
+        torch.cuda.current_stream().synchronize()
+    return outs
+
+
+def to_host(t, dtype=None):
+    return to_host_many([t], [dtype])[0]
+
+
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 

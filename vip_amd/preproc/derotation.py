@@ -52,7 +52,7 @@ def cube_derotate(array, angle_list, imlib="vip-fft", interpolation="lanczos4", 
         out = B.derotate(t, angle_list, mask_nan=mv_nan, mask_zero=not mv_nan, method=method, mask_val=mask_val)
     if dev_in:
         return out
-    return out.cpu().numpy().astype(array.dtype if array.dtype.kind == "f" else np.float64, copy=False)
+    return B.to_host(out, array.dtype if array.dtype.kind == "f" else np.float64)
 
 
 def _derotate_numpy_pipelined(array, angle_list, mv_nan, method, mask_val):

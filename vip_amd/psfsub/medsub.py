@@ -202,7 +202,7 @@ def median_sub(*all_args: List, **all_kwargs: dict):
         print("Done derotating and combining")
 
     def host(v):
-        return v if dev_in else v.cpu().numpy().astype(out_dtype, copy=False)
+        return v if dev_in else B.to_host(v, out_dtype)
 
     if algo_params.full_output:
         return host(cube_out), host(cube_der), host(frame)

@@ -699,12 +699,14 @@ def pca(*all_args: List, **all_kwargs: dict):
     def host(t, dtype=None):
         if dev_in:
             return t
-        return t.cpu().numpy().astype(dtype or out_dtype, copy=False)
+        return B.to_host(t, dtype or out_dtype)
 
     out64 = _float64_fused(algo_params, rot_options, cube)
     if out64 is None:
         out64 = _hostin_fused(algo_params, rot_options, cube)
     if out64 is not None:
+        if algo_params.full_output and not dev_in:
+            return tuple(B.to_host_many(list(out64), [out_dtype] * len(out64)))       # (all copies enqueued, one synchronisation)
         return tuple(host(t) for t in out64) if algo_params.full_output else host(out64)
     out64 = _float64_fused_4d(algo_params, rot_options, cube)
     if out64 is None:
@@ -929,6 +931,8 @@ def pca(*all_args: List, **all_kwargs: dict):
         return host(out)
     if fo:
         pcs, recon, residuals_cube, residuals_cube_, frame = out
+        if not dev_in:
+            return tuple(B.to_host_many([frame, pcs, recon, residuals_cube, residuals_cube_], [out_dtype] * 5))
         return host(frame), host(pcs), host(recon), host(residuals_cube), host(residuals_cube_)
     return host(out)
 
@@ -1024,5 +1028,5 @@ def pca_many(cubes, angle_lists, depth=2, **kwargs):
             res.append(o)
         else:
             c = cubes[i]
-            res.append(o.cpu().numpy().astype(c.dtype if c.dtype.kind == "f" else np.float64, copy=False))
+            res.append(B.to_host(o, c.dtype if c.dtype.kind == "f" else np.float64))
     return res

@@ -558,10 +558,10 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
     out_dtype = None if dev_in else (cube.dtype if cube.dtype.kind == "f" else np.float64)
 
     def host(t):
-        return t if dev_in else t.cpu().numpy().astype(out_dtype, copy=False)
+        return t if dev_in else B.to_host(t, out_dtype)
 
     def host4(t):          # the reference builds the per-channel frames in a float64 array (pca_local.py:281)
-        return t if dev_in else t.cpu().numpy().astype(np.float64, copy=False)
+        return t if dev_in else B.to_host(t, np.float64)
 
     cube_t = B.to_device_f32(cube)
     if cube.ndim == 4:

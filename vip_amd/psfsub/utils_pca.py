@@ -176,7 +176,7 @@ def pca_grid(cube, angle_list, fwhm=None, range_pcs=None, source_xy=None, cube_r
         cubeout = torch.stack(frames)
 
     def host(t):
-        return t if dev_in else t.cpu().numpy().astype(out_dtype, copy=False)
+        return t if dev_in else B.to_host(t, out_dtype)
 
     if x is not None and y is not None and fwhm is not None:
         frames_h = cubeout.cpu().numpy().astype(np.float64)
@@ -226,7 +226,7 @@ def pca_annulus(cube, angs, ncomp, annulus_width, r_guess, cube_ref=None, svd_mo
     angles = None if angs is None else check_pa_vector(np.asarray(angs, dtype=np.float64))
 
     def host(t, dt=None):
-        return t if dev_in else t.cpu().numpy().astype(dt or out_dtype, copy=False)
+        return t if dev_in else B.to_host(t, dt or out_dtype)
 
     def one(cube_t, ref_t, k):
         n, ysz, xsz = cube_t.shape
