@@ -264,8 +264,9 @@ def shape_legs(pca, B, torch, c2_latency_ms):
     from vip_amd.synth import synth_adi
     ctx = B.get_context()
 
-    def lat(fn, reps):
-        fn()
+    def lat(fn, reps, warm=1):
+        for _ in range(warm):            # (the first few dozen frame-sized pageable D2H copies of a process run 3x slower:
+            fn()                         #  tools/small_shape_probe.py measured 1.35 ms per call, then 0.45)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -288,8 +289,8 @@ def shape_legs(pca, B, torch, c2_latency_ms):
     n, N, k = 61, 101, 5
     cube, ang = synth_adi(n, N, seed=11)
     ct = torch.from_numpy(cube).cuda()
-    ms_res = lat(lambda: pca(ct, ang, ncomp=k, verbose=False, check_memory=False).cpu(), 50)
-    ms_np = lat(lambda: pca(cube, ang, ncomp=k, verbose=False, check_memory=False), 50)
+    ms_res = lat(lambda: pca(ct, ang, ncomp=k, verbose=False, check_memory=False).cpu(), 100, warm=60)
+    ms_np = lat(lambda: pca(cube, ang, ncomp=k, verbose=False, check_memory=False), 100, warm=20)
     many = [ct] * 64
     pca_many(many[:4], [ang] * 4, ncomp=k, check_memory=False)
     t0 = time.perf_counter()
