@@ -28,12 +28,24 @@ find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # per-configuration kernel stats (round 4's single CSV mixed the plans of four configurations): one rocprofv3 --kernel-trace --stats
 # run per BASELINE config through the public API
 cd /tmp
-for cfg in c2 c3 c4; do
+for cfg in c2 c3 c4 odd; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -o k -- python $REPO/tools/time_configs.py $cfg > $OUT/stats_$cfg.log 2>&1
   find $OUT/stats_$cfg -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$cfg.csv \;
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o k -- python $REPO/tools/run_c5.py > $OUT/stats_c5.log 2>&1
 find $OUT/stats_c5 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_c5.csv \;
+# (round 6) HBM traffic of the other configurations' kernels -- the `traffic` of the strong legs' roofline objects in bench.py:
+# FETCH_SIZE and WRITE_SIZE in separate passes of one configuration each -> pmc_hbm_<cfg>.json
+for cfg in c3 c4; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${cfg}_$ctr -o p -- python $REPO/tools/time_configs.py $cfg > $OUT/pmc_${cfg}_$ctr.log 2>&1 || echo "pass $cfg $ctr failed rc=$?" >> $OUT/failed_passes.txt
+  done
+  (cd $REPO && python tools/pmc_summary.py $OUT/pmc_hbm_$cfg.json $OUT/pmc_${cfg}_FETCH_SIZE $OUT/pmc_${cfg}_WRITE_SIZE "python tools/time_configs.py $cfg" > $OUT/pmc_summary_$cfg.log 2>&1)
+done
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_c5_$ctr -o p -- python $REPO/tools/run_c5.py > $OUT/pmc_c5_$ctr.log 2>&1 || echo "pass c5 $ctr failed rc=$?" >> $OUT/failed_passes.txt
+done
+(cd $REPO && python tools/pmc_summary.py $OUT/pmc_hbm_c5.json $OUT/pmc_c5_FETCH_SIZE $OUT/pmc_c5_WRITE_SIZE "python tools/run_c5.py" > $OUT/pmc_summary_c5.log 2>&1)
 cd $REPO
 # socket power / shader clock under each chip-filling stage (sysfs hwmon)
 for w in rot512 rot256 rot1024 gram; do timeout 60 python tools/power_probe.py $w 2>&1 | grep -v amdgpu.ids >> $OUT/power.txt; done

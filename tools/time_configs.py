@@ -30,3 +30,7 @@ if "c4" in which:
     ct = torch.from_numpy(cubes).cuda()
     t = timeit(lambda: pca(ct, ang, ncomp=20, verbose=False, check_memory=False).cpu(), 2)
     print("C4 39x200x256x256 k=20: %.3f ms  %.0f frames/s" % (t * 1e3, 39 * 200 / t))
+if "odd" in which:        # C2 with the reference's odd frame size: Le = 2044 is not a power of two (csrc/derotate_conv.inc)
+    cube, ang = synth_adi(400, 511, 0); ct = torch.from_numpy(cube).cuda()
+    t = timeit(lambda: pca(ct, ang, ncomp=20, verbose=False, check_memory=False).cpu(), 5)
+    print("400x511x511 k=20: %.3f ms  %.0f frames/s" % (t * 1e3, 400 / t))
