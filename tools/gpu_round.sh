@@ -7,4 +7,4 @@ timeout 900 python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_benc
 timeout 900 python tools/time_configs.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_configs.txt
 timeout 300 python tools/time_topk.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/${R}_configs.txt
 timeout 300 python tools/prof_stage.py pca 400 512 3 2>&1 | grep -v amdgpu.ids | tail -1 >> gpurun_out/${R}_configs.txt
-timeout 1500 bash tools/profile_round.sh $R > gpurun_out/${R}_profile_round.log 2>&1
+timeout 2700 bash tools/profile_round.sh $R > gpurun_out/${R}_profile_round.log 2>&1
