@@ -73,6 +73,13 @@ __global__ __launch_bounds__(256) void gram_split_kernel(const float* __restrict
         const float4 f = *reinterpret_cast<const float4*>(src + e + 4 * u4);
         av[ps][4 * u4] = f.x; av[ps][4 * u4 + 1] = f.y; av[ps][4 * u4 + 2] = f.z; av[ps][4 * u4 + 3] = f.w;
       }
+    } else if (e + 16 <= valid) {        // rows of an odd length start at every alignment: 16-byte loads at 4-byte alignment
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        const f4u f = *reinterpret_cast<const f4u*>(src + e + 4 * u4);
+        av[ps][4 * u4] = f[0]; av[ps][4 * u4 + 1] = f[1]; av[ps][4 * u4 + 2] = f[2]; av[ps][4 * u4 + 3] = f[3];
+      }
     } else {
 #pragma unroll
       for (int u = 0; u < 16; ++u) av[ps][u] = (e + u < valid) ? src[e + u] : 0.f;

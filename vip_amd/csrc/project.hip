@@ -17,6 +17,10 @@
 namespace vipmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// the same four floats at 4-byte alignment: ONE global_load / global_store_dwordx4 that the hardware splits where it crosses a
+// line (unaligned access mode of the HSA target) -- rows of an odd-sized frame (P = 511 x 511: the reference's own convention) start
+// at every alignment, and four scalar accesses per lane cost the projection kernels 1.3-1.5x (r06_kernel_stats_odd.csv)
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -29,6 +33,8 @@ __device__ __forceinline__ f32x4 ldrow4(const float* __restrict__ base, int64_t 
   const float* p = base + row * P + px;
   if (VEC && px + 4 <= P) {
     v = *reinterpret_cast<const f32x4*>(p);
+  } else if (px + 4 <= P) {
+    v = *reinterpret_cast<const f32x4_u*>(p);
   } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -44,6 +50,8 @@ __device__ __forceinline__ void strow4(float* __restrict__ base, int64_t row, in
   float* p = base + row * P + px;
   if (VEC && px + 4 <= P) {
     *reinterpret_cast<f32x4*>(p) = v;
+  } else if (px + 4 <= P) {
+    *reinterpret_cast<f32x4_u*>(p) = v;
   } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
