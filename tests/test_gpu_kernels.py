@@ -1285,6 +1285,89 @@ def test_annular_eigh_gathers_the_libraries_itself(B, nseg, n, m, k):
         np.testing.assert_allclose(ev[p, :k].cpu().numpy(), w[:k], atol=1e-12 * w[0])
 
 
+@pytest.mark.parametrize("n,sizes,klen", [(70, (300, 1000, 37), 256), (200, (5000, 2049, 4096), 2048), (129, (513, 511), 512)])
+def test_annular_fronts_of_all_segments_through_the_c_entries(B, n, sizes, klen):
+    """vipmi_annular_gram_all_f32 / vipmi_annular_apply_all_f32 (round 6) called directly: ragged segments side by side (each padded
+    to whole K-slices), their Gram matrices from ONE int8 product against float64 numpy, and the residual product written through the
+    pixel list -- -1 entries (padding, pixels a later segment owns) untouched, the rest equal to (I - C) A of the per-segment entry."""
+    import torch
+    rng = np.random.default_rng(n + sum(sizes))
+    side = int(np.ceil(np.sqrt(sum(sizes) * 1.3)))
+    P = side * side
+    cube = (rng.standard_normal((n, P)) * rng.uniform(0.2, 3.0, (1, P))).astype(np.float32)
+    cube[:, ::17] *= 1e-3                                       # faint pixels beside bright ones
+    perm = rng.permutation(P)
+    segs, o = [], 0
+    for sz in sizes:
+        segs.append(np.sort(perm[o:o + sz]).astype(np.int32))
+        o += sz - 5                                             # the next segment shares 5 pixels: the later one wins
+    nseg = len(segs)
+    offs = [0]
+    for sg in segs:
+        offs.append(offs[-1] + -(-sg.size // klen) * klen)
+    Ptot = offs[-1]
+    pix_all = np.full(Ptot, -1, dtype=np.int32)
+    tile_seg = np.full(Ptot // 128, -1, dtype=np.int32)
+    for si, sg in enumerate(segs):
+        pix_all[offs[si]:offs[si] + sg.size] = sg
+        tile_seg[offs[si] // 128:(offs[si] + sg.size + 127) // 128] = si
+    pix_out = pix_all.copy()
+    seen = set()
+    for si in range(nseg - 1, -1, -1):                          # later segments first: they keep their pixels
+        for j in range(offs[si], offs[si] + segs[si].size):
+            if int(pix_all[j]) in seen:
+                pix_out[j] = -1
+            seen.add(int(pix_all[j]))
+    seg_slice = (np.asarray(offs) // klen).astype(np.int32)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ct = up(cube)
+    A_all = torch.empty((n, Ptot), dtype=torch.float32, device="cuda")
+    G_all = torch.empty((nseg, n, n), dtype=torch.float64, device="cuda")
+    ctx = B.get_context()
+    pa_t, po_t, ts_t, ss_t = up(pix_all), up(pix_out), up(tile_seg), up(seg_slice)      # (named: they must outlive the enqueued launches)
+    ctx.call("vipmi_annular_gram_all_f32", B.ptr(ct), n, P, B.ptr(pa_t), Ptot, klen, B.ptr(ss_t), nseg, B.ptr(A_all), B.ptr(G_all))
+    Ah = A_all.cpu().numpy()
+    for si, sg in enumerate(segs):
+        Aseg = cube[:, sg]
+        assert np.array_equal(Ah[:, offs[si]:offs[si] + sg.size], Aseg) and not Ah[:, offs[si] + sg.size:offs[si + 1]].any()
+        Gref = Aseg.astype(np.float64) @ Aseg.astype(np.float64).T
+        assert np.abs(G_all[si].cpu().numpy() - Gref).max() < 2e-11 * np.abs(Gref).max(), si
+    # libraries: every frame's library = the frames at least 3 away, at most m of them; k components
+    m, k = min(n - 8, 60), 4
+    idx = np.zeros((nseg * n, m), dtype=np.int32)
+    ln = np.zeros(nseg * n, dtype=np.int32)
+    for p_ in range(nseg * n):
+        j = p_ % n
+        lib = np.array([f for f in range(n) if abs(f - j) >= 3][:m], dtype=np.int32)
+        idx[p_, :lib.size] = lib
+        ln[p_] = lib.size
+    it, lt = up(idx), up(ln)
+    work = torch.empty((nseg * n, m, m), dtype=torch.float64, device="cuda")
+    ev = torch.zeros((nseg * n, m), dtype=torch.float64, device="cuda")
+    ec = torch.zeros((nseg * n, m, m), dtype=torch.float64, device="cuda")
+    ctx.call("vipmi_annular_eigh_f64", B.ptr(G_all), nseg, n, B.ptr(it), B.ptr(lt), m, k, B.ptr(work), B.ptr(ev), B.ptr(ec))
+    out = torch.full((n, P), 7.0, dtype=torch.float32, device="cuda")
+    kseg = up(np.full(nseg, k, dtype=np.int32))
+    ctx.call("vipmi_annular_apply_all_f32", B.ptr(A_all), n, Ptot, B.ptr(ts_t), B.ptr(po_t), nseg, B.ptr(it), B.ptr(lt), m,
+             B.ptr(G_all), B.ptr(ev), B.ptr(ec), B.ptr(kseg), k, P, B.ptr(out))
+    oh = out.cpu().numpy()
+    written = np.zeros(P, dtype=bool)
+    kk = np.array([k], dtype=np.int32)
+    for si, sg in enumerate(segs):
+        # the per-segment entry on the same matrix, Gram matrix, eigenpairs: the same product, element by element
+        Aseg = A_all[:, offs[si]:offs[si] + ((sg.size + 3) // 4) * 4].contiguous()
+        R = torch.empty((1, n, Aseg.shape[1]), dtype=torch.float32, device="cuda")
+        sl = slice(si * n, (si + 1) * n)
+        its, lts, evs, ecs = it[sl].contiguous(), lt[sl].contiguous(), ev[sl].contiguous(), ec[sl].contiguous()
+        ctx.call("vipmi_annular_apply_f32", B.ptr(Aseg), n, Aseg.shape[1], B.ptr(its), B.ptr(lts), m, m, B.ptr(G_all[si]), B.ptr(evs),
+                 B.ptr(ecs), kk.ctypes.data_as(__import__("ctypes").c_void_p), 1, B.ptr(R))
+        Rh = R[0].cpu().numpy()[:, :sg.size]
+        own = pix_out[offs[si]:offs[si] + sg.size] >= 0
+        assert np.array_equal(oh[:, sg[own]], Rh[:, own]), si
+        written[sg[own]] = True
+    assert written.sum() == len(seen) and np.all(oh[:, ~written] == 7.0)
+
+
 @pytest.mark.parametrize("n,k", [(200, 10), (120, 16), (96, 32), (150, 8)])
 def test_eigh_batched_all_leading_values_from_one_wave(B, n, k):
     """Second launch of a big batch (>= 4 problems per CU, k >= 8): the k leading eigenvalues of every tridiagonal matrix come
