@@ -230,13 +230,22 @@ int vipmi_annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_
  * apply_all: after vipmi_annular_eigh_f64 on G_all -- the coefficient matrices of all segments and ONE product
  *   residuals = (I - C_seg) A_seg written straight into cube_out[n][P] through pix_out[Ptot] (as pix_all, with -1 also for the pixels
  *   a LATER segment owns: the reference applies the segments in order, pca_local.py:786-787); tile_seg: device int32[Ptot / 128], the
- *   segment of every 128-column tile (-1: padding only); kseg: device int32[nseg], min(ncomp, pixels) of every segment, <= kmax. */
+ *   segment of every 128-column tile (-1: padding only); kseg: device int32[nseg], min(ncomp, pixels) of every segment, <= kmax;
+ *   mu32: NULL, or float32[Ptot] for the float64 front below (the rank-one term rho mu^T is added on the way out). */
 int vipmi_annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot,
                                int64_t klen, const int32_t* seg_slice, int64_t nseg, float* A_all, double* G_all);
 int vipmi_annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg,
                                 const int32_t* pix_out, int64_t nseg, const int32_t* lib_idx, const int32_t* lib_len, int64_t m,
                                 const double* G_all, const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax,
-                                int64_t P, float* cube_out);
+                                int64_t P, float* cube_out, const float* mu32);
+/* gram_all for a FLOAT64 cube (the reference's do_pca_patch keeps the caller's dtype, pca_local.py:830-909): the gather and the
+ * centring of vipmi_center_f64 in one pass -- D_all[n][Ptot] = float32((cube[:, pix_all] - 1 mu^T) / sd), mode 0 / 1: centre, 2:
+ * 'temp-standard'; mu[Ptot] float64, mu32[Ptot] = float32(mu) --, the ragged Gram product of D_all, and for mode 0 (no scaling) the
+ * float64 offset terms of vipmi_gram_offset_f64 for every segment: G_all[seg] is the Gram matrix of D + 1 mu^T.  apply_all then
+ * takes A_all = D_all and, for mode 0, mu32 (NULL otherwise): residuals = (I - C) D + rho mu^T, rho = (I - C) 1 in float64. */
+int vipmi_annular_gram_all_f64(vipmi_ctx* ctx, const double* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot,
+                               int64_t klen, const int32_t* seg_slice, int64_t nseg, int mode, float* D_all, double* mu, float* mu32,
+                               double* G_all);
 /* float64 cubes (round 5): the per-pixel temporal mean -- what float32 cannot hold beside the signal in a cube of detector counts --
  * is carried in float64 (csrc/pca_f64.hip; the reference keeps the caller's dtype through svd_wrapper / do_pca_patch):
  * center: D[n][P] = float32((M - 1 mu^T) / sd), mu[P] float64, mu32[P] = float32(mu) (optional); mode 0 / 1: centre ('temp-mean'),

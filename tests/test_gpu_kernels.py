@@ -1349,7 +1349,7 @@ def test_annular_fronts_of_all_segments_through_the_c_entries(B, n, sizes, klen)
     out = torch.full((n, P), 7.0, dtype=torch.float32, device="cuda")
     kseg = up(np.full(nseg, k, dtype=np.int32))
     ctx.call("vipmi_annular_apply_all_f32", B.ptr(A_all), n, Ptot, B.ptr(ts_t), B.ptr(po_t), nseg, B.ptr(it), B.ptr(lt), m,
-             B.ptr(G_all), B.ptr(ev), B.ptr(ec), B.ptr(kseg), k, P, B.ptr(out))
+             B.ptr(G_all), B.ptr(ev), B.ptr(ec), B.ptr(kseg), k, P, B.ptr(out), None)
     oh = out.cpu().numpy()
     written = np.zeros(P, dtype=bool)
     kk = np.array([k], dtype=np.int32)

@@ -75,8 +75,10 @@ _SIGS = {
     "vipmi_annular_gram_all_f32": ([c_f32p, i64, i64, ctypes.c_void_p, i64, i64, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p],
                                    True, ctypes.c_int),
     "vipmi_annular_apply_all_f32": ([c_f32p, i64, i64, ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p, ctypes.c_void_p, i64,
-                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64, i64, c_f32p],
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64, i64, c_f32p, c_f32p],
                                     True, ctypes.c_int),
+    "vipmi_annular_gram_all_f64": ([ctypes.c_void_p, i64, i64, ctypes.c_void_p, i64, i64, ctypes.c_void_p, i64, ctypes.c_int, c_f32p,
+                                    ctypes.c_void_p, c_f32p, ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_annular_apply_f32": ([c_f32p, i64, i64, ctypes.c_void_p, ctypes.c_void_p, i64, i64, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64, c_f32p], True, ctypes.c_int),
     "vipmi_pca_project_f32": ([c_f32p, i64, c_f32p, i64, i64, i64, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],

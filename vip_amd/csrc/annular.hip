@@ -256,7 +256,8 @@ int annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P
 // as vipmi_annular_eigh_f64 leaves them; kseg: device array of the segments' numbers of components (<= kmax).
 int annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg, const int32_t* pix_out,
                           int64_t nseg, const int32_t* lib_idx, const int32_t* lib_len, int64_t m, const double* G_all,
-                          const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax, int64_t P, float* cube_out) {
+                          const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax, int64_t P, float* cube_out,
+                          const float* mu32) {
   VIPMI_REQUIRE(A_all && tile_seg && pix_out && lib_idx && lib_len && G_all && evals && evecs && kseg && cube_out,
                 "annular_apply_all: null pointer");
   VIPMI_REQUIRE(n > 0 && Ptot > 0 && nseg > 0 && nseg <= 65535 && m > 0 && kmax > 0 && P > 0, "annular_apply_all: bad sizes");
@@ -271,10 +272,12 @@ int annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t
   }
   VIPMI_CHECK_HIP(hipMemsetAsync(Wt, 0, sizeof(float) * (size_t)nseg * n * kld, ctx->stream));
   const size_t shm = (size_t)(m + kmax + 8) * sizeof(double);
+  float* rho = nullptr;                  // mu32: A_all is D = M - 1 mu^T of a float64 cube; residuals = (I - C) D + rho mu^T
+  if (mu32) VIPMI_TRY(ws(ctx, "ann_rho_all", (size_t)nseg * n, &rho));
   hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n, (unsigned)nseg), dim3(256), shm, ctx->stream, G_all, (int)n, lib_idx, lib_len, (int)m,
-                     (int)m, evals, evecs, (int)kmax, (int)(Ptot < 2147483647 ? Ptot : 2147483647), Wt, (float*)nullptr, kseg, kld);
+                     (int)m, evals, evecs, (int)kmax, (int)(Ptot < 2147483647 ? Ptot : 2147483647), Wt, rho, kseg, kld);
   VIPMI_CHECK_HIP(hipGetLastError());
-  return rowspace_scatter_f32(ctx, Wt, kld, A_all, n, Ptot, tile_seg, pix_out, frange, P, cube_out);
+  return rowspace_scatter_f32(ctx, Wt, kld, A_all, n, Ptot, tile_seg, pix_out, frange, P, cube_out, rho, mu32);
 }
 
 // ncomps: HOST array of nk truncation ranks (the reference's list `ncomp`, pca_local.py:665-668,892-902: one

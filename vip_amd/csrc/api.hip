@@ -219,7 +219,7 @@ extern "C" {
 //                 recovery of cooperating solves
 // 106 (round 5): + vipmi_pca_fullframe_hostin_f32 (the Gram under the upload); float-domain median selection
 // 107 (round 6): option sub_guard (the subtraction's zero guard is opt-out per call: median_sub); + vipmi_annular_gram_all_f32,
-//                 vipmi_annular_apply_all_f32 (the fronts of all annulus segments in a handful of launches)
+//                 vipmi_annular_apply_all_f32, vipmi_annular_gram_all_f64 (the fronts of all annulus segments in a handful of launches)
 int vipmi_version(void) { return 107; }
 
 const char* vipmi_last_error(void) { return g_err; }
@@ -612,10 +612,17 @@ int vipmi_annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int
 int vipmi_annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg,
                                 const int32_t* pix_out, int64_t nseg, const int32_t* lib_idx, const int32_t* lib_len, int64_t m,
                                 const double* G_all, const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax,
-                                int64_t P, float* cube_out) {
+                                int64_t P, float* cube_out, const float* mu32) {
   CTX_GUARD();
   return annular_apply_all_f32(ctx, A_all, n, Ptot, tile_seg, pix_out, nseg, lib_idx, lib_len, m, G_all, evals, evecs, kseg, kmax, P,
-                               cube_out);
+                               cube_out, mu32);
+}
+
+int vipmi_annular_gram_all_f64(vipmi_ctx* ctx, const double* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot,
+                               int64_t klen, const int32_t* seg_slice, int64_t nseg, int mode, float* D_all, double* mu, float* mu32,
+                               double* G_all) {
+  CTX_GUARD();
+  return annular_gram_all_f64(ctx, cube, n, P, pix_all, Ptot, klen, seg_slice, nseg, mode, D_all, mu, mu32, G_all);
 }
 
 int vipmi_annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,

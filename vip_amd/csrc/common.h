@@ -213,7 +213,8 @@ int gram_i8_ragged_f32(vipmi_ctx* ctx, const float* M, int64_t n, int64_t Ptot, 
                        int64_t nseg, double* G_all);
 // R = W M for the segments of M side by side, written THROUGH a pixel list into a cube (project.hip): Wt_all [nseg][n][kld]
 int rowspace_scatter_f32(vipmi_ctx* ctx, const float* Wt_all, int kld, const float* M, int64_t n, int64_t Ptot,
-                         const int32_t* tile_seg, const int32_t* pix_out, const int* frange_all, int64_t P, float* out);
+                         const int32_t* tile_seg, const int32_t* pix_out, const int* frange_all, int64_t P, float* out,
+                         const float* rho_all = nullptr, const float* mu32 = nullptr);
 int eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs);
 // leading k eigenpairs only (eigh_tri.hip); falls back to eigh_f64 when the sizes are outside its range or
 // option "eigh_method" == 1.  nact: optional device array with the active size of each (zero padded) problem.
@@ -273,7 +274,10 @@ int annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P
                          const int32_t* seg_slice, int64_t nseg, float* A_all, double* G_all);
 int annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg, const int32_t* pix_out,
                           int64_t nseg, const int32_t* lib_idx, const int32_t* lib_len, int64_t m, const double* G_all,
-                          const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax, int64_t P, float* cube_out);
+                          const double* evals, const double* evecs, const int32_t* kseg, int64_t kmax, int64_t P, float* cube_out,
+                          const float* mu32 = nullptr);
+int annular_gram_all_f64(vipmi_ctx* ctx, const double* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot, int64_t klen,
+                         const int32_t* seg_slice, int64_t nseg, int mode, float* D_all, double* mu, float* mu32, double* G_all);
 bool eigh_gather_supported(int64_t m, int64_t k);
 int eigh_topk_gather_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t per_seg, int64_t ldg, const int32_t* idx,
                          const int32_t* len, int64_t m, int64_t k, double* work, double* evals, double* evecs);

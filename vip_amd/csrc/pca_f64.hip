@@ -21,10 +21,16 @@ namespace {
 
 // one thread per pixel column (coalesced across threads): temporal mean (and population std) in float64, D = float32((x - mu) / sd)
 // mode 0 / 1: centre only; 2: 'temp-standard' (sklearn: sd < 10 eps(float64) -> 1).  mask: 1 = masked (the sample is 0).
-__global__ void center_f64_kernel(const double* __restrict__ M, int n, int64_t P, const uint8_t* __restrict__ mask, int mode,
-                                  float* __restrict__ D, double* __restrict__ mu, float* __restrict__ mu32) {
+// pix (optional, round 6: the annular front): column p of D is pixel pix[p] of the cube (rows of Psrc samples; -1 = a zero column):
+// the gather of all segments' pixels and the centring in one pass.
+__global__ void center_f64_kernel(const double* __restrict__ Msrc, int n, int64_t P, const uint8_t* __restrict__ mask, int mode,
+                                  float* __restrict__ D, double* __restrict__ mu, float* __restrict__ mu32,
+                                  const int32_t* __restrict__ pix = nullptr, int64_t Psrc = 0) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
-    if (mask && mask[p]) {
+    const int64_t src = pix ? pix[p] : p;
+    const double* M = Msrc + src - p;                 // M[f * ldm + p] below is Msrc[f * ldm + src]
+    const int64_t ldm = pix ? Psrc : P;
+    if ((mask && mask[p]) || src < 0) {
       for (int f = 0; f < n; ++f) D[(int64_t)f * P + p] = 0.f;
       mu[p] = 0.0;
       if (mu32) mu32[p] = 0.f;
@@ -35,17 +41,17 @@ __global__ void center_f64_kernel(const double* __restrict__ M, int n, int64_t P
     for (; f0 + 8 <= n; f0 += 8) {
       double v8[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v8[u] = M[(int64_t)(f0 + u) * P + p];
+      for (int u = 0; u < 8; ++u) v8[u] = M[(int64_t)(f0 + u) * ldm + p];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v8[u];
     }
-    for (; f0 < n; ++f0) s += M[(int64_t)f0 * P + p];
+    for (; f0 < n; ++f0) s += M[(int64_t)f0 * ldm + p];
     const double m = s / n;
     double sd = 1.0;
     if (mode == 2) {
       double v = 0.0;
       for (int f = 0; f < n; ++f) {
-        const double d = M[(int64_t)f * P + p] - m;
+        const double d = M[(int64_t)f * ldm + p] - m;
         v += d * d;
       }
       sd = sqrt(v / n);
@@ -56,11 +62,11 @@ __global__ void center_f64_kernel(const double* __restrict__ M, int n, int64_t P
     for (; f0 + 8 <= n; f0 += 8) {
       double v8[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v8[u] = M[(int64_t)(f0 + u) * P + p];
+      for (int u = 0; u < 8; ++u) v8[u] = M[(int64_t)(f0 + u) * ldm + p];
 #pragma unroll
       for (int u = 0; u < 8; ++u) D[(int64_t)(f0 + u) * P + p] = (float)((v8[u] - m) * inv);
     }
-    for (; f0 < n; ++f0) D[(int64_t)f0 * P + p] = (float)((M[(int64_t)f0 * P + p] - m) * inv);
+    for (; f0 < n; ++f0) D[(int64_t)f0 * P + p] = (float)((M[(int64_t)f0 * ldm + p] - m) * inv);
     mu[p] = m;
     if (mu32) mu32[p] = (float)m;
   }
@@ -92,12 +98,33 @@ __global__ __launch_bounds__(256) void offset_dots_kernel(const float* __restric
   if (threadIdx.x == 0) g[f] = s;
 }
 
-// G[i, j] += g[i] + g[j] + g[n]
+// G[i, j] += g[i] + g[j] + g[n]      (blockIdx.y = matrix of a batch: G[y][n][n], g[y][n + 1])
 __global__ void gram_offset_kernel(double* __restrict__ G, const double* __restrict__ g, int n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * n) return;
+  G += (size_t)blockIdx.y * n * n;
+  g += (size_t)blockIdx.y * (n + 1);
   const int i = e / n, j = e - i * n;
   G[e] += g[i] + g[j] + g[n];
+}
+
+// the same dot products for the column SEGMENTS of one matrix D[n][ld] (annular PCA: every segment its own decomposition):
+// g[seg][f] = sum over the segment's columns of D[f, p] mu[p], g[seg][n] = sum mu[p]^2; blockIdx.y = segment, columns
+// seg_slice[seg] * klen .. seg_slice[seg + 1] * klen
+__global__ __launch_bounds__(256) void offset_dots_seg_kernel(const float* __restrict__ D, const double* __restrict__ mu, int n, int64_t ld,
+                                                              const int32_t* __restrict__ seg_slice, int klen, double* __restrict__ g) {
+  __shared__ double sh[4];
+  const int f = blockIdx.x, seg = blockIdx.y;
+  const int64_t p0 = (int64_t)seg_slice[seg] * klen, p1 = (int64_t)seg_slice[seg + 1] * klen;
+  double s = 0.0;
+  if (f < n) {
+    const float* row = D + (int64_t)f * ld;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) s += (double)row[p] * mu[p];
+  } else {
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) s += mu[p] * mu[p];
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) g[(size_t)seg * (n + 1) + f] = s;
 }
 
 // r = 1 - E^T (E 1) over the components that convert_evecs keeps (eigenvalue > 1e-12 of the largest); row k of the subtraction's
@@ -164,6 +191,33 @@ int gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n,
   hipLaunchKernelGGL(offset_dots_kernel, dim3((unsigned)n + 1), dim3(256), 0, ctx->stream, D, mu, (int)n, P, g);
   hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256)), dim3(256), 0, ctx->stream, G, g, (int)n);
   VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+
+// The float64 front of annular PCA for ALL segments (round 6): D_all[n][Ptot] = float32 of the centred (mode 0 / 1) or standardised
+// (mode 2) pixel columns pix_all of the float64 cube, mu / mu32 their temporal means, G_all[seg] = the Gram matrix of the segment's
+// columns of D_all (ONE ragged int8 product) and, mode 0 (no scaling), of D + 1 mu^T (the offset terms of every segment in float64).
+int annular_gram_all_f64(vipmi_ctx* ctx, const double* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot, int64_t klen,
+                         const int32_t* seg_slice, int64_t nseg, int mode, float* D_all, double* mu, float* mu32, double* G_all) {
+  VIPMI_REQUIRE(cube && pix_all && seg_slice && D_all && mu && mu32 && G_all, "annular_gram_all_f64: null pointer");
+  VIPMI_REQUIRE(n > 0 && P > 0 && Ptot > 0 && nseg > 0 && nseg <= 65535 && mode >= 0 && mode <= 2, "annular_gram_all_f64: bad arguments");
+  {
+    StageScope sc(ctx, "scale");
+    const int64_t blocks = cdiv(Ptot, 256);
+    hipLaunchKernelGGL(center_f64_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, cube, (int)n, Ptot,
+                       (const uint8_t*)nullptr, mode, D_all, mu, mu32, pix_all, P);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
+  VIPMI_TRY(gram_i8_ragged_f32(ctx, D_all, n, Ptot, klen, seg_slice, nseg, G_all));
+  if (mode == 0) {
+    StageScope sc(ctx, "gram");
+    double* g = nullptr;
+    VIPMI_TRY(ws(ctx, "ann64_g", (size_t)nseg * (n + 1), &g));
+    hipLaunchKernelGGL(offset_dots_seg_kernel, dim3((unsigned)n + 1, (unsigned)nseg), dim3(256), 0, ctx->stream, D_all, mu, (int)n, Ptot,
+                       seg_slice, (int)klen, g);
+    hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256), (unsigned)nseg), dim3(256), 0, ctx->stream, G_all, g, (int)n);
+    VIPMI_CHECK_HIP(hipGetLastError());
+  }
   return VIPMI_OK;
 }
 

@@ -145,7 +145,10 @@ __global__ __launch_bounds__(256, 2) void rowspace_kernel(const float* __restric
 __global__ __launch_bounds__(256, 2) void rowspace_scatter_kernel(const float* __restrict__ Wt_all, int kld, const float* __restrict__ M,
                                                                 int n, int64_t Ptot, const int32_t* __restrict__ tile_seg,
                                                                 const int32_t* __restrict__ pix_out, const int* __restrict__ frange_all,
-                                                                int64_t P, float* __restrict__ out) {
+                                                                int64_t P, float* __restrict__ out,
+                                                                const float* __restrict__ rho_all, const float* __restrict__ mu32) {
+  // rho_all / mu32 (optional: a float64 cube whose per-pixel temporal mean is carried apart, pca_f64.hip): M is D = cube - 1 mu^T and
+  // the residuals are (I - C) D + rho mu^T, rho[seg * n + i] the row sums of I - C: one multiply-add per element on the way out
   constexpr int NG = 2;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -201,6 +204,9 @@ __global__ __launch_bounds__(256, 2) void rowspace_scatter_kernel(const float* _
   }
   const int4 q = *reinterpret_cast<const int4*>(pix_out + px);
   const bool run4 = q.x >= 0 && q.y == q.x + 1 && q.z == q.x + 2 && q.w == q.x + 3;
+  f32x4 m4 = {0.f, 0.f, 0.f, 0.f};
+  if (rho_all) m4 = *reinterpret_cast<const f32x4*>(mu32 + px);
+  const float* rho = rho_all ? rho_all + (int64_t)seg * n : nullptr;
 #pragma unroll
   for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -208,7 +214,14 @@ __global__ __launch_bounds__(256, 2) void rowspace_scatter_kernel(const float* _
       const int i = (grp0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (i < n) {
         float* row = out + (int64_t)i * P;
-        const float v0 = acc[g][0][r], v1 = acc[g][1][r], v2 = acc[g][2][r], v3 = acc[g][3][r];
+        float v0 = acc[g][0][r], v1 = acc[g][1][r], v2 = acc[g][2][r], v3 = acc[g][3][r];
+        if (rho) {
+          const float ri = rho[i];
+          v0 = fmaf(ri, m4[0], v0);
+          v1 = fmaf(ri, m4[1], v1);
+          v2 = fmaf(ri, m4[2], v2);
+          v3 = fmaf(ri, m4[3], v3);
+        }
         if (run4) {
           float* d = row + q.x;
           const int al = (int)((reinterpret_cast<uintptr_t>(d) >> 2) & 3);
@@ -468,14 +481,16 @@ int subtract_gemm_t(vipmi_ctx* ctx, const float* M, const float* Ct, int nld, co
 }
 
 int rowspace_scatter_f32(vipmi_ctx* ctx, const float* Wt_all, int kld, const float* M, int64_t n, int64_t Ptot,
-                         const int32_t* tile_seg, const int32_t* pix_out, const int* frange_all, int64_t P, float* out) {
+                         const int32_t* tile_seg, const int32_t* pix_out, const int* frange_all, int64_t P, float* out,
+                         const float* rho_all, const float* mu32) {
+  VIPMI_REQUIRE((rho_all == nullptr) == (mu32 == nullptr) && (!mu32 || aligned16(mu32)), "rowspace_scatter: rho / mu go together");
   VIPMI_REQUIRE(Wt_all && M && tile_seg && pix_out && out, "rowspace_scatter: null pointer");
   VIPMI_REQUIRE(n > 0 && Ptot > 0 && Ptot % 128 == 0 && aligned16(M) && aligned16(pix_out), "rowspace_scatter: bad sizes / alignment");
   StageScope sc(ctx, "project");
   const int groups = (int)cdiv(n, 32);
   dim3 grid((unsigned)cdiv(Ptot / 128, 4), (unsigned)cdiv(groups, 2));
   hipLaunchKernelGGL(rowspace_scatter_kernel, grid, dim3(256), 0, ctx->stream, Wt_all, kld, M, (int)n, Ptot, tile_seg, pix_out, frange_all, P,
-                     out);
+                     out, rho_all, mu32);
   VIPMI_CHECK_HIP(hipGetLastError());
   return VIPMI_OK;
 }

@@ -388,7 +388,7 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     # (no reference cube, no cube_sig, one ncomp per annulus, temporal or no scaling) from the size at which the int8 Gram pays
     # (VIPMI_ANNULAR_FUSED=1 forces it: the parity tests run it on the small goldens, =0 disables it)
     fused_env = os.environ.get("VIPMI_ANNULAR_FUSED", "")
-    if plan and not f64_route and nref == 0 and cube_sig is None and ks is None and pad_ok and fused_env != "0":
+    if plan and nref == 0 and cube_sig is None and ks is None and pad_ok and fused_env != "0":
         npx_tot = sum(int(sg["pix"].size) for sg in plan)
         m_all = max(max(len(li) for li in sg["libs"]) for sg in plan)
         k_all = min(m_all, max(int(sg["ncomp"]) for sg in plan))
@@ -413,7 +413,17 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             nseg, Ptot = len(plan), fp_["Ptot"]
             A_all = B.empty((n, Ptot), device=dev)
             G_all = torch.empty((nseg, n, n), dtype=torch.float64, device=cube.device)
-            if scaling is None:
+            mu32 = None
+            if f64_route:
+                # a float64 cube: gather + centring in float64 in one pass (A_all = D = float32(cube - 1 mu^T) (/ sd)), the Gram
+                # matrices of D -- plus the float64 offset terms when the matrix is not scaled --, and residuals = (I - C) D + rho mu^T
+                mu64 = torch.empty((Ptot,), dtype=torch.float64, device=cube.device)
+                mu32_t = B.empty((Ptot,), device=dev)
+                mode = {None: 0, "temp-mean": 1, "temp-standard": 2}[scaling]
+                ctx.call("vipmi_annular_gram_all_f64", B.ptr(cube64), n, P, B.ptr(fp_["pix_all"]), Ptot, fp_["klen"],
+                         B.ptr(fp_["seg_slice"]), nseg, mode, B.ptr(A_all), B.ptr(mu64), B.ptr(mu32_t), B.ptr(G_all))
+                mu32 = mu32_t if scaling is None else None
+            elif scaling is None:
                 ctx.call("vipmi_annular_gram_all_f32", B.ptr(cube), n, P, B.ptr(fp_["pix_all"]), Ptot, fp_["klen"],
                          B.ptr(fp_["seg_slice"]), nseg, B.ptr(A_all), B.ptr(G_all))
             else:
@@ -430,9 +440,10 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
                      B.ptr(H_all), B.ptr(ev_all), B.ptr(ec_all))
             ctx.call("vipmi_annular_apply_all_f32", B.ptr(A_all), n, Ptot, B.ptr(fp_["tile_seg"]), B.ptr(fp_["pix_out"]), nseg,
                      B.ptr(fp_["idx"]), B.ptr(fp_["len"]), m_all, B.ptr(G_all), B.ptr(ev_all), B.ptr(ec_all), B.ptr(fp_["kseg"]),
-                     k_all, P, B.ptr(cube_out))
+                     k_all, P, B.ptr(cube_out), B.ptr(mu32))
             plan = []                                 # (nothing left for the per-segment routes below)
             pipelined = False
+            f64_route = False
     if f64_route:
         for si, seg in enumerate(plan):
             do_segment_f64(si, seg)
