@@ -1368,6 +1368,30 @@ def test_annular_fronts_of_all_segments_through_the_c_entries(B, n, sizes, klen)
     assert written.sum() == len(seen) and np.all(oh[:, ~written] == 7.0)
 
 
+@pytest.mark.parametrize("n,k", [(200, 150), (400, 330), (640, 300)])
+def test_many_vectors_of_one_matrix_take_the_jacobi_kernel_with_the_exact_path_behind_it(B, n, k):
+    """k > 0.4 n eigenpairs of one matrix (pca(ncomp = 200), a float ncomp whose CEVR asks for most of the spectrum): the one-sided
+    Jacobi kernel first (every pair in ~10 ms at n = 400 where the tridiagonal solvers take 64 vectors at a time: 53 ms for 400),
+    on a copy; when it does not converge within its sweep limit (forced here with eigh_max_sweeps = 1) the exact tridiagonal path
+    runs on the untouched matrix.  Both against numpy."""
+    import torch
+    G = _spectrum_matrix(n, (1.0 + np.arange(n)) ** -1.2, seed=n + k)
+    w, E = np.linalg.eigh(G)
+    w, E = w[::-1], E[:, ::-1]
+    ctx = B.get_context()
+    for sweeps in (40, 1):
+        ctx.set_option("eigh_max_sweeps", sweeps)
+        try:
+            ev, ec = B.eigh_topk(torch.from_numpy(G.copy()).cuda(), k)
+        finally:
+            ctx.set_option("eigh_max_sweeps", 40)
+        ev, X = ev.cpu().numpy(), ec.cpu().numpy().T
+        assert np.abs(ev - w[:k]).max() < 1e-12 * w[0], sweeps
+        assert np.abs(X.T @ X - np.eye(k)).max() < 1e-10
+        assert np.linalg.norm(G @ X - X * ev, axis=0).max() < 1e-11 * w[0], sweeps
+    assert not B._lib.last_error()
+
+
 @pytest.mark.parametrize("n,k", [(200, 10), (120, 16), (96, 32), (150, 8)])
 def test_eigh_batched_all_leading_values_from_one_wave(B, n, k):
     """Second launch of a big batch (>= 4 problems per CU, k >= 8): the k leading eigenvalues of every tridiagonal matrix come

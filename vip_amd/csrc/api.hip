@@ -308,7 +308,7 @@ int vipmi_synchronize(vipmi_ctx* ctx) {
 int vipmi_set_option(vipmi_ctx* ctx, const char* key, int64_t value) {
   VIPMI_REQUIRE(ctx && key, "null argument");
   static const char* known[] = {"timing", "eigh_split", "rot_4096_w1", "ann_large_min", "gram_f32", "gram_tb", "gram_slices", "eigh_max_sweeps",
-                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_many", "hostin_overlap", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "median_xcd_chunk", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", "ann_gather", "ann_range", "sub_guard", nullptr};
+                                "eigh_check", "rot_ws_mb", "rot_batch", "rot_conv", "reserve_cus", "eigh_method", "eigh_multi", "eigh_nt", "eigh_reg", "eigh_many", "hostin_overlap", "eigh_large_w", "eigh_xl_min", "gram_wpw", "bgemm_tb", "bgemm_lds", "warp_direct", "median_tp", "median_reg", "median_xcd_chunk", "eigh_fast", "eigh_fast_tol", "eigh_fast_budget", "eigh_fast_min", "gram_i8", "gram_i8_slices", "gram_i8_nbuf", "gram_i8_min_n", "gram_i8_dma", "eigh_one_xcd", "eigh_w", "eigh_wave", "eigh_wave_drop", "rot_pair_store", "subtract_lds", "upload_ring", "rot_1024_q", "eigh_recover", "eigh_multi_drop", "eigh_wave_async", "ann_gather", "ann_range", "sub_guard", "eigh_many_jacobi", nullptr};
   bool ok = false;
   for (int i = 0; known[i]; ++i) ok = ok || strcmp(known[i], key) == 0;
   VIPMI_REQUIRE(ok, "unknown option '%s'", key);

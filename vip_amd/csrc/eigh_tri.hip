@@ -1648,6 +1648,22 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
     ctx->options["eigh_fast_last_reason"] = info[3];
     if (conv) return VIPMI_OK;
   }
+  // MANY vectors of one matrix (pca(ncomp = 200), a float ncomp whose CEVR asks for most of the spectrum): the tridiagonal solvers
+  // take their vectors 64 at a time, one back-transformation of n reflectors per vector -- 16.6 ms for 200 of 400, 53 ms for all 400,
+  // 357 ms for 800 of 800 --, while the one-sided Jacobi kernel delivers every eigenpair in ~10 ms at n = 400, 22-50 ms at n = 800
+  // (tools/time_manyvec.py; residuals 5e-14 of the largest eigenvalue against 3e-16).  From k > 0.4 n on (synchronous mode: the
+  // convergence flag is read back) Jacobi goes first, on a copy: graded spectra beyond ~600 rows may not converge within its sweep
+  // limit, and the tridiagonal path then runs on the untouched matrix.
+  if (batch == 1 && !nact && n <= 2048 && k > 64 && 5 * k > 2 * n && ctx->opt("eigh_check", 1) != 0 && ctx->opt("eigh_method", 0) == 0 &&
+      ctx->opt("eigh_many_jacobi", 1) != 0) {
+    double* Gc = nullptr;
+    VIPMI_TRY(ws(ctx, "eigh_jacobi_copy", (size_t)n * n, &Gc));
+    VIPMI_CHECK_HIP(hipMemcpyAsync(Gc, G, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    const int st = eigh_f64(ctx, Gc, 1, n, evals, evecs);
+    if (st == VIPMI_OK) return VIPMI_OK;
+    if (st != VIPMI_ERR_NOCONV) return st;
+    set_error("");                                  // (not converged: the exact path below)
+  }
   if (ctx->opt("eigh_method", 0) != 1 && eigh_topk_supported(n, k))
     return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs, all_evals);
   // 513 .. 640 rows, a few problems: still LDS-resident on 32 workgroups (20 rows of 640 doubles + ten vectors = 154 KB each) --
