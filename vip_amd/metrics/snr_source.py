@@ -39,23 +39,29 @@ def circle_pixel_overlap(dx0, dy0, r):
 def aperture_sums_exact(array, xx, yy, r):
     """Sum of ``array`` over circular apertures of radius r centred on (xx[i], yy[i]) (pixel centres at integer
     coordinates, as photutils), every pixel weighted by its exact overlap with the circle; the part of an aperture
-    outside the frame contributes nothing."""
+    outside the frame contributes nothing.  All apertures in one vectorised pass (round 6: a ring at 128 px holds ~200
+    apertures, and the S/N-scored grids call this per pixel of the test aperture: a Python loop over the apertures made a
+    five-entry grid at 512 px cost 0.95 s of host time against 26 ms of device work)."""
     array = np.asarray(array, dtype=np.float64)
     ny, nx = array.shape
-    out = np.zeros(len(xx), dtype=np.float64)
-    for i, (xc, yc) in enumerate(zip(xx, yy)):
-        x_lo, x_hi = int(np.floor(xc - r + 0.5)), int(np.ceil(xc + r - 0.5))
-        y_lo, y_hi = int(np.floor(yc - r + 0.5)), int(np.ceil(yc + r - 0.5))
-        xs = np.arange(max(x_lo, 0), min(x_hi, nx - 1) + 1)
-        ys = np.arange(max(y_lo, 0), min(y_hi, ny - 1) + 1)
-        if xs.size == 0 or ys.size == 0:
-            continue
-        gx, gy = np.meshgrid(xs - 0.5 - xc, ys - 0.5 - yc)            # lower-left pixel corners relative to the centre
-        w = circle_pixel_overlap(gx, gy, float(r))
-        sub = array[ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1]
-        covered = w > 0                      # (photutils sums only the pixels the aperture touches: a NaN corner of the
-        out[i] = float(np.sum(w[covered] * sub[covered]))        # bounding box outside the circle must not poison the sum)
-    return out
+    xc = np.asarray(xx, dtype=np.float64).reshape(-1)
+    yc = np.asarray(yy, dtype=np.float64).reshape(-1)
+    if xc.size == 0:
+        return np.zeros(0, dtype=np.float64)
+    r = float(r)
+    width = int(np.ceil(2.0 * r)) + 2                              # pixels an aperture's bounding box can span per axis
+    off = np.arange(width)
+    ix = np.floor(xc - r + 0.5).astype(np.int64)[:, None] + off    # (m, width) pixel columns / rows of every aperture's box
+    iy = np.floor(yc - r + 0.5).astype(np.int64)[:, None] + off
+    gx = ix - 0.5 - xc[:, None]                                    # lower-left pixel corners relative to the centre
+    gy = iy - 0.5 - yc[:, None]
+    w = circle_pixel_overlap(gx[:, None, :], gy[:, :, None], r)    # (m, rows, columns)
+    inside = ((iy >= 0) & (iy < ny))[:, :, None] & ((ix >= 0) & (ix < nx))[:, None, :]
+    vals = array[np.clip(iy, 0, ny - 1)[:, :, None], np.clip(ix, 0, nx - 1)[:, None, :]]
+    # (photutils sums only the pixels the aperture touches: a NaN corner of the bounding box outside the circle must not
+    #  poison the sum)
+    covered = inside & (w > 0)
+    return np.where(covered, w * np.where(covered, vals, 0.0), 0.0).sum(axis=(1, 2))
 
 
 def _ring_geometry(array, source_xy, fwhm):
