@@ -16,7 +16,7 @@ import numpy as np
 from .. import backend as B
 from ..config.paramenum import ALGO_KEY, Collapse, Imlib, Interpolation
 from ..config.utils_param import separate_kwargs_dict
-from ..preproc.derotation import _define_annuli, _find_indices_adi
+from ..preproc.derotation import _define_annuli, _find_indices_adi_nframes_all
 from ..preproc.parangles import check_pa_vector
 from ..var.shapes import center_mask_u8, get_annulus_segments
 
@@ -87,7 +87,7 @@ def _annular_pass(cube_t, sub_t, angle_list, algo_params, rdi):
             if pa_thr != 0:
                 if nframes is None:
                     raise NotImplementedError("median_sub(mode='annular', nframes=None) is not accelerated")
-                libs = [_find_indices_adi(angle_list, fr, pa_thr, nframes=nframes) for fr in range(n)]
+                libs = _find_indices_adi_nframes_all(angle_list, pa_thr, nframes)
             else:
                 libs = [np.arange(n, dtype=np.int32) for _ in range(n)]
             wmax = max(1, max(len(li) for li in libs))

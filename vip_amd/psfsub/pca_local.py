@@ -94,6 +94,7 @@ def annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, delta_r
             ang = np.rad2deg(2 * np.arctan(ld / (2 * i * asize)))
             n_segments.append(int(np.ceil(360 / ang)))
     plan = []
+    lib_memo = {}                     # libraries by exclusion windows: shared by the annuli whose thresholds give the same windows
     for ann in range(n_annuli):
         if isinstance(ncomp, (tuple, np.ndarray)):
             if len(ncomp) != n_annuli:
@@ -105,7 +106,7 @@ def annulus_plan(shape, angle_list, radius_int, fwhm, asize, n_segments, delta_r
                                                           delta_rot[ann], n_segments[ann], False, True)
         segs = get_annulus_segments(np.zeros((y, x)), inner_radius, asize, n_segments[ann], theta_init)
         if pa_thr != 0:
-            libs = _find_indices_adi_all(angle_list, pa_thr, truncate=True, max_frames=max_frames_lib)
+            libs = _find_indices_adi_all(angle_list, pa_thr, truncate=True, max_frames=max_frames_lib, memo=lib_memo)
             for fr, li in enumerate(libs):
                 if li.shape[0] < min_frames_lib:
                     msg = "Too few frames left in the PCA library. Accepted indices length ({:.0f}) less than {:.0f}. "

@@ -86,6 +86,31 @@ def get_annulus_segments(data, inner_radius, width, nsegm=1, theta_init=0, optim
     twopi = 2 * np.pi
     rad, phirot = _polar_grids(array.shape[0], array.shape[1])
     outer_radius = inner_radius + (width * optim_scale_fact)
+    if mode == "ind" and not out:
+        # index sets only (what the annular plans ask for, once per annulus): the same float64 comparisons on the annulus' bounding
+        # box instead of the whole frame, and no azimuth tests when one segment covers the full turn -- phirot lies in [0, 2 pi) and
+        # deg2rad(360) is 2 pi exactly, so the reference's `(phirot >= 0) & (phirot < 2 pi)` holds everywhere
+        cy, cx = frame_center(array)
+        reach = int(np.ceil(outer_radius)) + 1
+        y0, y1 = max(int(cy) - reach, 0), min(int(cy) + reach + 1, array.shape[0])
+        x0, x1 = max(int(cx) - reach, 0), min(int(cx) + reach + 1, array.shape[1])
+        rad_b, phi_b = rad[y0:y1, x0:x1], phirot[y0:y1, x0:x1]
+        ring_b = (rad_b >= inner_radius) & (rad_b < outer_radius)
+        res = []
+        for i in range(nsegm):
+            phi_start = np.deg2rad(theta_init) + (i * azimuth_coverage)
+            phi_end = phi_start + azimuth_coverage
+            if nsegm == 1 and phi_start == 0 and phi_end == twopi:
+                m_b = ring_b
+            elif phi_start < twopi and phi_end > twopi:
+                m_b = (ring_b & (phi_b >= phi_start) & (phi_b <= twopi) | ring_b & (phi_b >= 0) & (phi_b < phi_end - twopi))
+            elif phi_start >= twopi and phi_end > twopi:
+                m_b = ring_b & (phi_b >= phi_start - twopi) & (phi_b < phi_end - twopi)
+            else:
+                m_b = ring_b & (phi_b >= phi_start) & (phi_b < phi_end)
+            yy, xx = np.where(m_b)
+            res.append((yy + y0, xx + x0))
+        return res
     ring = (rad >= inner_radius) & (rad < outer_radius)
     masks = []
     for i in range(nsegm):
