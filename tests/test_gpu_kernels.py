@@ -1389,7 +1389,7 @@ def test_many_vectors_of_one_matrix_take_the_jacobi_kernel_with_the_exact_path_b
         assert np.abs(ev - w[:k]).max() < 1e-12 * w[0], sweeps
         assert np.abs(X.T @ X - np.eye(k)).max() < 1e-10
         assert np.linalg.norm(G @ X - X * ev, axis=0).max() < 1e-11 * w[0], sweeps
-    assert not B._lib.last_error()
+    B.check_deferred()                      # the forced non-convergence left nothing latched behind
 
 
 @pytest.mark.parametrize("n,k", [(200, 10), (120, 16), (96, 32), (150, 8)])

@@ -1663,6 +1663,18 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
     if (st == VIPMI_OK) return VIPMI_OK;
     if (st != VIPMI_ERR_NOCONV) return st;
     set_error("");                                  // (not converged: the exact path below)
+    // the kernel also latched the failure for vipmi_check_deferred (sticky word 0): taken back, the caller gets its eigenpairs
+    {
+      int* fail = nullptr;
+      VIPMI_TRY(deferred_fail_words(ctx, &fail, false));
+      int v = 0;
+      VIPMI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      VIPMI_CHECK_HIP(hipMemcpy(&v, fail, sizeof(int), hipMemcpyDeviceToHost));
+      if (v > 0) {
+        v -= 1;
+        VIPMI_CHECK_HIP(hipMemcpy(fail, &v, sizeof(int), hipMemcpyHostToDevice));
+      }
+    }
   }
   if (ctx->opt("eigh_method", 0) != 1 && eigh_topk_supported(n, k))
     return eigh_topk_f64(ctx, G, batch, n, k, nact, evals, evecs, all_evals);
