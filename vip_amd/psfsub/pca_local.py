@@ -386,15 +386,15 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     pipelined = n_ann >= 3 and not B.is_async() and not f64_route
     # Fused fronts (round 6): ONE gather of all segments, ONE ragged Gram product on the int8 matrix cores, ONE batched eigensolve,
     # ONE coefficient launch and ONE residual product that writes through the pixel list into cube_out -- for the plain ADI call
-    # (no reference cube, no cube_sig, one ncomp per annulus, temporal or no scaling) from the size at which the int8 Gram pays
-    # (VIPMI_ANNULAR_FUSED=1 forces it: the parity tests run it on the small goldens, =0 disables it)
+    # (no reference cube, no cube_sig, one ncomp per annulus, temporal or no scaling); VIPMI_ANNULAR_FUSED=0 disables it (the parity
+    # tests compare the two routes)
     fused_env = os.environ.get("VIPMI_ANNULAR_FUSED", "")
     if plan and nref == 0 and cube_sig is None and ks is None and pad_ok and fused_env != "0":
-        npx_tot = sum(int(sg["pix"].size) for sg in plan)
         m_all = max(max(len(li) for li in sg["libs"]) for sg in plan)
         k_all = min(m_all, max(int(sg["ncomp"]) for sg in plan))
-        big = n >= 128 and n * npx_tot >= (1 << 25)
-        if (big or fused_env == "1") and m_all <= 512 and k_all <= 64 and n * len(plan) * m_all * m_all * 16 <= 8e9 and P < 2 ** 31:
+        # (every size: measured from 64 x 101 x 101 to 400 x 512 x 512, 4- and 16-px annuli, the fused fronts are 0-45 % faster than
+        #  the per-segment launches on two streams, tools/fused_threshold.py; the first version switched at 128 frames and 2^25 samples)
+        if m_all <= 512 and k_all <= 64 and n * len(plan) * m_all * m_all * 16 <= 8e9 and P < 2 ** 31:
             fp_ = plan_dev.get(("fused", dev))
             if fp_ is None:
                 h = _fused_front_plan(plan, n)
