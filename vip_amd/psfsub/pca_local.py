@@ -389,9 +389,9 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
     # (no reference cube, no cube_sig, one ncomp per annulus, temporal or no scaling); VIPMI_ANNULAR_FUSED=0 disables it (the parity
     # tests compare the two routes)
     fused_env = os.environ.get("VIPMI_ANNULAR_FUSED", "")
-    if plan and nref == 0 and cube_sig is None and ks is None and pad_ok and fused_env != "0":
+    if plan and nref == 0 and cube_sig is None and pad_ok and fused_env != "0" and not (ks is not None and f64_route):
         m_all = max(max(len(li) for li in sg["libs"]) for sg in plan)
-        k_all = min(m_all, max(int(sg["ncomp"]) for sg in plan))
+        k_all = min(m_all, max(int(sg["ncomp"]) for sg in plan) if ks is None else int(ks.max()))
         # (every size: measured from 64 x 101 x 101 to 400 x 512 x 512, 4- and 16-px annuli, the fused fronts are 0-45 % faster than
         #  the per-segment launches on two streams, tools/fused_threshold.py; the first version switched at 128 frames and 2^25 samples)
         if m_all <= 512 and k_all <= 64 and n * len(plan) * m_all * m_all * 16 <= 8e9 and P < 2 ** 31:
@@ -439,9 +439,20 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             ec_all = torch.empty((nseg * n, m_all, m_all), dtype=torch.float64, device=cube.device)
             ctx.call("vipmi_annular_eigh_f64", B.ptr(G_all), nseg, n, B.ptr(fp_["idx"]), B.ptr(fp_["len"]), m_all, k_all,
                      B.ptr(H_all), B.ptr(ev_all), B.ptr(ec_all))
-            ctx.call("vipmi_annular_apply_all_f32", B.ptr(A_all), n, Ptot, B.ptr(fp_["tile_seg"]), B.ptr(fp_["pix_out"]), nseg,
-                     B.ptr(fp_["idx"]), B.ptr(fp_["len"]), m_all, B.ptr(G_all), B.ptr(ev_all), B.ptr(ec_all), B.ptr(fp_["kseg"]),
-                     k_all, P, B.ptr(cube_out), B.ptr(mu32))
+            if ks is None:
+                ctx.call("vipmi_annular_apply_all_f32", B.ptr(A_all), n, Ptot, B.ptr(fp_["tile_seg"]), B.ptr(fp_["pix_out"]), nseg,
+                         B.ptr(fp_["idx"]), B.ptr(fp_["len"]), m_all, B.ptr(G_all), B.ptr(ev_all), B.ptr(ec_all), B.ptr(fp_["kseg"]),
+                         k_all, P, B.ptr(cube_out), B.ptr(mu32))
+            else:
+                # a list of ncomp (pca_local.py:665-668,892-902): one decomposition with max(ncomp), the coefficient / residual stage
+                # once per truncation into its own residual cube
+                npx_h = np.asarray([int(sg["pix"].size) for sg in plan], dtype=np.int32)
+                ksegs = [torch.from_numpy(np.minimum(npx_h, int(kk_))).to(cube.device) for kk_ in ks]       # (alive until the sync below)
+                for nn in range(len(ks)):
+                    ctx.call("vipmi_annular_apply_all_f32", B.ptr(A_all), n, Ptot, B.ptr(fp_["tile_seg"]), B.ptr(fp_["pix_out"]), nseg,
+                             B.ptr(fp_["idx"]), B.ptr(fp_["len"]), m_all, B.ptr(G_all), B.ptr(ev_all), B.ptr(ec_all),
+                             B.ptr(ksegs[nn]), k_all, P, B.ptr(cube_out[nn]), None)
+                plan_dev[("fused_ksegs", dev)] = ksegs            # (kept with the plan: the launches above may still be queued)
             plan = []                                 # (nothing left for the per-segment routes below)
             pipelined = False
             f64_route = False
