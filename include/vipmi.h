@@ -293,8 +293,9 @@ int vipmi_pca_fullframe_f32(vipmi_ctx* ctx, const float* cube, const double* ang
  * caller's dtype through prepare_matrix / svd_wrapper (psfsub/pca_fullfr.py:1552-1737, psfsub/svd.py:342-620); here the per-pixel
  * temporal mean -- the part of a cube of detector counts that float32 cannot hold beside the signal -- is carried in float64:
  * D = float32(cube - 1 mu^T) goes through the float32 kernels, the decomposition is that of D + 1 mu^T (Gram corrected in float64),
- * residual = [D - E^T (E D)] + (1 - E^T E 1) mu^T.  scaling: 0 (None), 1 (temp-mean), 2 (temp-standard); others return
- * VIPMI_ERR_UNSUPPORTED (convert to float32 and call vipmi_pca_fullframe_f32). */
+ * residual = [D - E^T (E D)] + (1 - E^T E 1) mu^T.  scaling: 0 (None) or any VIPMI_SCALE_*; the spatial scalings (round 6:
+ * matrix_scaling with axis=1, var/shapes.py:740-781) have the same shape with the frames' inverse standard deviations u in the
+ * place of 1:  diag(u) (M - m 1^T) = D + u (mu - mean(mu))^T,  D = float32 of diag(u) [(M - 1 mu^T) - (m - mean(m)) 1^T] formed in float64. */
 int vipmi_pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp,
                             int scaling, const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon,
                             float* residuals, float* residuals_der);

@@ -44,3 +44,25 @@ if want("g29"):
         g["ms_%s_out" % tag], g["ms_%s_der" % tag], g["ms_%s_frame" % tag] = co, cd, fr_
         print("   %s: exact zeros in cube_out outside the mask: %d" % (tag, int((np.asarray(co) == 0).sum())))
     save("g29_medsub_odd", **g)
+
+
+# ---- G30: the SPATIAL scalings on a float64 cube of detector counts (g28's cube, not stored again): the reference's own float64
+# frames and residual cubes for matrix_scaling(axis=1) (var/shapes.py:740-781), and -- the yardstick -- its result when the cube is
+# handed over as float32.
+if want("g30"):
+    g28 = np.load(os.path.join(OUT, "g28_f64_counts.npz"))
+    cube, ang = g28["cube"], g28["angles"]
+    g = {}
+    for tag, kw in (("smean", dict(ncomp=4, scaling="spat-mean")), ("sstd", dict(ncomp=5, scaling="spat-standard")),
+                    ("sstd_mask", dict(ncomp=3, scaling="spat-standard", mask_center_px=6))):
+        fo = ref.pca(cube, ang, full_output=True, verbose=False, nproc=1, **kw)
+        g["frame64_" + tag] = np.asarray(fo[0], dtype=np.float64)
+        if tag == "smean":
+            g["res64_" + tag] = np.asarray(fo[3], dtype=np.float32)
+        f32 = ref.pca(cube.astype(np.float32), ang, full_output=False, verbose=False, nproc=1, **kw)
+        g["frame_ref_f32_" + tag] = np.asarray(f32, dtype=np.float64)
+        d = np.nanmax(np.abs(g["frame_ref_f32_" + tag] - g["frame64_" + tag]))
+        o = O.pca_fullframe(cube, ang, **kw)
+        print("   %s: reference(float32 cube) vs reference(float64 cube): max|d| = %.3e; oracle vs reference %.3e (frame scale %.3f)"
+              % (tag, d, np.nanmax(np.abs(o - g["frame64_" + tag])), np.nanmax(np.abs(g["frame64_" + tag]))))
+    save("g30_f64_spat", **g)

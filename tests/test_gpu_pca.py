@@ -1651,19 +1651,52 @@ def test_float64_cube_of_detector_counts_vs_reference(tag, kw):
         assert np.nanmax(np.abs(f32r - g["frame64_" + tag])) <= 2.0 ** -21 * np.abs(cube).max()
 
 
+@pytest.mark.parametrize("tag,kw", [("smean", dict(ncomp=4, scaling="spat-mean")), ("sstd", dict(ncomp=5, scaling="spat-standard")),
+                                    ("sstd_mask", dict(ncomp=3, scaling="spat-standard", mask_center_px=6))])
+def test_float64_cube_spatial_scalings_vs_reference(tag, kw):
+    """matrix_scaling(axis=1) (var/shapes.py:740-781) of a float64 cube of detector counts on the float64 route: the scaled matrix
+    is D + u mu'^T with D formed in float64 and the offset mu' carried beside it (csrc/pca_f64.hip).  g30 = the reference's OWN
+    float64 runs on g28's cube (oracle/gen_golden_r6.py); handed the cube as float32 the reference itself ends 3.1e-4 away for
+    'spat-mean' (above the BASELINE gate), and so did the device path before round 6."""
+    from vip_amd.psfsub import pca
+    g28, g = load_golden("g28_f64_counts"), load_golden("g30_f64_spat")
+    cube, ang = g28["cube"], g28["angles"]
+    fr = pca(cube, ang, verbose=False, **kw)
+    assert fr.dtype == np.float64
+    exp = g["frame64_" + tag]
+    dev = np.nanmax(np.abs(fr - exp))
+    ref32 = np.nanmax(np.abs(g["frame_ref_f32_" + tag] - exp))
+    print("g30 %s: float64 route vs reference(f64) %.3e; reference(f32 cube) vs reference(f64) %.3e" % (tag, dev, ref32))
+    assert np.array_equal(np.isnan(fr), np.isnan(exp))
+    assert dev < TOL * max(1.0, np.nanmax(np.abs(exp)) / 10.0)
+    if tag == "smean":
+        assert dev < 0.2 * ref32
+    fo = pca(cube, ang, verbose=False, full_output=True, **kw)
+    ro = O.pca_fullframe(cube, ang, full_output=True, **kw)
+    if tag == "smean":
+        assert np.nanmax(np.abs(fo[3] - g["res64_smean"])) < 2 * TOL                   # the reference's own residual cube
+    for nm, a, b in zip(("frame", "pcs", "recon", "res", "resder"), fo, ro):
+        assert a.dtype == np.float64 and a.shape == b.shape, nm
+        if nm == "pcs":
+            a = sign_align(a, b)
+        tol = {"pcs": 1e-6, "recon": 2e-3}.get(nm, 2 * TOL)          # (recon holds the scaled counts: float32 of up to 7e3)
+        assert np.nanmax(np.abs(a - b)) < tol, (nm, np.nanmax(np.abs(a - b)))
+
+
 def test_float64_route_scalings_collapses_and_fallbacks():
-    """vipmi_pca_fullframe_f64 beyond the goldens: 'temp-standard', every collapse it serves, ncomp > n clamped; the shapes it does
-    not serve (spatial scalings, cube_ref, a tuple of ncomp) fall back on the float32 route -- all against the float64 oracle."""
+    """vipmi_pca_fullframe_f64 beyond the goldens: 'temp-standard', the spatial scalings with a mask / a long basis, every collapse it serves, ncomp > n clamped; the shapes it does
+    not serve (cube_ref, a tuple of ncomp) fall back on the float32 route -- all against the float64 oracle."""
     from vip_amd.psfsub import pca
     g = load_golden("g28_f64_counts")
     cube, ang = g["cube"][:, 8:56, 8:56].copy(), g["angles"]
     for kw in (dict(ncomp=5, scaling="temp-standard"), dict(ncomp=3, collapse="mean"), dict(ncomp=3, collapse="max"),
-               dict(ncomp=6, collapse="sum"), dict(ncomp=100), dict(ncomp=2, scaling="temp-mean", mask_center_px=4)):
+               dict(ncomp=6, collapse="sum"), dict(ncomp=100), dict(ncomp=2, scaling="temp-mean", mask_center_px=4),
+               dict(ncomp=3, scaling="spat-mean", mask_center_px=5, collapse="mean"), dict(ncomp=30, scaling="spat-standard")):
         ref = O.pca_fullframe(cube, ang, **{k_: min(v, cube.shape[0]) if k_ == "ncomp" else v for k_, v in kw.items()})
         fr = pca(cube, ang, verbose=False, **kw)
         scale = max(1.0, np.nanmax(np.abs(ref)))
         assert np.nanmax(np.abs(fr - ref)) < TOL * max(1.0, scale / 10.0), kw
-    for kw in (dict(ncomp=3, scaling="spat-mean"), dict(ncomp=3, cube_ref=cube[:9].copy()), dict(ncomp=(1, 3))):
+    for kw in (dict(ncomp=3, cube_ref=cube[:9].copy()), dict(ncomp=(1, 3))):
         out = pca(cube, ang, verbose=False, **kw)          # float32 route: runs, same shapes as ever
         assert out is not None
 

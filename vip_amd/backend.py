@@ -704,7 +704,7 @@ def collapse_batched(cubes, mode="median", w=None, trim_n=50):
 
 def pca_fullframe_f64(cube64, angles, ncomp, scaling=None, mask_u8=None, collapse_mode="median", full_output=False):
     """Fused 3-D ADI path for a FLOAT64 cuda cube (vipmi_pca_fullframe_f64: the per-pixel temporal mean carried in float64, the
-    float32 kernels on what is left).  ``scaling``: None, 'temp-mean' or 'temp-standard'.  Returns the frame (float32 cuda
+    float32 kernels on what is left).  ``scaling``: None or any of the reference's modes.  Returns the frame (float32 cuda
     tensor), or (frame, pcs, recon, residuals, residuals_der) with ``full_output``."""
     torch = _torch()
     assert cube64.dtype == torch.float64 and cube64.is_cuda

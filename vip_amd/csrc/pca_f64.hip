@@ -98,14 +98,89 @@ __global__ __launch_bounds__(256) void offset_dots_kernel(const float* __restric
   if (threadIdx.x == 0) g[f] = s;
 }
 
-// G[i, j] += g[i] + g[j] + g[n]      (blockIdx.y = matrix of a batch: G[y][n][n], g[y][n + 1])
-__global__ void gram_offset_kernel(double* __restrict__ G, const double* __restrict__ g, int n) {
+// G[i, j] += g[i] u[j] + u[i] g[j] + g[n] u[i] u[j]   (the Gram matrix of D + u mu^T from that of D; u == nullptr: ones)
+// (blockIdx.y = matrix of a batch: G[y][n][n], g[y][n + 1])
+__global__ void gram_offset_kernel(double* __restrict__ G, const double* __restrict__ g, int n, const double* __restrict__ u = nullptr) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * n) return;
   G += (size_t)blockIdx.y * n * n;
   g += (size_t)blockIdx.y * (n + 1);
   const int i = e / n, j = e - i * n;
-  G[e] += g[i] + g[j] + g[n];
+  if (u) G[e] += g[i] * u[j] + u[i] * g[j] + g[n] * u[i] * u[j];
+  else G[e] += g[i] + g[j] + g[n];
+}
+
+// ---- the spatial scalings ('spat-mean' / 'spat-standard': sklearn scale(axis=1), var/shapes.py:740-781) of a float64 cube ----
+// The scaled matrix is  S (M - m 1^T),  m = the frames' means, S = diag(u), u = 1 / the frames' standard deviations (ones for
+// 'spat-mean').  With mu = the per-pixel temporal mean of M and mubar = mean(mu) = mean(m):
+//     S (M - m 1^T) = S [(M - 1 mu^T) - (m - mubar 1) 1^T] + u (mu - mubar 1)^T = D + u mu'^T
+// -- the same "small matrix + rank-one offset" shape as scaling None, with the vector u in the place of 1: every entry of D is
+// formed in float64 from the counts and rounded once, the offset mu' never meets it in float32.
+// One 1024-thread workgroup per frame: st[f] = mean of the (masked) frame, st[n + 1 + f] = u[f]; all sums in float64, fixed order.
+__global__ __launch_bounds__(1024) void spat_stats_f64_kernel(const double* __restrict__ M, int n, int64_t P, const uint8_t* __restrict__ mask,
+                                                              int with_std, double* __restrict__ st) {
+  __shared__ double sh[16];
+  const int f = blockIdx.x;
+  const double* row = M + (int64_t)f * P;
+  auto total = [&](double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    return t;
+  };
+  double s = 0.0;
+  for (int64_t p = threadIdx.x; p < P; p += 1024) s += (mask && mask[p]) ? 0.0 : row[p];
+  const double m = total(s) / (double)P;
+  double u = 1.0;
+  if (with_std) {
+    double v = 0.0;
+    for (int64_t p = threadIdx.x; p < P; p += 1024) {
+      const double d = ((mask && mask[p]) ? 0.0 : row[p]) - m;
+      v += d * d;
+    }
+    double sd = sqrt(total(v) / (double)P);
+    if (sd < 10.0 * 2.220446049250313e-16) sd = 1.0;       // sklearn _handle_zeros_in_scale
+    u = 1.0 / sd;
+  }
+  if (threadIdx.x == 0) {
+    st[f] = m;
+    st[n + 1 + f] = u;
+  }
+}
+// st[n] = mubar = mean of the frames' means (one workgroup)
+__global__ __launch_bounds__(256) void spat_mubar_kernel(int n, double* __restrict__ st) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int f = threadIdx.x; f < n; f += 256) s += st[f];
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) st[n] = s / n;
+}
+// D[f, p] = float32(((x - mu[p]) - (m[f] - mubar)) u[f]), x = the (masked) sample; then mu[p] -= mubar, mu32 = float32(mu).
+// One thread per pixel column, like center_f64_kernel (which has filled mu).
+__global__ void spat_apply_f64_kernel(const double* __restrict__ M, int n, int64_t P, const uint8_t* __restrict__ mask,
+                                      const double* __restrict__ st, float* __restrict__ D, double* __restrict__ mu,
+                                      float* __restrict__ mu32) {
+  const double mubar = st[n];
+  const double* u = st + n + 1;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const bool dead = mask && mask[p];
+    const double base = mu[p] - mubar;                  // (mu is zero at masked pixels)
+    int f0 = 0;
+    for (; f0 + 8 <= n; f0 += 8) {
+      double v8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v8[q] = dead ? 0.0 : M[(int64_t)(f0 + q) * P + p];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) D[(int64_t)(f0 + q) * P + p] = (float)(((v8[q] - base) - st[f0 + q]) * u[f0 + q]);
+    }
+    for (; f0 < n; ++f0) D[(int64_t)f0 * P + p] = (float)((((dead ? 0.0 : M[(int64_t)f0 * P + p]) - base) - st[f0]) * u[f0]);
+    mu[p] = base;
+    mu32[p] = (float)base;
+  }
 }
 
 // the same dot products for the column SEGMENTS of one matrix D[n][ld] (annular PCA: every segment its own decomposition):
@@ -129,14 +204,16 @@ __global__ __launch_bounds__(256) void offset_dots_seg_kernel(const float* __res
 
 // r = 1 - E^T (E 1) over the components that convert_evecs keeps (eigenvalue > 1e-12 of the largest); row k of the subtraction's
 // coefficient matrix Ct[k][nld] = -r (zero padded): the rank-one term r mu^T as one more component.  One workgroup.
+// (u != nullptr, the spatial scalings: the offset is u mu^T, so r = u - E^T (E u) and e1 = E u)
 __global__ __launch_bounds__(256) void offset_coeff_kernel(const double* __restrict__ evecs, const double* __restrict__ evals, int n,
-                                                           int k, float* __restrict__ Ct_row, int nld, float* __restrict__ e1_out) {
+                                                           int k, float* __restrict__ Ct_row, int nld, float* __restrict__ e1_out,
+                                                           const double* __restrict__ u = nullptr) {
   extern __shared__ double e1[];          // [k]
   const double thr = evals[0] * 1e-12;
   for (int c = threadIdx.x; c < k; c += blockDim.x) {
     double s = 0.0;
     if (evals[c] > thr)
-      for (int f = 0; f < n; ++f) s += evecs[(int64_t)c * n + f];
+      for (int f = 0; f < n; ++f) s += u ? evecs[(int64_t)c * n + f] * u[f] : evecs[(int64_t)c * n + f];
     e1[c] = s;
     e1_out[c] = (float)s;                 // E 1: the offset's share of the principal components (pcs_offset_kernel)
   }
@@ -146,7 +223,7 @@ __global__ __launch_bounds__(256) void offset_coeff_kernel(const double* __restr
     if (f < n) {
       double s = 0.0;
       for (int c = 0; c < k; ++c) s += evecs[(int64_t)c * n + f] * e1[c];
-      r = 1.0 - s;
+      r = (u ? u[f] : 1.0) - s;
     }
     Ct_row[f] = (float)(-r);
   }
@@ -162,11 +239,14 @@ __global__ void pcs_offset_kernel(const float* __restrict__ T, const float* __re
   }
 }
 // recon = (the matrix the decomposition saw) - residuals = D (+ mu) - residuals
+// (u: the offset is u[f] mu -- the spatial scalings)
 __global__ void recon_offset_kernel(const float* __restrict__ D, const float* __restrict__ mu32, const float* __restrict__ res,
-                                    int64_t n, int64_t P, float* __restrict__ out) {
+                                    int64_t n, int64_t P, float* __restrict__ out, const double* __restrict__ u = nullptr) {
   const int64_t total = n * P;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
-    out[e] = D[e] + (mu32 ? mu32[e % P] : 0.f) - res[e];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const float off = mu32 ? (u ? (float)u[e / P] : 1.f) * mu32[e % P] : 0.f;
+    out[e] = D[e] + off - res[e];
+  }
 }
 
 }  // namespace
@@ -227,17 +307,19 @@ int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_h
   VIPMI_REQUIRE(cube && angles_host && frame, "pca_fullframe_f64: null pointer");
   VIPMI_REQUIRE(n > 0 && N > 1, "pca_fullframe_f64: bad sizes");
   VIPMI_REQUIRE(ncomp > 0, "Number of PCs too low. It should be > 0.");
-  if (scaling < 0 || scaling > 2) {
-    set_error("pca_fullframe_f64: scaling mode %d is not served in float64 (None, temp-mean, temp-standard are)", scaling);
+  if (scaling < 0 || scaling > 4) {
+    set_error("pca_fullframe_f64: unknown scaling mode %d", scaling);
     return VIPMI_ERR_UNSUPPORTED;
   }
+  const bool spat = scaling == VIPMI_SCALE_SPAT_MEAN || scaling == VIPMI_SCALE_SPAT_STANDARD;
   const int64_t P = N * N;
   const int64_t k = ncomp > n ? n : ncomp;          // pca_fullfr.py:876-881 (clamp, not an error)
   VIPMI_REQUIRE(k <= P, "%ld PCs cannot be obtained from a matrix with size [%ld,%ld].", (long)k, (long)n, (long)P);
-  const bool offset = scaling == 0;
+  const bool offset = scaling == 0 || spat;         // the matrix of the decomposition is D + u mu^T (u = 1 without scaling)
   const int64_t kk = offset ? k + 1 : k;            // components of the subtraction: the k PCs (+ the rank-one offset term)
   float *D = nullptr, *T = nullptr;
-  double *mu = nullptr, *G = nullptr, *evals = nullptr, *evecs = nullptr, *g = nullptr;
+  double *mu = nullptr, *G = nullptr, *evals = nullptr, *evecs = nullptr, *g = nullptr, *spat_st = nullptr;
+  const double* u = nullptr;                        // the offset's frame vector (spatial scalings; nullptr = ones)
   VIPMI_TRY(ws(ctx, "pca64_D", (size_t)n * P, &D));
   VIPMI_TRY(ws(ctx, "pca64_mu", (size_t)P, &mu));
   VIPMI_TRY(ws(ctx, "pca64_T", (size_t)kk * P, &T));
@@ -248,7 +330,16 @@ int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_h
     StageScope sc(ctx, "scale");
     const int64_t blocks = cdiv(P, 256);
     hipLaunchKernelGGL(center_f64_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, cube, (int)n, P, mask,
-                       scaling, D, mu, offset ? T + (size_t)k * P : (float*)nullptr);
+                       spat ? 0 : scaling, D, mu, offset ? T + (size_t)k * P : (float*)nullptr);
+    if (spat) {
+      VIPMI_TRY(ws(ctx, "pca64_spat", (size_t)2 * n + 1, &spat_st));
+      hipLaunchKernelGGL(spat_stats_f64_kernel, dim3((unsigned)n), dim3(1024), 0, ctx->stream, cube, (int)n, P, mask,
+                         scaling == VIPMI_SCALE_SPAT_STANDARD ? 1 : 0, spat_st);
+      hipLaunchKernelGGL(spat_mubar_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)n, spat_st);
+      hipLaunchKernelGGL(spat_apply_f64_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, cube, (int)n, P,
+                         mask, spat_st, D, mu, T + (size_t)k * P);
+      u = spat_st + n + 1;
+    }
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   VIPMI_TRY(gram_f32(ctx, D, n, D, n, P, P, G));
@@ -256,7 +347,7 @@ int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_h
     StageScope sc(ctx, "gram");
     VIPMI_TRY(ws(ctx, "pca64_g", (size_t)n + 1, &g));
     hipLaunchKernelGGL(offset_dots_kernel, dim3((unsigned)n + 1), dim3(256), 0, ctx->stream, D, mu, (int)n, P, g);
-    hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256)), dim3(256), 0, ctx->stream, G, g, (int)n);
+    hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256)), dim3(256), 0, ctx->stream, G, g, (int)n, u);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   float* res = residuals;
@@ -277,7 +368,7 @@ int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_h
     if (offset) {
       VIPMI_TRY(ws(ctx, "pca64_e1", (size_t)k, &e1));
       hipLaunchKernelGGL(offset_coeff_kernel, dim3(1), dim3(256), sizeof(double) * (size_t)k, ctx->stream, evecs, evals, (int)n, (int)k,
-                         Ekn + (size_t)k * nld, nld, e1);
+                         Ekn + (size_t)k * nld, nld, e1, u);
       VIPMI_CHECK_HIP(hipGetLastError());
     }
     VIPMI_TRY(subtract_gemm_t(ctx, D, Ekn, nld, T, n, kk, P, res, nullptr));
@@ -290,7 +381,7 @@ int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_h
     if (recon) {
       const int64_t blocks = cdiv(n * P, 2048);
       hipLaunchKernelGGL(recon_offset_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, D, mu32, res, n, P,
-                         recon);
+                         recon, u);
     }
     VIPMI_CHECK_HIP(hipGetLastError());
   }

@@ -387,7 +387,7 @@ def _float64_fused(algo_params, rot_options, cube):
     if not isinstance(ap.ncomp, (int, np.integer)) or isinstance(ap.ncomp, bool) or ap.ncomp <= 0:
         return None
     scaling, collapse = _s(ap.scaling), _s(ap.collapse)
-    if scaling not in (None, "temp-mean", "temp-standard") or collapse not in ("median", "mean", "sum", "max", "absmean"):
+    if scaling not in B.SCALE_MODES or collapse not in ("median", "mean", "sum", "max", "absmean"):
         return None
     if _s(ap.imlib) != "vip-fft" or _s(ap.svd_mode) not in SVD_MODES or rot_options.get("edge_blend") not in (None, ""):
         return None
