@@ -254,6 +254,19 @@ int vipmi_annular_gram_all_f64(vipmi_ctx* ctx, const double* cube, int64_t n, in
  *   plain apply). */
 int vipmi_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32);
 int vipmi_gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G);
+/* The SPATIAL scalings (matrix_scaling axis=1, var/shapes.py:740-781) of a float64 matrix M[n][P] whose first Preal columns are
+ * samples (the rest zero padding): the scaled matrix diag(u) (M - m 1^T) -- m the rows' means, u their inverse standard deviations
+ * (with_std = 0, 'spat-mean': ones) -- is D + u mu^T with D[n][P] = float32 of diag(u) [(M - 1 mu0^T) - (m - mean(m) 1) 1^T] formed
+ * in float64, mu[P] = mu0 - mean(mu0) (mu0 = the columns' means; zero in the padding), mu32 = float32(mu), u[n] float64 (device).
+ * gram_offset_u: G (= D D^T) += u (D mu)^T + (D mu) u^T + |mu|^2 u u^T; annular_apply_mu_u: residuals = (I - C) D + rho mu32^T with
+ * rho = (I - C) u.  u NULL in either: ones, i.e. vipmi_gram_offset_f64 / vipmi_annular_apply_mu_f32. */
+int vipmi_spat_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int64_t Preal, int with_std, float* D, double* mu,
+                          float* mu32, double* u);
+int vipmi_gram_offset_u_f64(vipmi_ctx* ctx, const float* D, const double* mu, const double* u, int64_t n, int64_t P, double* G);
+int vipmi_annular_apply_mu_u_f32(vipmi_ctx* ctx, const float* D, int64_t n, int64_t npx, const int32_t* lib_idx,
+                                 const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
+                                 const double* evecs, const int32_t* ncomps_host, int64_t nk, const float* mu32, const double* u,
+                                 float* residuals);
 int vipmi_annular_apply_mu_f32(vipmi_ctx* ctx, const float* D, int64_t n, int64_t npx, const int32_t* lib_idx,
                                const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
                                const double* evecs, const int32_t* ncomps_host, int64_t nk, const float* mu32,

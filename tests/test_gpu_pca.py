@@ -1721,14 +1721,17 @@ def test_float64_route_4d_cube():
 
 
 @pytest.mark.parametrize("kw", [dict(ncomp=3), dict(ncomp=(2, 3, 4, 3), delta_rot=(0.2, 0.8)), dict(ncomp=3, scaling="temp-mean"),
-                                dict(ncomp=2, scaling="temp-standard"), dict(ncomp=3, n_segments=2, radius_int=4)])
+                                dict(ncomp=2, scaling="temp-standard"), dict(ncomp=3, n_segments=2, radius_int=4),
+                                dict(ncomp=3, scaling="spat-mean"), dict(ncomp=(2, 3, 2, 4), scaling="spat-standard", n_segments=2)])
 @pytest.mark.parametrize("fused", ["0", "1"])
 def test_float64_route_annular(kw, fused, monkeypatch):
     """pca_annular on a float64 cube of detector counts: every segment matrix centred in float64 (vipmi_center_f64), the Gram
     matrix corrected by the offset terms, residuals = (I - C) D + rho mu^T -- against the float64 oracle at the BASELINE gate;
     the float32 route (a float32 copy of the cube) ends at least ten times further away.  fused = 1: the same through the fronts of
     all segments at once (vipmi_annular_gram_all_f64: gather + centring in one pass, one ragged Gram product, the offset terms of every
-    segment, the rank-one term added as the residual product scatters; forced: the cube is below the route's size threshold)."""
+    segment, the rank-one term added as the residual product scatters; forced: the cube is below the route's size threshold).
+    The spatial scalings (round 6: per segment, vipmi_spat_center_f64 -> D + u mu^T, rho = (I - C) u) keep the per-segment launches
+    either way."""
     from vip_amd.psfsub import pca_annular
     monkeypatch.setenv("VIPMI_ANNULAR_FUSED", fused)
     g = load_golden("g28_f64_counts")
@@ -1744,7 +1747,7 @@ def test_float64_route_annular(kw, fused, monkeypatch):
     print("annular float64 route %s: %.3e (float32 route %.3e)" % (kw, d64, d32))
     scale = max(10.0, np.nanmax(np.abs(ref)))
     assert d64 < TOL * scale / 10.0
-    if kw.get("scaling") != "temp-standard":
+    if kw.get("scaling") not in ("temp-standard", "spat-standard"):
         assert d32 > 5 * d64
 
 

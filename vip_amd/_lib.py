@@ -68,6 +68,12 @@ _SIGS = {
                                     ctypes.c_void_p], True, ctypes.c_int),
     "vipmi_center_f64": ([ctypes.c_void_p, i64, i64, ctypes.c_int, c_f32p, ctypes.c_void_p, c_f32p], True, ctypes.c_int),
     "vipmi_gram_offset_f64": ([c_f32p, ctypes.c_void_p, i64, i64, ctypes.c_void_p], True, ctypes.c_int),
+    "vipmi_spat_center_f64": ([ctypes.c_void_p, i64, i64, i64, ctypes.c_int, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_void_p], True,
+                              ctypes.c_int),
+    "vipmi_gram_offset_u_f64": ([c_f32p, ctypes.c_void_p, ctypes.c_void_p, i64, i64, ctypes.c_void_p], True, ctypes.c_int),
+    "vipmi_annular_apply_mu_u_f32": ([c_f32p, i64, i64, ctypes.c_void_p, ctypes.c_void_p, i64, i64, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, c_f32p], True,
+                                     ctypes.c_int),
     "vipmi_annular_apply_mu_f32": ([c_f32p, i64, i64, ctypes.c_void_p, ctypes.c_void_p, i64, i64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64, c_f32p, c_f32p], True, ctypes.c_int),
     "vipmi_annular_eigh_f64": ([ctypes.c_void_p, i64, i64, ctypes.c_void_p, ctypes.c_void_p, i64, i64, ctypes.c_void_p,

@@ -44,13 +44,15 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
                                                     const double* __restrict__ evals,
                                                     const double* __restrict__ evecs, int k, int npx,
                                                     float* __restrict__ C, float* __restrict__ rho,
-                                                    const int32_t* __restrict__ kseg = nullptr, int ldt = 0) {
+                                                    const int32_t* __restrict__ kseg = nullptr, int ldt = 0,
+                                                    const double* __restrict__ u = nullptr) {
   // blockIdx.y = segment of a batch (round 6: all annuli in one launch): G[seg][n][n], C[seg][n][ldt or n]; the per-library arrays
   // (idx, len, evals, evecs, rho) are indexed by seg * n + j; kseg (optional): the segment's number of components.
   // ldt > 0: the matrix is written TRANSPOSED with row length ldt -- element (row j, frame f) at C[f * ldt + j], the layout the
   // row-space kernels read (no transposition pass afterwards).
   // rho (optional): rho[j] = 1 - sum_a c_j[a], the row sum of I - C in float64: with A = D + 1 mu^T (a float64 cube whose per-pixel
-  // temporal mean is carried apart, pca_f64.hip) the residuals are (I - C) D + rho mu^T
+  // temporal mean is carried apart, pca_f64.hip) the residuals are (I - C) D + rho mu^T.  u (optional, [seg][n]): the offset is
+  // u mu^T (the spatial scalings of a float64 cube) and rho = (I - C) u.
   extern __shared__ double sh[];      // g[m] | proj[k]
   double* g = sh;
   double* proj = sh + m;
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
   const size_t jj = (size_t)blockIdx.y * n + j;
   G += (size_t)blockIdx.y * n * n;
   C += (size_t)blockIdx.y * n * (ldt > 0 ? ldt : n);
+  if (u) u += (size_t)blockIdx.y * n;
   if (kseg) k = kseg[blockIdx.y];
   const int lj = len[jj];
   const int32_t* ij = idx + jj * max_lib;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
     for (int c = 0; c < kk; ++c) s += E[(size_t)c * m + a] * proj[c];
     if (ldt > 0) C[(size_t)ij[a] * ldt + j] = (float)(-s);
     else C[(size_t)j * n + ij[a]] = (float)(-s);
-    csum += s;
+    csum += u ? s * u[ij[a]] : s;
   }
   __syncthreads();                       // (the frame may belong to its own library: add the identity afterwards)
   if (threadIdx.x == 0) C[ldt > 0 ? (size_t)j * ldt + j : (size_t)j * n + j] += 1.0f;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void coeff_kernel(const double* __restrict__ G
     if (threadIdx.x == 0) {
       double t = 0.0;
       for (int w = 0; w < nw; ++w) t += sh[w];
-      rho[jj] = (float)(1.0 - t);
+      rho[jj] = (float)((u ? u[j] : 1.0) - t);
     }
   }
 }
@@ -199,8 +202,9 @@ int annular_eigh_f64(vipmi_ctx* ctx, const double* G, int64_t nseg, int64_t n, c
 // libraries (evals[j][m], evecs[j][m][m]: rows = vectors, as the top-k eigensolver returns them)
 int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                       const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
-                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals, const float* mu32) {
+                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals, const float* mu32, const double* u) {
   VIPMI_REQUIRE(A && lib_idx && lib_len && G && evals && evecs && ncomps && residuals, "annular_apply: null pointer");
+  VIPMI_REQUIRE(!u || mu32, "annular_apply: offset weights without an offset");
   VIPMI_REQUIRE(n > 0 && npx > 0 && max_lib > 0 && m >= max_lib && nk > 0, "annular_apply: bad sizes");
   int64_t kmax = 0;
   for (int64_t i = 0; i < nk; ++i) {
@@ -223,7 +227,7 @@ int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, co
   for (int64_t i = 0; i < nk; ++i) {
     VIPMI_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * n * n, ctx->stream));
     hipLaunchKernelGGL(coeff_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, G, (int)n, lib_idx, lib_len,
-                       (int)max_lib, (int)m, evals, evecs, (int)ncomps[i], (int)npx, C, rho);
+                       (int)max_lib, (int)m, evals, evecs, (int)ncomps[i], (int)npx, C, rho, (const int32_t*)nullptr, 0, u);
     VIPMI_CHECK_HIP(hipGetLastError());
     // residuals = A - C A = (I - C) A: one (n x n) x (n x npx) product on the matrix cores.  (Round 1 ran it through the
     // skinny-k subtract kernel, k = n components: 14 TF/s, 4.7 of C3's 35 ms; the row-space kernel does it at ~60 TF/s.)

@@ -220,7 +220,9 @@ extern "C" {
 // 106 (round 5): + vipmi_pca_fullframe_hostin_f32 (the Gram under the upload); float-domain median selection
 // 107 (round 6): option sub_guard (the subtraction's zero guard is opt-out per call: median_sub); + vipmi_annular_gram_all_f32,
 //                 vipmi_annular_apply_all_f32, vipmi_annular_gram_all_f64 (the fronts of all annulus segments in a handful of launches)
-int vipmi_version(void) { return 107; }
+// 108 (round 6): the spatial scalings on the float64 routes: vipmi_pca_fullframe_f64 serves every scaling; + vipmi_spat_center_f64,
+//                 vipmi_gram_offset_u_f64, vipmi_annular_apply_mu_u_f32 (the offset u mu^T in the place of 1 mu^T)
+int vipmi_version(void) { return 108; }
 
 const char* vipmi_last_error(void) { return g_err; }
 
@@ -809,6 +811,24 @@ int vipmi_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int 
 int vipmi_gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G) {
   CTX_GUARD();
   return gram_offset_f64(ctx, D, mu, n, P, G);
+}
+
+int vipmi_spat_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int64_t Preal, int with_std, float* D, double* mu,
+                          float* mu32, double* u) {
+  CTX_GUARD();
+  return spat_center_f64(ctx, M, n, P, Preal, with_std, D, mu, mu32, u);
+}
+
+int vipmi_gram_offset_u_f64(vipmi_ctx* ctx, const float* D, const double* mu, const double* u, int64_t n, int64_t P, double* G) {
+  CTX_GUARD();
+  return gram_offset_f64(ctx, D, mu, n, P, G, u);
+}
+
+int vipmi_annular_apply_mu_u_f32(vipmi_ctx* ctx, const float* D, int64_t n, int64_t npx, const int32_t* lib_idx, const int32_t* lib_len,
+                                 int64_t max_lib, int64_t m, const double* G, const double* evals, const double* evecs,
+                                 const int32_t* ncomps_host, int64_t nk, const float* mu32, const double* u, float* residuals) {
+  CTX_GUARD();
+  return annular_apply_f32(ctx, D, n, npx, lib_idx, lib_len, max_lib, m, G, evals, evecs, ncomps_host, nk, residuals, mu32, u);
 }
 
 int vipmi_annular_apply_mu_f32(vipmi_ctx* ctx, const float* D, int64_t n, int64_t npx, const int32_t* lib_idx, const int32_t* lib_len,

@@ -259,7 +259,9 @@ bool eigh_large_supported(int64_t n, int64_t k);
 int eigh_large_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k, double* evals, double* evecs,
                    bool all_evals = false);
 int center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, float* D, double* mu, float* mu32);
-int gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G);
+int gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G, const double* u = nullptr);
+int spat_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int64_t Preal, int with_std, float* D, double* mu, float* mu32,
+                    double* u);
 int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_host, int64_t n, int64_t N, int64_t ncomp, int scaling,
                       const uint8_t* mask, int collapse_mode, float* frame, float* pcs, float* recon, float* residuals,
                       float* residuals_der);
@@ -269,7 +271,8 @@ int annular_subgrams_f64(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx,
                          const int32_t* lib_len, int64_t max_lib, int64_t m, double* G, double* H);
 int annular_apply_f32(vipmi_ctx* ctx, const float* A, int64_t n, int64_t npx, const int32_t* lib_idx,
                       const int32_t* lib_len, int64_t max_lib, int64_t m, const double* G, const double* evals,
-                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals, const float* mu32 = nullptr);
+                      const double* evecs, const int32_t* ncomps, int64_t nk, float* residuals, const float* mu32 = nullptr,
+                      const double* u = nullptr);
 int annular_gram_all_f32(vipmi_ctx* ctx, const float* cube, int64_t n, int64_t P, const int32_t* pix_all, int64_t Ptot, int64_t klen,
                          const int32_t* seg_slice, int64_t nseg, float* A_all, double* G_all);
 int annular_apply_all_f32(vipmi_ctx* ctx, const float* A_all, int64_t n, int64_t Ptot, const int32_t* tile_seg, const int32_t* pix_out,

@@ -117,11 +117,12 @@ __global__ void gram_offset_kernel(double* __restrict__ G, const double* __restr
 // -- the same "small matrix + rank-one offset" shape as scaling None, with the vector u in the place of 1: every entry of D is
 // formed in float64 from the counts and rounded once, the offset mu' never meets it in float32.
 // One 1024-thread workgroup per frame: st[f] = mean of the (masked) frame, st[n + 1 + f] = u[f]; all sums in float64, fixed order.
+// (ld: row length of M; the statistics run over its first P samples -- the zero columns that pad a segment matrix stay out)
 __global__ __launch_bounds__(1024) void spat_stats_f64_kernel(const double* __restrict__ M, int n, int64_t P, const uint8_t* __restrict__ mask,
-                                                              int with_std, double* __restrict__ st) {
+                                                              int with_std, double* __restrict__ st, int64_t ld) {
   __shared__ double sh[16];
   const int f = blockIdx.x;
-  const double* row = M + (int64_t)f * P;
+  const double* row = M + (int64_t)f * ld;
   auto total = [&](double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void spat_mubar_kernel(int n, double* __restri
 // One thread per pixel column, like center_f64_kernel (which has filled mu).
 __global__ void spat_apply_f64_kernel(const double* __restrict__ M, int n, int64_t P, const uint8_t* __restrict__ mask,
                                       const double* __restrict__ st, float* __restrict__ D, double* __restrict__ mu,
-                                      float* __restrict__ mu32) {
+                                      float* __restrict__ mu32, int64_t ld) {
   const double mubar = st[n];
   const double* u = st + n + 1;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
@@ -173,11 +174,11 @@ __global__ void spat_apply_f64_kernel(const double* __restrict__ M, int n, int64
     for (; f0 + 8 <= n; f0 += 8) {
       double v8[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v8[q] = dead ? 0.0 : M[(int64_t)(f0 + q) * P + p];
+      for (int q = 0; q < 8; ++q) v8[q] = dead ? 0.0 : M[(int64_t)(f0 + q) * ld + p];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) D[(int64_t)(f0 + q) * P + p] = (float)(((v8[q] - base) - st[f0 + q]) * u[f0 + q]);
+      for (int q = 0; q < 8; ++q) D[(int64_t)(f0 + q) * ld + p] = (float)(((v8[q] - base) - st[f0 + q]) * u[f0 + q]);
     }
-    for (; f0 < n; ++f0) D[(int64_t)f0 * P + p] = (float)((((dead ? 0.0 : M[(int64_t)f0 * P + p]) - base) - st[f0]) * u[f0]);
+    for (; f0 < n; ++f0) D[(int64_t)f0 * ld + p] = (float)((((dead ? 0.0 : M[(int64_t)f0 * ld + p]) - base) - st[f0]) * u[f0]);
     mu[p] = base;
     mu32[p] = (float)base;
   }
@@ -263,14 +264,36 @@ int center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int mode, 
   return VIPMI_OK;
 }
 // G (= D D^T, n x n float64) += 1 (D mu)^T + (D mu) 1^T + |mu|^2 1 1^T : the Gram matrix of D + 1 mu^T
-int gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G) {
+// (u: G += u (D mu)^T + (D mu) u^T + |mu|^2 u u^T, the Gram matrix of D + u mu^T -- the spatial scalings; nullptr: ones)
+int gram_offset_f64(vipmi_ctx* ctx, const float* D, const double* mu, int64_t n, int64_t P, double* G, const double* u) {
   VIPMI_REQUIRE(D && mu && G && n > 0 && P > 0, "gram_offset_f64: bad arguments");
   StageScope sc(ctx, "gram");
   double* g = nullptr;
   VIPMI_TRY(ws(ctx, "pca64_g", (size_t)n + 1, &g));
   hipLaunchKernelGGL(offset_dots_kernel, dim3((unsigned)n + 1), dim3(256), 0, ctx->stream, D, mu, (int)n, P, g);
-  hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256)), dim3(256), 0, ctx->stream, G, g, (int)n);
+  hipLaunchKernelGGL(gram_offset_kernel, dim3((unsigned)cdiv(n * n, 256)), dim3(256), 0, ctx->stream, G, g, (int)n, u);
   VIPMI_CHECK_HIP(hipGetLastError());
+  return VIPMI_OK;
+}
+// The spatial scalings of a float64 matrix M[n][P] whose first Preal columns are samples (the rest zero padding):
+// D = float32 of diag(u) [(M - 1 mu^T) - (m - mubar 1) 1^T], mu <- mu - mubar (zero in the padding), mu32 = float32(mu), u[n] = the
+// frames' inverse standard deviations (with_std = 0: ones).  The scaled matrix is D + u mu^T.
+int spat_center_f64(vipmi_ctx* ctx, const double* M, int64_t n, int64_t P, int64_t Preal, int with_std, float* D, double* mu, float* mu32,
+                    double* u) {
+  VIPMI_REQUIRE(M && D && mu && mu32 && u && n > 0 && P > 0 && Preal > 0 && Preal <= P, "spat_center_f64: bad arguments");
+  StageScope sc(ctx, "scale");
+  double* st = nullptr;
+  VIPMI_TRY(ws(ctx, "pca64_spat", (size_t)2 * n + 1, &st));
+  const int64_t blocks = cdiv(P, 256), blocks_r = cdiv(Preal, 256);
+  hipLaunchKernelGGL(center_f64_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, M, (int)n, P,
+                     (const uint8_t*)nullptr, 0, D, mu, mu32);
+  hipLaunchKernelGGL(spat_stats_f64_kernel, dim3((unsigned)n), dim3(1024), 0, ctx->stream, M, (int)n, Preal, (const uint8_t*)nullptr,
+                     with_std ? 1 : 0, st, P);
+  hipLaunchKernelGGL(spat_mubar_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)n, st);
+  hipLaunchKernelGGL(spat_apply_f64_kernel, dim3((unsigned)(blocks_r < 65535 ? blocks_r : 65535)), dim3(256), 0, ctx->stream, M, (int)n,
+                     Preal, (const uint8_t*)nullptr, st, D, mu, mu32, P);
+  VIPMI_CHECK_HIP(hipGetLastError());
+  VIPMI_CHECK_HIP(hipMemcpyAsync(u, st + n + 1, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
   return VIPMI_OK;
 }
 
@@ -334,10 +357,10 @@ int pca_fullframe_f64(vipmi_ctx* ctx, const double* cube, const double* angles_h
     if (spat) {
       VIPMI_TRY(ws(ctx, "pca64_spat", (size_t)2 * n + 1, &spat_st));
       hipLaunchKernelGGL(spat_stats_f64_kernel, dim3((unsigned)n), dim3(1024), 0, ctx->stream, cube, (int)n, P, mask,
-                         scaling == VIPMI_SCALE_SPAT_STANDARD ? 1 : 0, spat_st);
+                         scaling == VIPMI_SCALE_SPAT_STANDARD ? 1 : 0, spat_st, P);
       hipLaunchKernelGGL(spat_mubar_kernel, dim3(1), dim3(256), 0, ctx->stream, (int)n, spat_st);
       hipLaunchKernelGGL(spat_apply_f64_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, ctx->stream, cube, (int)n, P,
-                         mask, spat_st, D, mu, T + (size_t)k * P);
+                         mask, spat_st, D, mu, T + (size_t)k * P, P);
       u = spat_st + n + 1;
     }
     VIPMI_CHECK_HIP(hipGetLastError());

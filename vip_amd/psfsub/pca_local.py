@@ -357,11 +357,22 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
             A64[:, npx - npad:] = 0.0                               # (the zero columns that pad the rows to 16 bytes)
         aug = B.empty((n + 1, npx), device=dev)                     # rows 0 .. n-1: D, row n: float32(mu)
         mu = torch.empty((npx,), dtype=torch.float64, device=cube.device)
-        mode = {None: 0, "temp-mean": 1, "temp-standard": 2}[scaling]
-        ctx.call("vipmi_center_f64", B.ptr(A64), n, npx, mode, B.ptr(aug), B.ptr(mu), B.ptr(aug[n]))
+        spat = scaling in ("spat-mean", "spat-standard")
+        u = None
+        if spat:
+            # matrix_scaling(axis=1) of the segment matrix (var/shapes.py:740-781): diag(u) (A - m 1^T) = D + u mu^T, the frames'
+            # means m and inverse standard deviations u over the segment's own pixels (the padding stays out)
+            u = torch.empty((n,), dtype=torch.float64, device=cube.device)
+            ctx.call("vipmi_spat_center_f64", B.ptr(A64), n, npx, npx - npad, 1 if scaling == "spat-standard" else 0, B.ptr(aug),
+                     B.ptr(mu), B.ptr(aug[n]), B.ptr(u))
+        else:
+            mode = {None: 0, "temp-mean": 1, "temp-standard": 2}[scaling]
+            ctx.call("vipmi_center_f64", B.ptr(A64), n, npx, mode, B.ptr(aug), B.ptr(mu), B.ptr(aug[n]))
         G = torch.empty((n, n), dtype=torch.float64, device=cube.device)
         ctx.call("vipmi_gram_f32", B.ptr(aug), n, npx, npx, B.ptr(G))
-        if scaling is None:
+        if spat:
+            ctx.call("vipmi_gram_offset_u_f64", B.ptr(aug), B.ptr(mu), B.ptr(u), n, npx, B.ptr(G))
+        elif scaling is None:
             ctx.call("vipmi_gram_offset_f64", B.ptr(aug), B.ptr(mu), n, npx, B.ptr(G))
         idx_t, ln_t, max_lib = libs_of(seg)
         kseg = min(int(seg["ncomp"]), max_lib)
@@ -371,12 +382,15 @@ def _pca_adi_rdi(cube, angle_list, radius_int=0, fwhm=4, asize=2, n_segments=1, 
         ctx.call("vipmi_annular_eigh_f64", B.ptr(G), 1, n, B.ptr(idx_t), B.ptr(ln_t), max_lib, kseg, B.ptr(work), B.ptr(ev), B.ptr(ec))
         kk_ = np.array([int(seg["ncomp"])], dtype=np.int32)
         R = B.empty((1, n, npx), device=dev)
-        ctx.call("vipmi_annular_apply_mu_f32", B.ptr(aug), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib, max_lib, B.ptr(G), B.ptr(ev),
-                 B.ptr(ec), kk_.ctypes.data_as(ctypes.c_void_p), 1, B.ptr(aug[n]) if scaling is None else None, B.ptr(R))
+        if spat:
+            ctx.call("vipmi_annular_apply_mu_u_f32", B.ptr(aug), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib, max_lib, B.ptr(G), B.ptr(ev),
+                     B.ptr(ec), kk_.ctypes.data_as(ctypes.c_void_p), 1, B.ptr(aug[n]), B.ptr(u), B.ptr(R))
+        else:
+            ctx.call("vipmi_annular_apply_mu_f32", B.ptr(aug), n, npx, B.ptr(idx_t), B.ptr(ln_t), max_lib, max_lib, B.ptr(G), B.ptr(ev),
+                     B.ptr(ec), kk_.ctypes.data_as(ctypes.c_void_p), 1, B.ptr(aug[n]) if scaling is None else None, B.ptr(R))
         ctx.call("vipmi_scatter_f32", B.ptr(R[0].contiguous()), n, P, B.ptr(pix), npx, B.ptr(cube_out))
 
-    f64_route = (cube64 is not None and nref == 0 and cube_sig is None and ks is None
-                 and scaling in (None, "temp-mean", "temp-standard"))
+    f64_route = cube64 is not None and nref == 0 and cube_sig is None and ks is None and scaling in B.SCALE_MODES
 
     # Independent segments: issue the annuli round-robin on a few streams in asynchronous mode, so that the 400 per-frame
     # eigenproblems of one annulus (1.6 rounds of workgroups on 256 CUs) fill the idle tail of the previous one, and
@@ -652,7 +666,7 @@ def pca_annular(*all_args: List, **all_kwargs: dict):
     if algo_params.cube_sig is not None:
         extra["cube_sig"] = B.to_device_f32(algo_params.cube_sig)
     # a float64 cube keeps its dtype through the decomposition (the reference's do_pca_patch): the float64 copy goes along and the
-    # segment matrices are centred in float64 (plain ADI, scaling None / temp-mean / temp-standard; _pca_adi_rdi decides)
+    # segment matrices are centred in float64 (plain ADI, every scaling; _pca_adi_rdi decides)
     if algo_params.cube_ref is None and algo_params.cube_sig is None:
         torch = B._torch()
         if dev_in and cube.dtype == torch.float64:
