@@ -1499,3 +1499,41 @@ def test_cube_derotate_numpy_pipelined_is_bit_identical():
             os.environ.pop("VIPMI_HOSTIN", None)
         assert res["1"].dtype == dt and res["0"].dtype == dt
         assert np.array_equal(res["0"], res["1"], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_std", [0, 1])
+def test_spatial_scaling_of_a_float64_matrix_through_the_c_entries(B, with_std):
+    """vipmi_spat_center_f64 / vipmi_gram_offset_u_f64 (round 6) called directly on a matrix of detector counts with zero padding:
+    D + u mu^T reproduces sklearn's scale(M, axis=1) (var/shapes.py:740-781) formed in float64 numpy to float32 rounding of the SMALL
+    matrix D, the padding stays zero, and D D^T plus the offset terms is the Gram matrix of the scaled matrix."""
+    import torch
+    rng = np.random.default_rng(40 + with_std)
+    n, Preal, P = 37, 1003, 1008
+    M = np.zeros((n, P))
+    M[:, :Preal] = 7000.0 + 45.0 * rng.standard_normal((n, Preal)) * rng.uniform(0.5, 2.0, (n, 1)) + rng.uniform(-300, 300, (1, Preal))
+    ctx = B.get_context()
+    Mt = torch.from_numpy(M).cuda()
+    D = torch.full((n, P), 9.0, dtype=torch.float32, device="cuda")
+    mu = torch.empty((P,), dtype=torch.float64, device="cuda")
+    mu32 = torch.empty((P,), dtype=torch.float32, device="cuda")
+    u = torch.empty((n,), dtype=torch.float64, device="cuda")
+    ctx.call("vipmi_spat_center_f64", B.ptr(Mt), n, P, Preal, with_std, B.ptr(D), B.ptr(mu), B.ptr(mu32), B.ptr(u))
+    torch.cuda.synchronize()
+    X = M[:, :Preal]
+    m = X.mean(axis=1, keepdims=True)
+    sd = X.std(axis=1, keepdims=True) if with_std else np.ones_like(m)
+    want = (X - m) / sd
+    Dh, muh, uh = D.cpu().numpy().astype(np.float64), mu.cpu().numpy(), u.cpu().numpy()
+    assert np.allclose(uh, 1.0 / sd[:, 0], rtol=1e-13)
+    assert not Dh[:, Preal:].any() and not muh[Preal:].any()
+    got = Dh[:, :Preal] + uh[:, None] * muh[None, :Preal]
+    small = np.abs(want - uh[:, None] * muh[None, :Preal]).max()           # the size of D: what float32 has to hold
+    assert np.abs(got - want).max() <= 2.0 ** -23 * small
+    assert np.array_equal(mu32.cpu().numpy(), muh.astype(np.float32))
+    G = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    ctx.call("vipmi_gram_f32", B.ptr(D), n, P, P, B.ptr(G))
+    ctx.call("vipmi_gram_offset_u_f64", B.ptr(D), B.ptr(mu), B.ptr(u), n, P, B.ptr(G))
+    torch.cuda.synchronize()
+    Gw = got @ got.T
+    assert np.abs(G.cpu().numpy() - Gw).max() <= 1e-11 * np.abs(Gw).max()
