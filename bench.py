@@ -293,8 +293,8 @@ def shape_legs(pca, B, torch, c2_latency_ms):
 
     def resident_call():                 # (the frame into pinned memory, as the headline's steps: a pageable destination is bimodal
         fr = pca(ct, ang, ncomp=k, verbose=False, check_memory=False)      # here, 0.45 or 1.2 ms per call from run to run)
-        pin_small.copy_(fr, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        pin_small.copy_(fr, non_blocking=False)      # (blocking copy: returns with the frame on the host; stream.synchronize() after an
+                                                     #  asynchronous copy cost 0.7 ms more on some boxes, tools/sync_probe.py)
     ms_res = lat(resident_call, 100, warm=60)
     ms_np = lat(lambda: pca(cube, ang, ncomp=k, verbose=False, check_memory=False), 100, warm=20)
     many = [ct] * 64
@@ -326,8 +326,7 @@ def shape_legs(pca, B, torch, c2_latency_ms):
 
     def fn():
         fr = pca(ct, ang, ncomp=k, verbose=False, check_memory=False)
-        pin_odd.copy_(fr, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        pin_odd.copy_(fr, non_blocking=False)
     ms_odd = lat(fn, 8)
     out["odd_400x511x511_k20"] = {
         "metric": "ADI cube frames/sec at ncomp=20, 400x511x511 (one synchronous pca() call, cube resident)",
@@ -661,10 +660,9 @@ def main():
 
     def step():
         # D2H of the final frame is part of the metric: into pinned memory, as the pipelined loop below does (a pageable
-        # destination costs 0.14 ms more per 1 MB frame: tools/frame_d2h_probe.py), synchronised before the call counts as done
+        # destination costs 0.14 ms more per 1 MB frame: tools/frame_d2h_probe.py); the blocking copy returns with the frame on the host
         frame = pca(cube_t, angles, ncomp=k, scaling=args.scaling, verbose=False, check_memory=False)
-        frame_host.copy_(frame, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        frame_host.copy_(frame, non_blocking=False)
         return frame_host
 
     def barrier():
