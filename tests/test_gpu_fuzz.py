@@ -283,3 +283,35 @@ def test_input_container_variants():
     assert np.array_equal(cube_collapse(big[::2, 3:44, ::2]), np.nanmedian(cube, axis=0))
     fa = pca_annular(cube.astype(np.float64), list(ang), asize=6, ncomp=2, fwhm=4, verbose=False)
     assert np.nanmax(np.abs(fa - O.pca_annular(cube, ang, asize=6, ncomp=2, fwhm=4))) < TOL
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_pca_float64_counts_random_parameters(seed):
+    """float64 cubes of detector counts (7000 +- 45: what float32 cannot hold beside the signal) through pca() and pca_annular()
+    with random scalings, masks and collapses: the float64 routes (csrc/pca_f64.hip -- every scaling since round 6) against the
+    float64 oracle at the BASELINE gate scaled to the frame."""
+    from vip_amd.psfsub import pca, pca_annular
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(8, 30))
+    N = int(rng.integers(40, 72))
+    base = _cube(rng, n, N).astype(np.float64)
+    cube = 7000.0 + 45.0 * base + 1e-4 * rng.standard_normal(base.shape)
+    scaling = SCALINGS[rng.integers(len(SCALINGS))]
+    if seed % 2 == 0:
+        ang = _angles(rng, n)
+        kw = dict(ncomp=int(rng.integers(1, min(n, 8) + 1)), scaling=scaling, collapse=("median", "mean", "sum")[rng.integers(3)])
+        if rng.integers(3) == 0:
+            kw["mask_center_px"] = int(rng.integers(2, N // 5))
+        ref = O.pca_fullframe(cube, ang, **kw)
+        out = pca(cube, ang, verbose=False, **kw)
+    else:
+        ang = np.linspace(0, float(rng.uniform(80, 200)), n)
+        kw = dict(ncomp=int(rng.integers(1, 5)), scaling=scaling, asize=int(rng.integers(6, 10)), fwhm=4,
+                  delta_rot=(0.2, float(rng.uniform(0.5, 1.0))), n_segments=int(rng.integers(1, 3)))
+        ref = O.pca_annular(cube, ang, **kw)
+        out = pca_annular(cube, ang, verbose=False, **kw)
+    assert out.dtype == np.float64 and out.shape == ref.shape
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(out), ok), (seed, kw)
+    tol = TOL * max(1.0, float(np.abs(ref[ok]).max()) / 10.0)
+    assert np.abs(out[ok] - ref[ok]).max() < tol, (seed, n, N, kw, np.abs(out[ok] - ref[ok]).max(), tol)
