@@ -47,14 +47,24 @@ def test_pca_fullframe_random_parameters(seed):
     ref = O.pca_fullframe(cube, ang, full_output=True, **kw)
     out = pca(cube, ang, full_output=True, verbose=False, **kw)
     scale = max(1.0, float(np.abs(cube).max()) / 10.0)
-    for nm, a, b in zip(("frame", "pcs", "recon", "res", "resder"), out, ref):
+    ref64 = None
+    for i, (nm, a, b) in enumerate(zip(("frame", "pcs", "recon", "res", "resder"), out, ref)):
         if nm == "pcs":
             continue                                          # (defined up to a sign; every other output contains them)
         assert a.shape == b.shape, (seed, nm, kw)
         ok = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), ok), (seed, nm, kw)
         tol = (1e-3 if nm == "recon" else TOL) * scale
-        assert np.abs(a[ok] - b[ok]).max() < tol, (seed, nm, n, N, kw, np.abs(a[ok] - b[ok]).max())
+        d = np.abs(a[ok] - b[ok]).max()
+        if d >= tol:
+            # The reference in float32 is itself this far from the float64 result when the eigenvalues at the truncation are
+            # nearly degenerate (tools/fuzz_more.py, seeds 2327 / 2677: relative gap 1e-4, svd_mode='eigen' forms the Gram matrix in
+            # float32 -- 2.3e-4 from its own float64 run): the device result, whose Gram matrix is exact, has to sit at the float64
+            # result then, and the float32 reference must be the one that is off
+            if ref64 is None:
+                ref64 = O.pca_fullframe(cube.astype(np.float64), ang, full_output=True, **kw)
+            d64, dref = np.abs(a[ok] - ref64[i][ok]).max(), np.abs(b[ok] - ref64[i][ok]).max()
+            assert d64 < tol and dref > 0.5 * tol, (seed, nm, n, N, kw, d, d64, dref)
 
 
 @pytest.mark.parametrize("seed", range(12))
