@@ -1,19 +1,46 @@
 """Randomised differential runs at MEDIUM sizes (40..260 frames of 90..300 px, odd and even: the plans between the fuzz suite's
 small cubes and the BASELINE shapes -- wave-resident / multi-workgroup eigensolvers, LDS subtraction tiles, the power-of-two and the
-circular-convolution shears): pca / pca_annular / float64 routes against the oracle.   python tools/fuzz_medium.py [first [count]]"""
+circular-convolution shears): pca / pca_annular / float64 routes against the oracle.   python tests/hunt_fuzz_medium.py [first [count]]
+Split runs (the CPU oracle is most of the time, one annular case took 371 s): `gen DIR first count [kinds]` writes the oracle's
+results to DIR/*.npz on any host, `check DIR` compares the device results on the GPU box."""
 import sys, os, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import ref_cpu as O
-from vip_amd.psfsub import pca, pca_annular, median_sub
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+mode, refdir, kinds = "both", None, (0, 1, 2, 3)
+argv = sys.argv[1:]
+if argv and argv[0] in ("gen", "check"):
+    mode, refdir = argv[0], argv[1]
+    argv = argv[2:]
+    os.makedirs(refdir, exist_ok=True)
+first = int(argv[0]) if len(argv) > 0 else 0
+count = int(argv[1]) if len(argv) > 1 else 30
+if len(argv) > 2:
+    kinds = tuple(int(c) for c in argv[2].split(","))
+if mode == "check":
+    have = sorted(int(f[4:-4]) for f in os.listdir(refdir) if f.startswith("ref_") and f.endswith(".npz"))
+    seeds = have
+else:
+    seeds = range(first, first + count)
+
+
+def oracle_or_file(seed, fn):
+    """the oracle's result: computed (both / gen) or read back (check)"""
+    path = os.path.join(refdir, "ref_%d.npz" % seed) if refdir else None
+    if mode == "check":
+        return np.load(path)["ref"]
+    ref = fn()
+    if mode == "gen":
+        np.savez_compressed(path, ref=ref)
+    return ref
 TOL = 1e-4
 SCALINGS = (None, "temp-mean", "spat-mean", "temp-standard", "spat-standard")
 bad = 0
-for seed in range(first, first + count):
+if mode != 'gen':
+    from vip_amd.psfsub import pca, pca_annular, median_sub
+for seed in seeds:
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.integers(40, 260))
     N = int(rng.integers(90, 300))
@@ -22,26 +49,28 @@ for seed in range(first, first + count):
     ang = np.linspace(0, float(rng.uniform(40, 200)), n) if rng.integers(2) else np.sort(rng.uniform(-150, 150, n))
     scaling = SCALINGS[rng.integers(len(SCALINGS))]
     kind = seed % 4
+    if kind not in kinds:
+        continue
     t0 = time.time()
     try:
         if kind == 0:
             kw = dict(ncomp=int(rng.integers(1, min(n, 40))), scaling=scaling, collapse=("median", "mean", "trimmean")[rng.integers(3)])
             if rng.integers(3) == 0:
                 kw["mask_center_px"] = int(rng.integers(3, N // 6))
-            ref = O.pca_fullframe(cube, ang, **kw); out = pca(cube, ang, verbose=False, **kw)
+            ref = oracle_or_file(seed, lambda: O.pca_fullframe(cube, ang, **kw)); out = pca(cube, ang, verbose=False, **kw) if mode != 'gen' else ref
         elif kind == 1:
             kw = dict(ncomp=int(rng.integers(1, 12)), scaling=scaling, asize=int(rng.integers(6, 20)), fwhm=4, delta_rot=(0.1, float(rng.uniform(0.4, 1.0))),
                       n_segments=int(rng.integers(1, 3)), radius_int=int(rng.integers(0, 8)))
             ang = np.linspace(0, float(rng.uniform(60, 200)), n)
-            ref = O.pca_annular(cube, ang, **kw); out = pca_annular(cube, ang, verbose=False, **kw)
+            ref = oracle_or_file(seed, lambda: O.pca_annular(cube, ang, **kw)); out = pca_annular(cube, ang, verbose=False, **kw) if mode != 'gen' else ref
         elif kind == 2:
             c64 = 7000.0 + 45.0 * cube.astype(np.float64)
             kw = dict(ncomp=int(rng.integers(1, 20)), scaling=scaling)
-            ref = O.pca_fullframe(c64, ang, **kw); out = pca(c64, ang, verbose=False, **kw)
+            ref = oracle_or_file(seed, lambda: O.pca_fullframe(c64, ang, **kw)); out = pca(c64, ang, verbose=False, **kw) if mode != 'gen' else ref
         else:
             kw = dict(mode="annular", asize=int(rng.integers(4, 10)), fwhm=4, delta_rot=float(rng.uniform(0.3, 1.0)), nframes=int(rng.integers(2, 6)) * 2)
             ang = np.linspace(0, float(rng.uniform(60, 200)), n)
-            ref = O.median_sub_annular(cube, ang, **{a: b for a, b in kw.items() if a != "mode"}); out = median_sub(cube, ang, verbose=False, **kw)
+            ref = oracle_or_file(seed, lambda: O.median_sub_annular(cube, ang, **{a: b for a, b in kw.items() if a != "mode"})); out = median_sub(cube, ang, verbose=False, **kw) if mode != 'gen' else ref
         ok = np.isfinite(ref)
         assert out.shape == ref.shape and np.array_equal(np.isfinite(out), ok), "shape / NaN pattern"
         tol = TOL * max(1.0, float(np.abs(ref[ok]).max()) / 10.0)

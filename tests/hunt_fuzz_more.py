@@ -1,5 +1,5 @@
 """The randomised differential tests of tests/test_gpu_fuzz.py on seeds the suite does not run (a one-off hunt):
-   python tools/fuzz_more.py [first_seed [count]]"""
+   python tests/hunt_fuzz_more.py [first_seed [count]]"""
 import sys, os, traceback, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -58,7 +58,7 @@ def test_pca_fullframe_random_parameters(seed):
         d = np.abs(a[ok] - b[ok]).max()
         if d >= tol:
             # The reference in float32 is itself this far from the float64 result when the eigenvalues at the truncation are
-            # nearly degenerate (tools/fuzz_more.py, seeds 2327 / 2677: relative gap 1e-4, svd_mode='eigen' forms the Gram matrix in
+            # nearly degenerate (tests/hunt_fuzz_more.py, seeds 2327 / 2677: relative gap 1e-4, svd_mode='eigen' forms the Gram matrix in
             # float32 -- 2.3e-4 from its own float64 run): the device result, whose Gram matrix is exact, has to sit at the float64
             # result then, and the float32 reference must be the one that is off
             if ref64 is None:
