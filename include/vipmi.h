@@ -106,7 +106,9 @@ int vipmi_cross_gram_f32(vipmi_ctx* ctx, const float* A, int64_t na, const float
                          int64_t P, int64_t ld, double* C);
 /* Batched symmetric eigendecomposition (float64, one-sided block Jacobi).  G: batch x n x n,
  * destroyed.  evals: batch x n descending.  evecs: batch x n x n, row i = eigenvector of evals[i]
- * (unit norm, sign: largest-|component| positive). */
+ * (unit norm, sign: largest-|component| positive).  Rank-deficient input: the rows of eigenvalues that are numerically null
+ * (below ~1e-13 of the largest column norm) are unit vectors without meaning -- the PCA callers drop every component below 1e-12
+ * of the largest eigenvalue (the reference divides by its singular value, psfsub/svd.py:447-475). */
 int vipmi_eigh_f64(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, double* evals, double* evecs);
 
 /* Leading k eigenpairs only (k <= 64, n <= 512: Householder tridiagonalisation + multisection + inverse iteration,

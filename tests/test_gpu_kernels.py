@@ -1537,3 +1537,38 @@ def test_spatial_scaling_of_a_float64_matrix_through_the_c_entries(B, with_std):
     torch.cuda.synchronize()
     Gw = got @ got.T
     assert np.abs(G.cpu().numpy() - Gw).max() <= 1e-11 * np.abs(Gw).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,batch", [(82, 1), (250, 6), (259, 3), (513, 2)])
+def test_jacobi_converges_on_clusters_and_rank_deficient_matrices(B, n, batch):
+    """vipmi_eigh_f64 (one-sided Jacobi) on spectra it did not converge on before round 6 (tools/hunt_eigh_sizes.py: 'did not
+    converge in 40 sweeps', nor in 300): a cluster of eigenvalues that agree to nine digits -- the rotation angle was steered by
+    beta - alpha formed in float32 -- and rank-deficient Gram matrices, whose null columns are rounding noise that no rotation
+    orthogonalises to a relative tolerance.  Eigenvalues to 1e-12 of the largest, the vectors of the live eigenvalues orthonormal with
+    small residuals."""
+    import torch
+    rng = np.random.default_rng(n)
+    for shape in ("cluster", "rank"):
+        Gs = []
+        for _ in range(batch):
+            if shape == "cluster":
+                Q, _r = np.linalg.qr(rng.standard_normal((n, n)))
+                lam = np.concatenate([np.full(n // 2, 5.0) + 1e-9 * rng.standard_normal(n // 2), rng.uniform(0.1, 1.0, n - n // 2)])
+                X = Q * np.sqrt(lam)
+            else:
+                X = rng.standard_normal((n, n // 3))
+            Gs.append(X @ X.T)
+        G = np.stack(Gs)
+        ev, ec = B.eigh(torch.from_numpy(G).cuda())
+        B.check_deferred()
+        print("jacobi %s n %d batch %d: %d sweeps (problem 0)" % (shape, n, batch, B.get_context().get_option("eigh_last_sweeps")))
+        ev, ec = ev.cpu().numpy(), ec.cpu().numpy()
+        for b in range(batch):
+            w = np.linalg.eigvalsh(G[b])[::-1]
+            assert np.abs(ev[b] - w).max() < 1e-12 * w[0], (shape, b)
+            live = ev[b] > 1e-11 * w[0]
+            V = ec[b][live]
+            assert np.abs(V @ V.T - np.eye(int(live.sum()))).max() < 1e-10, (shape, b)
+            assert np.abs(G[b] @ V.T - V.T * ev[b][live]).max() < 1e-10 * w[0], (shape, b)
+            assert np.abs((ec[b] ** 2).sum(1) - 1).max() < 1e-12

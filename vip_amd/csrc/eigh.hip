@@ -30,8 +30,11 @@ namespace {
 // ~1e-7 relative); orthogonality is what accuracy needs, so c = 1/sqrt(1+t^2) is refined to float64 with
 // two Newton steps from the float32 seed and s = c*t.  (IEEE float64 sqrt/div expansions used to be
 // ~60 % of a Jacobi step.)
+// null2: columns whose squared norm is below it are numerically null with respect to the MATRIX (rounding garbage of a rank-deficient
+// Gram matrix): a pair of two such columns is left alone -- their inner products are noise that no rotation brings under a relative
+// tolerance (300 sweeps did not, round 6), and every consumer drops eigenvalues below 1e-12 of the largest anyway.
 template <int RPL>
-__device__ __forceinline__ float rotate_pair(double (&ap)[RPL], double (&aq)[RPL], float tol) {
+__device__ __forceinline__ float rotate_pair(double (&ap)[RPL], double (&aq)[RPL], float tol, double null2) {
   double al = 0, be = 0, ga = 0;
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
@@ -43,13 +46,17 @@ __device__ __forceinline__ float rotate_pair(double (&ap)[RPL], double (&aq)[RPL
   be = wave_sum(be);
   ga = wave_sum(ga);
   if (!(al > 0.0) || !(be > 0.0)) return 0.f;
+  if (al < null2 && be < null2) return 0.f;
   // scale-free float32 quantities: r = beta/alpha, g = gamma/alpha (exponents removed in float64)
   const int ea = ilogb(al > be ? al : be);
   const float alf = (float)scalbn(al, -ea), bef = (float)scalbn(be, -ea), gaf = (float)scalbn(ga, -ea);
   if (!(alf > 1e-30f) || !(bef > 1e-30f)) return 0.f;   // one column is numerically null w.r.t. the other
   const float rel = fabsf(gaf) * __frsqrt_rn(alf) * __frsqrt_rn(bef);
   if (!(rel > tol)) return rel;
-  const float zeta = (bef - alf) / (2.0f * gaf);
+  // beta - alpha in float64 BEFORE the conversion: for eigenvalues that agree to more than seven digits (a cluster, duplicated
+  // frames) the float32 values are equal or differ by rounding noise, the angle is arbitrary and the pair never converges
+  // (clusters 5 +- 1e-9: stuck at 2e-10 for 300 sweeps, round 6)
+  const float zeta = (float)scalbn(be - al, -ea) / (2.0f * gaf);
   float t = 1.0f / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
   if (!(fabsf(zeta) < 1e18f)) t = 0.5f / fabsf(zeta);          // huge zeta: avoid inf*0
   if (zeta < 0.f) t = -t;
@@ -75,9 +82,10 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
     double* __restrict__ Gall, int n, int nblk, int max_sweeps, double tol, unsigned* __restrict__ bars,
     unsigned* __restrict__ conv, int* __restrict__ info, double* __restrict__ evals_all,
     double* __restrict__ evecs_all, double* __restrict__ norms_all, int prob0,
-    int* __restrict__ fail) {
+    int* __restrict__ fail, const double* __restrict__ null2_all) {
   extern __shared__ __attribute__((aligned(16))) double lds[];   // B columns x ldn
   const int prob = prob0 + blockIdx.y;
+  const double null2 = null2_all[prob];
   const int g = blockIdx.x, nwg = gridDim.x;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* A = Gall + (size_t)prob * n * n;   // column j = A + j*n (G symmetric)
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
             double ap[RPL], aq[RPL];
             lds_get(u, ap);
             lds_get(v, aq);
-            float rel = rotate_pair<RPL>(ap, aq, (float)tol);
+            float rel = rotate_pair<RPL>(ap, aq, (float)tol, null2);
             mymax = fmaxf(mymax, rel);
             lds_put(u, ap);
             lds_put(v, aq);
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
         if (pvalid && J * B + v < n) {
           double aq[RPL];
           lds_get(v, aq);
-          float rel = rotate_pair<RPL>(ap, aq, (float)tol);
+          float rel = rotate_pair<RPL>(ap, aq, (float)tol, null2);
           mymax = fmaxf(mymax, rel);
           lds_put(v, aq);
         }
@@ -269,6 +277,32 @@ __global__ __launch_bounds__(64 * B) void jacobi_kernel(
   }
 }
 
+// null2[prob] = (nulltol * largest column norm)^2, nulltol = max(1e-13, 4e-16 n): one workgroup per problem
+__global__ __launch_bounds__(256) void jacobi_null_kernel(const double* __restrict__ Gall, int n, double* __restrict__ null2) {
+  __shared__ double sh[4];
+  const double* A = Gall + (size_t)blockIdx.x * n * n;
+  double best = 0.0;
+  for (int col = threadIdx.x >> 6; col < n; col += 4) {          // one wave per column (G symmetric: column = row, contiguous)
+    double s = 0.0;
+    for (int i = threadIdx.x & 63; i < n; i += 64) {
+      const double v = A[(size_t)col * n + i];
+      s += v * v;
+    }
+    s = wave_sum(s);
+    best = s > best ? s : best;
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = sh[0] > sh[1] ? sh[0] : sh[1];
+    m = m > sh[2] ? m : sh[2];
+    m = m > sh[3] ? m : sh[3];
+    double nt = 4e-16 * n;
+    if (nt < 1e-13) nt = 1e-13;
+    null2[blockIdx.x] = nt * nt * m;
+  }
+}
+
 template <int B, int RPL>
 int launch_jacobi(vipmi_ctx* ctx, double* G, int64_t batch, int n, double* evals, double* evecs) {
   int nblk = (int)cdiv(n, B);
@@ -302,13 +336,17 @@ int launch_jacobi(vipmi_ctx* ctx, double* G, int64_t batch, int n, double* evals
   VIPMI_TRY(ws(ctx, "eigh_norms", (size_t)batch * nblk * B, &norms));
   int* fail = nullptr;
   VIPMI_TRY(deferred_fail_words(ctx, &fail));
+  double* null2 = nullptr;
+  VIPMI_TRY(ws(ctx, "eigh_null2", (size_t)batch, &null2));
+  hipLaunchKernelGGL(jacobi_null_kernel, dim3((unsigned)batch), dim3(256), 0, ctx->stream, G, n, null2);
+  VIPMI_CHECK_HIP(hipGetLastError());
   VIPMI_CHECK_HIP(hipMemsetAsync(bars, 0, sizeof(unsigned) * batch, ctx->stream));
   VIPMI_CHECK_HIP(hipMemsetAsync(conv, 0, sizeof(unsigned) * batch * max_sweeps, ctx->stream));
   VIPMI_CHECK_HIP(hipMemsetAsync(info, 0xff, sizeof(int) * batch, ctx->stream));
   for (int64_t p0 = 0; p0 < batch; p0 += chunk) {
     int64_t nb = batch - p0 < chunk ? batch - p0 : chunk;
     hipLaunchKernelGGL(kern, dim3(nwg, (unsigned)nb), dim3(64 * B), lds_bytes, ctx->stream, G, n, nblk,
-                       max_sweeps, tol, bars, conv, info, evals, evecs, norms, (int)p0, fail);
+                       max_sweeps, tol, bars, conv, info, evals, evecs, norms, (int)p0, fail, null2);
     VIPMI_CHECK_HIP(hipGetLastError());
   }
   if (ctx->opt("eigh_check", 1)) {
