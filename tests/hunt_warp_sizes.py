@@ -1,6 +1,6 @@
 """cube_derotate(imlib='opencv') -- the interpolating rotation (csrc/warp.hip) -- at random frame sizes, interpolations, border
 modes and rotation centres against the oracle's warp_rotate (a restatement of the published algorithm: parity unpinned, no cv2
-here).   python tests/hunt_warp_sizes.py [first [count]]"""
+here); cube_derotate rotates frame i by -angle_list[i] (derotation.py:395).   python tests/hunt_warp_sizes.py [first [count]]"""
 import sys, os, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,7 +22,7 @@ for seed in range(first, first + count):
     cxy = None if rng.integers(2) else (float(rng.uniform(N / 3, 2 * N / 3)), float(rng.uniform(N / 3, 2 * N / 3)))
     what = "N %d n %d %s %s cxy %s" % (N, n, interp, border, None if cxy is None else "(%.2f, %.2f)" % cxy)
     try:
-        ref = np.stack([O.warp_rotate(cube[i], ang[i], interpolation=interp, cxy=cxy, border_mode=border) for i in range(n)])
+        ref = np.stack([O.warp_rotate(cube[i], -ang[i], interpolation=interp, cxy=cxy, border_mode=border) for i in range(n)])
         got = cube_derotate(cube, ang, imlib="opencv", interpolation=interp, cxy=cxy, border_mode=border)
         assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref)), "shape / NaN pattern"
         d = np.abs(got - ref)
