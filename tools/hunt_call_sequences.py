@@ -2,7 +2,8 @@
 median_sub, cube_derotate; shapes that share sizes but not data, angle lists of equal length but different values, parameters that
 share a plan key but not a result) are each run once, then 150 times more in random order -- interleaved with workspace releases,
 fresh copies of the inputs (same values, other objects), float64 / cuda variants -- and every repeat must reproduce its first result
-bit for bit.   python tools/hunt_call_sequences.py [seed [repeats]]"""
+bit for bit.   python tools/hunt_call_sequences.py [seed [repeats [threads]]]
+threads > 1: the repeats run on that many host threads at once, each under its own torch stream (a context per stream)."""
 import sys, os, time, gc, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,6 +14,8 @@ from vip_amd.synth import synth_adi
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 repeats = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+import threading
 rng = np.random.default_rng(31000 + seed)
 shapes = [(24, 48), (24, 48), (40, 63), (40, 63), (61, 101), (100, 128), (100, 128), (37, 130)]
 cubes = [synth_adi(n, N, seed=100 * seed + i)[0].astype(np.float32) for i, (n, N) in enumerate(shapes)]
@@ -70,25 +73,47 @@ for i, cfg in enumerate(configs):
     first.append(run(cfg, 0))
 bad = 0
 t0 = time.time()
-for r in range(repeats):
-    i = int(rng.integers(len(configs)))
-    variant = int(rng.integers(3))
-    ev = int(rng.integers(12))
-    if ev == 0:
-        B.release_workspaces()
-    elif ev == 1:
-        gc.collect()
-    elif ev == 2:
-        torch.cuda.empty_cache()
-    try:
-        out = run(configs[i], variant)
-        same = out.shape == first[i].shape and np.array_equal(np.nan_to_num(out, nan=123.0), np.nan_to_num(first[i], nan=123.0))
-        if not same:
-            d = np.nanmax(np.abs(out - first[i])) if out.shape == first[i].shape else -1
-            bad += 1
-            print("FAIL repeat %d config %d %s (variant %d, event %d): differs from its first result, max|d| %.3e" % (r, i, configs[i][2], variant, ev, d), flush=True)
-    except Exception as e:
-        bad += 1
-        print("FAIL repeat %d config %d %s: %s" % (r, i, configs[i][2], "".join(traceback.format_exception_only(type(e), e)).strip()[:300]), flush=True)
+lock = threading.Lock()
+
+
+def worker(tid, nrep):
+    global bad
+    lrng = np.random.default_rng(41000 + 97 * seed + tid)
+    stream = torch.cuda.Stream() if nthreads > 1 else torch.cuda.current_stream()
+    with torch.cuda.stream(stream):
+        for r in range(nrep):
+            i = int(lrng.integers(len(configs)))
+            variant = int(lrng.integers(3))
+            ev = int(lrng.integers(12))
+            if ev == 0 and nthreads == 1:
+                B.release_workspaces()
+            elif ev == 1:
+                gc.collect()
+            elif ev == 2 and nthreads == 1:
+                torch.cuda.empty_cache()
+            try:
+                out = run(configs[i], variant)
+                same = out.shape == first[i].shape and np.array_equal(np.nan_to_num(out, nan=123.0), np.nan_to_num(first[i], nan=123.0))
+                if not same:
+                    d = np.nanmax(np.abs(out - first[i])) if out.shape == first[i].shape else -1
+                    with lock:
+                        bad += 1
+                    print("FAIL thread %d repeat %d config %d %s (variant %d, event %d): differs from its first result, max|d| %.3e" % (tid, r, i, configs[i][2], variant, ev, d), flush=True)
+            except Exception as e:
+                with lock:
+                    bad += 1
+                print("FAIL thread %d repeat %d config %d %s: %s" % (tid, r, i, configs[i][2], "".join(traceback.format_exception_only(type(e), e)).strip()[:300]), flush=True)
+        B.check_deferred()
+        stream.synchronize()
+
+
+if nthreads == 1:
+    worker(0, repeats)
+else:
+    ths = [threading.Thread(target=worker, args=(t, repeats // nthreads)) for t in range(nthreads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
 B.check_deferred()
-print("seed %d: %d repeats of %d configurations in %.0f s, failures: %d" % (seed, repeats, len(configs), time.time() - t0, bad))
+print("seed %d: %d repeats of %d configurations on %d thread(s) in %.0f s, failures: %d" % (seed, repeats, len(configs), nthreads, time.time() - t0, bad))
