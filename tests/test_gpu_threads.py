@@ -148,3 +148,18 @@ def test_small_and_odd_sized_cubes_from_threads():
         stop[0] = True
         [t.join() for t in tl]
     assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("0", "150"), ("1", "240", "4")])
+def test_repeated_calls_in_random_order_reproduce_their_first_results(args):
+    """State between calls (plan / table / library caches, workspaces; tools/hunt_call_sequences.py): twenty call configurations that
+    share sizes but not data and angle lists of equal length but different values, each run once and then repeated in random order --
+    interleaved with workspace releases, fresh copies of the inputs and cuda inputs; on one thread and on four threads with a stream
+    each -- bit for bit the first result every time."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cp = subprocess.run([sys.executable, os.path.join(root, "tools", "hunt_call_sequences.py")] + list(args), capture_output=True, text=True,
+                        timeout=600)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    assert "failures: 0" in cp.stdout, cp.stdout[-3000:]
