@@ -1687,6 +1687,37 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
   }
   if (ctx->opt("eigh_method", 0) != 1 && !nact && batch <= 4 && eigh_large_supported(n, k))
     return eigh_large_f64(ctx, G, batch, n, k, evals, evecs, all_evals);
+  // Bigger batches that the matrix-in-L2 solver could serve one problem at a time (more than 64 vectors per matrix: a 4-D cube with
+  // ncomp = 100) take the one-sided Jacobi kernel -- every problem at once -- and, in synchronous mode, fall back on that solver for
+  // the problems Jacobi gives up on (a spectrum graded over twelve decades: round 6) instead of failing the call.
+  if (ctx->opt("eigh_method", 0) == 0 && !nact && batch > 4 && eigh_large_supported(n, k) && ctx->opt("eigh_check", 1) != 0) {
+    double* Gc = nullptr;
+    VIPMI_TRY(ws(ctx, "eigh_batch_copy", (size_t)batch * n * n, &Gc));
+    VIPMI_CHECK_HIP(hipMemcpyAsync(Gc, G, sizeof(double) * (size_t)batch * n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    const int st = eigh_f64(ctx, G, batch, n, evals, evecs);
+    if (st != VIPMI_ERR_NOCONV) return st;
+    int* info = nullptr;
+    VIPMI_TRY(ws(ctx, "eigh_info", (size_t)batch, &info));             // (sweeps per problem of the launch above; < 0: gave up)
+    std::vector<int> h(batch);
+    VIPMI_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    VIPMI_CHECK_HIP(hipMemcpy(h.data(), info, sizeof(int) * batch, hipMemcpyDeviceToHost));
+    int nf = 0;
+    for (int64_t p = 0; p < batch; ++p) nf += h[p] < 0 ? 1 : 0;
+    set_error("");
+    {                                                                   // the latched failures are taken back: the caller gets its eigenpairs
+      int* fail = nullptr;
+      VIPMI_TRY(deferred_fail_words(ctx, &fail, false));
+      int v = 0;
+      VIPMI_CHECK_HIP(hipMemcpy(&v, fail, sizeof(int), hipMemcpyDeviceToHost));
+      v = v > nf ? v - nf : 0;
+      VIPMI_CHECK_HIP(hipMemcpy(fail, &v, sizeof(int), hipMemcpyHostToDevice));
+    }
+    for (int64_t p = 0; p < batch; ++p)
+      if (h[p] < 0)
+        VIPMI_TRY(eigh_large_f64(ctx, Gc + (size_t)p * n * n, 1, n, k, evals + (size_t)p * n, evecs + (size_t)p * n * n, all_evals));
+    ctx->options["eigh_batch_fallback"] = nf;
+    return VIPMI_OK;
+  }
   return eigh_f64(ctx, G, batch, n, evals, evecs);
 }
 
