@@ -1692,7 +1692,11 @@ int eigh_leading(vipmi_ctx* ctx, double* G, int64_t batch, int64_t n, int64_t k,
   // the problems Jacobi gives up on (a spectrum graded over twelve decades: round 6) instead of failing the call.
   if (ctx->opt("eigh_method", 0) == 0 && !nact && batch > 4 && eigh_large_supported(n, k) && ctx->opt("eigh_check", 1) != 0) {
     double* Gc = nullptr;
-    VIPMI_TRY(ws(ctx, "eigh_batch_copy", (size_t)batch * n * n, &Gc));
+    if (ws(ctx, "eigh_batch_copy", (size_t)batch * n * n, &Gc) != VIPMI_OK) {      // (no room for the copy: the plain call, as before)
+      set_error("");
+      (void)hipGetLastError();                          // (the failed hipMalloc is HIP's "last error" otherwise)
+      return eigh_f64(ctx, G, batch, n, evals, evecs);
+    }
     VIPMI_CHECK_HIP(hipMemcpyAsync(Gc, G, sizeof(double) * (size_t)batch * n * n, hipMemcpyDeviceToDevice, ctx->stream));
     const int st = eigh_f64(ctx, G, batch, n, evals, evecs);
     if (st != VIPMI_ERR_NOCONV) return st;
